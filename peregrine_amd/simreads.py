@@ -1,0 +1,125 @@
+"""Deterministic synthetic read sets (numpy PCG64) for parity tests and benchmarks.
+
+The recipe follows the *spirit* of the reference's read simulators
+(/root/reference/test/ecoli_K12/simulate_reads.py:10-45, py-utils/simread.py:8-41): reads of length
+int(15000 + N(0,1500)) drawn from a genome extended by its first 40 kb, every base hit with probability
+1 % by one of {A, C, G, T, deletion, base+A, base+C, base+G, base+T}, half of the reads reverse-complemented.
+K12MG1655.fa / CHM13 are not obtainable offline, so genomes are uniform-random (optionally with planted
+repeat families), SURVEY.md 8(d).  This is our own vectorised generator, not the reference's script.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .formats import SeqDB
+
+_COMP = np.array([3, 2, 1, 0], np.uint8)
+
+
+def make_genome(length: int, seed: int, repeat_families: int = 0, repeat_len: int = 6000,
+                repeat_copies: int = 0, divergence: float = 0.01, tandem: int = 0) -> np.ndarray:
+    """Uniform-random genome of 2-bit codes; optional planted repeat families / tandem arrays / low complexity."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    g = rng.integers(0, 4, size=length, dtype=np.uint8)
+    for _ in range(repeat_families):
+        unit = rng.integers(0, 4, size=repeat_len, dtype=np.uint8)
+        for _c in range(repeat_copies):
+            s = int(rng.integers(0, length - repeat_len))
+            cp = unit.copy()
+            hit = rng.random(repeat_len) < divergence
+            cp[hit] = rng.integers(0, 4, size=int(hit.sum()), dtype=np.uint8)
+            g[s:s + repeat_len] = cp
+    for _ in range(tandem):
+        period = int(rng.integers(1, 40))
+        n = int(rng.integers(200, 3000))
+        unit = rng.integers(0, 4, size=period, dtype=np.uint8)
+        s = int(rng.integers(0, length - n))
+        g[s:s + n] = np.resize(unit, n)
+    return g
+
+
+def simulate_reads(genome: np.ndarray, n_reads: int | None = None, coverage: float | None = None,
+                   seed: int = 42, mean_len: int = 15000, sd_len: int = 1500, err: float = 0.01,
+                   wrap: int = 40000, n_files: int = 1, batch_reads: int = 2048, min_len: int = 200) -> SeqDB:
+    """Simulate reads and return them already in seqdb encoding (1 byte/base, both strands)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    wrap = min(wrap, genome.shape[0])
+    ext = np.concatenate([genome, genome[:wrap]])
+    if n_reads is None:
+        n_reads = int(coverage * ext.shape[0] / mean_len)
+    per_file = -(-n_reads // n_files)
+    out_chunks, rlen_all, names = [], [], []
+    done = 0
+    while done < n_reads:
+        nb = min(batch_reads, n_reads - done)
+        tl = np.maximum((mean_len + rng.normal(0.0, sd_len, nb)).astype(np.int64), min_len)
+        tl = np.minimum(tl, ext.shape[0])
+        st = (rng.random(nb) * (ext.shape[0] - tl + 1)).astype(np.int64)
+        rc = rng.integers(0, 2, nb).astype(bool)
+        tot = int(tl.sum())
+        seg0 = np.concatenate([[0], np.cumsum(tl)[:-1]])
+        src = np.repeat(st - seg0, tl) + np.arange(tot, dtype=np.int64)
+        tmpl = ext[src]
+        # error model: one draw per template base
+        hit = rng.random(tot) < err
+        kind = rng.integers(0, 9, tot, dtype=np.int8)
+        kind[~hit] = -1
+        sub = (kind >= 0) & (kind < 4)
+        base = tmpl.copy()
+        base[sub] = kind[sub].astype(np.uint8)
+        emit = np.ones(tot, np.int64)
+        emit[kind == 4] = 0
+        ins = kind >= 5
+        emit[ins] = 2
+        olen = np.add.reduceat(emit, seg0) if tot else np.zeros(0, np.int64)
+        ototal = int(emit.sum())
+        opos = np.cumsum(emit) - emit                      # output offset of each template base
+        raw = np.empty(ototal, np.uint8)
+        keep = emit > 0
+        raw[opos[keep]] = base[keep]
+        raw[opos[ins] + 1] = (kind[ins] - 5).astype(np.uint8)
+        # strand flip + seqdb encoding need the within-read mirrored index
+        oseg0 = np.concatenate([[0], np.cumsum(olen)[:-1]])
+        seg_start = np.repeat(oseg0, olen)
+        seg_len = np.repeat(olen, olen)
+        idx = np.arange(ototal, dtype=np.int64)
+        mirror = 2 * seg_start + seg_len - 1 - idx
+        rc_rep = np.repeat(rc, olen)
+        codes = np.where(rc_rep, _COMP[raw[mirror]], raw)
+        enc = (np.uint8(1) << codes) | ((np.uint8(8) >> codes[mirror]) << np.uint8(4))
+        out_chunks.append(enc.astype(np.uint8))
+        rlen_all.append(olen.astype(np.uint32))
+        for i in range(nb):
+            j = done + i
+            names.append("%02d/%06d/0_%d" % (j // per_file, j % per_file, int(olen[i])))
+        done += nb
+    seqdb = np.concatenate(out_chunks) if out_chunks else np.zeros(0, np.uint8)
+    rlen = np.concatenate(rlen_all) if rlen_all else np.zeros(0, np.uint32)
+    roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
+    return SeqDB(seqdb, np.arange(n_reads, dtype=np.uint32), rlen, roff, names)
+
+
+def seqdb_to_fasta(db: SeqDB, path: str) -> None:
+    """Write the forward strand of every read as FASTA (for feeding the real shmr_mkseqdb in oracle tests)."""
+    lut = np.full(16, ord("N"), np.uint8)
+    lut[[1, 2, 4, 8]] = [ord(c) for c in "ACGT"]
+    with open(path, "wb") as f:
+        for nm, ln, off in zip(db.names, db.rlen, db.roff):
+            f.write(b">" + nm.encode() + b"\n")
+            f.write(lut[db.seqdb[int(off):int(off) + int(ln)] & 0x0F].tobytes() + b"\n")
+
+
+# ---- the named workloads of BASELINE.json / SURVEY.md 8(d) -------------------------------------------------
+WORKLOADS = {
+    # name: (genome_len, genome_seed, coverage or n_reads, kwargs)
+    "tiny": dict(genome_len=60_000, genome_seed=7, n_reads=60, mean_len=5000, sd_len=500, wrap=0),
+    "small": dict(genome_len=1_000_000, genome_seed=1002, coverage=16.0),
+    "ecoli": dict(genome_len=4_639_675, genome_seed=1001, n_reads=4984, n_files=8),          # C1 / C2
+    "c3": dict(genome_len=150_000_000, genome_seed=1003, coverage=30.0),                      # C3
+}
+
+
+def make_workload(name: str) -> SeqDB:
+    cfg = dict(WORKLOADS[name])
+    g = make_genome(cfg.pop("genome_len"), cfg.pop("genome_seed"))
+    return simulate_reads(g, seed=42, **cfg)
