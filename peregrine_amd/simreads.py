@@ -112,7 +112,7 @@ def seqdb_to_fasta(db: SeqDB, path: str) -> None:
 # ---- the named workloads of BASELINE.json / SURVEY.md 8(d) -------------------------------------------------
 WORKLOADS = {
     # name: (genome_len, genome_seed, coverage or n_reads, kwargs)
-    "tiny": dict(genome_len=60_000, genome_seed=7, n_reads=60, mean_len=5000, sd_len=500, wrap=0),
+    "tiny": dict(genome_len=50_000, genome_seed=7, n_reads=160, mean_len=5000, sd_len=500, wrap=0),
     "small": dict(genome_len=1_000_000, genome_seed=1002, coverage=16.0),
     "ecoli": dict(genome_len=4_639_675, genome_seed=1001, n_reads=4984, n_files=8),          # C1 / C2
     "c3": dict(genome_len=150_000_000, genome_seed=1003, coverage=30.0),                      # C3

@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (oracle/_ref, compiled in place from /root/reference/src).
+
+Run in the build container only:   python tests/golden/make_golden.py
+The fixtures are DATA (inputs + the reference's outputs); no reference source text is stored.
+The reference's own tests hold no golden vectors, so these pin the oracle.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle_util as U  # noqa: E402
+from peregrine_amd import formats, simreads  # noqa: E402
+
+
+def adversarial_strings(rng):
+    """ASCII test strings for mm_sketch: random, tandem repeats, homopolymers, palindromic k-mers, short, with N."""
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    out = []
+
+    def rnd(n):
+        return acgt[rng.integers(0, 4, n)].tobytes()
+
+    def revcomp(s):
+        return s[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+
+    for n in (1, 5, 15, 16, 17, 40, 94, 95, 96, 97, 120, 200, 500, 2000, 6000):
+        out.append(rnd(n))
+    for period in (1, 2, 3, 4, 5, 7, 11, 16, 23, 40):
+        unit = rnd(period)
+        out.append((unit * (1500 // period + 1))[:1500])
+        out.append(rnd(300) + (unit * (900 // period + 1))[:900] + rnd(300))
+    for _ in range(12):  # planted palindromic 16-mers / long AT runs
+        h = rnd(8)
+        pal = h + revcomp(h)
+        out.append(rnd(int(rng.integers(50, 400))) + pal + rnd(int(rng.integers(50, 400))) + pal + rnd(200))
+    out.append(rnd(200) + b"AT" * 150 + rnd(200))
+    out.append(b"AT" * 400)
+    out.append(rnd(100) + b"ACGT" * 100 + rnd(300))
+    for _ in range(12):  # ambiguous bases
+        s = bytearray(rnd(int(rng.integers(150, 1500))))
+        for p in rng.integers(0, len(s), int(rng.integers(1, 6))):
+            s[int(p)] = ord("N")
+        out.append(bytes(s))
+    out.append(b"N" * 50 + rnd(300))
+    out.append(rnd(97) + b"N" + rnd(97) + b"N" + rnd(30))
+    return out
+
+
+def main():
+    assert U.have_ref(), "build the reference first: make -C oracle ref"
+    rng = np.random.Generator(np.random.PCG64(20260928))
+    tmp = tempfile.mkdtemp(prefix="golden_")
+
+    # ---------------- function level ----------------
+    strings = adversarial_strings(rng)
+    cases = []
+    for s in strings:
+        for (w, k) in ((80, 16), (24, 12), (40, 15), (255, 28)):
+            cases.append((s, w, k))
+    blob = b"".join(c[0] for c in cases)
+    soff = np.cumsum([0] + [len(c[0]) for c in cases]).astype(np.int64)
+    sk_out = [U.ref_sketch_ascii(s, w, k, 7 + i) for i, (s, w, k) in enumerate(cases)]
+    ooff = np.cumsum([0] + [len(o) for o in sk_out]).astype(np.int64)
+    np.savez_compressed(
+        os.path.join(HERE, "sketch_cases.npz"), blob=np.frombuffer(blob, np.uint8), soff=soff,
+        w=np.array([c[1] for c in cases], np.int32), k=np.array([c[2] for c in cases], np.int32),
+        out=np.concatenate(sk_out), ooff=ooff)
+
+    # mm_reduce chains on random lists with heavy ties
+    red_in, red_rs, red_out = [], [], []
+    for i in range(60):
+        n = int(rng.integers(0, 400))
+        nread = int(rng.integers(1, 6))
+        rid = np.sort(rng.integers(0, nread, n)).astype(np.uint64) + 3
+        x = (rng.integers(0, 12 if i % 2 else 2**32, n).astype(np.uint64) << np.uint64(8)) | np.uint64(16)
+        pos = np.arange(n, dtype=np.uint64) * 37
+        mm = np.zeros(n, formats.MM_DTYPE)
+        mm["x"] = x
+        mm["y"] = (rid << np.uint64(32)) | (pos << np.uint64(1)) | rng.integers(0, 2, n).astype(np.uint64)
+        rs = int([2, 3, 6, 24][i % 4])
+        red_in.append(mm); red_rs.append(rs); red_out.append(U.ref_reduce(mm, rs))
+    np.savez_compressed(
+        os.path.join(HERE, "reduce_cases.npz"), inp=np.concatenate(red_in),
+        ioff=np.cumsum([0] + [len(a) for a in red_in]).astype(np.int64), rs=np.array(red_rs, np.int32),
+        out=np.concatenate(red_out), ooff=np.cumsum([0] + [len(a) for a in red_out]).astype(np.int64))
+
+    # ovlp_match tuples: identical, 1 % error, diverged (band break), unrelated, both strands, short
+    g = simreads.make_genome(40000, 99)
+    mcases = []
+
+    def enc(codes):
+        codes = np.asarray(codes, np.uint8)
+        return ((np.uint8(1) << codes) | ((np.uint8(8) >> codes[::-1]) << np.uint8(4))).astype(np.uint8)
+
+    def mutate(codes, rate):
+        db = simreads.simulate_reads(codes, n_reads=1, seed=int(rng.integers(1, 1 << 30)), mean_len=len(codes),
+                                     sd_len=0, err=rate, wrap=0)
+        return db  # one read covering ~ the whole template (start 0 forced by len==genome)
+
+    for i in range(40):
+        L = int(rng.integers(600, 9000))
+        s = int(rng.integers(0, 40000 - L))
+        tmpl = g[s:s + L]
+        rate = [0.0, 0.01, 0.01, 0.03, 0.12, 0.30][i % 6]
+        a = mutate(tmpl, rate).seqdb if rate > 0 else enc(tmpl)
+        b = mutate(tmpl, rate).seqdb if rate > 0 else enc(tmpl)
+        if i % 7 == 3:
+            b = enc(g[(s + 20000) % 30000:(s + 20000) % 30000 + L])  # unrelated
+        shift = int(rng.integers(0, 300))
+        qs, ts = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+        if i % 5 == 4:  # use the reverse-strand nibbles of both: still a true overlap
+            qs = ts = 1
+        elif rate > 0 or True:
+            qs = ts = int(i % 2)
+        q = a[shift:] if qs == 0 else a[:len(a) - shift]
+        band = [100, 100, 20, 60][i % 4]
+        mcases.append((q, qs, b, ts, band))
+    mcases.append((enc(g[:100]), 0, enc(g[:100]), 0, 100))
+    mcases.append((enc(g[:3]), 0, enc(g[:3]), 0, 100))
+    mcases.append((enc(g[:1]), 0, enc(g[5:6]), 0, 100))
+    mt = np.array([U.ref_ovlp_match(*c) for c in mcases], np.int32)
+    np.savez_compressed(
+        os.path.join(HERE, "match_cases.npz"),
+        q=np.concatenate([c[0] for c in mcases]), qoff=np.cumsum([0] + [len(c[0]) for c in mcases]).astype(np.int64),
+        t=np.concatenate([c[2] for c in mcases]), toff=np.cumsum([0] + [len(c[2]) for c in mcases]).astype(np.int64),
+        qs=np.array([c[1] for c in mcases], np.uint8), ts=np.array([c[3] for c in mcases], np.uint8),
+        band=np.array([c[4] for c in mcases], np.int32), out=mt)
+
+    # ---------------- stage level: the "tiny" dataset ----------------
+    db = simreads.make_workload("tiny")
+    # sprinkle a few ambiguous bases and one low-complexity read so the fixtures cover those paths
+    sd = db.seqdb.copy()
+    for r in (3, 17):
+        o = int(db.roff[r]); L = int(db.rlen[r])
+        for p in (100, 2500, L - 60):
+            sd[o + p] = (sd[o + p] & 0xF0)            # forward nibble 0 -> 'N'
+            sd[o + L - 1 - p] = (sd[o + L - 1 - p] & 0x0F)  # keep the two strands consistent
+    db.seqdb = sd
+    pre = os.path.join(tmp, "sd")
+    formats.write_seqdb(pre, db)
+    store = {"seqdb": db.seqdb, "rlen": db.rlen, "idx_text": np.frombuffer(open(pre + ".idx", "rb").read(), np.uint8)}
+    for T in (1, 2):
+        for c in range(1, T + 1):
+            for lv, r in ((2, 6), (1, 6)):
+                o = os.path.join(tmp, f"ix{T}l{lv}")
+                U.ref_run("shmr_index", "-p", pre, "-t", T, "-c", c, "-l", lv, "-r", r, "-m", 1, "-o", o)
+                for L in (("L0", f"L{lv}") if lv == 2 else (f"L{lv}",)):
+                    tag = f"{c:02d}-of-{T:02d}"
+                    store[f"ix{T}l{lv}_{L}_{c}"] = formats.read_mmlist(f"{o}-{L}-{tag}.dat")
+                    store[f"ix{T}l{lv}_{L}MC_{c}"] = formats.mc_as_sorted_pairs(formats.read_mm_count(f"{o}-{L}-MC-{tag}.dat"))
+    runs = {  # name: (index prefix, level, overlap T, extra flags)
+        "ov_i1_t1": ("ix1l2", 2, 1, []),
+        "ov_i2_t1": ("ix2l2", 2, 1, []),
+        "ov_i2_t2": ("ix2l2", 2, 2, []),
+        "ov_i2_t3": ("ix2l2", 2, 3, []),
+        "ov_l1_t1": ("ix2l1", 1, 1, []),
+        "ov_par_t2": ("ix2l2", 2, 2, ["-b", 2, "-M", 30, "-w", 60, "-n", 40, "-m", 2]),
+    }
+    for name, (ip, lv, OT, extra) in runs.items():
+        for c in range(1, OT + 1):
+            out = os.path.join(tmp, f"{name}.{c}")
+            U.ref_run("shmr_overlap", "-p", pre, "-l", os.path.join(tmp, f"{ip}-L{lv}"), "-t", OT, "-c", c, "-o", out, *extra)
+            store[f"{name}_{c}"] = formats.read_ovlp(out)
+            print(name, c, len(store[f"{name}_{c}"]))
+    np.savez_compressed(os.path.join(HERE, "tiny_stage.npz"), **store)
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

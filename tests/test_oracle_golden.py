@@ -1,0 +1,78 @@
+"""The CPU oracle against the committed outputs of the REAL reference (tests/golden/).  Runs everywhere (no GPU,
+no /root/reference)."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_util as U
+from peregrine_amd import formats
+
+
+def test_sketch_matches_reference_vectors():
+    n = 0
+    for i, s, w, k, want in G.sketch_cases():
+        got = U.orc_sketch_ascii(s, w, k, 7 + i)
+        assert np.array_equal(got, want), f"case {i} w={w} k={k} len={len(s)}"
+        n += 1
+    assert n > 200
+
+
+def test_reduce_matches_reference_vectors():
+    for i, inp, rs, want in G.reduce_cases():
+        assert np.array_equal(U.orc_reduce(inp, rs), want), f"case {i} rs={rs}"
+
+
+def test_ovlp_match_matches_reference_vectors():
+    kinds = set()
+    for i, q, qs, t, ts, band, want in G.match_cases():
+        got = U.orc_ovlp_match(q, qs, t, ts, band)
+        assert got == want, f"case {i}"
+        kinds.add(want[3] > 0)
+    assert kinds == {True, False}  # both matched and unmatched/band-break cases are covered
+
+
+def test_seqdb_path_equals_ascii_path():
+    db = G.tiny_db()
+    for r in (0, 3, 17, 50):
+        b = db.seqdb[int(db.roff[r]):int(db.roff[r]) + int(db.rlen[r])]
+        lut = np.full(16, ord("N"), np.uint8)
+        lut[[1, 2, 4, 8]] = [ord(c) for c in "ACGT"]
+        assert np.array_equal(U.orc_sketch_seqdb(b, 80, 16, r), U.orc_sketch_ascii(lut[b & 15].tobytes(), 80, 16, r))
+
+
+@pytest.mark.parametrize("T", [1, 2])
+def test_index_stage_matches_reference(tmp_path, T):
+    z = G.load("tiny_stage.npz")
+    db = G.tiny_db(z)
+    pre = str(tmp_path / "sd")
+    formats.write_seqdb(pre, db)
+    assert open(pre + ".idx", "rb").read() == z["idx_text"].tobytes()
+    for c in range(1, T + 1):
+        for lv in (2, 1):
+            o = str(tmp_path / f"o{lv}")
+            U.orc_index_chunk(pre, o, T, c, lv, 6, 1, 80, 16)
+            tag = f"{c:02d}-of-{T:02d}"
+            for L in (("L0", "L2") if lv == 2 else ("L1",)):
+                assert np.array_equal(formats.read_mmlist(f"{o}-{L}-{tag}.dat"), z[f"ix{T}l{lv}_{L}_{c}"])
+                mc = formats.mc_as_sorted_pairs(formats.read_mm_count(f"{o}-{L}-MC-{tag}.dat"))
+                assert np.array_equal(mc, z[f"ix{T}l{lv}_{L}MC_{c}"])
+
+
+@pytest.mark.parametrize("name", sorted(G.OVERLAP_RUNS))
+def test_overlap_stage_matches_reference(tmp_path, name):
+    z = G.load("tiny_stage.npz")
+    db = G.tiny_db(z)
+    IT, lv, OT, kw = G.OVERLAP_RUNS[name]
+    pre = str(tmp_path / "sd")
+    formats.write_seqdb(pre, db)
+    for c in range(1, IT + 1):
+        U.orc_index_chunk(pre, str(tmp_path / "ix"), IT, c, lv, 6, 0, 80, 16)
+    for c in range(1, OT + 1):
+        out = str(tmp_path / f"ov.{c}")
+        n, st = U.orc_overlap_chunk(pre, str(tmp_path / f"ix-L{lv}"), out, OT, c, **kw)
+        got = formats.read_ovlp(out)
+        want = z[f"{name}_{c}"]
+        assert len(got) == n == len(want)
+        assert formats.ovlp_fields_equal(got, want), name
