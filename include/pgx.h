@@ -1,0 +1,151 @@
+/*
+ * pgx.h -- C-ABI of libpgx.so: the MI355X (gfx950) implementation of Peregrine's SHIMMER index + overlap
+ * hot path.  Plain pointers and sizes only; no torch / C++ types.  Every entry point returns 0 on success
+ * or a negative PGX_E* code (the reference exit(1)s / asserts instead: shmr_index.c:15-19,111-114,
+ * shmr_utils.c:101-104); pgx_last_error() gives the message.  One context per process, one process per GPU.
+ *
+ * What each group replaces in the reference (/root/reference):
+ *   stage level    : main() of src/shmr_index.c:37-245 and src/shmr_overlap.c:233-419 (the two executables that
+ *                    py/scripts/pg_run.py:232-244,305-317 runs per chunk)
+ *   resident level : the same stages with the seqdb already in HBM (what bench.py times)
+ *   batch level    : mm_sketch (src/mm_sketch.c:70-151), mm_reduce (src/shmr_reduce.c:53-90), mm_count
+ *                    (src/shmr_utils.c:131-160), ovlp_match (src/DWmatch.c:66-204) over many reads / pairs
+ *   shimmer4py     : the cdef surface of py/peregrine/build_shimmer4py.py:8-84 (same symbol names and C
+ *                    signatures) so a ctypes / cffi-ABI loader can stand in for peregrine._shimmer4py
+ */
+#ifndef PGX_H
+#define PGX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGX_OK 0
+#define PGX_EARG -1    /* bad argument (the reference would assert) */
+#define PGX_EIO -2     /* file open/read/write failure (the reference would exit(1)) */
+#define PGX_EHIP -3    /* HIP runtime error / no device */
+#define PGX_ENOMEM -4
+#define PGX_ESTATE -5  /* pgx_init not called */
+
+/* ---- types shared with the on-disk formats (src/shimmer.h:24-30,61-64,97-110) ---- */
+typedef struct { uint64_t x, y; } pgx_mm128;                        /* x = hash<<8|span ; y = rid<<32|lastPos<<1|strand */
+typedef struct { uint64_t mer; uint32_t count; uint32_t pad; } pgx_mm_count;
+typedef struct { int32_t m_size, dist, q_bgn, q_end, t_bgn, t_end, t_m_end, q_m_end; } pgx_match;
+typedef struct {
+  uint64_t y0, y1;
+  uint32_t rl0, rl1;
+  uint8_t strand0, strand1, ovlp_type, pad0;
+  pgx_match match;
+  uint32_t pad1;
+} pgx_ovlp; /* 64 bytes; pad0/pad1 are written as 0 */
+
+/* one candidate alignment: query = read rid0 from byte q_off on strand dir0, target = whole read rid1 on dir1
+ * (the arguments shimmer_to_overlap passes to ovlp_match, src/shmr_overlap.c:117-125) */
+typedef struct { uint32_t rid0, rid1, q_off; uint8_t dir0, dir1, pad[2]; } pgx_align_key;
+
+typedef struct pgx_seqdb pgx_seqdb; /* opaque: a read database resident in HBM */
+
+/* ---- context ---- */
+int pgx_init(int device);            /* select the GPU, create the stream; idempotent */
+void pgx_shutdown(void);
+const char *pgx_last_error(void);
+int pgx_device_count(void);
+const char *pgx_version(void);
+void pgx_free(void *p);              /* releases any host array returned by this library */
+
+/* per-kernel device time (HIP events on the library's stream), accumulated since the last reset.
+ * names: "sketch", "sketch_literal", "reduce", "count", "pairs", "align". */
+int pgx_timing_get(const char *kernel, double *total_ms, uint64_t *launches, uint64_t *units);
+void pgx_timing_reset(void);
+
+/* ---- resident read database ---- */
+/* rid/rlen/roff: the idx file's columns in file order (src/shmr_mkseqdb.c:111-112); copies to HBM. */
+int pgx_seqdb_upload(const uint8_t *seqdb, size_t nbytes, const uint32_t *rid, const uint32_t *rlen,
+                     const uint64_t *roff, uint32_t nreads, pgx_seqdb **out);
+int pgx_seqdb_load(const char *seqdb_prefix, pgx_seqdb **out); /* reads <prefix>.idx + <prefix>.seqdb */
+void pgx_seqdb_free(pgx_seqdb *db);
+uint64_t pgx_seqdb_bases(const pgx_seqdb *db);
+uint32_t pgx_seqdb_reads(const pgx_seqdb *db);
+
+/* ---- index stage (replaces shmr_index) ---- */
+typedef struct {
+  int total_chunk;   /* -t */
+  int mychunk;       /* -c, 1-based; selects reads with rid % t == c % t (shmr_index.c:157) */
+  int levels;        /* -l 1|2 */
+  int reduction;     /* -r (<256) */
+  int window;        /* -w (24..255) */
+  int kmer;          /* -k (12..28) */
+  int want_l0;       /* -m : also return / write the L0 list and its counts */
+} pgx_index_params;
+
+typedef struct {
+  pgx_mm128 *l0; size_t n_l0;           /* only when want_l0 */
+  pgx_mm_count *l0_mc; size_t n_l0_mc;
+  pgx_mm128 *top; size_t n_top;         /* L1 (levels==1) or L2 */
+  pgx_mm_count *top_mc; size_t n_top_mc;/* sorted by mer (the reference writes khash slot order; consumers only aggregate) */
+  uint64_t bases; uint32_t reads;       /* what this chunk sketched */
+  uint32_t reads_literal;               /* reads routed to the literal-state-machine kernel (N, short, k>16 ...) */
+  double gpu_ms;                        /* device time of this call */
+} pgx_index_result;
+
+int pgx_index_resident(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out);
+void pgx_index_result_free(pgx_index_result *r);
+/* file level: same flags, same output file names/bytes as shmr_index (MC files: same (mer,count) multiset) */
+int pgx_index_chunk(const char *seqdb_prefix, const char *out_prefix, const pgx_index_params *p,
+                    pgx_index_result *stats /* nullable; arrays are not returned */);
+
+/* ---- overlap stage (replaces shmr_overlap) ---- */
+typedef struct {
+  int total_chunk, mychunk;  /* -t -c : bucket ownership (x>>8) % t == c % t (shmr_utils.c:337,362) */
+  int bestn;                 /* -b (uint8 in the reference) */
+  int mc_lower, mc_upper;    /* -m -M */
+  int align_bandwidth;       /* -w */
+  int ovlp_upper;            /* -n */
+} pgx_overlap_params;
+
+typedef struct {
+  uint64_t n_records;        /* ovlp_t records produced */
+  uint64_t n_pair_records;   /* shimmer-pair records built (build_map) */
+  uint64_t n_buckets;        /* buckets processed (2 < n <= ovlp_upper) */
+  uint64_t n_align_needed;   /* alignments the reference would have computed */
+  uint64_t n_align_gpu;      /* alignments computed on the GPU (>= needed: speculative replay) */
+  uint64_t n_seen_skip;
+  uint32_t rounds;           /* replay rounds until the fixed point */
+  double gpu_ms;             /* device time */
+  double host_ms;            /* host orchestration time (order emulation + replay) */
+} pgx_overlap_stats;
+
+/* mmers: concatenation of all index chunks' final-level lists in chunk order; counts: all MC entries */
+int pgx_overlap_resident(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts,
+                         size_t n_counts, const pgx_overlap_params *p, pgx_ovlp **out, size_t *n_out,
+                         pgx_overlap_stats *stats);
+/* file level: globs <shimmer_prefix>-[0-9]*-of-[0-9]*.dat and -MC- twins like shmr_overlap.c:355-384 */
+int pgx_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, const char *out_path,
+                      const pgx_overlap_params *p, pgx_overlap_stats *stats);
+
+/* ---- batch level ---- */
+int pgx_sketch_batch(pgx_seqdb *db, const uint32_t *read_slots, uint32_t n, int w, int k, pgx_mm128 **out,
+                     size_t *n_out);  /* read_slots index the idx-file order; output in that order */
+int pgx_reduce_batch(const pgx_mm128 *in, size_t n, int rs, pgx_mm128 **out, size_t *n_out);
+int pgx_count_batch(const pgx_mm128 *in, size_t n, pgx_mm_count **out, size_t *n_out);
+int pgx_align_batch(pgx_seqdb *db, const pgx_align_key *keys, size_t n, int band, pgx_match *out);
+
+/* ---- shimmer4py surface (py/peregrine/build_shimmer4py.py:8-84), GPU-backed single-call forms ---- */
+typedef struct { size_t n, m; pgx_mm128 *a; } mm128_v; /* kvec layout, src/shimmer.h:27-30; .a is malloc'd, caller frees */
+typedef pgx_match ovlp_match_t;
+void decode_biseq(uint8_t *src, char *seq, size_t len, uint8_t strand);
+void encode_biseq(uint8_t *target, char *seq, size_t len);
+void mm_sketch(void *km, const char *str, int len, int w, int k, uint32_t rid, int is_hpc, mm128_v *p);
+void mm_reduce(mm128_v *in, mm128_v *out, uint8_t rs);
+ovlp_match_t *ovlp_match(uint8_t *query_seq, int32_t q_len, uint8_t q_strand, uint8_t *target_seq,
+                         int32_t t_len, uint8_t t_strand, int32_t band_tolerance);
+void free_ovlp_match(ovlp_match_t *m);
+mm128_v read_mmlist(char *fn);
+void write_mmlist(char *fn, mm128_v *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,130 @@
+"""ctypes binding of libpgx.so (the C-ABI declared in include/pgx.h).  No CPU fallback: if the HIP library is
+missing or no GPU is visible, every compute entry point raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .formats import MC_DTYPE, MM_DTYPE, OVLP_DTYPE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgx.so")
+
+MATCH_DTYPE = np.dtype([(f, "<i4") for f in ("m_size", "dist", "q_bgn", "q_end", "t_bgn", "t_end", "t_m_end", "q_m_end")])
+ALIGN_KEY_DTYPE = np.dtype([("rid0", "<u4"), ("rid1", "<u4"), ("q_off", "<u4"), ("dir0", "u1"), ("dir1", "u1"), ("pad", "u1", 2)])
+assert MATCH_DTYPE.itemsize == 32 and ALIGN_KEY_DTYPE.itemsize == 16
+
+
+class PgxError(RuntimeError):
+    pass
+
+
+class IndexParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("total_chunk", "mychunk", "levels", "reduction", "window", "kmer", "want_l0")]
+
+
+class IndexResult(C.Structure):
+    _fields_ = [("l0", C.c_void_p), ("n_l0", C.c_size_t), ("l0_mc", C.c_void_p), ("n_l0_mc", C.c_size_t),
+                ("top", C.c_void_p), ("n_top", C.c_size_t), ("top_mc", C.c_void_p), ("n_top_mc", C.c_size_t),
+                ("bases", C.c_uint64), ("reads", C.c_uint32), ("reads_literal", C.c_uint32), ("gpu_ms", C.c_double)]
+
+
+class OverlapParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("total_chunk", "mychunk", "bestn", "mc_lower", "mc_upper", "align_bandwidth", "ovlp_upper")]
+
+
+class OverlapStats(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_pair_records", C.c_uint64), ("n_buckets", C.c_uint64),
+                ("n_align_needed", C.c_uint64), ("n_align_gpu", C.c_uint64), ("n_seen_skip", C.c_uint64),
+                ("rounds", C.c_uint32), ("gpu_ms", C.c_double), ("host_ms", C.c_double)]
+
+    def asdict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+# every symbol include/pgx.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "pgx_init", "pgx_shutdown", "pgx_last_error", "pgx_device_count", "pgx_version", "pgx_free",
+    "pgx_timing_get", "pgx_timing_reset",
+    "pgx_seqdb_upload", "pgx_seqdb_load", "pgx_seqdb_free", "pgx_seqdb_bases", "pgx_seqdb_reads",
+    "pgx_index_resident", "pgx_index_result_free", "pgx_index_chunk",
+    "pgx_overlap_resident", "pgx_overlap_chunk",
+    "pgx_sketch_batch", "pgx_reduce_batch", "pgx_count_batch", "pgx_align_batch",
+    "decode_biseq", "encode_biseq", "mm_sketch", "mm_reduce", "ovlp_match", "free_ovlp_match", "read_mmlist", "write_mmlist",
+]
+
+_lib = None
+
+
+def load():
+    """Load libpgx.so (building it is __graft_entry__.build()'s job).  Raises if absent: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PgxError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(LIB_PATH)
+        lib.pgx_last_error.restype = C.c_char_p
+        lib.pgx_version.restype = C.c_char_p
+        lib.pgx_free.argtypes = [C.c_void_p]
+        lib.pgx_seqdb_free.argtypes = [C.c_void_p]
+        lib.pgx_seqdb_bases.restype = C.c_uint64
+        lib.pgx_seqdb_bases.argtypes = [C.c_void_p]
+        lib.pgx_seqdb_reads.restype = C.c_uint32
+        lib.pgx_seqdb_reads.argtypes = [C.c_void_p]
+        lib.pgx_seqdb_upload.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.pgx_seqdb_load.argtypes = [C.c_char_p, C.c_void_p]
+        lib.pgx_index_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pgx_index_chunk.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p]
+        lib.pgx_overlap_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pgx_overlap_chunk.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p]
+        lib.pgx_sketch_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        lib.pgx_reduce_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        lib.pgx_count_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        lib.pgx_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        lib.pgx_timing_get.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str = "pgx"):
+    if rc != 0:
+        raise PgxError(f"{what} failed (code {rc}): {load().pgx_last_error().decode(errors='replace')}")
+
+
+_inited = None
+
+
+def init(device: int | None = None):
+    """Select the GPU (default: LOCAL_RANK or 0).  Raises when no GPU is visible."""
+    global _inited
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    if _inited != device:
+        check(load().pgx_init(int(device)), "pgx_init")
+        _inited = device
+    return device
+
+
+def take(ptr, n: int, dtype: np.dtype) -> np.ndarray:
+    """Copy a library-owned host array into numpy and release it."""
+    n = int(n)
+    if n and ptr:
+        out = np.frombuffer((C.c_uint8 * (n * dtype.itemsize)).from_address(ptr), dtype=dtype).copy()
+    else:
+        out = np.zeros(0, dtype)
+    if ptr:
+        load().pgx_free(C.c_void_p(ptr))
+    return out
+
+
+def timing(name: str):
+    ms, launches, units = C.c_double(0), C.c_uint64(0), C.c_uint64(0)
+    load().pgx_timing_get(name.encode(), C.byref(ms), C.byref(launches), C.byref(units))
+    return float(ms.value), int(launches.value), int(units.value)
+
+
+def timing_reset():
+    load().pgx_timing_reset()

@@ -1,0 +1,300 @@
+// pgx_api.cpp -- context, timing, resident seqdb, file formats, batch-level and shimmer4py entry points.
+#include <glob.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+
+#include "pgx_internal.h"
+
+namespace pgx {
+
+static thread_local std::string g_err;
+void set_error(const char *fmt, ...) {
+  char buf[2048];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+Context &ctx() {
+  static Context c;
+  return c;
+}
+void require_ready() { PGX_REQUIRE(ctx().ready, PGX_ESTATE, "pgx_init() has not been called (or failed)"); }
+
+// ---- timing ----------------------------------------------------------------------------------------------
+struct TimeAcc {
+  double ms = 0;
+  uint64_t launches = 0, units = 0;
+};
+struct Pending {
+  std::string name;
+  uint64_t units;
+  hipEvent_t e0, e1;
+};
+static std::map<std::string, TimeAcc> g_time;
+static std::vector<Pending> g_pending;
+
+KernelTimer::KernelTimer(const char *nm, uint64_t u) : name(nm), units(u) {
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  (void)hipEventRecord(e0, ctx().stream);
+}
+KernelTimer::~KernelTimer() {
+  (void)hipEventRecord(e1, ctx().stream);
+  g_pending.push_back(Pending{name, units, e0, e1});
+}
+void timing_flush() {
+  if (g_pending.empty()) return;
+  (void)hipStreamSynchronize(ctx().stream);
+  for (auto &p : g_pending) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+      auto &a = g_time[p.name];
+      a.ms += ms, a.launches += 1, a.units += p.units;
+    }
+    (void)hipEventDestroy(p.e0);
+    (void)hipEventDestroy(p.e1);
+  }
+  g_pending.clear();
+}
+
+// ---- files -----------------------------------------------------------------------------------------------
+int load_idx(const char *path, std::vector<uint32_t> &rid, std::vector<uint32_t> &rlen, std::vector<uint64_t> &roff) {
+  FILE *f = fopen(path, "r");
+  if (!f) return -1;
+  char name[256];
+  unsigned r, l;
+  unsigned long o;
+  // same tokenisation as the reference's fscanf("%u %255s %u %lu") (src/shmr_utils.c:259-260)
+  while (fscanf(f, "%u %255s %u %lu", &r, name, &l, &o) == 4) rid.push_back(r), rlen.push_back(l), roff.push_back(o);
+  fclose(f);
+  return 0;
+}
+bool read_file(const std::string &path, std::vector<uint8_t> &out) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  fseek(f, 0, SEEK_END);
+  long sz = ftell(f);
+  fseek(f, 0, SEEK_SET);
+  out.resize(sz > 0 ? (size_t)sz : 0);
+  bool ok = sz <= 0 || fread(out.data(), 1, (size_t)sz, f) == (size_t)sz;
+  fclose(f);
+  return ok;
+}
+
+}  // namespace pgx
+
+using namespace pgx;
+
+#define PGX_GUARD_BEGIN try {
+#define PGX_GUARD_END                          \
+  }                                            \
+  catch (const pgx::Fail &f) { return f.code; } \
+  catch (const std::bad_alloc &) {             \
+    pgx::set_error("out of host memory");      \
+    return PGX_ENOMEM;                         \
+  }                                            \
+  return PGX_OK;
+
+extern "C" {
+
+const char *pgx_last_error(void) { return pgx::g_err.c_str(); }
+const char *pgx_version(void) { return "pgx 0.1 (gfx950)"; }
+void pgx_free(void *p) { free(p); }
+
+int pgx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int pgx_init(int device) {
+  PGX_GUARD_BEGIN
+  Context &c = ctx();
+  if (c.ready && c.device == device) return PGX_OK;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  PGX_REQUIRE(e == hipSuccess && n > 0, PGX_EHIP, "no HIP device visible (%s)", hipGetErrorString(e));
+  PGX_REQUIRE(device >= 0 && device < n, PGX_EARG, "device %d out of range (have %d)", device, n);
+  PGX_HIP(hipSetDevice(device));
+  if (c.stream) (void)hipStreamDestroy(c.stream);
+  PGX_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+  hipDeviceProp_t prop;
+  PGX_HIP(hipGetDeviceProperties(&prop, device));
+  c.num_cu = prop.multiProcessorCount;
+  c.device = device;
+  c.ready = true;
+  PGX_GUARD_END
+}
+
+void pgx_shutdown(void) {
+  Context &c = ctx();
+  if (c.stream) (void)hipStreamDestroy(c.stream);
+  c.stream = nullptr;
+  c.ready = false;
+}
+
+int pgx_timing_get(const char *kernel, double *total_ms, uint64_t *launches, uint64_t *units) {
+  timing_flush();
+  auto it = g_time.find(kernel ? kernel : "");
+  if (it == g_time.end()) {
+    if (total_ms) *total_ms = 0;
+    if (launches) *launches = 0;
+    if (units) *units = 0;
+    return PGX_EARG;
+  }
+  if (total_ms) *total_ms = it->second.ms;
+  if (launches) *launches = it->second.launches;
+  if (units) *units = it->second.units;
+  return PGX_OK;
+}
+void pgx_timing_reset(void) {
+  timing_flush();
+  g_time.clear();
+}
+
+// ---- resident seqdb --------------------------------------------------------------------------------------
+int pgx_seqdb_upload(const uint8_t *seqdb, size_t nbytes, const uint32_t *rid, const uint32_t *rlen,
+                     const uint64_t *roff, uint32_t nreads, pgx_seqdb **out) {
+  PGX_GUARD_BEGIN
+  require_ready();
+  PGX_REQUIRE(out && (nreads == 0 || (rid && rlen && roff)), PGX_EARG, "pgx_seqdb_upload: null argument");
+  auto *db = new pgx_seqdb();
+  db->rid.assign(rid, rid + nreads);
+  db->rlen.assign(rlen, rlen + nreads);
+  db->roff.assign(roff, roff + nreads);
+  uint32_t max_rid = 0;
+  for (uint32_t i = 0; i < nreads; ++i) {
+    max_rid = std::max(max_rid, rid[i]);
+    db->bases += rlen[i];
+    if ((size_t)roff[i] + rlen[i] > nbytes) {
+      delete db;
+      PGX_REQUIRE(false, PGX_EARG, "read %u exceeds the seqdb (%zu bytes)", rid[i], nbytes);
+    }
+  }
+  const size_t nr = nreads ? (size_t)max_rid + 1 : 0;
+  db->rlen_by_rid.assign(nr, 0);
+  db->roff_by_rid.assign(nr, 0);
+  for (uint32_t i = 0; i < nreads; ++i) db->rlen_by_rid[rid[i]] = rlen[i], db->roff_by_rid[rid[i]] = roff[i];
+  db->nbytes = nbytes;
+  try {
+    db->d_seq.alloc(nbytes + 64);
+    PGX_HIP(hipMemsetAsync(db->d_seq.p + nbytes, 0, 64, ctx().stream));
+    if (nbytes) PGX_HIP(hipMemcpyAsync(db->d_seq.p, seqdb, nbytes, hipMemcpyHostToDevice, ctx().stream));
+    db->d_roff.alloc(nr ? nr : 1);
+    db->d_rlen.alloc(nr ? nr : 1);
+    db->d_roff.upload(db->roff_by_rid.data(), nr);
+    db->d_rlen.upload(db->rlen_by_rid.data(), nr);
+    sync();
+  } catch (...) {
+    delete db;
+    throw;
+  }
+  *out = db;
+  PGX_GUARD_END
+}
+
+int pgx_seqdb_load(const char *prefix, pgx_seqdb **out) {
+  PGX_GUARD_BEGIN
+  require_ready();
+  PGX_REQUIRE(prefix && out, PGX_EARG, "pgx_seqdb_load: null argument");
+  std::vector<uint32_t> rid, rlen;
+  std::vector<uint64_t> roff;
+  std::string p(prefix);
+  PGX_REQUIRE(load_idx((p + ".idx").c_str(), rid, rlen, roff) == 0, PGX_EIO, "cannot open %s.idx", prefix);
+  std::vector<uint8_t> bytes;
+  PGX_REQUIRE(read_file(p + ".seqdb", bytes), PGX_EIO, "cannot read %s.seqdb", prefix);
+  int rc = pgx_seqdb_upload(bytes.data(), bytes.size(), rid.data(), rlen.data(), roff.data(), (uint32_t)rid.size(), out);
+  if (rc) return rc;
+  PGX_GUARD_END
+}
+
+void pgx_seqdb_free(pgx_seqdb *db) { delete db; }
+uint64_t pgx_seqdb_bases(const pgx_seqdb *db) { return db ? db->bases : 0; }
+uint32_t pgx_seqdb_reads(const pgx_seqdb *db) { return db ? (uint32_t)db->rid.size() : 0; }
+
+// ---- batch level -----------------------------------------------------------------------------------------
+int pgx_sketch_batch(pgx_seqdb *db, const uint32_t *read_slots, uint32_t n, int w, int k, pgx_mm128 **out,
+                     size_t *n_out) {
+  PGX_GUARD_BEGIN
+  require_ready();
+  PGX_REQUIRE(db && out && n_out, PGX_EARG, "pgx_sketch_batch: null argument");
+  PGX_REQUIRE(w > 0 && w < 256 && k > 0 && k <= 28, PGX_EARG, "need 0<w<256, 0<k<=28 (src/mm_sketch.c:77-78)");
+  std::vector<ReadDesc> reads(n);
+  for (uint32_t i = 0; i < n; ++i) {
+    PGX_REQUIRE(read_slots[i] < db->rid.size(), PGX_EARG, "read slot %u out of range", read_slots[i]);
+    const uint32_t s = read_slots[i];
+    PGX_REQUIRE(db->rlen[s] > 0, PGX_EARG, "read slot %u is empty (mm_sketch asserts len > 0)", s);
+    reads[i] = ReadDesc{db->roff[s], db->rlen[s], db->rid[s]};
+  }
+  DevBuf<pgx_mm128> d;
+  size_t m = 0;
+  dev_sketch(db, reads, w, k, d, m, nullptr);
+  std::vector<pgx_mm128> h(m);
+  d.download(h.data(), m);
+  sync();
+  *out = host_copy(h);
+  *n_out = m;
+  PGX_GUARD_END
+}
+
+int pgx_reduce_batch(const pgx_mm128 *in, size_t n, int rs, pgx_mm128 **out, size_t *n_out) {
+  PGX_GUARD_BEGIN
+  require_ready();
+  PGX_REQUIRE(out && n_out && (n == 0 || in), PGX_EARG, "pgx_reduce_batch: null argument");
+  PGX_REQUIRE(rs > 0 && rs < 256, PGX_EARG, "reduction factor must be 1..255");
+  PGX_REQUIRE(n < (1ULL << 31), PGX_EARG, "list too long");
+  DevBuf<pgx_mm128> d_in(n), d_out;
+  d_in.upload(in, n);
+  size_t m = 0;
+  dev_reduce(d_in.p, n, rs, d_out, m);
+  std::vector<pgx_mm128> h(m);
+  d_out.download(h.data(), m);
+  sync();
+  *out = host_copy(h);
+  *n_out = m;
+  PGX_GUARD_END
+}
+
+int pgx_count_batch(const pgx_mm128 *in, size_t n, pgx_mm_count **out, size_t *n_out) {
+  PGX_GUARD_BEGIN
+  require_ready();
+  PGX_REQUIRE(out && n_out && (n == 0 || in), PGX_EARG, "pgx_count_batch: null argument");
+  PGX_REQUIRE(n < (1ULL << 31), PGX_EARG, "list too long");
+  DevBuf<pgx_mm128> d_in(n);
+  DevBuf<pgx_mm_count> d_out;
+  d_in.upload(in, n);
+  size_t m = 0;
+  dev_count(d_in.p, n, 56, d_out, m);
+  std::vector<pgx_mm_count> h(m);
+  d_out.download(h.data(), m);
+  sync();
+  *out = host_copy(h);
+  *n_out = m;
+  PGX_GUARD_END
+}
+
+int pgx_align_batch(pgx_seqdb *db, const pgx_align_key *keys, size_t n, int band, pgx_match *out) {
+  PGX_GUARD_BEGIN
+  require_ready();
+  PGX_REQUIRE(db && (n == 0 || (keys && out)), PGX_EARG, "pgx_align_batch: null argument");
+  PGX_REQUIRE(band > 0 && band < (1 << 20), PGX_EARG, "bad band");
+  for (size_t i = 0; i < n; ++i) {
+    const auto &k = keys[i];
+    PGX_REQUIRE(k.rid0 < db->rlen_by_rid.size() && k.rid1 < db->rlen_by_rid.size() && k.q_off <= db->rlen_by_rid[k.rid0],
+                PGX_EARG, "alignment key %zu out of range", i);
+  }
+  DevBuf<pgx_align_key> d_keys(n);
+  DevBuf<pgx_match> d_out(n);
+  d_keys.upload(keys, n);
+  dev_align(db, d_keys.p, n, band, d_out.p);
+  d_out.download(out, n);
+  sync();
+  PGX_GUARD_END
+}
+
+}  // extern "C"

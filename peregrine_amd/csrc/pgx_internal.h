@@ -1,0 +1,147 @@
+// pgx_internal.h -- shared declarations of libpgx.so (not part of the C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pgx.h"
+
+namespace pgx {
+
+// ---------------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+struct Fail {
+  int code;
+};
+#define PGX_HIP(call)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (call);                                                                   \
+    if (e_ != hipSuccess) {                                                                   \
+      pgx::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      throw pgx::Fail{PGX_EHIP};                                                              \
+    }                                                                                         \
+  } while (0)
+#define PGX_REQUIRE(cond, code, ...) \
+  do {                               \
+    if (!(cond)) {                   \
+      pgx::set_error(__VA_ARGS__);   \
+      throw pgx::Fail{code};         \
+    }                                \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// context: one device, one stream
+// ---------------------------------------------------------------------------------------------------------
+struct Context {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  bool ready = false;
+  int num_cu = 256;
+};
+Context &ctx();
+void require_ready();
+
+// device buffer (RAII, grow-only reuse is up to the caller)
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  explicit DevBuf(size_t count) { alloc(count); }
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr, o.n = 0; }
+  DevBuf &operator=(DevBuf &&o) noexcept {
+    if (this != &o) {
+      release();
+      p = o.p, n = o.n;
+      o.p = nullptr, o.n = 0;
+    }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void alloc(size_t count) {
+    release();
+    n = count;
+    if (count) PGX_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr, n = 0;
+  }
+  void upload(const T *src, size_t count) {
+    if (count) PGX_HIP(hipMemcpyAsync(p, src, count * sizeof(T), hipMemcpyHostToDevice, ctx().stream));
+  }
+  void download(T *dst, size_t count) const {
+    if (count) PGX_HIP(hipMemcpyAsync(dst, p, count * sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
+  }
+};
+inline void sync() { PGX_HIP(hipStreamSynchronize(ctx().stream)); }
+
+// ---------------------------------------------------------------------------------------------------------
+// per-kernel timing with HIP events on the library stream
+// ---------------------------------------------------------------------------------------------------------
+struct KernelTimer {
+  KernelTimer(const char *name, uint64_t units);
+  ~KernelTimer();
+  const char *name;
+  uint64_t units;
+  hipEvent_t e0, e1;
+};
+void timing_flush();  // resolve pending events into the totals (synchronises the stream)
+
+// ---------------------------------------------------------------------------------------------------------
+// resident read database
+// ---------------------------------------------------------------------------------------------------------
+struct ReadDesc {
+  uint64_t off;
+  uint32_t len;
+  uint32_t rid;
+};
+}  // namespace pgx
+
+struct pgx_seqdb {
+  pgx::DevBuf<uint8_t> d_seq;      // seqdb bytes + 64 bytes of zero padding
+  pgx::DevBuf<uint64_t> d_roff;    // indexed by rid
+  pgx::DevBuf<uint32_t> d_rlen;    // indexed by rid
+  std::vector<uint32_t> rid, rlen; // idx-file order
+  std::vector<uint64_t> roff;
+  std::vector<uint32_t> rlen_by_rid;
+  std::vector<uint64_t> roff_by_rid;
+  size_t nbytes = 0;
+  uint64_t bases = 0;
+};
+
+namespace pgx {
+
+// ---------------------------------------------------------------------------------------------------------
+// device stages (pgx_kernels.hip).  All take/return device pointers and run on ctx().stream.
+// ---------------------------------------------------------------------------------------------------------
+// L0 minimizers of the given reads (device array of ReadDesc, in output order). Returns device list.
+void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, DevBuf<pgx_mm128> &out,
+                size_t &n_out, uint32_t *n_literal);
+// one mm_reduce level over a device list
+void dev_reduce(const pgx_mm128 *d_in, size_t n, int rs, DevBuf<pgx_mm128> &out, size_t &n_out);
+// multiplicity of x>>8, sorted by mer
+void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_count> &out, size_t &n_out);
+// banded O(ND) confirmation of n candidate alignments (keys on device)
+void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out);
+
+// host helpers (pgx_api.cpp)
+int load_idx(const char *path, std::vector<uint32_t> &rid, std::vector<uint32_t> &rlen, std::vector<uint64_t> &roff);
+bool read_file(const std::string &path, std::vector<uint8_t> &out);
+template <typename T>
+T *host_copy(const std::vector<T> &v) {
+  T *p = (T *)malloc(v.size() ? v.size() * sizeof(T) : 1);
+  if (v.size()) memcpy(p, v.data(), v.size() * sizeof(T));
+  return p;
+}
+}  // namespace pgx

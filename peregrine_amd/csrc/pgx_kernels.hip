@@ -1,0 +1,489 @@
+// pgx_kernels.hip -- gfx950 device code of libpgx.so (index stage + banded O(ND) confirmation).
+//
+// Kernels (each cites the reference routine whose results it must reproduce bit-for-bit):
+//   k_sketch_literal : mm_sketch      src/mm_sketch.c:70-151   general state machine, one lane per read
+//                                     (reads with ambiguous bases, k > 16, reads shorter than a window ...)
+//   k_sketch_wave    : mm_sketch      closed form, one wavefront per read            (pgx_sketch_fast.hip)
+//   k_reduce_*       : mm_reduce      src/shmr_reduce.c:53-90
+//   count            : mm_count       src/shmr_utils.c:131-160  radix sort + run-length
+//   k_align          : ovlp_match     src/DWmatch.c:66-204      one wavefront per candidate pair
+#include <hipcub/hipcub.hpp>
+
+#include "pgx_internal.h"
+
+namespace pgx {
+
+static inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// =========================================================================================================
+// minimizer hash (src/mm_sketch.c:23-32), 64-bit form for any k <= 28
+// =========================================================================================================
+__device__ __forceinline__ uint64_t mix64(uint64_t key, uint64_t mask) {
+  key = (~key + (key << 21)) & mask;
+  key = key ^ key >> 24;
+  key = ((key + (key << 3)) + (key << 8)) & mask;
+  key = key ^ key >> 14;
+  key = ((key + (key << 2)) + (key << 4)) & mask;
+  key = key ^ key >> 28;
+  key = (key + (key << 31)) & mask;
+  return key;
+}
+
+__device__ __forceinline__ int code_of_nibble(uint32_t b) {
+  // seqdb low nibble is one-hot A=1 C=2 G=4 T=8 (src/shmr_utils.c:18-30); anything else decodes to 'N'
+  b &= 0xF;
+  return (b == 1) ? 0 : (b == 2) ? 1 : (b == 4) ? 2 : (b == 8) ? 3 : 4;
+}
+
+// =========================================================================================================
+// k_sketch_literal: the reference's streaming state machine, one lane per read.  Used for every read the
+// closed-form wave kernel does not cover.  MODE 0 counts, MODE 1 writes at out_off[slot].
+// ring_ws: per-thread ring of w entries, interleaved (slot j of thread t at j*nthreads + t).
+// =========================================================================================================
+template <int MODE>
+__global__ void k_sketch_literal(const uint8_t *__restrict__ seq, const ReadDesc *__restrict__ reads,
+                                 const uint32_t *__restrict__ list, uint32_t n_list, int w, int k,
+                                 pgx_mm128 *__restrict__ ring_ws, uint32_t *__restrict__ counts,
+                                 const uint64_t *__restrict__ out_off, pgx_mm128 *__restrict__ out) {
+  const uint32_t nthreads = gridDim.x * blockDim.x;
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t mask = (1ULL << (2 * k)) - 1, top = 2ULL * (uint64_t)(k - 1);
+  const uint64_t MAXV = ~0ULL;
+  for (uint32_t it = tid; it < n_list; it += nthreads) {
+    const uint32_t slot = list[it];
+    const ReadDesc rd = reads[slot];
+    const uint8_t *s = seq + rd.off;
+    pgx_mm128 *ring = ring_ws + tid;
+    for (int j = 0; j < w; ++j) ring[(size_t)j * nthreads] = pgx_mm128{MAXV, MAXV};
+    uint64_t fwd = 0, rev = 0;
+    pgx_mm128 cur{MAXV, MAXV};
+    int run = 0, ring_pos = 0, cur_pos = 0;
+    uint32_t cnt = 0;
+    pgx_mm128 *dst = MODE ? out + out_off[slot] : nullptr;
+#define PGX_EMIT(e)                  \
+  do {                               \
+    if (MODE) dst[cnt] = (e);        \
+    ++cnt;                           \
+  } while (0)
+    for (int i = 0; i < (int)rd.len; ++i) {
+      const int c = code_of_nibble(s[i]);
+      pgx_mm128 e{MAXV, MAXV};
+      if (c < 4) {
+        const int span = run + 1 < k ? run + 1 : k;
+        fwd = (fwd << 2 | (uint64_t)c) & mask;
+        rev = (rev >> 2) | (3ULL ^ (uint64_t)c) << top;
+        if (fwd == rev) continue;  // strand-ambiguous k-mer consumes no window slot (mm_sketch.c:104-105)
+        const int z = fwd < rev ? 0 : 1;
+        ++run;
+        if (run >= k) {
+          e.x = mix64(z ? rev : fwd, mask) << 8 | (uint64_t)span;
+          e.y = (uint64_t)rd.rid << 32 | (uint64_t)(uint32_t)i << 1 | (uint64_t)z;
+        }
+      } else {
+        run = 0;  // mm_sketch.c:112-113: the window state is NOT flushed
+      }
+      ring[(size_t)ring_pos * nthreads] = e;
+      if (run == w + k - 1 && cur.x != MAXV) {  // first full window: ties of the pre-update minimum
+        for (int j = ring_pos + 1; j < w; ++j) {
+          pgx_mm128 r = ring[(size_t)j * nthreads];
+          if (r.x == cur.x && r.y != cur.y) PGX_EMIT(r);
+        }
+        for (int j = 0; j < ring_pos; ++j) {
+          pgx_mm128 r = ring[(size_t)j * nthreads];
+          if (r.x == cur.x && r.y != cur.y) PGX_EMIT(r);
+        }
+      }
+      if (e.x <= cur.x) {
+        if (run >= w + k && cur.x != MAXV) PGX_EMIT(cur);
+        cur = e, cur_pos = ring_pos;
+      } else if (ring_pos == cur_pos) {
+        if (run >= w + k - 1 && cur.x != MAXV) PGX_EMIT(cur);
+        cur.x = MAXV;
+        for (int j = ring_pos + 1; j < w; ++j) {
+          pgx_mm128 r = ring[(size_t)j * nthreads];
+          if (cur.x >= r.x) cur = r, cur_pos = j;
+        }
+        for (int j = 0; j <= ring_pos; ++j) {
+          pgx_mm128 r = ring[(size_t)j * nthreads];
+          if (cur.x >= r.x) cur = r, cur_pos = j;
+        }
+        if (run >= w + k - 1 && cur.x != MAXV) {
+          for (int j = ring_pos + 1; j < w; ++j) {
+            pgx_mm128 r = ring[(size_t)j * nthreads];
+            if (cur.x == r.x && cur.y != r.y) PGX_EMIT(r);
+          }
+          for (int j = 0; j <= ring_pos; ++j) {
+            pgx_mm128 r = ring[(size_t)j * nthreads];
+            if (cur.x == r.x && cur.y != r.y) PGX_EMIT(r);
+          }
+        }
+      }
+      if (++ring_pos == w) ring_pos = 0;
+    }
+    if (cur.x != MAXV) PGX_EMIT(cur);
+#undef PGX_EMIT
+    if (!MODE) counts[slot] = cnt;
+  }
+}
+
+// =========================================================================================================
+// mm_reduce (src/shmr_reduce.c:53-90), data-parallel restatement:
+//   element t of a read segment [s, e) closes the window [t-rs+1, t] once t-s >= rs-1; the winner is the
+//   smallest x>>8 with ties to the lowest ring slot ((t'-s) % rs); it is emitted iff its y differs from the
+//   winner of the previous window (== the last emitted element; the first window of a read always emits).
+// =========================================================================================================
+__global__ void k_mark_starts(const pgx_mm128 *__restrict__ in, size_t n, uint8_t *__restrict__ flag) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  flag[t] = (t == 0) || ((in[t].y >> 32) != (in[t - 1].y >> 32));
+}
+
+__device__ __forceinline__ size_t seg_start_of(const uint64_t *starts, uint32_t nseg, size_t t) {
+  uint32_t lo = 0, hi = nseg;  // last start <= t
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (starts[mid] <= t) lo = mid;
+    else hi = mid;
+  }
+  return starts[lo];
+}
+
+__device__ __forceinline__ pgx_mm128 reduce_winner(const pgx_mm128 *in, size_t s, size_t t, int rs) {
+  // window elements t-rs+1 .. t ; slot of element u is (u - s) % rs
+  pgx_mm128 best = in[t - rs + 1];
+  uint64_t bh = best.x >> 8;
+  int bslot = (int)((t - rs + 1 - s) % (size_t)rs);
+  for (int j = 1; j < rs; ++j) {
+    const size_t u = t - rs + 1 + j;
+    const pgx_mm128 e = in[u];
+    const uint64_t h = e.x >> 8;
+    const int slot = (int)((u - s) % (size_t)rs);
+    if (h < bh || (h == bh && slot < bslot)) best = e, bh = h, bslot = slot;
+  }
+  return best;
+}
+
+__global__ void k_reduce_flag(const pgx_mm128 *__restrict__ in, size_t n, const uint64_t *__restrict__ starts,
+                              uint32_t nseg, int rs, pgx_mm128 *__restrict__ win, uint8_t *__restrict__ flag) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const size_t s = seg_start_of(starts, nseg, t);
+  const size_t off = t - s;
+  uint8_t f = 0;
+  pgx_mm128 w{0, 0};
+  if (off >= (size_t)rs - 1) {
+    w = reduce_winner(in, s, t, rs);
+    if (off == (size_t)rs - 1) f = 1;
+    else f = reduce_winner(in, s, t - 1, rs).y != w.y;
+  }
+  win[t] = w;
+  flag[t] = f;
+}
+
+// generic temp-storage helper for hipcub
+struct CubTemp {
+  DevBuf<uint8_t> buf;
+  void *get(size_t bytes) {
+    if (bytes > buf.n) buf.alloc(bytes + (bytes >> 2) + 256);
+    return buf.p;
+  }
+};
+
+using CountIt = hipcub::CountingInputIterator<uint64_t, ptrdiff_t>;
+
+void dev_reduce(const pgx_mm128 *d_in, size_t n, int rs, DevBuf<pgx_mm128> &out, size_t &n_out) {
+  n_out = 0;
+  if (n == 0) { out.alloc(0); return; }
+  hipStream_t st = ctx().stream;
+  KernelTimer tm("reduce", n);
+  DevBuf<uint8_t> flag(n);
+  DevBuf<uint64_t> starts(n);  // worst case every element its own read
+  DevBuf<uint64_t> d_num(1);
+  CubTemp tmp;
+  hipLaunchKernelGGL(k_mark_starts, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, n, flag.p);
+  size_t bytes = 0;
+  PGX_HIP(hipcub::DeviceSelect::Flagged(nullptr, bytes, CountIt(0), flag.p, starts.p, d_num.p, (int)n, st));
+  PGX_HIP(hipcub::DeviceSelect::Flagged(tmp.get(bytes), bytes, CountIt(0), flag.p, starts.p, d_num.p, (int)n, st));
+  uint64_t nseg = 0;
+  d_num.download(&nseg, 1);
+  sync();
+  DevBuf<pgx_mm128> win(n);
+  hipLaunchKernelGGL(k_reduce_flag, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, n, starts.p, (uint32_t)nseg, rs, win.p,
+                     flag.p);
+  out.alloc(n);
+  bytes = 0;
+  PGX_HIP(hipcub::DeviceSelect::Flagged(nullptr, bytes, win.p, flag.p, out.p, d_num.p, (int)n, st));
+  PGX_HIP(hipcub::DeviceSelect::Flagged(tmp.get(bytes), bytes, win.p, flag.p, out.p, d_num.p, (int)n, st));
+  uint64_t m = 0;
+  d_num.download(&m, 1);
+  sync();
+  n_out = (size_t)m;
+}
+
+// =========================================================================================================
+// mm_count: multiplicity of x>>8.  Radix sort + run-length encode; output sorted by mer.
+// =========================================================================================================
+__global__ void k_extract_hash(const pgx_mm128 *__restrict__ in, size_t n, uint64_t *__restrict__ keys) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) keys[t] = in[t].x >> 8;
+}
+__global__ void k_pack_counts(const uint64_t *__restrict__ mer, const uint32_t *__restrict__ cnt, size_t n,
+                              pgx_mm_count *__restrict__ out) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) out[t] = pgx_mm_count{mer[t], cnt[t], 0u};
+}
+
+void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_count> &out, size_t &n_out) {
+  n_out = 0;
+  if (n == 0) { out.alloc(0); return; }
+  hipStream_t st = ctx().stream;
+  KernelTimer tm("count", n);
+  DevBuf<uint64_t> keys(n), sorted(n), uniq(n);
+  DevBuf<uint32_t> cnt(n);
+  DevBuf<uint64_t> d_num(1);
+  CubTemp tmp;
+  hipLaunchKernelGGL(k_extract_hash, dim3(cdiv(n, 256)), dim3(256), 0, st, d_in, n, keys.p);
+  size_t bytes = 0;
+  PGX_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, keys.p, sorted.p, (int)n, 0, kmer_bits, st));
+  PGX_HIP(hipcub::DeviceRadixSort::SortKeys(tmp.get(bytes), bytes, keys.p, sorted.p, (int)n, 0, kmer_bits, st));
+  bytes = 0;
+  PGX_HIP(hipcub::DeviceRunLengthEncode::Encode(nullptr, bytes, sorted.p, uniq.p, cnt.p, d_num.p, (int)n, st));
+  PGX_HIP(hipcub::DeviceRunLengthEncode::Encode(tmp.get(bytes), bytes, sorted.p, uniq.p, cnt.p, d_num.p, (int)n, st));
+  uint64_t m = 0;
+  d_num.download(&m, 1);
+  sync();
+  n_out = (size_t)m;
+  out.alloc(n_out);
+  if (n_out) hipLaunchKernelGGL(k_pack_counts, dim3(cdiv(n_out, 256)), dim3(256), 0, st, uniq.p, cnt.p, n_out, out.p);
+}
+
+// =========================================================================================================
+// sketch driver: literal kernel for now for every read; the closed-form wave kernel takes over eligible reads
+// =========================================================================================================
+bool sketch_wave_eligible(const ReadDesc &rd, int w, int k);  // pgx_sketch_fast.hip
+void launch_sketch_wave(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n_list, int w,
+                        int k, int mode, uint32_t *d_counts, const uint64_t *d_off, pgx_mm128 *d_out,
+                        uint32_t *d_fallback_flag);
+
+void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, DevBuf<pgx_mm128> &out,
+                size_t &n_out, uint32_t *n_literal) {
+  n_out = 0;
+  if (n_literal) *n_literal = 0;
+  const uint32_t n = (uint32_t)reads.size();
+  if (n == 0) { out.alloc(0); return; }
+  hipStream_t st = ctx().stream;
+  DevBuf<ReadDesc> d_reads(n);
+  d_reads.upload(reads.data(), n);
+  DevBuf<uint32_t> counts(n);
+  DevBuf<uint64_t> offs(n + 1);
+  PGX_HIP(hipMemsetAsync(counts.p, 0, n * sizeof(uint32_t), st));
+
+  // ---- split: wave kernel (closed form) vs literal kernel -------------------------------------------------
+  std::vector<uint32_t> fast, slow;
+  uint64_t fast_bases = 0, slow_bases = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (sketch_wave_eligible(reads[i], w, k)) fast.push_back(i), fast_bases += reads[i].len;
+    else slow.push_back(i), slow_bases += reads[i].len;
+  }
+  DevBuf<uint32_t> d_fast(fast.size()), d_flag(n);
+  PGX_HIP(hipMemsetAsync(d_flag.p, 0, n * sizeof(uint32_t), st));
+  if (!fast.empty()) {
+    d_fast.upload(fast.data(), fast.size());
+    {
+      KernelTimer tm("sketch_count", fast_bases);
+      launch_sketch_wave(db, d_reads.p, d_fast.p, (uint32_t)fast.size(), w, k, 0, counts.p, nullptr, nullptr, d_flag.p);
+    }
+    // reads the wave kernel declined at run time (ambiguous base, too many strand-ambiguous k-mers ...)
+    std::vector<uint32_t> flag(n);
+    d_flag.download(flag.data(), n);
+    sync();
+    std::vector<uint32_t> keep;
+    for (uint32_t i : fast)
+      if (flag[i]) slow.push_back(i), slow_bases += reads[i].len, fast_bases -= reads[i].len;
+      else keep.push_back(i);
+    fast.swap(keep);
+    if (!fast.empty()) d_fast.upload(fast.data(), fast.size());
+  }
+  // literal kernel: bounded grid, ring workspace in global memory
+  const uint32_t lit_threads = 256 * 64;
+  DevBuf<uint32_t> d_slow(slow.size());
+  DevBuf<pgx_mm128> ring;
+  if (!slow.empty()) {
+    d_slow.upload(slow.data(), slow.size());
+    ring.alloc((size_t)lit_threads * (size_t)w);
+    KernelTimer tm("sketch_literal", slow_bases);
+    hipLaunchKernelGGL(k_sketch_literal<0>, dim3(lit_threads / 64), dim3(64), 0, st, db->d_seq.p, d_reads.p, d_slow.p,
+                       (uint32_t)slow.size(), w, k, ring.p, counts.p, (const uint64_t *)nullptr, (pgx_mm128 *)nullptr);
+  }
+  if (n_literal) *n_literal = (uint32_t)slow.size();
+  // exclusive scan of counts -> offsets
+  {
+    CubTemp tmp;
+    size_t bytes = 0;
+    PGX_HIP(hipMemsetAsync(offs.p, 0, sizeof(uint64_t), st));
+    PGX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, bytes, counts.p, offs.p + 1, (int)n, st));
+    PGX_HIP(hipcub::DeviceScan::InclusiveSum(tmp.get(bytes), bytes, counts.p, offs.p + 1, (int)n, st));
+    uint64_t total = 0;
+    PGX_HIP(hipMemcpyAsync(&total, offs.p + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    sync();
+    n_out = (size_t)total;
+  }
+  out.alloc(n_out);
+  if (n_out == 0) return;
+  if (!fast.empty()) {
+    KernelTimer tm("sketch", fast_bases);
+    launch_sketch_wave(db, d_reads.p, d_fast.p, (uint32_t)fast.size(), w, k, 1, counts.p, offs.p, out.p, d_flag.p);
+  }
+  if (!slow.empty()) {
+    KernelTimer tm("sketch_literal", slow_bases);
+    hipLaunchKernelGGL(k_sketch_literal<1>, dim3(lit_threads / 64), dim3(64), 0, st, db->d_seq.p, d_reads.p, d_slow.p,
+                       (uint32_t)slow.size(), w, k, ring.p, counts.p, offs.p, out.p);
+  }
+  sync();
+}
+
+// =========================================================================================================
+// k_align: banded O(ND) furthest-reaching search (src/DWmatch.c:66-204), one wavefront per candidate pair.
+//
+// Lane j of a round owns diagonal k = min_k + 2*(base+j).  V lives in an LDS ring indexed by k (the reference
+// reads only values written in the previous step, so a ring of >= 2*band+4 slots never aliases live data).
+// Per step: (1) every lane picks its start point from V[k-1], V[k+1] and extends along its diagonal comparing
+// 8 codes per 64-bit load; (2) the order-dependent side results (first extension > 16, longest extension,
+// first diagonal that reaches an end) are resolved lowest-k-first with ballots.
+// =========================================================================================================
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t *p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+
+__global__ __launch_bounds__(64) void k_align(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
+                                              const uint32_t *__restrict__ rlen,
+                                              const pgx_align_key *__restrict__ keys, uint32_t n, int band,
+                                              int ring, pgx_match *__restrict__ out) {
+  extern __shared__ int32_t V[];
+  const int lane = threadIdx.x;
+  const uint32_t a = blockIdx.x;
+  if (a >= n) return;
+  const pgx_align_key key = keys[a];
+  const uint8_t *q = seq + roff[key.rid0] + key.q_off;
+  const uint8_t *t = seq + roff[key.rid1];
+  const int q_len = (int)(rlen[key.rid0] - key.q_off);
+  const int t_len = (int)rlen[key.rid1];
+  const int qs = key.dir0 ? 4 : 0, ts = key.dir1 ? 4 : 0;
+  const int max_d = (int)(0.3 * (double)(q_len + t_len));  // DWmatch.c:96, one IEEE double multiply
+  const int band_size = band * 2;
+  const int mask = ring - 1;
+  for (int i = lane; i < ring; i += 64) V[i] = 0;
+  __syncthreads();
+
+  int best_m = -1, min_k = 0, max_k = 0;
+  uint32_t longest = 0;
+  bool started = false, matched = false;
+  int q_bgn = 0, t_bgn = 0, q_m_end = 0, t_m_end = 0, q_end = 0, t_end = 0, dist = 0;
+
+  for (int d = 0; d < max_d; ++d) {
+    if (max_k - min_k > band_size) break;
+    const int nk = max_k >= min_k ? ((max_k - min_k) >> 1) + 1 : 0;
+    int x = 0, y = 0;
+    for (int base = 0; base < nk && !matched; base += 64) {
+      const int j = base + lane;
+      const bool active = j < nk;
+      const int k = min_k + 2 * j;
+      int x1 = 0, y1 = 0;
+      x = 0, y = 0;
+      if (active) {
+        const int va = V[(k - 1) & mask], vb = V[(k + 1) & mask];
+        x = (k == min_k || (k != max_k && va < vb)) ? vb : va + 1;
+        y = x - k;
+        x1 = x, y1 = y;
+        for (;;) {
+          const int rem = min(q_len - x, t_len - y);
+          if (rem <= 0) break;
+          const uint64_t qa = load_u64_unaligned(q + x), ta = load_u64_unaligned(t + y);
+          const uint64_t diff = ((qa >> qs) ^ (ta >> ts)) & 0x0F0F0F0F0F0F0F0FULL;
+          int m = diff ? (__builtin_ctzll(diff) >> 3) : 8;
+          m = min(m, rem);
+          x += m, y += m;
+          if (m < 8) break;
+        }
+      }
+      const int ext = x - x1;
+      const bool hit = active && (x >= q_len || y >= t_len);
+      const uint64_t hitmask = __ballot(hit);
+      const int hl = hitmask ? __builtin_ctzll(hitmask) : 64;
+      const bool valid = active && lane <= hl;
+      if (!started) {
+        const uint64_t m = __ballot(valid && ext > 16);
+        if (m) {
+          const int l = __builtin_ctzll(m);
+          q_bgn = __shfl(x1, l, 64), t_bgn = __shfl(y1, l, 64);
+          started = true;
+        }
+      }
+      if (__ballot(valid && (uint32_t)ext > longest)) {
+        const int mx = wave_max_i32(valid ? ext : -1);
+        const int l = __builtin_ctzll(__ballot(valid && ext == mx));
+        longest = (uint32_t)mx;
+        q_m_end = __shfl(x, l, 64), t_m_end = __shfl(y, l, 64);
+      }
+      if (valid) V[k & mask] = x;
+      best_m = max(best_m, wave_max_i32(valid ? x + y : -1));
+      if (hitmask) {
+        matched = true;
+        q_end = __shfl(x, hl, 64), t_end = __shfl(y, hl, 64);
+      }
+    }
+    __syncthreads();
+    if (matched) {
+      dist = d;
+      break;
+    }
+    // band update (DWmatch.c:166-183)
+    int new_min = max_k, new_max = min_k;
+    const int thr = best_m - band;
+    for (int base = 0; base < nk; base += 64) {
+      const int j = base + lane;
+      const int k2 = min_k + 2 * j;
+      int u;
+      if (nk <= 64) u = x + y;  // still in registers
+      else u = j < nk ? 2 * V[k2 & mask] - k2 : 0;
+      const uint64_t m = __ballot(j < nk && u >= thr);
+      if (m) {
+        new_min = min(new_min, min_k + 2 * (base + __builtin_ctzll(m)));
+        new_max = max(new_max, min_k + 2 * (base + 63 - __builtin_clzll(m)));
+      }
+    }
+    max_k = new_max + 1;
+    min_k = new_min - 1;
+  }
+  if (lane == 0) {
+    pgx_match r;
+    if (matched) {
+      r.q_bgn = q_bgn, r.t_bgn = t_bgn, r.q_end = q_end, r.t_end = t_end, r.dist = dist;
+      r.m_size = (q_end - q_bgn + t_end - t_bgn + 2 * dist) / 2;
+    } else {
+      r.q_bgn = 0, r.t_bgn = 0, r.q_end = 0, r.t_end = 0, r.dist = 0, r.m_size = 0;
+    }
+    r.q_m_end = q_m_end, r.t_m_end = t_m_end;
+    out[a] = r;
+  }
+}
+
+void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out) {
+  if (n == 0) return;
+  KernelTimer tm("align", n);
+  int ring = 64;
+  while (ring < 2 * band + 8) ring <<= 1;
+  hipLaunchKernelGGL(k_align, dim3((unsigned)n), dim3(64), ring * sizeof(int32_t), ctx().stream, db->d_seq.p, db->d_roff.p,
+                     db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out);
+  PGX_HIP(hipGetLastError());
+}
+
+}  // namespace pgx

@@ -1,0 +1,137 @@
+"""Host-side mirror of the reference interface for the SHIMMER index + overlap path.
+
+`shmr_index(...)` / `shmr_overlap(...)` take the same options as the reference executables
+(/root/reference/src/shmr_index.c:64-114, src/shmr_overlap.c:271-326) and produce the same files; the
+`ResidentDB` class is the HBM-resident form used by bench.py and the multi-GPU driver.  All compute happens in
+libpgx.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from .formats import MC_DTYPE, MM_DTYPE, OVLP_DTYPE, SeqDB
+
+
+@dataclass
+class IndexOut:
+    top: np.ndarray            # L1 or L2 minimizers (mm128)
+    top_mc: np.ndarray         # (mer, count), sorted by mer
+    l0: np.ndarray | None
+    l0_mc: np.ndarray | None
+    bases: int
+    reads: int
+    reads_literal: int
+    ms: float
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class ResidentDB:
+    """A read database uploaded once to HBM (pgx_seqdb)."""
+
+    def __init__(self, db: SeqDB, device: int | None = None):
+        _lib.init(device)
+        self._lib = _lib.load()
+        self.h = C.c_void_p()
+        seq = np.ascontiguousarray(db.seqdb, np.uint8)
+        rid = np.ascontiguousarray(db.rid, np.uint32)
+        rlen = np.ascontiguousarray(db.rlen, np.uint32)
+        roff = np.ascontiguousarray(db.roff, np.uint64)
+        _lib.check(self._lib.pgx_seqdb_upload(_ptr(seq), seq.size, _ptr(rid), _ptr(rlen), _ptr(roff), len(rid),
+                                              C.byref(self.h)), "pgx_seqdb_upload")
+        self.n_reads, self.n_bases = len(rid), int(rlen.sum(dtype=np.uint64))
+
+    def close(self):
+        if self.h:
+            self._lib.pgx_seqdb_free(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- stages ------------------------------------------------------------------------------------------
+    def index(self, total_chunk=1, mychunk=1, levels=2, reduction=6, window=80, kmer=16, want_l0=False) -> IndexOut:
+        p = _lib.IndexParams(total_chunk, mychunk, levels, reduction, window, kmer, 1 if want_l0 else 0)
+        r = _lib.IndexResult()
+        _lib.check(self._lib.pgx_index_resident(self.h, C.byref(p), C.byref(r)), "pgx_index_resident")
+        return IndexOut(
+            top=_lib.take(r.top, r.n_top, MM_DTYPE), top_mc=_lib.take(r.top_mc, r.n_top_mc, MC_DTYPE),
+            l0=_lib.take(r.l0, r.n_l0, MM_DTYPE) if want_l0 else None,
+            l0_mc=_lib.take(r.l0_mc, r.n_l0_mc, MC_DTYPE) if want_l0 else None,
+            bases=int(r.bases), reads=int(r.reads), reads_literal=int(r.reads_literal), ms=float(r.gpu_ms))
+
+    def overlap(self, mmers: np.ndarray, counts: np.ndarray, total_chunk=1, mychunk=1, bestn=4, mc_lower=2,
+                mc_upper=240, align_bandwidth=100, ovlp_upper=120):
+        mm = np.ascontiguousarray(mmers, MM_DTYPE)
+        mc = np.ascontiguousarray(counts, MC_DTYPE)
+        p = _lib.OverlapParams(total_chunk, mychunk, bestn, mc_lower, mc_upper, align_bandwidth, ovlp_upper)
+        out, n, st = C.c_void_p(), C.c_size_t(0), _lib.OverlapStats()
+        _lib.check(self._lib.pgx_overlap_resident(self.h, _ptr(mm), len(mm), _ptr(mc), len(mc), C.byref(p),
+                                                  C.byref(out), C.byref(n), C.byref(st)), "pgx_overlap_resident")
+        return _lib.take(out.value, n.value, OVLP_DTYPE), st.asdict()
+
+    # ---- batch level -------------------------------------------------------------------------------------
+    def sketch(self, read_slots, w=80, k=16) -> np.ndarray:
+        slots = np.ascontiguousarray(read_slots, np.uint32)
+        out, n = C.c_void_p(), C.c_size_t(0)
+        _lib.check(self._lib.pgx_sketch_batch(self.h, _ptr(slots), len(slots), w, k, C.byref(out), C.byref(n)),
+                   "pgx_sketch_batch")
+        return _lib.take(out.value, n.value, MM_DTYPE)
+
+    def align(self, keys: np.ndarray, band=100) -> np.ndarray:
+        keys = np.ascontiguousarray(keys, _lib.ALIGN_KEY_DTYPE)
+        out = np.zeros(len(keys), _lib.MATCH_DTYPE)
+        _lib.check(self._lib.pgx_align_batch(self.h, _ptr(keys), len(keys), band, _ptr(out)), "pgx_align_batch")
+        return out
+
+
+def mm_reduce(mm: np.ndarray, rs: int) -> np.ndarray:
+    """GPU mm_reduce over an arbitrary multi-read list (src/shmr_reduce.c:53-90)."""
+    _lib.init()
+    mm = np.ascontiguousarray(mm, MM_DTYPE)
+    out, n = C.c_void_p(), C.c_size_t(0)
+    _lib.check(_lib.load().pgx_reduce_batch(_ptr(mm), len(mm), rs, C.byref(out), C.byref(n)), "pgx_reduce_batch")
+    return _lib.take(out.value, n.value, MM_DTYPE)
+
+
+def mm_count(mm: np.ndarray) -> np.ndarray:
+    """GPU mm_count (src/shmr_utils.c:131-160); sorted by mer."""
+    _lib.init()
+    mm = np.ascontiguousarray(mm, MM_DTYPE)
+    out, n = C.c_void_p(), C.c_size_t(0)
+    _lib.check(_lib.load().pgx_count_batch(_ptr(mm), len(mm), C.byref(out), C.byref(n)), "pgx_count_batch")
+    return _lib.take(out.value, n.value, MC_DTYPE)
+
+
+# ---- file-level stages: drop-ins for the two executables -------------------------------------------------------
+def shmr_index(seqdb_prefix: str, out_prefix: str = "shimmer", total_chunk=1, mychunk=1, levels=2, reduction=6,
+               write_l0=1, window=80, kmer=16, device=None) -> dict:
+    """shmr_index -p -o -t -c -l -r -m -w -k   (defaults of src/shmr_index.c:21-23,49-55)."""
+    _lib.init(device)
+    p = _lib.IndexParams(total_chunk, mychunk, levels, reduction, window, kmer, write_l0)
+    r = _lib.IndexResult()
+    _lib.check(_lib.load().pgx_index_chunk(seqdb_prefix.encode(), out_prefix.encode(), C.byref(p), C.byref(r)),
+               "pgx_index_chunk")
+    return dict(bases=int(r.bases), reads=int(r.reads), reads_literal=int(r.reads_literal), ms=float(r.gpu_ms))
+
+
+def shmr_overlap(seqdb_prefix: str, shimmer_prefix: str, out_path: str | None = None, total_chunk=1, mychunk=1,
+                 bestn=4, mc_lower=2, mc_upper=240, align_bandwidth=100, ovlp_upper=120, device=None) -> dict:
+    """shmr_overlap -p -l -t -c -b -m -M -w -n -o   (defaults of src/shmr_overlap.c:28-42,245-251,341-344)."""
+    _lib.init(device)
+    if out_path is None:
+        out_path = "ovlp.%02d" % mychunk
+    p = _lib.OverlapParams(total_chunk, mychunk, bestn, mc_lower, mc_upper, align_bandwidth, ovlp_upper)
+    st = _lib.OverlapStats()
+    _lib.check(_lib.load().pgx_overlap_chunk(seqdb_prefix.encode(), shimmer_prefix.encode(), out_path.encode(),
+                                             C.byref(p), C.byref(st)), "pgx_overlap_chunk")
+    return st.asdict()

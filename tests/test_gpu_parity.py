@@ -1,0 +1,189 @@
+"""GPU parity tests proper: every call goes through the C-ABI of libpgx.so and is compared bit-for-bit with
+(1) the committed outputs of the real reference (tests/golden) and (2) the CPU oracle on seeded inputs."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import oracle_util as U
+from peregrine_amd import _lib, formats, simreads
+from peregrine_amd.shimmer import ResidentDB, mm_count, mm_reduce, shmr_index, shmr_overlap
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    _lib.init(0)
+    return _lib.load()
+
+
+class KV(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.c_void_p)]
+
+
+def _take_kv(v, libc=C.CDLL(None)):
+    n = int(v.n)
+    out = np.frombuffer((C.c_uint8 * (n * 16)).from_address(v.a), dtype=formats.MM_DTYPE).copy() if n else np.zeros(0, formats.MM_DTYPE)
+    if v.a:
+        libc.free.argtypes = [C.c_void_p]
+        libc.free(C.c_void_p(v.a))
+    return out
+
+
+def test_mm_sketch_symbol_on_reference_vectors(lib):
+    """the shimmer4py mm_sketch symbol (ASCII in, kvec out) against the reference's outputs for adversarial strings"""
+    n = 0
+    for i, s, w, k, want in G.sketch_cases():
+        v = KV()
+        lib.mm_sketch(None, C.c_char_p(s), C.c_int(len(s)), C.c_int(w), C.c_int(k), C.c_uint32(7 + i), C.c_int(0), C.byref(v))
+        got = _take_kv(v)
+        assert np.array_equal(got, want), f"case {i} w={w} k={k} len={len(s)}"
+        n += 1
+    assert n > 200
+
+
+def test_mm_reduce_on_reference_vectors(lib):
+    for i, inp, rs, want in G.reduce_cases():
+        assert np.array_equal(mm_reduce(inp, rs), want), f"case {i} rs={rs}"
+
+
+def test_ovlp_match_symbol_on_reference_vectors(lib):
+    lib.ovlp_match.restype = C.POINTER(U.Match)
+    for i, q, qs, t, ts, band, want in G.match_cases():
+        q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
+        p = lib.ovlp_match(q.ctypes.data_as(C.c_void_p), C.c_int32(len(q)), C.c_uint8(qs), t.ctypes.data_as(C.c_void_p),
+                           C.c_int32(len(t)), C.c_uint8(ts), C.c_int32(band))
+        got = p.contents.astuple()
+        lib.free_ovlp_match(p)
+        assert got == want, f"case {i}: {got} != {want}"
+
+
+@pytest.mark.parametrize("T", [1, 2])
+def test_index_files_match_reference(tmp_path, T):
+    z = G.load("tiny_stage.npz")
+    db = G.tiny_db(z)
+    pre = str(tmp_path / "sd")
+    formats.write_seqdb(pre, db)
+    for c in range(1, T + 1):
+        for lv in (2, 1):
+            o = str(tmp_path / f"o{lv}")
+            shmr_index(pre, o, T, c, lv, 6, 1, 80, 16)
+            tag = f"{c:02d}-of-{T:02d}"
+            for L in (("L0", "L2") if lv == 2 else ("L1",)):
+                assert np.array_equal(formats.read_mmlist(f"{o}-{L}-{tag}.dat"), z[f"ix{T}l{lv}_{L}_{c}"]), (T, c, L)
+                mc = formats.mc_as_sorted_pairs(formats.read_mm_count(f"{o}-{L}-MC-{tag}.dat"))
+                assert np.array_equal(mc, z[f"ix{T}l{lv}_{L}MC_{c}"]), (T, c, L)
+
+
+@pytest.mark.parametrize("name", sorted(G.OVERLAP_RUNS))
+def test_overlap_files_match_reference(tmp_path, name):
+    z = G.load("tiny_stage.npz")
+    db = G.tiny_db(z)
+    IT, lv, OT, kw = G.OVERLAP_RUNS[name]
+    kw = dict(kw)
+    if "band" in kw:
+        kw["align_bandwidth"] = kw.pop("band")
+    pre = str(tmp_path / "sd")
+    formats.write_seqdb(pre, db)
+    for c in range(1, IT + 1):
+        shmr_index(pre, str(tmp_path / "ix"), IT, c, lv, 6, 0, 80, 16)
+    for c in range(1, OT + 1):
+        out = str(tmp_path / f"ov.{c}")
+        st = shmr_overlap(pre, str(tmp_path / f"ix-L{lv}"), out, OT, c, **kw)
+        got = formats.read_ovlp(out)
+        want = z[f"{name}_{c}"]
+        assert len(got) == st["n_records"] == len(want), (name, c, len(got), len(want))
+        assert formats.ovlp_fields_equal(got, want), (name, c)
+        assert st["n_align_gpu"] >= st["n_align_needed"] > 0
+
+
+@pytest.fixture(scope="module")
+def small():
+    db = simreads.make_workload("small")  # 1 Mb x 16x, ~1.1k reads, 16.7 Mbases
+    rdb = ResidentDB(db, 0)
+    yield db, rdb
+    rdb.close()
+
+
+def test_small_dataset_index_vs_oracle(small):
+    db, rdb = small
+    ix = rdb.index(want_l0=True)
+    l0 = np.concatenate([U.orc_sketch_seqdb(db.seqdb[int(o):int(o) + int(n)], 80, 16, int(r))
+                         for r, n, o in zip(db.rid, db.rlen, db.roff)])
+    assert np.array_equal(ix.l0, l0)
+    l1 = U.orc_reduce(l0, 6)
+    l2 = U.orc_reduce(l1, 6)
+    assert np.array_equal(ix.top, l2)
+    assert np.array_equal(formats.mc_as_sorted_pairs(ix.top_mc), formats.mc_as_sorted_pairs(U.orc_count(l2)))
+    assert np.array_equal(formats.mc_as_sorted_pairs(ix.l0_mc), formats.mc_as_sorted_pairs(U.orc_count(l0)))
+    assert np.array_equal(rdb.index(levels=1).top, l1)
+    # other parameters
+    for (w, k, r) in ((24, 12, 3), (40, 15, 6), (100, 16, 4)):
+        a = rdb.index(window=w, kmer=k, reduction=r, want_l0=True)
+        b0 = np.concatenate([U.orc_sketch_seqdb(db.seqdb[int(o):int(o) + int(n)], w, k, int(rr))
+                             for rr, n, o in list(zip(db.rid, db.rlen, db.roff))])
+        assert np.array_equal(a.l0, b0), (w, k)
+        assert np.array_equal(a.top, U.orc_reduce(U.orc_reduce(b0, r), r)), (w, k, r)
+
+
+@pytest.mark.parametrize("OT", [1, 3])
+def test_small_dataset_overlap_vs_oracle(small, OT):
+    db, rdb = small
+    parts = [rdb.index(total_chunk=2, mychunk=c) for c in (1, 2)]
+    mm = np.concatenate([p.top for p in parts])
+    mc = np.concatenate([p.top_mc for p in parts])
+    for c in range(1, OT + 1):
+        got, st = rdb.overlap(mm, mc, total_chunk=OT, mychunk=c)
+        want, ost = U.orc_overlap(db, mm, mc, mychunk=c, total=OT)
+        assert len(want) > 1000
+        assert formats.ovlp_fields_equal(got, want)
+        assert st["n_align_needed"] == ost["n_align"] and st["n_pair_records"] == ost["n_records"]
+
+
+def test_align_batch_vs_oracle(small):
+    db, rdb = small
+    rng = np.random.default_rng(9)
+    n = 400
+    keys = np.zeros(n, _lib.ALIGN_KEY_DTYPE)
+    keys["rid0"] = rng.integers(0, db.n_reads, n)
+    keys["rid1"] = rng.integers(0, db.n_reads, n)
+    keys["q_off"] = rng.integers(0, 3000, n)
+    keys["dir0"] = rng.integers(0, 2, n)
+    keys["dir1"] = rng.integers(0, 2, n)
+    for band in (100, 20, 130):
+        got = rdb.align(keys, band)
+        for i in range(n):
+            a, b = int(keys["rid0"][i]), int(keys["rid1"][i])
+            q = db.seqdb[int(db.roff[a]) + int(keys["q_off"][i]):int(db.roff[a]) + int(db.rlen[a])]
+            t = db.seqdb[int(db.roff[b]):int(db.roff[b]) + int(db.rlen[b])]
+            want = U.orc_ovlp_match(q, int(keys["dir0"][i]), t, int(keys["dir1"][i]), band)
+            assert tuple(int(v) for v in got[i].tolist()) == want, (i, band)
+
+
+def test_edge_cases(lib):
+    # empty selections, a chunk that owns no read, reads shorter than a window, an all-N read
+    g = simreads.make_genome(20000, 3)
+    db = simreads.simulate_reads(g, n_reads=3, seed=1, mean_len=300, sd_len=200, wrap=0, min_len=20)
+    sd = db.seqdb.copy()
+    sd[int(db.roff[1]):int(db.roff[1]) + int(db.rlen[1])] = 0
+    db.seqdb = sd
+    rdb = ResidentDB(db, 0)
+    ix = rdb.index(total_chunk=5, mychunk=4, want_l0=True)   # rid % 5 == 4: nobody
+    assert len(ix.l0) == 0 and len(ix.top) == 0 and len(ix.top_mc) == 0 and ix.reads == 0
+    ix = rdb.index(want_l0=True)
+    l0 = np.concatenate([U.orc_sketch_seqdb(db.seqdb[int(o):int(o) + int(n)], 80, 16, int(r))
+                         for r, n, o in zip(db.rid, db.rlen, db.roff)])
+    assert np.array_equal(ix.l0, l0)
+    assert np.array_equal(ix.top, U.orc_reduce(U.orc_reduce(l0, 6), 6))
+    ov, st = rdb.overlap(ix.top, ix.top_mc)
+    assert len(ov) == 0
+    assert len(mm_reduce(np.zeros(0, formats.MM_DTYPE), 6)) == 0 and len(mm_count(np.zeros(0, formats.MM_DTYPE))) == 0
+    # bad arguments return errors instead of aborting the process
+    with pytest.raises(_lib.PgxError):
+        rdb.index(window=10)
+    with pytest.raises(_lib.PgxError):
+        rdb.index(total_chunk=2, mychunk=3)
+    rdb.close()
