@@ -9,6 +9,8 @@
 //   k_align          : ovlp_match     src/DWmatch.c:66-204      one wavefront per candidate pair
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+
 #include "pgx_internal.h"
 
 namespace pgx {
@@ -258,12 +260,24 @@ void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_cou
 }
 
 // =========================================================================================================
-// sketch driver: literal kernel for now for every read; the closed-form wave kernel takes over eligible reads
+// sketch driver.  Reads the closed-form wave kernel covers (w=80, k=16, no ambiguous base, slab not overflowed)
+// go through k_sketch_wave (single pass into per-read slabs, then an ordered gather); every other read goes through
+// the literal state machine (count pass, write pass).  Output: one contiguous list in `reads` order.
 // =========================================================================================================
 bool sketch_wave_eligible(const ReadDesc &rd, int w, int k);  // pgx_sketch_fast.hip
 void launch_sketch_wave(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n_list, int w,
-                        int k, int mode, uint32_t *d_counts, const uint64_t *d_off, pgx_mm128 *d_out,
-                        uint32_t *d_fallback_flag);
+                        int k, pgx_mm128 *d_slab, const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags);
+
+__global__ void k_gather_slabs(const pgx_mm128 *__restrict__ slab, const uint64_t *__restrict__ slab_off,
+                               const uint32_t *__restrict__ list, uint32_t n_list, const uint32_t *__restrict__ counts,
+                               const uint64_t *__restrict__ out_off, pgx_mm128 *__restrict__ out) {
+  if (blockIdx.x >= n_list) return;
+  const uint32_t slot = list[blockIdx.x];
+  const pgx_mm128 *src = slab + slab_off[slot];
+  pgx_mm128 *dst = out + out_off[slot];
+  const uint32_t n = counts[slot];
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
 
 void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, DevBuf<pgx_mm128> &out,
                 size_t &n_out, uint32_t *n_literal) {
@@ -274,35 +288,44 @@ void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, 
   hipStream_t st = ctx().stream;
   DevBuf<ReadDesc> d_reads(n);
   d_reads.upload(reads.data(), n);
-  DevBuf<uint32_t> counts(n);
+  DevBuf<uint32_t> counts(n), d_flag(n);
   DevBuf<uint64_t> offs(n + 1);
   PGX_HIP(hipMemsetAsync(counts.p, 0, n * sizeof(uint32_t), st));
+  PGX_HIP(hipMemsetAsync(d_flag.p, 0, n * sizeof(uint32_t), st));
 
-  // ---- split: wave kernel (closed form) vs literal kernel -------------------------------------------------
   std::vector<uint32_t> fast, slow;
+  std::vector<uint64_t> slab_off(n + 1, 0);
   uint64_t fast_bases = 0, slow_bases = 0;
   for (uint32_t i = 0; i < n; ++i) {
-    if (sketch_wave_eligible(reads[i], w, k)) fast.push_back(i), fast_bases += reads[i].len;
+    const bool f = sketch_wave_eligible(reads[i], w, k);
+    // slab capacity: 5x the expected density 2/(w+1); overflow (low-complexity reads) falls back to the literal kernel
+    slab_off[i + 1] = slab_off[i] + (f ? (uint64_t)reads[i].len / 8 + 64 : 0);
+    if (f) fast.push_back(i), fast_bases += reads[i].len;
     else slow.push_back(i), slow_bases += reads[i].len;
   }
-  DevBuf<uint32_t> d_fast(fast.size()), d_flag(n);
-  PGX_HIP(hipMemsetAsync(d_flag.p, 0, n * sizeof(uint32_t), st));
+  DevBuf<uint32_t> d_fast(fast.size());
+  DevBuf<uint64_t> d_slab_off(n + 1);
+  DevBuf<pgx_mm128> slab;
   if (!fast.empty()) {
     d_fast.upload(fast.data(), fast.size());
+    d_slab_off.upload(slab_off.data(), n + 1);
+    slab.alloc(slab_off[n]);
     {
-      KernelTimer tm("sketch_count", fast_bases);
-      launch_sketch_wave(db, d_reads.p, d_fast.p, (uint32_t)fast.size(), w, k, 0, counts.p, nullptr, nullptr, d_flag.p);
+      KernelTimer tm("sketch", fast_bases);
+      launch_sketch_wave(db, d_reads.p, d_fast.p, (uint32_t)fast.size(), w, k, slab.p, d_slab_off.p, counts.p, d_flag.p);
     }
-    // reads the wave kernel declined at run time (ambiguous base, too many strand-ambiguous k-mers ...)
     std::vector<uint32_t> flag(n);
     d_flag.download(flag.data(), n);
     sync();
     std::vector<uint32_t> keep;
     for (uint32_t i : fast)
-      if (flag[i]) slow.push_back(i), slow_bases += reads[i].len, fast_bases -= reads[i].len;
+      if (flag[i]) slow.push_back(i), slow_bases += reads[i].len;
       else keep.push_back(i);
-    fast.swap(keep);
-    if (!fast.empty()) d_fast.upload(fast.data(), fast.size());
+    if (keep.size() != fast.size()) {
+      fast.swap(keep);
+      std::sort(slow.begin(), slow.end());
+      if (!fast.empty()) d_fast.upload(fast.data(), fast.size());
+    }
   }
   // literal kernel: bounded grid, ring workspace in global memory
   const uint32_t lit_threads = 256 * 64;
@@ -316,7 +339,6 @@ void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, 
                        (uint32_t)slow.size(), w, k, ring.p, counts.p, (const uint64_t *)nullptr, (pgx_mm128 *)nullptr);
   }
   if (n_literal) *n_literal = (uint32_t)slow.size();
-  // exclusive scan of counts -> offsets
   {
     CubTemp tmp;
     size_t bytes = 0;
@@ -331,8 +353,9 @@ void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, 
   out.alloc(n_out);
   if (n_out == 0) return;
   if (!fast.empty()) {
-    KernelTimer tm("sketch", fast_bases);
-    launch_sketch_wave(db, d_reads.p, d_fast.p, (uint32_t)fast.size(), w, k, 1, counts.p, offs.p, out.p, d_flag.p);
+    KernelTimer tm("sketch_gather", fast_bases);
+    hipLaunchKernelGGL(k_gather_slabs, dim3((unsigned)fast.size()), dim3(64), 0, st, slab.p, d_slab_off.p, d_fast.p,
+                       (uint32_t)fast.size(), counts.p, offs.p, out.p);
   }
   if (!slow.empty()) {
     KernelTimer tm("sketch_literal", slow_bases);
