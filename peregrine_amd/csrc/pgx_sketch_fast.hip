@@ -8,33 +8,46 @@
 //      entries p <= w-2, p != m, hash(p) == hash(m)  are always emitted;   m is emitted iff hash(w-1) > hash(m);
 // and for n < w exactly one entry, the rightmost smallest, is emitted.  Output is in entry (= position) order.
 //
-// Mapping to the machine.  Phase A (lane = 16 consecutive bases, one aligned 16-byte load per lane per 1 KiB tile):
-// nibble -> 2-bit codes, forward and reverse-complement 32-bit packs, k-mers by v_alignbit across the neighbour lane's
-// pack, canonical k-mer, 32-bit invertible hash, entries compacted into an LDS ring.  Phase B (lane = chunk of 16
-// consecutive ENTRIES): sliding-window minimum WM over the last 80 entries by the chunked prefix/suffix-min method,
-// then G(p) == (max of WM over the 80 windows containing p) >= hash(p), again chunked (suffix/prefix max).  Emitted
-// entries are appended to the read's slab in global memory.  All cross-lane traffic goes through the LDS ring, which
-// is indexed by absolute entry number, so strand-ambiguous k-mers and tile boundaries need no special cases.
+// Mapping to the machine (per 1 KiB tile of one read):
+//  phase A  lane = one aligned 16-byte load -> 2-bit forward / reverse-complement packs of its 16 bases -> LDS (F,R).
+//           Then 16 steps; in step j lane l owns base 64 j + l, so its offset inside the 16-base block and both
+//           v_alignbit funnel-shift amounts are per-lane constants and the LDS reads use immediate offsets.
+//           canonical k-mer = min(fwd, rev); 32-bit invertible hash (12 VALU ops); entries are appended to a linear LDS
+//           buffer in position order (ballot + mbcnt compaction; lane-linear when nothing is dropped).
+//  phase B  lane = chunk of 16 consecutive ENTRIES (LDS chunk stride 20 dwords => conflict-free ds_read_b128):
+//           B1 window minimum WM for the window ending at each entry = min(suffix-min of chunk q-5, minima of chunks
+//              q-4..q-1, prefix-min of chunk q)  (chunked van Herk, 80 = 5 x 16);
+//           B2 G(p) <=> max(WM over the 80 windows containing p) >= hash(p), the same trick with maxima.
+//           Windows that are not full or end beyond the last entry are 0 (a hash of 0 is the minimum of every window,
+//           so 0 never yields a false positive when a full window exists).
+//  The buffer is indexed by entry number, so strand-ambiguous k-mers and tile boundaries need no special cases in B.
+//  Interior tiles/rounds run check-free code; the first five chunks and the last tile of a read take the SPECIAL paths.
 #include "pgx_internal.h"
 
 namespace pgx {
 
 namespace {
 constexpr int W = 80, K = 16;
-constexpr int CH = 16;               // entries per chunk
-constexpr int RING_CH = 80;          // chunks in the LDS ring (>= 64 new + 1 partial + 6 pad + 5 lag)
-constexpr int RING = RING_CH * CH;   // entries
-constexpr int TILE = 1024;           // bases per tile (64 lanes x 16)
+constexpr int CH = 16;    // entries per chunk
+constexpr int CST = 20;   // dwords per chunk in LDS (16 + 4 pad)
+constexpr int NB = 80;    // chunks in the buffer: <= 7 carried + 65 new + 6 zero pad (+ slack)
+constexpr int TILE = 1024;
 constexpr uint32_t INF = 0xFFFFFFFFu;
 
+template <int S>
+__device__ __forceinline__ uint32_t lshl_add(uint32_t a, uint32_t b) {  // (a << S) + b as ONE v_lshl_add_u32
+  uint32_t r;
+  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(S), "v"(b));
+  return r;
+}
 __device__ __forceinline__ uint32_t mix32(uint32_t key) {  // src/mm_sketch.c:23-32 with mask = 2^32-1 (k = 16)
-  key = ~key + (key << 21);
+  key = lshl_add<21>(key, ~key);                  // ~key + (key << 21)
   key ^= key >> 24;
-  key = key + (key << 3) + (key << 8);
+  key = lshl_add<8>(key, lshl_add<3>(key, key));  // key + (key<<3) + (key<<8)   (no v_mul_lo)
   key ^= key >> 14;
-  key = key + (key << 2) + (key << 4);
+  key = lshl_add<4>(key, lshl_add<2>(key, key));  // key + (key<<2) + (key<<4)
   key ^= key >> 28;
-  key = key + (key << 31);
+  key = lshl_add<31>(key, key);
   return key;
 }
 
@@ -51,7 +64,6 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
   }
   return v;
 }
-
 __device__ __forceinline__ void lds_read16(const uint32_t *p, uint32_t (&v)[16]) {
   const uint4 *q = reinterpret_cast<const uint4 *>(p);
 #pragma unroll
@@ -65,21 +77,119 @@ __device__ __forceinline__ void lds_write16(uint32_t *p, const uint32_t (&v)[16]
 #pragma unroll
   for (int i = 0; i < 4; ++i) q[i] = make_uint4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
 }
-__device__ __forceinline__ int ring_ch(int q) {  // chunk number (may be slightly negative) -> ring chunk slot
-  int r = q % RING_CH;
-  return r < 0 ? r + RING_CH : r;
+__device__ __forceinline__ int chunk_addr(int e) { return (int)__umul24((uint32_t)(e >> 4), CST) + (e & 15); }
+
+struct Lds {
+  uint32_t H[NB * CST];   // hash of entry e at (e/16 - qbase) * CST + e % 16
+  uint32_t Wm[NB * CST];  // window minimum for the window ENDING at entry e
+  uint16_t P[NB * CST];   // (lastPos & 0x7fff) << 1 | strand
+  uint32_t C[NB];         // per chunk: min hash
+  uint32_t M[NB];         // per chunk: max of Wm
+  uint32_t F[68], R[68];  // 2-bit packs of the tile's 16-base blocks; [0] = last block of the previous tile
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// phase A step loop.  EDGE = the tile touches the first k-1 bases or the end of the read.
+// ---------------------------------------------------------------------------------------------------------
+template <bool EDGE>
+__device__ __forceinline__ int phase_a_steps(Lds &s, int lane, int t, int lead, int len, int ebuf /* E - 16*qbase */) {
+  const int o16 = lane & 15, g = lane >> 4;
+  const int shF = 2 * (15 - o16), shR = (2 * (o16 + 1)) & 31;
+  const uint32_t *pf = &s.F[g], *pr = &s.R[g];
+  int run = 0;  // entries appended so far in this tile (wave uniform)
+  const int ibase = t * TILE + lane - lead;
+  const int lbase = ebuf + lane;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t F0 = pf[4 * j], F1 = pf[4 * j + 1];
+    const uint32_t R0 = pr[4 * j], R1 = pr[4 * j + 1];
+    const uint32_t fw = __builtin_amdgcn_alignbit(F0, F1, shF);
+    const uint32_t ra = __builtin_amdgcn_alignbit(R1, R0, shR);
+    const uint32_t rv = o16 == 15 ? R1 : ra;
+    const int i = ibase + 64 * j;
+    bool valid = fw != rv;  // strand-ambiguous k-mers are not entries
+    if (EDGE) valid = valid && i >= K - 1 && i < len;
+    const uint64_t vm = __ballot(valid);
+    const uint32_t hh = mix32(min(fw, rv));
+    const uint32_t pz = (((uint32_t)i & 0x7FFFu) << 1) | (fw > rv ? 1u : 0u);
+    if (vm == ~0ull) {  // nothing dropped: lane-linear address
+      const int ad = chunk_addr(lbase + run);
+      s.H[ad] = hh;
+      s.P[ad] = (uint16_t)pz;
+      run += 64;
+    } else {
+      if (valid) {
+        const int idx = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
+        const int ad = chunk_addr(ebuf + run + idx);
+        s.H[ad] = hh;
+        s.P[ad] = (uint16_t)pz;
+      }
+      run += __builtin_popcountll(vm);
+    }
+  }
+  return run;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// phase B1: window minima of absolute chunk q (buffer chunk bq).  SPECIAL handles q < 5 and the read's end.
+// ---------------------------------------------------------------------------------------------------------
+template <bool SPECIAL>
+__device__ __forceinline__ void phase_b1(Lds &s, int lane, int q, int bq, bool active, int E) {
+  uint32_t v[16], wm[16];
+  uint32_t c = INF;
+  if (active) {
+    lds_read16(&s.H[bq * CST], v);
+    c = v[0];
+#pragma unroll
+    for (int o = 1; o < 16; ++o) c = min(c, v[o]);
+  }
+  // minima of the four preceding chunks: neighbours' registers, or LDS for chunks older than this round
+  uint32_t m4 = INF;
+#pragma unroll
+  for (int d = 1; d <= 4; ++d) {
+    uint32_t cd = (uint32_t)__shfl_up((int)c, d, 64);
+    if (lane < d) cd = (bq - d >= 0) ? s.C[bq - d] : INF;
+    if (SPECIAL && q - d < 0) cd = INF;
+    m4 = min(m4, cd);
+  }
+  if (active) {
+    uint32_t sfx[17];
+    sfx[16] = INF;
+    if (!SPECIAL || q >= 5) {
+      uint32_t u[16];
+      lds_read16(&s.H[(bq - 5) * CST], u);
+      sfx[15] = u[15];
+#pragma unroll
+      for (int o = 14; o >= 1; --o) sfx[o] = min(sfx[o + 1], u[o]);
+    } else {
+#pragma unroll
+      for (int o = 1; o < 16; ++o) sfx[o] = INF;
+    }
+    uint32_t p = INF, mx = 0;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      p = min(p, v[o]);
+      uint32_t x = min(min(sfx[o + 1], m4), p);
+      if (SPECIAL) {
+        const int jj = q * CH + o;
+        if (jj < W - 1 || jj >= E) x = 0;  // not a full window / beyond the last entry
+      }
+      wm[o] = x;
+      mx = max(mx, x);
+    }
+    lds_write16(&s.Wm[bq * CST], wm);
+    s.C[bq] = c;
+    s.M[bq] = mx;
+  }
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ seq, const ReadDesc *__restrict__ reads,
                                                     const uint32_t *__restrict__ list, uint32_t n_list,
                                                     pgx_mm128 *__restrict__ slab, const uint64_t *__restrict__ slab_off,
                                                     uint32_t *__restrict__ counts, uint32_t *__restrict__ flags) {
-  __shared__ __attribute__((aligned(16))) uint32_t sH[RING];  // hash of entry e at e % RING
-  __shared__ __attribute__((aligned(16))) uint32_t sP[RING];  // lastPos<<1 | strand
-  __shared__ __attribute__((aligned(16))) uint32_t sW[RING];  // window minimum for the window ENDING at entry e
-  __shared__ uint32_t sC[RING_CH];                            // per chunk: min hash
-  __shared__ uint32_t sM[RING_CH];                            // per chunk: max of sW
+  __shared__ __attribute__((aligned(16))) Lds s;
   const int lane = threadIdx.x;
   if (blockIdx.x >= n_list) return;
   const uint32_t slot = list[blockIdx.x];
@@ -92,20 +202,41 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
   pgx_mm128 *out = slab + slab_off[slot];
   const uint32_t cap = (uint32_t)(slab_off[slot + 1] - slab_off[slot]);
 
-  int E = 0;        // entries produced so far
-  int Er = 0;       // E % RING
-  int wdone = 0;    // chunks whose window minima are in sW
-  int ddone = 0;    // chunks already decided
+  int E = 0;       // entries produced so far
+  int qbase = 0;   // absolute chunk number of buffer chunk 0
+  int wdone = 0;   // chunks whose window minima are in Wm
+  int ddone = 0;   // chunks already decided
   uint32_t nout = 0;
   uint32_t bad = 0;
-  uint32_t Fcarry = 0, Rcarry = 0;
+  uint32_t Fkeep = 0, Rkeep = 0;  // this lane's packs of the previous tile (lane 63's become block -1)
 
   for (int t = 0; t < ntiles; ++t) {
-    // ------------------------------------------------------------------------------------------------------
-    // phase A: 16 bases per lane -> up to 16 entries per lane, compacted into the ring
-    // ------------------------------------------------------------------------------------------------------
-    const int b0 = t * TILE + lane * 16;  // byte offset from `base`
-    const int i0 = b0 - lead;             // read position of this lane's first base
+    // ---- compaction: move the live chunks [ddone, ceil(E/16)) to the front of the buffer -----------------------
+    if (ddone > qbase) {
+      const int shift = (ddone - qbase) * CST;
+      const int live = ((E + CH - 1) / CH - ddone) * CST;  // dwords to keep (<= 7 chunks)
+      uint32_t th[3], tw[3];
+      uint16_t tp[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int d = lane + 64 * r;
+        th[r] = tw[r] = 0, tp[r] = 0;
+        if (d < live) th[r] = s.H[shift + d], tw[r] = s.Wm[shift + d], tp[r] = s.P[shift + d];
+      }
+      uint32_t tc = 0, tm = 0;
+      if (lane * CST < live) tc = s.C[ddone - qbase + lane], tm = s.M[ddone - qbase + lane];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int d = lane + 64 * r;
+        if (d < live) s.H[d] = th[r], s.Wm[d] = tw[r], s.P[d] = tp[r];
+      }
+      if (lane * CST < live) s.C[lane] = tc, s.M[lane] = tm;
+      qbase = ddone;
+    }
+    // ---- phase A: load, decode, pack ------------------------------------------------------------------------
+    const int b0 = t * TILE + lane * 16;  // byte offset from `base` of this lane's 16-base block
+    const int i0 = b0 - lead;             // read position of the block's first base
     uint4 raw = make_uint4(0, 0, 0, 0);
     if (b0 < span) raw = *reinterpret_cast<const uint4 *>(base + b0);
     const uint32_t dw[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -114,11 +245,9 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
       const uint32_t n = dw[d] & 0x0F0F0F0Fu;  // forward-strand one-hot nibbles (src/shmr_utils.c:18-30)
-      // one-hot {1,2,4,8} -> {0,1,2,3}: (n>>1) - (n>>3), bytewise
-      const uint32_t c = ((n >> 1) & 0x07070707u) - ((n >> 3) & 0x01010101u);
-      // ambiguity check: a nibble that is zero or has two bits set
+      const uint32_t c = ((n >> 1) & 0x07070707u) - ((n >> 3) & 0x01010101u);  // {1,2,4,8} -> {0,1,2,3} bytewise
       const uint32_t tt = n - 0x01010101u;
-      uint32_t bd = (tt & ~n & 0x80808080u) | (n & tt);
+      uint32_t bd = (tt & ~n & 0x80808080u) | (n & tt);  // a nibble that is zero or has two bits set
       if (!inside) {  // partial block at a read end: test byte by byte
         bd = 0;
 #pragma unroll
@@ -129,127 +258,56 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
         }
       }
       bad |= bd;
-      // pack: earlier bases at higher bits (kmer = kmer<<2 | c)
-      const uint32_t f8 = ((c << 6) | (c >> 4) | (c >> 14) | (c >> 24)) & 0xFFu;
+      const uint32_t f8 = ((c << 6) | (c >> 4) | (c >> 14) | (c >> 24)) & 0xFFu;  // earlier bases at higher bits
       F = (F << 8) | f8;
     }
     const uint32_t rr = __builtin_bitreverse32(~F);
     const uint32_t R = ((rr & 0x55555555u) << 1) | ((rr >> 1) & 0x55555555u);  // complement, later bases higher
-    uint32_t Fp = (uint32_t)__shfl_up((int)F, 1, 64), Rp = (uint32_t)__shfl_up((int)R, 1, 64);
-    if (lane == 0) Fp = Fcarry, Rp = Rcarry;
-    Fcarry = (uint32_t)__builtin_amdgcn_readlane((int)F, 63);
-    Rcarry = (uint32_t)__builtin_amdgcn_readlane((int)R, 63);
-
-    uint32_t h[16];
-    uint32_t vmask = 0, zmask = 0;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const uint32_t fw = __builtin_amdgcn_alignbit(Fp, F, 2 * (15 - j));
-      const uint32_t rv = (j == 15) ? R : __builtin_amdgcn_alignbit(R, Rp, 2 * (j + 1));
-      h[j] = mix32(min(fw, rv));
-      const int i = i0 + j;
-      if (fw != rv && i >= K - 1 && i < len) vmask |= 1u << j;  // strand-ambiguous k-mers are not entries
-      if (fw > rv) zmask |= 1u << j;
-    }
-    const int cnt = __builtin_popcount(vmask);
-    const int incl = wave_incl_scan(cnt, lane);
-    const int total = __shfl(incl, 63, 64);
-    {
-      int r = Er + (incl - cnt);
-      if (r >= RING) r -= RING;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        if (vmask & (1u << j)) {
-          sH[r] = h[j];
-          sP[r] = ((uint32_t)(i0 + j) << 1) | ((zmask >> j) & 1u);
-          if (++r == RING) r = 0;
-        }
-      }
-    }
-    E += total;
-    Er += total;
-    if (Er >= RING) Er -= RING;
+    if (lane == 63) s.F[0] = Fkeep, s.R[0] = Rkeep;
+    s.F[1 + lane] = F;
+    s.R[1 + lane] = R;
+    Fkeep = F, Rkeep = R;
+    __syncthreads();
     const bool last = (t == ntiles - 1);
+    const bool edge = (t * TILE - lead < K - 1) || ((t + 1) * TILE - lead > len);
+    const int ebuf = E - qbase * CH;
+    E += edge ? phase_a_steps<true>(s, lane, t, lead, len, ebuf) : phase_a_steps<false>(s, lane, t, lead, len, ebuf);
     const int hch = last ? (E + CH - 1) / CH : E / CH;  // chunks whose hashes are final
     if (last) {                                          // pad the tail of the last chunk
       const int e = E + lane;
-      if (lane < CH && e < hch * CH) sH[e % RING] = INF;
+      if (lane < CH && e < hch * CH) s.H[(e / CH - qbase) * CST + (e & 15)] = INF;
     }
     __syncthreads();
 
-    // ------------------------------------------------------------------------------------------------------
-    // phase B1: window minima.  WM[16q+o] = min( suffix-min of chunk q-5 from o+1, min(c[q-4..q-1]), prefix-min of
-    // chunk q up to o ).  Windows that are not full (end < w-1) or end beyond the last entry get 0.
-    // ------------------------------------------------------------------------------------------------------
-    for (int q0 = wdone; q0 < hch; q0 += 64) {  // pass 1: chunk minima
+    // ---- phase B1 -------------------------------------------------------------------------------------------
+    for (int q0 = wdone; q0 < hch; q0 += 64) {
       const int q = q0 + lane;
-      if (q < hch) {
-        uint32_t v[16];
-        lds_read16(&sH[ring_ch(q) * CH], v);
-        uint32_t c = v[0];
-#pragma unroll
-        for (int o = 1; o < 16; ++o) c = min(c, v[o]);
-        sC[ring_ch(q)] = c;
-      }
-    }
-    __syncthreads();
-    for (int q0 = wdone; q0 < hch; q0 += 64) {  // pass 2
-      const int q = q0 + lane;
-      if (q < hch) {
-        uint32_t v[16], s[17], wm[16];
-        lds_read16(&sH[ring_ch(q) * CH], v);
-#pragma unroll
-        for (int o = 0; o < 17; ++o) s[o] = INF;
-        uint32_t m4 = INF;
-        if (q >= 5) {
-          uint32_t u[16];
-          lds_read16(&sH[ring_ch(q - 5) * CH], u);
-          s[15] = u[15];
-#pragma unroll
-          for (int o = 14; o >= 1; --o) s[o] = min(s[o + 1], u[o]);
-        }
-#pragma unroll
-        for (int d = 1; d <= 4; ++d)
-          if (q - d >= 0) m4 = min(m4, sC[ring_ch(q - d)]);
-        uint32_t p = INF, mx = 0;
-#pragma unroll
-        for (int o = 0; o < 16; ++o) {
-          p = min(p, v[o]);
-          uint32_t x = min(min(s[o + 1], m4), p);
-          const int jj = q * CH + o;
-          if (jj < W - 1 || jj >= E) x = 0;  // E is the final entry count whenever a chunk can extend past it
-          wm[o] = x;
-          mx = max(mx, x);
-        }
-        lds_write16(&sW[ring_ch(q) * CH], wm);
-        sM[ring_ch(q)] = mx;
-      }
+      if (q0 < 5 || last) phase_b1<true>(s, lane, q, q - qbase, q < hch, E);
+      else phase_b1<false>(s, lane, q, q - qbase, q < hch, E);
+      __syncthreads();
     }
     wdone = hch;
     if (last) {  // windows past the end do not exist: six all-zero chunks
-      if (lane < 6 * CH) sW[(ring_ch(hch) * CH + lane) % RING] = 0;
-      if (lane < 32) sW[(ring_ch(hch) * CH + 64 + lane) % RING] = 0;
-      if (lane < 6) sM[ring_ch(hch + lane)] = 0;
+      const int bz = hch - qbase;
+      s.Wm[(bz + (lane >> 4)) * CST + (lane & 15)] = 0;
+      if (lane < 32) s.Wm[(bz + 4 + (lane >> 4)) * CST + (lane & 15)] = 0;
+      if (lane < 6) s.M[bz + lane] = 0;
+      __syncthreads();
     }
-    __syncthreads();
 
-    // ------------------------------------------------------------------------------------------------------
-    // phase B2: decide and emit.  G(p) == max(WM over windows ending at p..p+79) >= hash(p).
-    // ------------------------------------------------------------------------------------------------------
+    // ---- phase B2: decide and emit ----------------------------------------------------------------------------
     const int dlimit = last ? hch : (wdone - 5 > 0 ? wdone - 5 : 0);
     const bool short_read = last && E < W;  // fewer than w entries: emit only the rightmost smallest
     for (int q0 = ddone; q0 < dlimit; q0 += 64) {
-      const int q = q0 + lane;
+      const int q = q0 + lane, bq = q - qbase;
       uint32_t emask = 0;
       uint32_t v[16];
       if (q < dlimit) {
         uint32_t wq[16], wn[16];
-        lds_read16(&sH[ring_ch(q) * CH], v);
-        lds_read16(&sW[ring_ch(q) * CH], wq);
-        lds_read16(&sW[ring_ch(q + 5) * CH], wn);
-        uint32_t m4 = 0;
-#pragma unroll
-        for (int d = 1; d <= 4; ++d) m4 = max(m4, sM[ring_ch(q + d)]);
+        lds_read16(&s.H[bq * CST], v);
+        lds_read16(&s.Wm[bq * CST], wq);
+        lds_read16(&s.Wm[(bq + 5) * CST], wn);
+        const uint32_t m4 = max(max(s.M[bq + 1], s.M[bq + 2]), max(s.M[bq + 3], s.M[bq + 4]));
         uint32_t sm[16];
         sm[15] = wq[15];
 #pragma unroll
@@ -259,21 +317,25 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
         for (int o = 0; o < 16; ++o) {
           const uint32_t f = max(max(sm[o], m4), pm);  // pm = prefix max of chunk q+5 up to o-1
           pm = max(pm, wn[o]);
-          if (f >= v[o] && q * CH + o < E) emask |= 1u << o;
+          if (f >= v[o]) emask |= 1u << o;
+        }
+        if (last) {  // entries past the end are padding
+          const int nvalid = E - q * CH;
+          if (nvalid < 16) emask &= (1u << (nvalid < 0 ? 0 : nvalid)) - 1u;
         }
         if (short_read) emask = 0;
       }
-      if (q0 == 0) {  // first-window correction / short-read rule; entries 0..79 sit at ring slots 0..79
+      if (q0 == 0) {  // first-window correction / short-read rule; entries 0..79 are buffer chunks 0..4 (qbase == 0)
         const int lim = short_read ? E : W - 1;  // candidates are entries [0, lim)
-        const uint32_t a = lane < lim ? sH[lane] : INF;
-        const uint32_t b = lane + 64 < lim ? sH[lane + 64] : INF;
+        const uint32_t a = lane < lim ? s.H[(lane >> 4) * CST + (lane & 15)] : INF;
+        const uint32_t b = lane + 64 < lim ? s.H[(4 + (lane >> 4)) * CST + (lane & 15)] : INF;
         const uint32_t mv = wave_min_u32(min(a, b));
         const uint64_t mb = __ballot(lane + 64 < lim && b == mv), ma = __ballot(lane < lim && a == mv);
         const int m = mb ? 64 + (63 - __builtin_clzll(mb)) : (ma ? 63 - __builtin_clzll(ma) : -1);
         if (short_read) {
           if (m >= 0 && q == m / CH) emask = 1u << (m % CH);
         } else if (q < 5 && q < dlimit) {
-          const uint32_t e79 = sH[W - 1];
+          const uint32_t e79 = s.H[((W - 1) >> 4) * CST + ((W - 1) & 15)];
 #pragma unroll
           for (int o = 0; o < 16; ++o) {
             const int pidx = q * CH + o;
@@ -286,20 +348,24 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
         }
       }
       const int ec = __builtin_popcount(emask);
-      const int einc = wave_incl_scan(ec, lane);
-      const int etot = __shfl(einc, 63, 64);
-      if (etot) {
+      if (__ballot(ec != 0)) {
+        const int einc = wave_incl_scan(ec, lane);
+        const int etot = __shfl(einc, 63, 64);
         uint32_t w = nout + (uint32_t)(einc - ec);
         if (nout + (uint32_t)etot <= cap) {
-          const uint32_t *pp = &sP[ring_ch(q) * CH];
-#pragma unroll
-          for (int o = 0; o < 16; ++o)
-            if (emask & (1u << o)) {
-              pgx_mm128 e;
-              e.x = ((uint64_t)v[o] << 8) | (uint64_t)K;
-              e.y = ((uint64_t)rd.rid << 32) | (uint64_t)pp[o];
-              out[w++] = e;
-            }
+          // positions were stored modulo 2^15; the newest base seen so far bounds them from above
+          const int imax = (t + 1) * TILE - lead - 1;
+          uint32_t em = emask;
+          while (em) {
+            const int o = __builtin_ctz(em);
+            em &= em - 1;
+            const uint32_t pz = s.P[bq * CST + o];
+            const int i = imax - ((imax - (int)(pz >> 1)) & 0x7FFF);
+            pgx_mm128 e;
+            e.x = ((uint64_t)s.H[bq * CST + o] << 8) | (uint64_t)K;
+            e.y = ((uint64_t)rd.rid << 32) | ((uint64_t)(uint32_t)i << 1) | (uint64_t)(pz & 1u);
+            out[w++] = e;
+          }
         } else {
           bad |= 1;  // slab overflow: the literal kernel redoes this read
         }
