@@ -182,8 +182,8 @@ int pgx_seqdb_upload(const uint8_t *seqdb, size_t nbytes, const uint32_t *rid, c
   for (uint32_t i = 0; i < nreads; ++i) db->rlen_by_rid[rid[i]] = rlen[i], db->roff_by_rid[rid[i]] = roff[i];
   db->nbytes = nbytes;
   try {
-    db->d_seq.alloc(nbytes + 64);
-    PGX_HIP(hipMemsetAsync(db->d_seq.p + nbytes, 0, 64, ctx().stream));
+    db->d_seq.alloc(nbytes + 1024);
+    PGX_HIP(hipMemsetAsync(db->d_seq.p + nbytes, 0, 1024, ctx().stream));
     if (nbytes) PGX_HIP(hipMemcpyAsync(db->d_seq.p, seqdb, nbytes, hipMemcpyHostToDevice, ctx().stream));
     db->d_roff.alloc(nr ? nr : 1);
     db->d_rlen.alloc(nr ? nr : 1);

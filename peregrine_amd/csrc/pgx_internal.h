@@ -109,7 +109,7 @@ struct ReadDesc {
 }  // namespace pgx
 
 struct pgx_seqdb {
-  pgx::DevBuf<uint8_t> d_seq;      // seqdb bytes + 64 bytes of zero padding
+  pgx::DevBuf<uint8_t> d_seq;      // seqdb bytes + 1 KiB of zero padding
   pgx::DevBuf<uint64_t> d_roff;    // indexed by rid
   pgx::DevBuf<uint32_t> d_rlen;    // indexed by rid
   std::vector<uint32_t> rid, rlen; // idx-file order

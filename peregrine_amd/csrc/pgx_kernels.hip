@@ -374,16 +374,29 @@ void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, 
 // 8 codes per 64-bit load; (2) the order-dependent side results (first extension > 16, longest extension,
 // first diagonal that reaches an end) are resolved lowest-k-first with ballots.
 // =========================================================================================================
-__device__ __forceinline__ int wave_max_i32(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
-  return v;
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_max_step(int v) {  // v = max(v, v from the DPP-selected lane); lanes without a source keep v
+  return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ int wave_max_i32(int v) {  // DPP tree: 6 VALU ops, result broadcast from lane 63
+  v = dpp_max_step<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_max_step<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_max_step<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_max_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row maximum
+  v = dpp_max_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+  v = dpp_max_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave maximum
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t *p) {
   uint64_t v;
   __builtin_memcpy(&v, p, 8);
   return v;
+}
+// number of leading equal codes (0..8) of two 8-byte groups under the strand nibble selection
+__device__ __forceinline__ int match8(uint64_t qa, uint64_t ta, int qs, int ts) {
+  const uint64_t diff = ((qa >> qs) ^ (ta >> ts)) & 0x0F0F0F0F0F0F0F0FULL;
+  return diff ? (__builtin_ctzll(diff) >> 3) : 8;
 }
 
 __global__ __launch_bounds__(64) void k_align(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
@@ -421,21 +434,40 @@ __global__ __launch_bounds__(64) void k_align(const uint8_t *__restrict__ seq, c
       const int k = min_k + 2 * j;
       int x1 = 0, y1 = 0;
       x = 0, y = 0;
+      bool more = false;
       if (active) {
         const int va = V[(k - 1) & mask], vb = V[(k + 1) & mask];
         x = (k == min_k || (k != max_k && va < vb)) ? vb : va + 1;
         y = x - k;
         x1 = x, y1 = y;
-        for (;;) {
-          const int rem = min(q_len - x, t_len - y);
-          if (rem <= 0) break;
-          const uint64_t qa = load_u64_unaligned(q + x), ta = load_u64_unaligned(t + y);
-          const uint64_t diff = ((qa >> qs) ^ (ta >> ts)) & 0x0F0F0F0F0F0F0F0FULL;
-          int m = diff ? (__builtin_ctzll(diff) >> 3) : 8;
+        // probe: the first 8 codes.  Off-diagonal fronts almost always stop here.
+        const int rem = min(q_len - x, t_len - y);
+        if (rem > 0) {
+          int m = match8(load_u64_unaligned(q + x), load_u64_unaligned(t + y), qs, ts);
           m = min(m, rem);
           x += m, y += m;
-          if (m < 8) break;
+          more = (m == 8) && (rem > 8);
         }
+      }
+      // long snakes (normally one per step): the whole wavefront extends one diagonal, 512 codes per iteration
+      uint64_t mm = __ballot(more);
+      while (mm) {
+        const int L = __builtin_ctzll(mm);
+        const int xs = __builtin_amdgcn_readlane(x, L), ys = __builtin_amdgcn_readlane(y, L);
+        const int rem = min(q_len - xs, t_len - ys);  // > 0 by construction
+        const int off = lane * 8;
+        int m = 0;
+        if (off < rem) m = min(match8(load_u64_unaligned(q + xs + off), load_u64_unaligned(t + ys + off), qs, ts), rem - off);
+        const uint64_t stop = __ballot(m < 8);
+        int ext;
+        if (stop) {
+          const int f = __builtin_ctzll(stop);
+          ext = 8 * f + __builtin_amdgcn_readlane(m, f);
+        } else {
+          ext = 512;
+        }
+        if (lane == L) x += ext, y += ext;
+        if (stop || ext >= rem) mm &= mm - 1;  // this diagonal is done (mismatch found or an end reached)
       }
       const int ext = x - x1;
       const bool hit = active && (x >= q_len || y >= t_len);
@@ -446,7 +478,7 @@ __global__ __launch_bounds__(64) void k_align(const uint8_t *__restrict__ seq, c
         const uint64_t m = __ballot(valid && ext > 16);
         if (m) {
           const int l = __builtin_ctzll(m);
-          q_bgn = __shfl(x1, l, 64), t_bgn = __shfl(y1, l, 64);
+          q_bgn = __builtin_amdgcn_readlane(x1, l), t_bgn = __builtin_amdgcn_readlane(y1, l);
           started = true;
         }
       }
@@ -454,13 +486,13 @@ __global__ __launch_bounds__(64) void k_align(const uint8_t *__restrict__ seq, c
         const int mx = wave_max_i32(valid ? ext : -1);
         const int l = __builtin_ctzll(__ballot(valid && ext == mx));
         longest = (uint32_t)mx;
-        q_m_end = __shfl(x, l, 64), t_m_end = __shfl(y, l, 64);
+        q_m_end = __builtin_amdgcn_readlane(x, l), t_m_end = __builtin_amdgcn_readlane(y, l);
       }
       if (valid) V[k & mask] = x;
       best_m = max(best_m, wave_max_i32(valid ? x + y : -1));
       if (hitmask) {
         matched = true;
-        q_end = __shfl(x, hl, 64), t_end = __shfl(y, hl, 64);
+        q_end = __builtin_amdgcn_readlane(x, hl), t_end = __builtin_amdgcn_readlane(y, hl);
       }
     }
     __syncthreads();

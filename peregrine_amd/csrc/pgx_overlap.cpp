@@ -252,46 +252,122 @@ struct Visit {
   std::vector<Entry> entries;
 };
 
+// A reusable inner table: same slot behaviour as SlotTable, but storage is recycled between key0 groups so the
+// ~10^5..10^6 tiny second-level tables cost no allocation.
+struct ScratchTable {
+  std::vector<uint64_t> keys;
+  std::vector<uint32_t> ids;
+  std::vector<uint8_t> used, fresh;
+  uint32_t nb = 0, size = 0, upper = 0;
+  void reset() {
+    if (nb) std::fill(used.begin(), used.begin() + nb, 0);
+    nb = size = upper = 0;
+  }
+  void enlarge() {
+    const uint32_t nn = nb ? nb * 2 : 4;
+    const uint32_t thr = (uint32_t)(nn * 0.77 + 0.5);
+    if (size >= thr) return;
+    if (keys.size() < nn) keys.resize(nn), ids.resize(nn), used.resize(nn, 0), fresh.resize(nn, 0);
+    std::fill(fresh.begin(), fresh.begin() + nn, 0);
+    const uint32_t m = nn - 1;
+    for (uint32_t j = 0; j < nb; ++j) {
+      if (!used[j]) continue;
+      uint64_t key = keys[j];
+      uint32_t id = ids[j];
+      used[j] = 0;
+      for (;;) {
+        uint32_t i = SlotTable::h32(key) & m, step = 0;
+        while (fresh[i]) i = (i + (++step)) & m;
+        fresh[i] = 1;
+        if (i < nb && used[i]) {
+          std::swap(key, keys[i]), std::swap(id, ids[i]);
+          used[i] = 0;
+        } else {
+          keys[i] = key, ids[i] = id;
+          break;
+        }
+      }
+    }
+    std::copy(fresh.begin(), fresh.begin() + nn, used.begin());
+    nb = nn, upper = thr;
+  }
+  uint32_t put(uint64_t key, uint32_t fresh_id, bool *absent) {
+    if (size >= upper) enlarge();
+    const uint32_t m = nb - 1;
+    uint32_t i = SlotTable::h32(key) & m, step = 0;
+    while (used[i] && keys[i] != key) i = (i + (++step)) & m;
+    if (used[i]) {
+      *absent = false;
+      return ids[i];
+    }
+    used[i] = 1, keys[i] = key, ids[i] = fresh_id, ++size;
+    *absent = true;
+    return fresh_id;
+  }
+};
+
 void build_visit(const PairRecs &pr, uint32_t ovlp_upper, Visit &v) {
   const size_t n = pr.n();
+  // level 1: one sequential pass over the key0 put sequence (repeats included: a put of a present key can resize)
   SlotTable outer;
-  std::vector<SlotTable> inner;
-  std::vector<uint32_t> bucket_of(n);
-  std::vector<uint32_t> bucket_n;
+  std::vector<uint32_t> id0_of(n), cnt0;
   bool absent;
   for (size_t i = 0; i < n; ++i) {
-    const uint32_t id0 = outer.put(pr.key0[i], (uint32_t)inner.size(), &absent);
-    if (absent) inner.emplace_back();
-    const uint32_t b = inner[id0].put(pr.key1[i], (uint32_t)bucket_n.size(), &absent);
-    if (absent) bucket_n.push_back(0);
-    bucket_of[i] = b;
-    ++bucket_n[b];
+    const uint32_t id0 = outer.put(pr.key0[i], (uint32_t)cnt0.size(), &absent);
+    if (absent) cnt0.push_back(0);
+    id0_of[i] = id0;
+    ++cnt0[id0];
   }
-  // group record indices by bucket, keeping scan order inside a bucket
-  std::vector<uint64_t> bstart(bucket_n.size() + 1, 0);
-  for (size_t b = 0; b < bucket_n.size(); ++b) bstart[b + 1] = bstart[b] + bucket_n[b];
-  std::vector<uint32_t> members(n);
+  // records grouped by key0, scan order kept inside a group
+  std::vector<uint64_t> g0(cnt0.size() + 1, 0);
+  for (size_t k = 0; k < cnt0.size(); ++k) g0[k + 1] = g0[k] + cnt0[k];
+  std::vector<uint32_t> by0(n);
   {
-    std::vector<uint64_t> fill(bstart.begin(), bstart.end() - 1);
-    for (size_t i = 0; i < n; ++i) members[fill[bucket_of[i]]++] = (uint32_t)i;
+    std::vector<uint64_t> fill(g0.begin(), g0.end() - 1);
+    for (size_t i = 0; i < n; ++i) by0[fill[id0_of[i]]++] = (uint32_t)i;
   }
+  // level 2: the inner tables are independent; emulate each on a scratch table, in outer slot order
   v.start.clear(), v.entries.clear();
   v.start.push_back(0);
-  std::vector<uint32_t> tmp;
+  ScratchTable in;
+  std::vector<uint32_t> lid, lcnt, lstart, lmem, tmp;
   for (uint32_t s0 = 0; s0 < outer.nb; ++s0) {
     if (!outer.used[s0]) continue;
-    const SlotTable &in = inner[outer.ids[s0]];
+    const uint32_t id0 = outer.ids[s0];
+    const uint32_t *rec = by0.data() + g0[id0];
+    const uint32_t m = cnt0[id0];
+    if (m <= 2) continue;  // no bucket of this key0 can have more than 2 records
+    in.reset();
+    lid.resize(m), lcnt.clear();
+    for (uint32_t r = 0; r < m; ++r) {
+      const uint32_t b = in.put(pr.key1[rec[r]], (uint32_t)lcnt.size(), &absent);
+      if (absent) lcnt.push_back(0);
+      lid[r] = b;
+      ++lcnt[b];
+    }
+    lstart.assign(lcnt.size() + 1, 0);
+    for (size_t b = 0; b < lcnt.size(); ++b) lstart[b + 1] = lstart[b] + lcnt[b];
+    lmem.resize(m);
+    {
+      tmp.assign(lstart.begin(), lstart.end() - 1);
+      for (uint32_t r = 0; r < m; ++r) lmem[tmp[lid[r]]++] = rec[r];
+    }
     for (uint32_t s1 = 0; s1 < in.nb; ++s1) {
       if (!in.used[s1]) continue;
-      const uint32_t b = in.ids[s1];
-      const uint32_t bn = bucket_n[b];
-      if (bn <= 2 || bn > ovlp_upper) continue;
-      tmp.assign(members.begin() + bstart[b], members.begin() + bstart[b + 1]);
-      std::stable_sort(tmp.begin(), tmp.end(),
-                       [&](uint32_t l, uint32_t r) { return pos_of(pr.y0[l]) > pos_of(pr.y0[r]); });
-      for (uint32_t i : tmp) {
-        const uint64_t y = pr.y0[i];
-        v.entries.push_back(Entry{(uint32_t)(y >> 32), pos_of(y) + 1, y, pr.dir[i]});
+      const uint32_t b = in.ids[s1], bn = lcnt[b];
+      if (bn <= 2 || bn > ovlp_upper) continue;  // shmr_overlap.c:216
+      uint32_t *mb = lmem.data() + lstart[b];
+      // stable, descending by position: what glibc's merge-sort qsort yields for mp128_comp (shmr_overlap.c:46-50,217)
+      for (uint32_t i = 1; i < bn; ++i) {
+        const uint32_t x = mb[i];
+        const uint32_t px = pos_of(pr.y0[x]);
+        uint32_t j = i;
+        while (j > 0 && pos_of(pr.y0[mb[j - 1]]) < px) mb[j] = mb[j - 1], --j;
+        mb[j] = x;
+      }
+      for (uint32_t i = 0; i < bn; ++i) {
+        const uint64_t y = pr.y0[mb[i]];
+        v.entries.push_back(Entry{(uint32_t)(y >> 32), pos_of(y) + 1, y, pr.dir[mb[i]]});
       }
       v.start.push_back(v.entries.size());
     }
@@ -426,13 +502,19 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   PairRecs pr;
   build_pairs(mmers, n_mm, mc, db->rlen_by_rid, p, pr);
   s.n_pair_records = pr.n();
+  const double t1 = now_ms();
   Visit visit;
   build_visit(pr, (uint32_t)p->ovlp_upper, visit);
   s.n_buckets = visit.start.size() - 1;
+  if (getenv("PGX_TRACE"))
+    fprintf(stderr, "[pgx] pairs %zu in %.2f ms; visit order (%llu buckets) in %.2f ms\n", pr.n(), t1 - t0,
+            (unsigned long long)s.n_buckets, now_ms() - t1);
   Replay rp(visit, db->rlen_by_rid, (uint32_t)(uint8_t)p->bestn);  // bestn is a uint8_t in the reference (:245)
   for (;;) {
+    const double p0 = now_ms();
     const size_t nreq = rp.pass();
     ++s.rounds;
+    if (getenv("PGX_TRACE")) fprintf(stderr, "[pgx] replay pass %u: %.2f ms\n", s.rounds, now_ms() - p0);
     if (nreq == 0) break;
     const double g0 = now_ms();
     DevBuf<pgx_align_key> d_keys(nreq);
@@ -443,6 +525,9 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     d_res.download(res.data(), nreq);
     sync();
     gpu_ms += now_ms() - g0;
+    if (getenv("PGX_TRACE"))
+      fprintf(stderr, "[pgx] round %u: %zu alignments, gpu %.3f ms (records so far %zu, lookups %llu)\n", s.rounds, nreq,
+              now_ms() - g0, rp.out.size(), (unsigned long long)rp.n_lookup);
     rp.absorb(res);
     s.n_align_gpu += nreq;
   }
