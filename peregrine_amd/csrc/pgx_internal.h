@@ -135,6 +135,23 @@ void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_cou
 // banded O(ND) confirmation of n candidate alignments (keys on device)
 void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out);
 
+// shimmer-pair join (pgx_pairs.hip): records sorted by (key0, key1, position desc, insertion order) plus the bucket /
+// key0-group tables the host needs to replay the khash slot order on distinct keys
+struct PairTables {
+  size_t n_rec = 0;
+  std::vector<uint64_t> y0;        // per record
+  std::vector<uint8_t> dir;        // per record
+  std::vector<uint64_t> bkey1;     // per bucket
+  std::vector<uint32_t> bstart;    // nb+1 record offsets
+  std::vector<uint32_t> bfirst;    // first insertion (record seq) of the bucket
+  std::vector<uint64_t> gkey0;     // per key0 group
+  std::vector<uint32_t> gstart;    // ng+1 record offsets
+  std::vector<uint32_t> gfirst, glast;  // first / last insertion of the group
+  std::vector<uint32_t> gbucket;   // ng+1: first bucket of the group
+};
+void dev_build_pairs(const pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts,
+                     size_t n_counts, const pgx_overlap_params *p, PairTables &out);
+
 // host helpers (pgx_api.cpp)
 int load_idx(const char *path, std::vector<uint32_t> &rid, std::vector<uint32_t> &rlen, std::vector<uint64_t> &roff);
 bool read_file(const std::string &path, std::vector<uint8_t> &out);

@@ -183,60 +183,7 @@ struct SlotTable {
   }
 };
 
-// ---------------------------------------------------------------------------------------------------------
-// shimmer-pair records (build_map, src/shmr_utils.c:295-404)
-// ---------------------------------------------------------------------------------------------------------
-struct PairRecs {
-  std::vector<uint64_t> key0, key1, y0;
-  std::vector<uint8_t> dir;
-  size_t n() const { return key0.size(); }
-};
-
 static inline uint32_t pos_of(uint64_t y) { return (uint32_t)((y & 0xFFFFFFFFu) >> 1); }
-
-static inline uint64_t flip_y(uint64_t y, uint64_t x, const std::vector<uint32_t> &rlen) {
-  const uint32_t span = (uint32_t)(x & 0xFF), rid = (uint32_t)(y >> 32);
-  const uint32_t rpos = rlen[rid] - (pos_of(y) + 1) + span - 1;  // shmr_utils.c:378-385
-  return ((y & 0xFFFFFFFF00000001ULL) | (uint64_t)(rpos << 1)) ^ 1ULL;
-}
-
-void build_pairs(const pgx_mm128 *mm, size_t n, U64Map<uint32_t> &mc, const std::vector<uint32_t> &rlen,
-                 const pgx_overlap_params *p, PairRecs &out) {
-  const uint32_t T = (uint32_t)p->total_chunk, c = (uint32_t)p->mychunk % T;
-  const uint32_t lower = (uint32_t)p->mc_lower, upper = (uint32_t)p->mc_upper;
-  auto count_of = [&](const pgx_mm128 &e) -> uint32_t {
-    uint32_t *v = mc.find(e.x >> 8);
-    PGX_REQUIRE(v, PGX_EARG, "shimmer hash %llu missing from the MC files", (unsigned long long)(e.x >> 8));
-    return *v;
-  };
-  size_t s = 0;
-  for (; s < n; ++s) {  // first anchor: lower <= count < upper, STRICT (shmr_utils.c:311-320)
-    const uint32_t cnt = count_of(mm[s]);
-    if (cnt >= lower && cnt < upper) break;
-  }
-  if (s >= n) return;
-  pgx_mm128 a = mm[s];
-  for (size_t i = s + 1; i < n; ++i) {
-    const pgx_mm128 b = mm[i];
-    const uint32_t cnt = count_of(b);
-    if (cnt < lower || cnt > upper) continue;  // inclusive upper; the anchor is not advanced (:327)
-    if ((a.y >> 32) == (b.y >> 32)) {
-      PGX_REQUIRE((uint32_t)(a.y >> 32) < rlen.size(), PGX_EARG, "rid %u not in the idx", (uint32_t)(a.y >> 32));
-      const uint32_t gap = (uint32_t)((b.y >> 1) & 0xFFFFFFF) - (uint32_t)((a.y >> 1) & 0xFFFFFFF);
-      if (gap < 100) {  // :332
-        a = b;
-        continue;
-      }
-      if ((a.x >> 8) % T == c) {  // forward record, bucket [a.x][b.x]
-        out.key0.push_back(a.x), out.key1.push_back(b.x), out.y0.push_back(a.y), out.dir.push_back(0);
-      }
-      if ((b.x >> 8) % T == c) {  // reverse record, bucket [b.x][a.x], coordinates on the other strand
-        out.key0.push_back(b.x), out.key1.push_back(a.x), out.y0.push_back(flip_y(b.y, b.x, rlen)), out.dir.push_back(1);
-      }
-    }
-    a = b;
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // bucket visit list: ascending slot order of both table levels, buckets with 2 < n <= ovlp_upper, each sorted
@@ -306,68 +253,45 @@ struct ScratchTable {
   }
 };
 
-void build_visit(const PairRecs &pr, uint32_t ovlp_upper, Visit &v) {
-  const size_t n = pr.n();
-  // level 1: one sequential pass over the key0 put sequence (repeats included: a put of a present key can resize)
-  SlotTable outer;
-  std::vector<uint32_t> id0_of(n), cnt0;
-  bool absent;
-  for (size_t i = 0; i < n; ++i) {
-    const uint32_t id0 = outer.put(pr.key0[i], (uint32_t)cnt0.size(), &absent);
-    if (absent) cnt0.push_back(0);
-    id0_of[i] = id0;
-    ++cnt0[id0];
-  }
-  // records grouped by key0, scan order kept inside a group
-  std::vector<uint64_t> g0(cnt0.size() + 1, 0);
-  for (size_t k = 0; k < cnt0.size(); ++k) g0[k + 1] = g0[k] + cnt0[k];
-  std::vector<uint32_t> by0(n);
-  {
-    std::vector<uint64_t> fill(g0.begin(), g0.end() - 1);
-    for (size_t i = 0; i < n; ++i) by0[fill[id0_of[i]]++] = (uint32_t)i;
-  }
-  // level 2: the inner tables are independent; emulate each on a scratch table, in outer slot order
+// The GPU join delivers every (key0,key1) bucket contiguous and internally ordered, plus the first/last insertion of every
+// bucket and key0 group.  klib-khash's final slot layout depends only on the order in which DISTINCT keys are first
+// inserted, plus one detail: a put of an already-present key still runs the load-factor check (khash.h:298-306), so if any
+// put follows the last first-insertion the table may grow once more.  Both levels are replayed on distinct keys only.
+void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
   v.start.clear(), v.entries.clear();
   v.start.push_back(0);
+  const size_t ng = pt.gkey0.size();
+  if (!ng) return;
+  bool absent;
+  // level 1: key0 groups in order of first insertion
+  std::vector<uint32_t> gord(ng);
+  for (size_t g = 0; g < ng; ++g) gord[g] = (uint32_t)g;
+  std::sort(gord.begin(), gord.end(), [&](uint32_t a, uint32_t b) { return pt.gfirst[a] < pt.gfirst[b]; });
+  SlotTable outer;
+  for (uint32_t g : gord) outer.put(pt.gkey0[g], g, &absent);
+  if ((size_t)pt.gfirst[gord.back()] + 1 < pt.n_rec) outer.put(pt.gkey0[gord[0]], 0, &absent);  // trailing repeat put
+  // level 2
   ScratchTable in;
-  std::vector<uint32_t> lid, lcnt, lstart, lmem, tmp;
+  std::vector<uint32_t> bord;
   for (uint32_t s0 = 0; s0 < outer.nb; ++s0) {
     if (!outer.used[s0]) continue;
-    const uint32_t id0 = outer.ids[s0];
-    const uint32_t *rec = by0.data() + g0[id0];
-    const uint32_t m = cnt0[id0];
-    if (m <= 2) continue;  // no bucket of this key0 can have more than 2 records
+    const uint32_t g = outer.ids[s0];
+    if (pt.gstart[g + 1] - pt.gstart[g] <= 2) continue;  // no bucket of this key0 can hold more than 2 records
+    const uint32_t b0 = pt.gbucket[g], b1 = pt.gbucket[g + 1];
+    bord.resize(b1 - b0);
+    for (uint32_t b = b0; b < b1; ++b) bord[b - b0] = b;
+    std::sort(bord.begin(), bord.end(), [&](uint32_t a, uint32_t b) { return pt.bfirst[a] < pt.bfirst[b]; });
     in.reset();
-    lid.resize(m), lcnt.clear();
-    for (uint32_t r = 0; r < m; ++r) {
-      const uint32_t b = in.put(pr.key1[rec[r]], (uint32_t)lcnt.size(), &absent);
-      if (absent) lcnt.push_back(0);
-      lid[r] = b;
-      ++lcnt[b];
-    }
-    lstart.assign(lcnt.size() + 1, 0);
-    for (size_t b = 0; b < lcnt.size(); ++b) lstart[b + 1] = lstart[b] + lcnt[b];
-    lmem.resize(m);
-    {
-      tmp.assign(lstart.begin(), lstart.end() - 1);
-      for (uint32_t r = 0; r < m; ++r) lmem[tmp[lid[r]]++] = rec[r];
-    }
+    for (uint32_t b : bord) in.put(pt.bkey1[b], b, &absent);
+    if (pt.bfirst[bord.back()] < pt.glast[g]) in.put(pt.bkey1[bord[0]], 0, &absent);  // trailing repeat put
     for (uint32_t s1 = 0; s1 < in.nb; ++s1) {
       if (!in.used[s1]) continue;
-      const uint32_t b = in.ids[s1], bn = lcnt[b];
+      const uint32_t b = in.ids[s1];
+      const uint32_t bn = pt.bstart[b + 1] - pt.bstart[b];
       if (bn <= 2 || bn > ovlp_upper) continue;  // shmr_overlap.c:216
-      uint32_t *mb = lmem.data() + lstart[b];
-      // stable, descending by position: what glibc's merge-sort qsort yields for mp128_comp (shmr_overlap.c:46-50,217)
-      for (uint32_t i = 1; i < bn; ++i) {
-        const uint32_t x = mb[i];
-        const uint32_t px = pos_of(pr.y0[x]);
-        uint32_t j = i;
-        while (j > 0 && pos_of(pr.y0[mb[j - 1]]) < px) mb[j] = mb[j - 1], --j;
-        mb[j] = x;
-      }
-      for (uint32_t i = 0; i < bn; ++i) {
-        const uint64_t y = pr.y0[mb[i]];
-        v.entries.push_back(Entry{(uint32_t)(y >> 32), pos_of(y) + 1, y, pr.dir[mb[i]]});
+      for (uint32_t r = pt.bstart[b]; r < pt.bstart[b + 1]; ++r) {
+        const uint64_t y = pt.y0[r];
+        v.entries.push_back(Entry{(uint32_t)(y >> 32), pos_of(y) + 1, y, pt.dir[r]});
       }
       v.start.push_back(v.entries.size());
     }
@@ -381,6 +305,37 @@ enum { T_OVERLAP = 0, T_CONTAINS = 1, T_CONTAINED = 2 };
 constexpr int END_FUZZ = 48;              // READ_END_FUZZINESS, shmr_overlap.c:36
 constexpr uint32_t PENDING = 0xFFFFFFFFu; // memo value of a requested, not yet computed alignment
 
+// U64Map with erase (backward-shift deletion for linear probing) is needed to roll the seen-pair table back
+template <typename V>
+static void u64map_erase(U64Map<V> &m, uint64_t k) {
+  if (!m.cap) return;
+  const size_t mask = m.cap - 1;
+  size_t i = mix(k) & mask;
+  while (m.used[i]) {
+    if (m.keys[i] == k) break;
+    i = (i + 1) & mask;
+  }
+  if (!m.used[i]) return;
+  size_t j = i;
+  for (;;) {  // shift later members of the cluster back over the hole
+    j = (j + 1) & mask;
+    if (!m.used[j]) break;
+    const size_t h = mix(m.keys[j]) & mask;
+    const bool between = (i <= j) ? (i < h && h <= j) : (i < h || h <= j);
+    if (!between) {
+      m.keys[i] = m.keys[j], m.vals[i] = m.vals[j];
+      i = j;
+    }
+  }
+  m.used[i] = 0;
+  --m.size;
+}
+
+struct Verdict {
+  bool accepted;
+  uint8_t type;
+};
+
 struct Replay {
   const Visit &v;
   const std::vector<uint32_t> &rlen;
@@ -389,25 +344,58 @@ struct Replay {
   std::vector<pgx_match> results;
   std::vector<pgx_align_key> requests;
   U64Map<uint8_t> seen;
+  std::vector<uint64_t> seen_log;  // pairs in insertion order (for rollback)
   std::vector<pgx_ovlp> out;
   std::vector<uint8_t> contained;
+  // per-bucket marks of the state at the START of the bucket, for resuming a pass there
+  std::vector<uint32_t> out_at, log_at;
+  std::vector<uint64_t> look_at, skip_at;
+  struct Guess {
+    uint32_t bucket, req, out_idx, rlen0, rlen1, q_off;
+    uint8_t type;
+  };
+  std::vector<Guess> guesses;
   uint64_t n_lookup = 0, n_skip = 0;
+  bool predict = true;  // PGX_PREDICT=0 disables the geometric type prediction (pure 'plain overlap' guess)
 
   Replay(const Visit &vv, const std::vector<uint32_t> &rl, uint32_t bn) : v(vv), rlen(rl), bestn(bn) {
     memo.init(1 << 16);
     seen.reserve_pow2(1 << 16);
+    const size_t nb = v.start.size() - 1;
+    out_at.assign(nb + 1, 0), log_at.assign(nb + 1, 0), look_at.assign(nb + 1, 0), skip_at.assign(nb + 1, 0);
   }
 
   static inline int64_t iabs(int64_t x) { return x < 0 ? -x : x; }
 
-  // one pass; returns the number of alignments requested (0 => `out` is exact)
-  size_t pass() {
-    seen.clear();
-    out.clear();
+  // acceptance test and classification of shimmer_to_overlap (shmr_overlap.c:134-160)
+  static Verdict classify(const pgx_match &m, uint32_t rlen0, uint32_t rlen1, uint32_t q_off) {
+    const uint32_t slen0 = rlen0 - q_off, slen1 = rlen1;
+    Verdict r{false, T_OVERLAP};
+    if (m.q_bgn < END_FUZZ && m.t_bgn < END_FUZZ &&
+        (iabs((int64_t)slen0 - m.q_end) < END_FUZZ || iabs((int64_t)slen1 - m.t_end) < END_FUZZ) && m.q_end > 500 &&
+        m.t_end > 500) {
+      r.accepted = true;
+      if (iabs((int64_t)rlen0 - ((int64_t)m.q_end - m.q_bgn)) < END_FUZZ * 2 ||
+          iabs((int64_t)rlen1 - ((int64_t)m.t_end - m.t_bgn)) < END_FUZZ * 2)
+        r.type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
+    }
+    return r;
+  }
+
+  void insert_seen(uint64_t pair, uint8_t type) {
+    *seen.slot(pair) = type;
+    seen_log.push_back(pair);
+  }
+
+  // Replay buckets [from, end).  Unknown alignments are requested and GUESSED (accepted, type from the geometry);
+  // the record of a guess is written with an empty match and patched by settle() if the guess was right.
+  // Returns the number of alignments requested.
+  size_t pass(size_t from) {
     requests.clear();
-    n_lookup = n_skip = 0;
+    guesses.clear();
     const size_t nb = v.start.size() - 1;
-    for (size_t b = 0; b < nb; ++b) {
+    for (size_t b = from; b < nb; ++b) {
+      out_at[b] = (uint32_t)out.size(), log_at[b] = (uint32_t)seen_log.size(), look_at[b] = n_lookup, skip_at[b] = n_skip;
       const Entry *e = v.entries.data() + v.start[b];
       const size_t n = v.start[b + 1] - v.start[b];
       contained.assign(n, 0);
@@ -432,52 +420,72 @@ struct Replay {
           bool fresh;
           uint32_t *mv = memo.slot(key, &fresh);
           ++n_lookup;
+          Verdict vd;
+          const pgx_match *mm = nullptr;
           if (fresh) {
+            // guess: the alignment will be accepted; its type follows from the geometry the shimmer pair implies
+            // (read1 starts q_off bases into read0): if read1 fits inside the rest of read0, or read0 starts (almost)
+            // at read1's start, the reference would classify a containment.
             *mv = PENDING;
-            pgx_align_key rq{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}};
-            requests.push_back(rq);
+            requests.push_back(pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}});
+            vd.accepted = true;
+            vd.type = T_OVERLAP;
+            if (predict && (rlen1 <= rlen0 - q_off || q_off < (uint32_t)(END_FUZZ * 2 - 8)))
+              vd.type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
+            guesses.push_back(Guess{(uint32_t)b, (uint32_t)requests.size() - 1, (uint32_t)out.size(), rlen0, rlen1, q_off, vd.type});
+          } else {
+            // a key is looked up at most once per pass while pending: its pair enters `seen` with the guess
+            PGX_REQUIRE(*mv != PENDING, PGX_ESTATE, "internal: pending alignment looked up twice");
+            mm = &results[*mv];
+            vd = classify(*mm, rlen0, rlen1, q_off);
           }
-          if (*mv == PENDING) {  // optimistic guess: accepted, plain overlap
-            ++got;
-            *seen.slot(pair) = T_OVERLAP;
-            continue;
-          }
-          const pgx_match &m = results[*mv];
-          const uint32_t slen0 = rlen0 - q_off, slen1 = rlen1;
-          if (m.q_bgn < END_FUZZ && m.t_bgn < END_FUZZ &&
-              (iabs((int64_t)slen0 - m.q_end) < END_FUZZ || iabs((int64_t)slen1 - m.t_end) < END_FUZZ) &&
-              m.q_end > 500 && m.t_end > 500) {
-            uint8_t type;
-            if (iabs((int64_t)rlen0 - ((int64_t)m.q_end - m.q_bgn)) < END_FUZZ * 2 ||
-                iabs((int64_t)rlen1 - ((int64_t)m.t_end - m.t_bgn)) < END_FUZZ * 2) {
-              if (rlen0 >= rlen1) type = T_CONTAINS, contained[pi] = 1;
-              else type = T_CONTAINED, contained[ai] = 1;
-            } else {
-              type = T_OVERLAP;
-              ++got;
-            }
-            *seen.slot(pair) = type;
+          if (vd.accepted) {
+            if (vd.type == T_OVERLAP) ++got;
+            else if (vd.type == T_CONTAINS) contained[pi] = 1;
+            else contained[ai] = 1;
+            insert_seen(pair, vd.type);
             pgx_ovlp o;
             memset(&o, 0, sizeof(o));
             o.y0 = e[ai].y0, o.y1 = e[pi].y0, o.rl0 = rlen0, o.rl1 = rlen1;
-            o.strand0 = e[ai].dir, o.strand1 = e[pi].dir, o.ovlp_type = type, o.match = m;
+            o.strand0 = e[ai].dir, o.strand1 = e[pi].dir, o.ovlp_type = vd.type;
+            if (mm) o.match = *mm;
             out.push_back(o);
           }
           if (contained[ai]) break;
         }
       }
     }
+    out_at[nb] = (uint32_t)out.size(), log_at[nb] = (uint32_t)seen_log.size(), look_at[nb] = n_lookup, skip_at[nb] = n_skip;
     return requests.size();
   }
 
-  // store the GPU results of the current request batch
-  void absorb(const std::vector<pgx_match> &r) {
+  // Store the GPU results of the current batch, patch the records of the guesses that were right and roll the state
+  // back to the start of the bucket holding the first wrong guess.  Returns that bucket, or SIZE_MAX if every guess
+  // was right (then `out` is final: every decision in it was taken with true results or with guesses equal to them).
+  size_t settle(const std::vector<pgx_match> &r) {
+    const uint32_t base = (uint32_t)results.size();
     for (size_t i = 0; i < requests.size(); ++i) {
       const pgx_align_key &k = requests[i];
       const AKey key{(uint64_t)k.rid0 << 32 | k.rid1, (uint64_t)k.q_off << 2 | (uint64_t)k.dir0 << 1 | k.dir1};
-      *memo.slot(key, nullptr) = (uint32_t)results.size();
+      *memo.slot(key, nullptr) = base + (uint32_t)i;
       results.push_back(r[i]);
     }
+    size_t resume = SIZE_MAX;
+    for (const Guess &g : guesses) {
+      const pgx_match &m = results[base + g.req];
+      const Verdict vd = classify(m, g.rlen0, g.rlen1, g.q_off);
+      if (!vd.accepted || vd.type != g.type) {
+        resume = g.bucket;
+        break;
+      }
+      out[g.out_idx].match = m;
+    }
+    if (resume == SIZE_MAX) return resume;
+    out.resize(out_at[resume]);
+    for (size_t i = log_at[resume]; i < seen_log.size(); ++i) u64map_erase(seen, seen_log[i]);
+    seen_log.resize(log_at[resume]);
+    n_lookup = look_at[resume], n_skip = skip_at[resume];
+    return resume;
   }
 };
 
@@ -495,26 +503,27 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   memset(&s, 0, sizeof(s));
   const double t0 = now_ms();
   double gpu_ms = 0;
-  // aggregate_mm_count (shmr_utils.c:162-176)
-  U64Map<uint32_t> mc;
-  mc.reserve_pow2(n_counts * 2 + 16);
-  for (size_t i = 0; i < n_counts; ++i) *mc.slot(counts[i].mer) += counts[i].count;
-  PairRecs pr;
-  build_pairs(mmers, n_mm, mc, db->rlen_by_rid, p, pr);
-  s.n_pair_records = pr.n();
+  PairTables pt;
+  dev_build_pairs(db, mmers, n_mm, counts, n_counts, p, pt);
+  sync();
+  s.n_pair_records = pt.n_rec;
   const double t1 = now_ms();
+  gpu_ms += t1 - t0;
   Visit visit;
-  build_visit(pr, (uint32_t)p->ovlp_upper, visit);
+  build_visit(pt, (uint32_t)p->ovlp_upper, visit);
   s.n_buckets = visit.start.size() - 1;
   if (getenv("PGX_TRACE"))
-    fprintf(stderr, "[pgx] pairs %zu in %.2f ms; visit order (%llu buckets) in %.2f ms\n", pr.n(), t1 - t0,
-            (unsigned long long)s.n_buckets, now_ms() - t1);
+    fprintf(stderr, "[pgx] GPU join: %zu records, %zu buckets, %zu key0 groups in %.2f ms; visit order (%llu buckets) in %.2f ms\n",
+            pt.n_rec, pt.bkey1.size(), pt.gkey0.size(), t1 - t0, (unsigned long long)s.n_buckets, now_ms() - t1);
   Replay rp(visit, db->rlen_by_rid, (uint32_t)(uint8_t)p->bestn);  // bestn is a uint8_t in the reference (:245)
+  if (const char *pv = getenv("PGX_PREDICT")) rp.predict = atoi(pv) != 0;
+  size_t from = 0;
   for (;;) {
     const double p0 = now_ms();
-    const size_t nreq = rp.pass();
+    const size_t nreq = rp.pass(from);
     ++s.rounds;
-    if (getenv("PGX_TRACE")) fprintf(stderr, "[pgx] replay pass %u: %.2f ms\n", s.rounds, now_ms() - p0);
+    if (getenv("PGX_TRACE"))
+      fprintf(stderr, "[pgx] replay pass %u from bucket %zu: %.2f ms, %zu requests\n", s.rounds, from, now_ms() - p0, nreq);
     if (nreq == 0) break;
     const double g0 = now_ms();
     DevBuf<pgx_align_key> d_keys(nreq);
@@ -525,11 +534,12 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     d_res.download(res.data(), nreq);
     sync();
     gpu_ms += now_ms() - g0;
-    if (getenv("PGX_TRACE"))
-      fprintf(stderr, "[pgx] round %u: %zu alignments, gpu %.3f ms (records so far %zu, lookups %llu)\n", s.rounds, nreq,
-              now_ms() - g0, rp.out.size(), (unsigned long long)rp.n_lookup);
-    rp.absorb(res);
     s.n_align_gpu += nreq;
+    from = rp.settle(res);
+    if (getenv("PGX_TRACE"))
+      fprintf(stderr, "[pgx] round %u: %zu alignments, gpu %.3f ms; first wrong guess in bucket %zd\n", s.rounds, nreq,
+              now_ms() - g0, (ssize_t)from);
+    if (from == SIZE_MAX) break;  // every guess was right: the replay is exact
   }
   timing_flush();
   s.n_align_needed = rp.n_lookup;
