@@ -303,66 +303,73 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
 // ---------------------------------------------------------------------------------------------------------
 enum { T_OVERLAP = 0, T_CONTAINS = 1, T_CONTAINED = 2 };
 constexpr int END_FUZZ = 48;              // READ_END_FUZZINESS, shmr_overlap.c:36
-constexpr uint32_t PENDING = 0xFFFFFFFFu; // memo value of a requested, not yet computed alignment
-
-// U64Map with erase (backward-shift deletion for linear probing) is needed to roll the seen-pair table back
-template <typename V>
-static void u64map_erase(U64Map<V> &m, uint64_t k) {
-  if (!m.cap) return;
-  const size_t mask = m.cap - 1;
-  size_t i = mix(k) & mask;
-  while (m.used[i]) {
-    if (m.keys[i] == k) break;
-    i = (i + 1) & mask;
-  }
-  if (!m.used[i]) return;
-  size_t j = i;
-  for (;;) {  // shift later members of the cluster back over the hole
-    j = (j + 1) & mask;
-    if (!m.used[j]) break;
-    const size_t h = mix(m.keys[j]) & mask;
-    const bool between = (i <= j) ? (i < h && h <= j) : (i < h || h <= j);
-    if (!between) {
-      m.keys[i] = m.keys[j], m.vals[i] = m.vals[j];
-      i = j;
-    }
-  }
-  m.used[i] = 0;
-  --m.size;
-}
 
 struct Verdict {
   bool accepted;
   uint8_t type;
 };
 
+// ---------------------------------------------------------------------------------------------------------
+// Incremental greedy replay.
+//
+// The reference walks the buckets once, in order, sharing one seen-pair table (shmr_overlap.c:194-228).  Here every
+// bucket's evaluation is a pure function of (a) the seen-pair entries OWNED BY EARLIER BUCKETS for the pairs it examines
+// and (b) the alignment results it looks up.  Each pair remembers which bucket inserted it ("owner") and which buckets
+// examined it ("readers").  A round scans the buckets in order and (re)evaluates only the dirty ones; when a bucket's
+// insertions change, the later readers of those pairs become dirty, and a later owner displaced by an earlier insertion
+// becomes dirty too.  Unknown alignments are requested and GUESSED (accepted; type predicted from the geometry); after
+// the GPU batch a wrong guess makes its bucket dirty, a right guess only has its record patched.  At the fixed point every
+// bucket was last evaluated against final inputs, which is exactly the sequential process.
+// ---------------------------------------------------------------------------------------------------------
 struct Replay {
+  static constexpr uint32_t NONE = 0xFFFFFFFFu;
   const Visit &v;
   const std::vector<uint32_t> &rlen;
   uint32_t bestn;
-  AKeyMap memo;
+  bool predict = true;  // PGX_PREDICT=0: guess "plain overlap" always
+
+  AKeyMap memo;                     // alignment key -> result index, or PENDING_BIT | request index
   std::vector<pgx_match> results;
   std::vector<pgx_align_key> requests;
-  U64Map<uint8_t> seen;
-  std::vector<uint64_t> seen_log;  // pairs in insertion order (for rollback)
-  std::vector<pgx_ovlp> out;
-  std::vector<uint8_t> contained;
-  // per-bucket marks of the state at the START of the bucket, for resuming a pass there
-  std::vector<uint32_t> out_at, log_at;
-  std::vector<uint64_t> look_at, skip_at;
+  static constexpr uint32_t PENDING_BIT = 0x80000000u;
+
+  U64Map<uint32_t> pair_id;         // read pair -> dense id
+  std::vector<uint8_t> ptype;
+  std::vector<uint32_t> powner;     // owning bucket or NONE
+  std::vector<uint32_t> rhead;      // head of the pair's reader list in rlog
+  struct RNode {
+    uint32_t next, bucket;
+  };
+  std::vector<RNode> rlog;
+
+  struct BState {
+    uint32_t rec0 = 0, nrec = 0;    // range in recs
+    uint32_t own0 = 0, nown = 0;    // range in owned (pair id, type)
+    uint32_t lookups = 0, skips = 0;
+  };
+  std::vector<BState> bs;
+  std::vector<pgx_ovlp> recs;       // arena; re-evaluated buckets append a fresh range
+  struct Own {
+    uint32_t pid;
+    uint8_t type;
+  };
+  std::vector<Own> owned;           // arena
+  std::vector<uint8_t> dirty;
   struct Guess {
-    uint32_t bucket, req, out_idx, rlen0, rlen1, q_off;
+    uint32_t bucket, req, rec, rlen0, rlen1, q_off;
     uint8_t type;
   };
   std::vector<Guess> guesses;
-  uint64_t n_lookup = 0, n_skip = 0;
-  bool predict = true;  // PGX_PREDICT=0 disables the geometric type prediction (pure 'plain overlap' guess)
+  std::vector<uint8_t> contained;
+  std::vector<Own> old_own;
+  uint64_t n_eval = 0;
 
   Replay(const Visit &vv, const std::vector<uint32_t> &rl, uint32_t bn) : v(vv), rlen(rl), bestn(bn) {
     memo.init(1 << 16);
-    seen.reserve_pow2(1 << 16);
+    pair_id.reserve_pow2(1 << 16);
     const size_t nb = v.start.size() - 1;
-    out_at.assign(nb + 1, 0), log_at.assign(nb + 1, 0), look_at.assign(nb + 1, 0), skip_at.assign(nb + 1, 0);
+    bs.assign(nb, BState());
+    dirty.assign(nb, 1);
   }
 
   static inline int64_t iabs(int64_t x) { return x < 0 ? -x : x; }
@@ -382,87 +389,129 @@ struct Replay {
     return r;
   }
 
-  void insert_seen(uint64_t pair, uint8_t type) {
-    *seen.slot(pair) = type;
-    seen_log.push_back(pair);
+  uint32_t pid_of(uint64_t pair) {
+    uint32_t *p = pair_id.slot(pair);
+    if (*p == 0) {  // ids are stored +1 so that the map's zero default means "new"
+      ptype.push_back(0), powner.push_back(NONE), rhead.push_back(NONE);
+      *p = (uint32_t)ptype.size();
+    }
+    return *p - 1;
+  }
+  void mark_readers_after(uint32_t pid, uint32_t b) {
+    for (uint32_t n = rhead[pid]; n != NONE; n = rlog[n].next)
+      if (rlog[n].bucket > b) dirty[rlog[n].bucket] = 1;
   }
 
-  // Replay buckets [from, end).  Unknown alignments are requested and GUESSED (accepted, type from the geometry);
-  // the record of a guess is written with an empty match and patched by settle() if the guess was right.
-  // Returns the number of alignments requested.
-  size_t pass(size_t from) {
-    requests.clear();
-    guesses.clear();
-    const size_t nb = v.start.size() - 1;
-    for (size_t b = from; b < nb; ++b) {
-      out_at[b] = (uint32_t)out.size(), log_at[b] = (uint32_t)seen_log.size(), look_at[b] = n_lookup, skip_at[b] = n_skip;
-      const Entry *e = v.entries.data() + v.start[b];
-      const size_t n = v.start[b + 1] - v.start[b];
-      contained.assign(n, 0);
-      for (size_t hi = n - 1; hi > 0; --hi) {
-        const size_t ai = hi - 1;
-        if (contained[ai]) continue;
-        const uint32_t rid0 = e[ai].rid, pos0 = e[ai].pos1, rlen0 = rlen[rid0];
-        size_t got = 0;
-        for (size_t pi = ai + 1; pi < n && got < bestn; ++pi) {
-          if (contained[pi]) continue;
-          const uint32_t rid1 = e[pi].rid;
-          if (rid0 == rid1) continue;
-          const uint64_t pair = rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0);
-          if (uint8_t *st = seen.find(pair)) {
-            if (*st == T_OVERLAP) ++got;
-            ++n_skip;
-            continue;
-          }
-          const uint32_t pos1 = e[pi].pos1, rlen1 = rlen[rid1];
-          const uint32_t q_off = pos0 - pos1;
-          const AKey key{(uint64_t)rid0 << 32 | rid1, (uint64_t)q_off << 2 | (uint64_t)e[ai].dir << 1 | e[pi].dir};
-          bool fresh;
-          uint32_t *mv = memo.slot(key, &fresh);
-          ++n_lookup;
-          Verdict vd;
-          const pgx_match *mm = nullptr;
-          if (fresh) {
-            // guess: the alignment will be accepted; its type follows from the geometry the shimmer pair implies
-            // (read1 starts q_off bases into read0): if read1 fits inside the rest of read0, or read0 starts (almost)
-            // at read1's start, the reference would classify a containment.
-            *mv = PENDING;
-            requests.push_back(pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}});
-            vd.accepted = true;
-            vd.type = T_OVERLAP;
-            if (predict && (rlen1 <= rlen0 - q_off || q_off < (uint32_t)(END_FUZZ * 2 - 8)))
-              vd.type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
-            guesses.push_back(Guess{(uint32_t)b, (uint32_t)requests.size() - 1, (uint32_t)out.size(), rlen0, rlen1, q_off, vd.type});
-          } else {
-            // a key is looked up at most once per pass while pending: its pair enters `seen` with the guess
-            PGX_REQUIRE(*mv != PENDING, PGX_ESTATE, "internal: pending alignment looked up twice");
-            mm = &results[*mv];
-            vd = classify(*mm, rlen0, rlen1, q_off);
-          }
-          if (vd.accepted) {
-            if (vd.type == T_OVERLAP) ++got;
-            else if (vd.type == T_CONTAINS) contained[pi] = 1;
-            else contained[ai] = 1;
-            insert_seen(pair, vd.type);
-            pgx_ovlp o;
-            memset(&o, 0, sizeof(o));
-            o.y0 = e[ai].y0, o.y1 = e[pi].y0, o.rl0 = rlen0, o.rl1 = rlen1;
-            o.strand0 = e[ai].dir, o.strand1 = e[pi].dir, o.ovlp_type = vd.type;
-            if (mm) o.match = *mm;
-            out.push_back(o);
-          }
-          if (contained[ai]) break;
+  // shimmer_to_overlap (shmr_overlap.c:52-180) for bucket b against the entries owned by earlier buckets
+  void eval(uint32_t b) {
+    ++n_eval;
+    BState &st = bs[b];
+    // withdraw what the previous evaluation of this bucket inserted
+    old_own.assign(owned.begin() + st.own0, owned.begin() + st.own0 + st.nown);
+    for (const Own &o : old_own)
+      if (powner[o.pid] == b) powner[o.pid] = NONE;
+    st.rec0 = (uint32_t)recs.size(), st.nrec = 0, st.own0 = (uint32_t)owned.size(), st.nown = 0;
+    st.lookups = st.skips = 0;
+    const Entry *e = v.entries.data() + v.start[b];
+    const size_t n = v.start[b + 1] - v.start[b];
+    contained.assign(n, 0);
+    for (size_t hi = n - 1; hi > 0; --hi) {
+      const size_t ai = hi - 1;
+      if (contained[ai]) continue;
+      const uint32_t rid0 = e[ai].rid, pos0 = e[ai].pos1, rlen0 = rlen[rid0];
+      size_t got = 0;
+      for (size_t pi = ai + 1; pi < n && got < bestn; ++pi) {
+        if (contained[pi]) continue;
+        const uint32_t rid1 = e[pi].rid;
+        if (rid0 == rid1) continue;
+        const uint64_t pair = rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0);
+        const uint32_t pid = pid_of(pair);
+        if (rhead[pid] == NONE || rlog[rhead[pid]].bucket != b) {  // register as a reader (once per evaluation run)
+          rlog.push_back(RNode{rhead[pid], b});
+          rhead[pid] = (uint32_t)rlog.size() - 1;
         }
+        if (powner[pid] != NONE && powner[pid] <= b) {  // present in the table as this bucket sees it
+          if (ptype[pid] == T_OVERLAP) ++got;
+          ++st.skips;
+          continue;
+        }
+        const uint32_t pos1 = e[pi].pos1, rlen1 = rlen[rid1];
+        const uint32_t q_off = pos0 - pos1;
+        const AKey key{(uint64_t)rid0 << 32 | rid1, (uint64_t)q_off << 2 | (uint64_t)e[ai].dir << 1 | e[pi].dir};
+        bool fresh;
+        uint32_t *mv = memo.slot(key, &fresh);
+        ++st.lookups;
+        Verdict vd;
+        const pgx_match *mm = nullptr;
+        if (fresh) {
+          *mv = PENDING_BIT | (uint32_t)requests.size();
+          requests.push_back(pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}});
+        }
+        if (*mv & PENDING_BIT) {
+          // guess: accepted; the type follows from the geometry the shimmer pair implies (read1 starts q_off bases into
+          // read0): if read1 fits inside the rest of read0, or read0 starts (almost) where read1 starts, a containment
+          vd.accepted = true;
+          vd.type = T_OVERLAP;
+          if (predict && (rlen1 <= rlen0 - q_off || q_off < (uint32_t)(END_FUZZ * 2 - 8)))
+            vd.type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
+          guesses.push_back(Guess{b, *mv & ~PENDING_BIT, (uint32_t)recs.size(), rlen0, rlen1, q_off, vd.type});
+        } else {
+          mm = &results[*mv];
+          vd = classify(*mm, rlen0, rlen1, q_off);
+        }
+        if (vd.accepted) {
+          if (vd.type == T_OVERLAP) ++got;
+          else if (vd.type == T_CONTAINS) contained[pi] = 1;
+          else contained[ai] = 1;
+          if (powner[pid] != NONE && powner[pid] > b) dirty[powner[pid]] = 1;  // a later bucket had inserted it
+          powner[pid] = b, ptype[pid] = vd.type;
+          owned.push_back(Own{pid, vd.type});
+          ++st.nown;
+          pgx_ovlp o;
+          memset(&o, 0, sizeof(o));
+          o.y0 = e[ai].y0, o.y1 = e[pi].y0, o.rl0 = rlen0, o.rl1 = rlen1;
+          o.strand0 = e[ai].dir, o.strand1 = e[pi].dir, o.ovlp_type = vd.type;
+          if (mm) o.match = *mm;
+          recs.push_back(o);
+          ++st.nrec;
+        }
+        if (contained[ai]) break;
       }
     }
-    out_at[nb] = (uint32_t)out.size(), log_at[nb] = (uint32_t)seen_log.size(), look_at[nb] = n_lookup, skip_at[nb] = n_skip;
+    // what changed for later buckets?  (skipped while everything behind is dirty anyway: first sweep)
+    if (!first_sweep) {
+      for (const Own &o : old_own)
+        if (powner[o.pid] != b || ptype[o.pid] != o.type) mark_readers_after(o.pid, b);
+      for (uint32_t i = 0; i < st.nown; ++i) {
+        const Own &o = owned[st.own0 + i];
+        bool same = false;
+        for (const Own &q : old_own)
+          if (q.pid == o.pid && q.type == o.type) {
+            same = true;
+            break;
+          }
+        if (!same) mark_readers_after(o.pid, b);
+      }
+    }
+  }
+  bool first_sweep = true;
+
+  // one round: evaluate the dirty buckets in order; returns the number of alignments requested
+  size_t sweep() {
+    requests.clear();
+    guesses.clear();
+    const size_t nb = bs.size();
+    for (size_t b = 0; b < nb; ++b)
+      if (dirty[b]) {
+        dirty[b] = 0;
+        eval((uint32_t)b);
+      }
+    first_sweep = false;
     return requests.size();
   }
 
-  // Store the GPU results of the current batch, patch the records of the guesses that were right and roll the state
-  // back to the start of the bucket holding the first wrong guess.  Returns that bucket, or SIZE_MAX if every guess
-  // was right (then `out` is final: every decision in it was taken with true results or with guesses equal to them).
-  size_t settle(const std::vector<pgx_match> &r) {
+  // store the GPU results; right guesses get their record patched, wrong ones make their bucket dirty
+  bool settle(const std::vector<pgx_match> &r) {
     const uint32_t base = (uint32_t)results.size();
     for (size_t i = 0; i < requests.size(); ++i) {
       const pgx_align_key &k = requests[i];
@@ -470,22 +519,26 @@ struct Replay {
       *memo.slot(key, nullptr) = base + (uint32_t)i;
       results.push_back(r[i]);
     }
-    size_t resume = SIZE_MAX;
+    bool any = false;
     for (const Guess &g : guesses) {
       const pgx_match &m = results[base + g.req];
       const Verdict vd = classify(m, g.rlen0, g.rlen1, g.q_off);
-      if (!vd.accepted || vd.type != g.type) {
-        resume = g.bucket;
-        break;
-      }
-      out[g.out_idx].match = m;
+      if (!vd.accepted || vd.type != g.type) dirty[g.bucket] = 1, any = true;
+      else recs[g.rec].match = m;
     }
-    if (resume == SIZE_MAX) return resume;
-    out.resize(out_at[resume]);
-    for (size_t i = log_at[resume]; i < seen_log.size(); ++i) u64map_erase(seen, seen_log[i]);
-    seen_log.resize(log_at[resume]);
-    n_lookup = look_at[resume], n_skip = skip_at[resume];
-    return resume;
+    return any;
+  }
+
+  void collect(std::vector<pgx_ovlp> &out, uint64_t &lookups, uint64_t &skips) const {
+    size_t total = 0;
+    for (const BState &b : bs) total += b.nrec;
+    out.clear();
+    out.reserve(total);
+    lookups = skips = 0;
+    for (const BState &b : bs) {
+      out.insert(out.end(), recs.begin() + b.rec0, recs.begin() + b.rec0 + b.nrec);
+      lookups += b.lookups, skips += b.skips;
+    }
   }
 };
 
@@ -517,13 +570,14 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
             pt.n_rec, pt.bkey1.size(), pt.gkey0.size(), t1 - t0, (unsigned long long)s.n_buckets, now_ms() - t1);
   Replay rp(visit, db->rlen_by_rid, (uint32_t)(uint8_t)p->bestn);  // bestn is a uint8_t in the reference (:245)
   if (const char *pv = getenv("PGX_PREDICT")) rp.predict = atoi(pv) != 0;
-  size_t from = 0;
   for (;;) {
     const double p0 = now_ms();
-    const size_t nreq = rp.pass(from);
+    const uint64_t ev0 = rp.n_eval;
+    const size_t nreq = rp.sweep();
     ++s.rounds;
     if (getenv("PGX_TRACE"))
-      fprintf(stderr, "[pgx] replay pass %u from bucket %zu: %.2f ms, %zu requests\n", s.rounds, from, now_ms() - p0, nreq);
+      fprintf(stderr, "[pgx] replay sweep %u: %llu buckets evaluated in %.2f ms, %zu requests\n", s.rounds,
+              (unsigned long long)(rp.n_eval - ev0), now_ms() - p0, nreq);
     if (nreq == 0) break;
     const double g0 = now_ms();
     DevBuf<pgx_align_key> d_keys(nreq);
@@ -535,19 +589,13 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     sync();
     gpu_ms += now_ms() - g0;
     s.n_align_gpu += nreq;
-    from = rp.settle(res);
-    if (getenv("PGX_TRACE"))
-      fprintf(stderr, "[pgx] round %u: %zu alignments, gpu %.3f ms; first wrong guess in bucket %zd\n", s.rounds, nreq,
-              now_ms() - g0, (ssize_t)from);
-    if (from == SIZE_MAX) break;  // every guess was right: the replay is exact
+    if (!rp.settle(res)) break;  // every guess was right: the replay is exact
   }
   timing_flush();
-  s.n_align_needed = rp.n_lookup;
-  s.n_seen_skip = rp.n_skip;
-  s.n_records = rp.out.size();
+  rp.collect(out, s.n_align_needed, s.n_seen_skip);
+  s.n_records = out.size();
   s.gpu_ms = gpu_ms;
   s.host_ms = now_ms() - t0 - gpu_ms;
-  out.swap(rp.out);
   if (st) *st = s;
 }
 

@@ -27,3 +27,15 @@ def allgather_records(t: torch.Tensor, world: int | None = None) -> list[torch.T
     bufs = [torch.empty(cap, dtype=t.dtype, device=t.device) for _ in range(world)]
     dist.all_gather(bufs, pad)   # one bucketed collective; sizes are a few MB..GB per rank
     return [b[:s] for b, s in zip(bufs, sizes)]
+
+
+def chunk_of_rank(rank: int, world: int) -> int:
+    """Rank r runs index chunk r+1 and overlap chunk r+1 of `world` (chunks are 1-based in the reference CLIs)."""
+    return rank + 1
+
+
+def reads_of_chunk(rid, chunk: int, total: int):
+    """Read ownership of an index chunk: rid % total == chunk % total (/root/reference/src/shmr_index.c:157)."""
+    import numpy as np
+    rid = np.asarray(rid)
+    return rid[rid % total == chunk % total]
