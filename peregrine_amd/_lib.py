@@ -109,14 +109,17 @@ def init(device: int | None = None):
 
 
 def take(ptr, n: int, dtype: np.dtype) -> np.ndarray:
-    """Copy a library-owned host array into numpy and release it."""
+    """Wrap a library-owned host array as a numpy array WITHOUT copying; pgx_free runs when the array is collected."""
+    import weakref
     n = int(n)
-    if n and ptr:
-        out = np.frombuffer((C.c_uint8 * (n * dtype.itemsize)).from_address(ptr), dtype=dtype).copy()
-    else:
-        out = np.zeros(0, dtype)
-    if ptr:
+    if not ptr:
+        return np.zeros(0, dtype)
+    if n == 0:
         load().pgx_free(C.c_void_p(ptr))
+        return np.zeros(0, dtype)
+    buf = (C.c_uint8 * (n * dtype.itemsize)).from_address(ptr)
+    out = np.frombuffer(buf, dtype=dtype)
+    weakref.finalize(buf, load().pgx_free, C.c_void_p(ptr))
     return out
 
 

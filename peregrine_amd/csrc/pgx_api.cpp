@@ -25,6 +25,17 @@ Context &ctx() {
 }
 void require_ready() { PGX_REQUIRE(ctx().ready, PGX_ESTATE, "pgx_init() has not been called (or failed)"); }
 
+// ---- persistent workspace --------------------------------------------------------------------------------
+static std::map<std::string, DevBuf<uint8_t>> g_ws;
+void *ws_raw(const char *name, size_t bytes) {
+  DevBuf<uint8_t> &b = g_ws[name];
+  if (b.n < bytes) {
+    (void)hipStreamSynchronize(ctx().stream);
+    b.alloc(bytes + (bytes >> 3) + 4096);
+  }
+  return b.p;
+}
+
 // ---- timing ----------------------------------------------------------------------------------------------
 struct TimeAcc {
   double ms = 0;
@@ -133,6 +144,7 @@ int pgx_init(int device) {
 
 void pgx_shutdown(void) {
   Context &c = ctx();
+  g_ws.clear();
   if (c.stream) (void)hipStreamDestroy(c.stream);
   c.stream = nullptr;
   c.ready = false;

@@ -45,6 +45,25 @@ void run_index(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out) 
   out->reads = (uint32_t)reads.size();
   const int kbits = 2 * p->kmer;
 
+  // fast path: everything of the chunk goes through the wave kernel and the in-LDS reduce (pg_run.py's defaults)
+  if (!p->want_l0) {
+    const pgx_mm128 *d_top = nullptr;
+    size_t ntop = 0;
+    if (dev_index_fused(db, reads, p->window, p->kmer, p->reduction, p->levels, &d_top, &ntop)) {
+      PGX_REQUIRE(ntop < (1ULL << 31), PGX_EARG, "chunk too large (use more index chunks)");
+      DevBuf<pgx_mm_count> mc;
+      size_t nmc = 0;
+      dev_count(d_top, ntop, kbits, mc, nmc);
+      out->top = (pgx_mm128 *)malloc(ntop ? ntop * sizeof(pgx_mm128) : 1);
+      if (ntop) PGX_HIP(hipMemcpyAsync(out->top, d_top, ntop * sizeof(pgx_mm128), hipMemcpyDeviceToHost, ctx().stream));
+      out->n_top = ntop;
+      out->top_mc = download_list(mc, nmc), out->n_top_mc = nmc;
+      sync();
+      timing_flush();
+      out->gpu_ms = now_ms() - t0;
+      return;
+    }
+  }
   DevBuf<pgx_mm128> l0, l1, l2;
   size_t n0 = 0, n1 = 0, n2 = 0;
   dev_sketch(db, reads, p->window, p->kmer, l0, n0, &out->reads_literal);

@@ -86,6 +86,13 @@ struct DevBuf {
 };
 inline void sync() { PGX_HIP(hipStreamSynchronize(ctx().stream)); }
 
+// grow-only named device buffers that persist across calls (hipMalloc/hipFree are synchronous and slow)
+void *ws_raw(const char *name, size_t bytes);
+template <typename T>
+T *ws(const char *name, size_t count) {
+  return (T *)ws_raw(name, (count ? count : 1) * sizeof(T));
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // per-kernel timing with HIP events on the library stream
 // ---------------------------------------------------------------------------------------------------------
@@ -128,6 +135,10 @@ namespace pgx {
 // L0 minimizers of the given reads (device array of ReadDesc, in output order). Returns device list.
 void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, DevBuf<pgx_mm128> &out,
                 size_t &n_out, uint32_t *n_literal);
+// fused index path: sketch (wave kernel) -> per-read reduce x levels in LDS -> ordered gather.  Returns false (and
+// leaves the outputs untouched) when a read needs the general path (other w/k, ambiguous bases, > 1024 minimizers ...).
+bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, int rs, int levels,
+                     const pgx_mm128 **d_top, size_t *n_top);
 // one mm_reduce level over a device list
 void dev_reduce(const pgx_mm128 *d_in, size_t n, int rs, DevBuf<pgx_mm128> &out, size_t &n_out);
 // multiplicity of x>>8, sorted by mer

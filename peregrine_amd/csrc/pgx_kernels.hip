@@ -272,7 +272,7 @@ __global__ void k_gather_slabs(const pgx_mm128 *__restrict__ slab, const uint64_
                                const uint32_t *__restrict__ list, uint32_t n_list, const uint32_t *__restrict__ counts,
                                const uint64_t *__restrict__ out_off, pgx_mm128 *__restrict__ out) {
   if (blockIdx.x >= n_list) return;
-  const uint32_t slot = list[blockIdx.x];
+  const uint32_t slot = list ? list[blockIdx.x] : blockIdx.x;
   const pgx_mm128 *src = slab + slab_off[slot];
   pgx_mm128 *dst = out + out_off[slot];
   const uint32_t n = counts[slot];
@@ -363,6 +363,136 @@ void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, 
                        (uint32_t)slow.size(), w, k, ring.p, counts.p, offs.p, out.p);
   }
   sync();
+}
+
+// =========================================================================================================
+// k_reduce_read: mm_reduce (src/shmr_reduce.c:53-90) applied `levels` times to ONE read's minimizers, in LDS, in place
+// in the read's slab.  Same restatement as k_reduce_flag (winner = smallest x>>8, ties to the lowest ring slot
+// offset % rs; emitted iff its y differs from the previous window's winner; the first window always emits).
+// =========================================================================================================
+constexpr int RMAX = 1024;  // minimizers per read handled in LDS (a 15 kb read has ~375 at w = 80)
+
+__global__ __launch_bounds__(64) void k_reduce_read(pgx_mm128 *__restrict__ slab, const uint64_t *__restrict__ slab_off,
+                                                    const ReadDesc *__restrict__ reads,
+                                                    const uint32_t *__restrict__ counts0,
+                                                    const uint32_t *__restrict__ flags, uint32_t n, int rs, int levels,
+                                                    uint32_t *__restrict__ counts_top, uint32_t *__restrict__ nbad) {
+  __shared__ uint64_t sx[RMAX];
+  __shared__ uint32_t sy[RMAX];
+  const int lane = threadIdx.x;
+  const uint32_t slot = blockIdx.x;
+  if (slot >= n) return;
+  const uint32_t c0 = counts0[slot];
+  if (flags[slot] || c0 > (uint32_t)RMAX) {
+    if (lane == 0) atomicAdd(nbad, 1u), counts_top[slot] = 0;
+    return;
+  }
+  pgx_mm128 *p = slab + slab_off[slot];
+  for (uint32_t i = lane; i < c0; i += 64) {
+    const pgx_mm128 e = p[i];
+    sx[i] = e.x, sy[i] = (uint32_t)e.y;
+  }
+  int ncur = (int)c0;
+  for (int lv = 0; lv < levels; ++lv) {
+    __syncthreads();
+    uint64_t wx[RMAX / 64];
+    uint32_t wy[RMAX / 64];
+    uint32_t emit = 0;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int r = 0; r < RMAX / 64; ++r) {
+      const int t = lane + 64 * r;
+      const bool valid = t < ncur && t >= rs - 1;
+      uint64_t bx = 0;
+      uint32_t by = 0;
+      if (valid) {
+        int u = t - rs + 1, sl = (t + 1) % rs;  // slot of element u is u % rs (offset within the read)
+        bx = sx[u], by = sy[u];
+        uint64_t bh = bx >> 8;
+        int bsl = sl;
+        for (int j = 1; j < rs; ++j) {
+          ++u;
+          if (++sl == rs) sl = 0;
+          const uint64_t x = sx[u], hsh = x >> 8;
+          if (hsh < bh || (hsh == bh && sl < bsl)) bx = x, by = sy[u], bh = hsh, bsl = sl;
+        }
+      }
+      uint32_t prevy = (uint32_t)__shfl_up((int)by, 1, 64);
+      if (lane == 0) prevy = carry;
+      carry = (uint32_t)__builtin_amdgcn_readlane((int)by, 63);
+      if (valid && (t == rs - 1 || by != prevy)) emit |= 1u << r;
+      wx[r] = bx, wy[r] = by;
+    }
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int r = 0; r < RMAX / 64; ++r) {
+      const bool em = (emit >> r) & 1u;
+      const uint64_t m = __ballot(em);
+      if (em) {
+        const int idx = base + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        sx[idx] = wx[r], sy[idx] = wy[r];
+      }
+      base += __builtin_popcountll(m);
+    }
+    ncur = base;
+  }
+  __syncthreads();
+  const uint64_t yhi = (uint64_t)reads[slot].rid << 32;
+  for (int i = lane; i < ncur; i += 64) p[i] = pgx_mm128{sx[i], yhi | sy[i]};
+  if (lane == 0) counts_top[slot] = (uint32_t)ncur;
+}
+
+bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, int rs, int levels,
+                     const pgx_mm128 **d_top, size_t *n_top) {
+  const uint32_t n = (uint32_t)reads.size();
+  if (n == 0 || levels < 1 || levels > 2 || rs < 1) return false;
+  std::vector<uint64_t> slab_off(n + 1, 0);
+  uint64_t bases = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (!sketch_wave_eligible(reads[i], w, k)) return false;
+    slab_off[i + 1] = slab_off[i] + (uint64_t)reads[i].len / 8 + 64;
+    bases += reads[i].len;
+  }
+  hipStream_t st = ctx().stream;
+  ReadDesc *d_reads = ws<ReadDesc>("ix.reads", n);
+  uint64_t *d_slab_off = ws<uint64_t>("ix.slab_off", n + 1);
+  uint32_t *d_cnt = ws<uint32_t>("ix.cnt", 3 * (size_t)n + 4);  // [counts0 | flags | counts_top | nbad]
+  uint32_t *d_flags = d_cnt + n, *d_ctop = d_cnt + 2 * (size_t)n, *d_nbad = d_cnt + 3 * (size_t)n;
+  uint64_t *d_offs = ws<uint64_t>("ix.offs", n + 1);
+  pgx_mm128 *slab = ws<pgx_mm128>("ix.slab", slab_off[n]);
+  PGX_HIP(hipMemcpyAsync(d_reads, reads.data(), n * sizeof(ReadDesc), hipMemcpyHostToDevice, st));
+  PGX_HIP(hipMemcpyAsync(d_slab_off, slab_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+  PGX_HIP(hipMemsetAsync(d_cnt, 0, (3 * (size_t)n + 4) * sizeof(uint32_t), st));
+  {
+    KernelTimer tm("sketch", bases);
+    launch_sketch_wave(db, d_reads, nullptr, n, w, k, slab, d_slab_off, d_cnt, d_flags);
+  }
+  {
+    KernelTimer tm("reduce", bases);
+    hipLaunchKernelGGL(k_reduce_read, dim3(n), dim3(64), 0, st, slab, d_slab_off, d_reads, d_cnt, d_flags, n, rs, levels,
+                       d_ctop, d_nbad);
+  }
+  size_t bytes = 0;
+  PGX_HIP(hipMemsetAsync(d_offs, 0, sizeof(uint64_t), st));
+  PGX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, bytes, d_ctop, d_offs + 1, (int)n, st));
+  void *tmp = ws_raw("ix.scan_tmp", bytes);
+  PGX_HIP(hipcub::DeviceScan::InclusiveSum(tmp, bytes, d_ctop, d_offs + 1, (int)n, st));
+  uint64_t total = 0;
+  uint32_t nbad = 0;
+  PGX_HIP(hipMemcpyAsync(&total, d_offs + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  PGX_HIP(hipMemcpyAsync(&nbad, d_nbad, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  sync();
+  if (nbad) return false;  // some read needs the general path; the caller redoes the chunk there
+  pgx_mm128 *top = ws<pgx_mm128>("ix.top", total);
+  if (total) {
+    KernelTimer tm("sketch_gather", bases);
+    hipLaunchKernelGGL(k_gather_slabs, dim3(n), dim3(64), 0, st, slab, d_slab_off, (const uint32_t *)nullptr, n, d_ctop, d_offs,
+                       top);
+  }
+  *d_top = top;
+  *n_top = (size_t)total;
+  return true;
 }
 
 // =========================================================================================================

@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
   __shared__ __attribute__((aligned(16))) Lds s;
   const int lane = threadIdx.x;
   if (blockIdx.x >= n_list) return;
-  const uint32_t slot = list[blockIdx.x];
+  const uint32_t slot = list ? list[blockIdx.x] : blockIdx.x;
   const ReadDesc rd = reads[slot];
   const int len = (int)rd.len;
   const int lead = (int)(rd.off & 15);

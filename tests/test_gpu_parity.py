@@ -120,6 +120,13 @@ def test_small_dataset_index_vs_oracle(small):
     assert np.array_equal(formats.mc_as_sorted_pairs(ix.top_mc), formats.mc_as_sorted_pairs(U.orc_count(l2)))
     assert np.array_equal(formats.mc_as_sorted_pairs(ix.l0_mc), formats.mc_as_sorted_pairs(U.orc_count(l0)))
     assert np.array_equal(rdb.index(levels=1).top, l1)
+    # the fused path (no L0 requested: wave sketch + in-LDS reduce) must agree with the general path and the oracle
+    fz = rdb.index()
+    assert fz.reads_literal == 0 and np.array_equal(fz.top, l2)
+    assert np.array_equal(formats.mc_as_sorted_pairs(fz.top_mc), formats.mc_as_sorted_pairs(U.orc_count(l2)))
+    for r in (2, 3, 24):
+        assert np.array_equal(rdb.index(reduction=r).top, U.orc_reduce(U.orc_reduce(l0, r), r)), r
+        assert np.array_equal(rdb.index(reduction=r, levels=1).top, U.orc_reduce(l0, r)), r
     # other parameters
     for (w, k, r) in ((24, 12, 3), (40, 15, 6), (100, 16, 4)):
         a = rdb.index(window=w, kmer=k, reduction=r, want_l0=True)
