@@ -84,36 +84,81 @@ struct AKey {
   uint64_t a, b;  // a = rid0<<32|rid1 ; b = q_off<<2|dir0<<1|dir1
   bool operator==(const AKey &o) const { return a == o.a && b == o.b; }
 };
-struct AKeyMap {  // alignment memo: key -> index into the result array
-  std::vector<AKey> keys;
-  std::vector<uint32_t> vals;
-  std::vector<uint8_t> used;
+struct AKeyMap {  // alignment memo: key -> index into the result array.  One 24-byte slot per probe (one cache miss).
+  struct Slot {
+    AKey k;
+    uint32_t val;
+    uint32_t used;
+  };
+  std::vector<Slot> slots;
   size_t size = 0, cap = 0;
   void init(size_t c) {
     cap = 1024;
     while (cap < c) cap <<= 1;
-    keys.assign(cap, AKey{0, 0}), vals.assign(cap, 0), used.assign(cap, 0), size = 0;
+    slots.assign(cap, Slot{AKey{0, 0}, 0, 0});
+    size = 0;
   }
   void grow() {
     AKeyMap n;
     n.init(cap * 2);
     for (size_t i = 0; i < cap; ++i)
-      if (used[i]) *n.slot(keys[i], nullptr) = vals[i];
+      if (slots[i].used) *n.slot(slots[i].k, nullptr) = slots[i].val;
     *this = std::move(n);
   }
   uint32_t *slot(const AKey &k, bool *inserted) {
     if ((size + 1) * 2 > cap) grow();
     size_t i = mix(k.a ^ mix(k.b)) & (cap - 1);
-    while (used[i]) {
-      if (keys[i] == k) {
+    while (slots[i].used) {
+      if (slots[i].k == k) {
         if (inserted) *inserted = false;
-        return &vals[i];
+        return &slots[i].val;
       }
       i = (i + 1) & (cap - 1);
     }
-    used[i] = 1, keys[i] = k, vals[i] = 0, ++size;
+    slots[i].used = 1, slots[i].k = k, slots[i].val = 0, ++size;
     if (inserted) *inserted = true;
-    return &vals[i];
+    return &slots[i].val;
+  }
+};
+
+// read pair -> dense id, 16-byte slots
+struct PairMap {
+  struct Slot {
+    uint64_t key;   // ~0 = empty (a pair key has min rid in the high half, so ~0 cannot occur)
+    uint32_t pid;
+    uint32_t pad;
+  };
+  std::vector<Slot> slots;
+  size_t size = 0, cap = 0;
+  void init(size_t c) {
+    cap = 1024;
+    while (cap < c) cap <<= 1;
+    slots.assign(cap, Slot{~0ULL, 0, 0});
+    size = 0;
+  }
+  void grow() {
+    PairMap n;
+    n.init(cap * 2);
+    for (size_t i = 0; i < cap; ++i)
+      if (slots[i].key != ~0ULL) {
+        bool f;
+        *n.slot(slots[i].key, &f) = slots[i].pid;
+      }
+    *this = std::move(n);
+  }
+  uint32_t *slot(uint64_t k, bool *fresh) {
+    if ((size + 1) * 2 > cap) grow();
+    size_t i = mix(k) & (cap - 1);
+    while (slots[i].key != ~0ULL) {
+      if (slots[i].key == k) {
+        *fresh = false;
+        return &slots[i].pid;
+      }
+      i = (i + 1) & (cap - 1);
+    }
+    slots[i].key = k, ++size;
+    *fresh = true;
+    return &slots[i].pid;
   }
 };
 
@@ -333,10 +378,14 @@ struct Replay {
   std::vector<pgx_align_key> requests;
   static constexpr uint32_t PENDING_BIT = 0x80000000u;
 
-  U64Map<uint32_t> pair_id;         // read pair -> dense id
-  std::vector<uint8_t> ptype;
-  std::vector<uint32_t> powner;     // owning bucket or NONE
-  std::vector<uint32_t> rhead;      // head of the pair's reader list in rlog
+  PairMap pair_id;                  // read pair -> dense id
+  struct PState {
+    uint32_t owner;                 // owning bucket or NONE
+    uint32_t rhead;                 // head of the pair's reader list in rlog
+    uint32_t type;
+    uint32_t last_reader;           // bucket of the newest reader-list node (avoids touching rlog on the hot path)
+  };
+  std::vector<PState> ps;
   struct RNode {
     uint32_t next, bucket;
   };
@@ -365,8 +414,8 @@ struct Replay {
   uint64_t n_eval = 0;
 
   Replay(const Visit &vv, const std::vector<uint32_t> &rl, uint32_t bn) : v(vv), rlen(rl), bestn(bn) {
-    memo.init(1 << 16);
-    pair_id.reserve_pow2(1 << 16);
+    pair_id.init(std::max<size_t>(1 << 16, v.entries.size()));
+    memo.init(std::max<size_t>(1 << 16, v.entries.size()));
     const size_t nb = v.start.size() - 1;
     bs.assign(nb, BState());
     dirty.assign(nb, 1);
@@ -390,15 +439,16 @@ struct Replay {
   }
 
   uint32_t pid_of(uint64_t pair) {
-    uint32_t *p = pair_id.slot(pair);
-    if (*p == 0) {  // ids are stored +1 so that the map's zero default means "new"
-      ptype.push_back(0), powner.push_back(NONE), rhead.push_back(NONE);
-      *p = (uint32_t)ptype.size();
+    bool fresh;
+    uint32_t *p = pair_id.slot(pair, &fresh);
+    if (fresh) {
+      *p = (uint32_t)ps.size();
+      ps.push_back(PState{NONE, NONE, 0, NONE});
     }
-    return *p - 1;
+    return *p;
   }
   void mark_readers_after(uint32_t pid, uint32_t b) {
-    for (uint32_t n = rhead[pid]; n != NONE; n = rlog[n].next)
+    for (uint32_t n = ps[pid].rhead; n != NONE; n = rlog[n].next)
       if (rlog[n].bucket > b) dirty[rlog[n].bucket] = 1;
   }
 
@@ -409,7 +459,7 @@ struct Replay {
     // withdraw what the previous evaluation of this bucket inserted
     old_own.assign(owned.begin() + st.own0, owned.begin() + st.own0 + st.nown);
     for (const Own &o : old_own)
-      if (powner[o.pid] == b) powner[o.pid] = NONE;
+      if (ps[o.pid].owner == b) ps[o.pid].owner = NONE;
     st.rec0 = (uint32_t)recs.size(), st.nrec = 0, st.own0 = (uint32_t)owned.size(), st.nown = 0;
     st.lookups = st.skips = 0;
     const Entry *e = v.entries.data() + v.start[b];
@@ -426,12 +476,14 @@ struct Replay {
         if (rid0 == rid1) continue;
         const uint64_t pair = rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0);
         const uint32_t pid = pid_of(pair);
-        if (rhead[pid] == NONE || rlog[rhead[pid]].bucket != b) {  // register as a reader (once per evaluation run)
-          rlog.push_back(RNode{rhead[pid], b});
-          rhead[pid] = (uint32_t)rlog.size() - 1;
+        PState &pst = ps[pid];
+        if (pst.last_reader != b) {  // register as a reader (once per evaluation run)
+          rlog.push_back(RNode{pst.rhead, b});
+          pst.rhead = (uint32_t)rlog.size() - 1;
+          pst.last_reader = b;
         }
-        if (powner[pid] != NONE && powner[pid] <= b) {  // present in the table as this bucket sees it
-          if (ptype[pid] == T_OVERLAP) ++got;
+        if (pst.owner != NONE && pst.owner <= b) {  // present in the table as this bucket sees it
+          if (pst.type == T_OVERLAP) ++got;
           ++st.skips;
           continue;
         }
@@ -463,8 +515,9 @@ struct Replay {
           if (vd.type == T_OVERLAP) ++got;
           else if (vd.type == T_CONTAINS) contained[pi] = 1;
           else contained[ai] = 1;
-          if (powner[pid] != NONE && powner[pid] > b) dirty[powner[pid]] = 1;  // a later bucket had inserted it
-          powner[pid] = b, ptype[pid] = vd.type;
+          PState &pw = ps[pid];  // (ps may have been reallocated by pid_of? no: no insertion since `pst`)
+          if (pw.owner != NONE && pw.owner > b) dirty[pw.owner] = 1;  // a later bucket had inserted it
+          pw.owner = b, pw.type = vd.type;
           owned.push_back(Own{pid, vd.type});
           ++st.nown;
           pgx_ovlp o;
@@ -481,7 +534,7 @@ struct Replay {
     // what changed for later buckets?  (skipped while everything behind is dirty anyway: first sweep)
     if (!first_sweep) {
       for (const Own &o : old_own)
-        if (powner[o.pid] != b || ptype[o.pid] != o.type) mark_readers_after(o.pid, b);
+        if (ps[o.pid].owner != b || ps[o.pid].type != o.type) mark_readers_after(o.pid, b);
       for (uint32_t i = 0; i < st.nown; ++i) {
         const Own &o = owned[st.own0 + i];
         bool same = false;

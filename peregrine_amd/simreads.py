@@ -99,6 +99,70 @@ def simulate_reads(genome: np.ndarray, n_reads: int | None = None, coverage: flo
     return SeqDB(seqdb, np.arange(n_reads, dtype=np.uint32), rlen, roff, names)
 
 
+def simulate_reads_torch(genome_len: int, genome_seed: int, coverage: float, seed: int = 42, device: str = "cuda",
+                         mean_len: int = 15000, sd_len: int = 1500, err: float = 0.01, wrap: int = 40000,
+                         batch_reads: int = 2048, min_len: int = 200) -> SeqDB:
+    """The same recipe as simulate_reads, vectorised with torch so that multi-Gbase sets (BASELINE configs[2], 150 Mb x
+    30x) are generated in seconds on the GPU.  Seeded torch generators: deterministic for a given device type, but NOT
+    the same stream as the numpy generator (the E. coli-size bench set stays on the numpy path)."""
+    import torch
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(genome_seed)
+    genome = torch.randint(0, 4, (genome_len,), dtype=torch.uint8, device=dev, generator=gen)
+    wrap = min(wrap, genome_len)
+    ext = torch.cat([genome, genome[:wrap]])
+    L = ext.numel()
+    n_reads = int(coverage * L / mean_len)
+    gen.manual_seed(seed)
+    comp = torch.tensor([3, 2, 1, 0], dtype=torch.uint8, device=dev)
+    chunks, lens = [], []
+    done = 0
+    while done < n_reads:
+        nb = min(batch_reads, n_reads - done)
+        tl = (mean_len + sd_len * torch.randn(nb, device=dev, generator=gen)).to(torch.int64).clamp_(min_len, L)
+        st = (torch.rand(nb, device=dev, generator=gen, dtype=torch.float64) * (L - tl + 1).to(torch.float64)).to(torch.int64)
+        rc = torch.randint(0, 2, (nb,), device=dev, generator=gen).bool()
+        tot = int(tl.sum())
+        seg0 = torch.cumsum(tl, 0) - tl
+        src = torch.repeat_interleave(st - seg0, tl) + torch.arange(tot, device=dev)
+        base = ext[src]
+        hit = torch.rand(tot, device=dev, generator=gen) < err
+        kind = torch.randint(0, 9, (tot,), device=dev, generator=gen, dtype=torch.int8)
+        kind = torch.where(hit, kind, torch.full_like(kind, -1))
+        sub = (kind >= 0) & (kind < 4)
+        base = torch.where(sub, kind.to(torch.uint8), base)
+        emit = torch.ones(tot, dtype=torch.int64, device=dev)
+        emit[kind == 4] = 0
+        ins = kind >= 5
+        emit[ins] = 2
+        cs = torch.cumsum(emit, 0)
+        opos = cs - emit
+        seg_end = seg0 + tl - 1
+        olen = cs[seg_end] - opos[seg0]
+        ototal = int(cs[-1]) if tot else 0
+        raw = torch.empty(ototal, dtype=torch.uint8, device=dev)
+        keep = emit > 0
+        raw[opos[keep]] = base[keep]
+        raw[opos[ins] + 1] = (kind[ins] - 5).to(torch.uint8)
+        oseg0 = torch.cumsum(olen, 0) - olen
+        seg_start = torch.repeat_interleave(oseg0, olen)
+        seg_len = torch.repeat_interleave(olen, olen)
+        idx = torch.arange(ototal, device=dev)
+        mirror = 2 * seg_start + seg_len - 1 - idx
+        rc_rep = torch.repeat_interleave(rc, olen)
+        codes = torch.where(rc_rep, comp[raw[mirror].long()], raw)
+        one = torch.ones_like(codes)
+        enc = torch.bitwise_left_shift(one, codes) | torch.bitwise_left_shift(torch.bitwise_right_shift(one * 8, codes[mirror]), 4)
+        chunks.append(enc.cpu().numpy())
+        lens.append(olen.to(torch.int32).cpu().numpy().astype(np.uint32))
+        done += nb
+    seqdb = np.concatenate(chunks) if chunks else np.zeros(0, np.uint8)
+    rlen = np.concatenate(lens) if lens else np.zeros(0, np.uint32)
+    roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
+    return SeqDB(seqdb, np.arange(len(rlen), dtype=np.uint32), rlen, roff, None)
+
+
 def seqdb_to_fasta(db: SeqDB, path: str) -> None:
     """Write the forward strand of every read as FASTA (for feeding the real shmr_mkseqdb in oracle tests)."""
     lut = np.full(16, ord("N"), np.uint8)
