@@ -1,0 +1,227 @@
+// pgx_align.hip -- banded O(ND) furthest-reaching confirmation (ovlp_match, /root/reference/src/DWmatch.c:66-204),
+// FOUR candidate alignments per wavefront.
+//
+// A candidate keeps on average ~4 diagonals alive (at most band+1 = 101), so one wavefront per candidate leaves most
+// lanes idle.  Here a wavefront is four independent 16-lane groups; each group runs the reference's d-loop for its own
+// candidate, in lock-step with the other three, and pulls the next candidate from a device-wide counter the moment it
+// finishes (persistent groups: no tail inside the wave).  Lane j of a group owns diagonal k = min_k + 2*(base+j) of the
+// current step; wider bands take several rounds of 16.  V lives in a per-group LDS ring indexed by k (only the previous
+// step's values are ever read, so 2*band+8 slots never alias live data; only V[1] needs to start at 0).
+// Per step: start point from V[k-1], V[k+1]; an 8-code probe per lane (off-diagonal fronts stop there); long snakes are
+// extended by the whole group, 128 codes per iteration, with coalesced loads; the order-dependent side results (first
+// diagonal reaching an end, first extension > 16, first occurrence of the strictly longest extension) are resolved
+// lowest-k-first with ballots restricted to the group; band update by ballot of U >= best - band.
+#include "pgx_internal.h"
+
+namespace pgx {
+namespace {
+
+__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t *p) {
+  uint64_t v;
+  __builtin_memcpy(&v, p, 8);
+  return v;
+}
+__device__ __forceinline__ int match8(uint64_t qa, uint64_t ta, int qs, int ts) {
+  const uint64_t diff = ((qa >> qs) ^ (ta >> ts)) & 0x0F0F0F0F0F0F0F0FULL;
+  return diff ? (__builtin_ctzll(diff) >> 3) : 8;
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_max(int v) {
+  return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false));
+}
+// maximum over the 16 lanes of a row, result in every lane: xor-butterfly with quad_perm / row_half_mirror / row_mirror
+__device__ __forceinline__ int row_max_i32(int v) {
+  v = dpp_max<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_max<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_max<0x141>(v);  // row_half_mirror
+  v = dpp_max<0x140>(v);  // row_mirror
+  return v;
+}
+__device__ __forceinline__ uint32_t group_bits(uint64_t wave_mask, int gbase) { return (uint32_t)(wave_mask >> gbase) & 0xFFFFu; }
+
+}  // namespace
+
+__global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
+                                               const uint32_t *__restrict__ rlen,
+                                               const pgx_align_key *__restrict__ keys, uint32_t n, int band, int ring,
+                                               pgx_match *__restrict__ out, uint32_t *__restrict__ counter) {
+  extern __shared__ int32_t Vall[];
+  const int lane = threadIdx.x, gl = lane & 15, gbase = lane & 48;
+  int32_t *V = Vall + (lane >> 4) * ring;
+  const int mask = ring - 1, band_size = band * 2;
+
+  // per-candidate state, uniform within a 16-lane group
+  bool alive = false, exhausted = false;
+  uint32_t a = 0;
+  const uint8_t *q = seq, *t = seq;
+  int q_len = 0, t_len = 0, qs = 0, ts = 0, max_d = 0, d = 0;
+  int best_m = -1, min_k = 0, max_k = 0;
+  uint32_t longest = 0;
+  bool started = false, matched = false;
+  int q_bgn = 0, t_bgn = 0, q_m_end = 0, t_m_end = 0, q_end = 0, t_end = 0;
+
+  for (;;) {
+    // ---- idle groups pull the next candidate ---------------------------------------------------------------
+    if (!alive && !exhausted) {
+      uint32_t na = 0;
+      if (gl == 0) na = atomicAdd(counter, 1u);
+      na = (uint32_t)__shfl((int)na, gbase, 64);
+      if (na >= n) {
+        exhausted = true;
+      } else {
+        a = na;
+        const pgx_align_key key = keys[a];
+        q = seq + roff[key.rid0] + key.q_off;
+        t = seq + roff[key.rid1];
+        q_len = (int)(rlen[key.rid0] - key.q_off);
+        t_len = (int)rlen[key.rid1];
+        qs = key.dir0 ? 4 : 0, ts = key.dir1 ? 4 : 0;
+        max_d = (int)(0.3 * (double)(q_len + t_len));  // DWmatch.c:96, one IEEE double multiply
+        d = 0, best_m = -1, min_k = 0, max_k = 0, longest = 0;
+        started = matched = false;
+        q_bgn = t_bgn = q_m_end = t_m_end = q_end = t_end = 0;
+        if (gl == 0) V[1 & mask] = 0;  // the only slot read before it is written (d = 0 reads V[k+1] = V[1])
+        alive = true;
+      }
+    }
+    if (!__ballot(alive)) break;
+    __syncthreads();
+
+    // ---- end of the d-loop without a match (DWmatch.c:118-122,196-199) ---------------------------------------
+    bool stepping = alive;
+    if (alive && (d >= max_d || max_k - min_k > band_size)) {
+      if (gl == 0) {
+        pgx_match r;
+        r.m_size = 0, r.dist = 0, r.q_bgn = 0, r.q_end = 0, r.t_bgn = 0, r.t_end = 0;
+        r.t_m_end = t_m_end, r.q_m_end = q_m_end;
+        out[a] = r;
+      }
+      alive = false, stepping = false;
+    }
+
+    // ---- one step: all diagonals of the current band, 16 per round -------------------------------------------
+    const int nk = max_k >= min_k ? ((max_k - min_k) >> 1) + 1 : 0;
+    int x = 0, y = 0;
+    for (int base = 0;; base += 16) {
+      const bool inround = stepping && !matched && base < nk;
+      if (!__ballot(inround)) break;
+      const int j = base + gl;
+      const bool active = inround && j < nk;
+      const int k = min_k + 2 * j;
+      int x1 = 0, y1 = 0;
+      bool more = false;
+      if (inround) x = 0, y = 0;
+      if (active) {
+        const int va = V[(k - 1) & mask], vb = V[(k + 1) & mask];
+        x = (k == min_k || (k != max_k && va < vb)) ? vb : va + 1;
+        y = x - k;
+        x1 = x, y1 = y;
+        const int rem = min(q_len - x, t_len - y);
+        if (rem > 0) {  // probe: the first 8 codes
+          int m = match8(load_u64_unaligned(q + x), load_u64_unaligned(t + y), qs, ts);
+          m = min(m, rem);
+          x += m, y += m;
+          more = (m == 8) && (rem > 8);
+        }
+      }
+      // long snakes: the group extends one diagonal at a time, 128 codes per iteration
+      uint64_t mw = __ballot(more);
+      while (mw) {
+        const uint32_t gm = group_bits(mw, gbase);
+        const bool has = gm != 0;
+        const int L = has ? __builtin_ctz(gm) : 0;
+        const int xs = __shfl(x, gbase + L, 64), ys = __shfl(y, gbase + L, 64);
+        const int rem = min(q_len - xs, t_len - ys);
+        const int off = gl * 8;
+        int m = 8;
+        if (has) {
+          m = 0;
+          if (off < rem) m = min(match8(load_u64_unaligned(q + xs + off), load_u64_unaligned(t + ys + off), qs, ts), rem - off);
+        }
+        const uint32_t sg = group_bits(__ballot(has && m < 8), gbase);
+        int ext = 128;
+        if (sg) {
+          const int f = __builtin_ctz(sg);
+          ext = 8 * f + __shfl(m, gbase + f, 64);
+        }
+        if (has && gl == L) {
+          x += ext, y += ext;
+          if (sg || ext >= rem) more = false;  // mismatch found or an end reached: this diagonal is done
+        }
+        mw = __ballot(more);
+      }
+      const int ext = x - x1;
+      const bool hit = active && (x >= q_len || y >= t_len);
+      const uint32_t hitm = group_bits(__ballot(hit), gbase);
+      const int hl = hitm ? __builtin_ctz(hitm) : 16;
+      const bool valid = active && gl <= hl;
+      {  // first extension > 16 fixes q_bgn/t_bgn once (DWmatch.c:142-146)
+        const uint32_t m = group_bits(__ballot(valid && ext > 16 && !started), gbase);
+        const int l = m ? __builtin_ctz(m) : 0;
+        const int bx = __shfl(x1, gbase + l, 64), by = __shfl(y1, gbase + l, 64);
+        if (m) q_bgn = bx, t_bgn = by, started = true;
+      }
+      if (__ballot(valid && (uint32_t)ext > longest)) {  // strictly longer extension (DWmatch.c:148-152)
+        const int mx = row_max_i32(valid ? ext : -1);
+        const uint32_t m = group_bits(__ballot(valid && ext == mx), gbase);
+        const int l = m ? __builtin_ctz(m) : 0;
+        const int ex = __shfl(x, gbase + l, 64), ey = __shfl(y, gbase + l, 64);
+        if (inround && mx >= 0 && (uint32_t)mx > longest) longest = (uint32_t)mx, q_m_end = ex, t_m_end = ey;
+      }
+      if (valid) V[k & mask] = x;
+      {
+        const int s = row_max_i32(valid ? x + y : -1);
+        if (inround) best_m = max(best_m, s);
+      }
+      {
+        const int ex = __shfl(x, gbase + (hl & 15), 64), ey = __shfl(y, gbase + (hl & 15), 64);
+        if (inround && hitm) matched = true, q_end = ex, t_end = ey;
+      }
+    }
+    __syncthreads();
+
+    if (stepping && matched) {  // DWmatch.c:185-194
+      if (gl == 0) {
+        pgx_match r;
+        r.q_bgn = q_bgn, r.t_bgn = t_bgn, r.q_end = q_end, r.t_end = t_end, r.dist = d;
+        r.m_size = (q_end - q_bgn + t_end - t_bgn + 2 * d) / 2;
+        r.t_m_end = t_m_end, r.q_m_end = q_m_end;
+        out[a] = r;
+      }
+      alive = false, stepping = false;
+    }
+    // ---- band update (DWmatch.c:166-183) -------------------------------------------------------------------------
+    int new_min = max_k, new_max = min_k;
+    const int thr = best_m - band;
+    for (int base = 0;; base += 16) {
+      const bool inround = stepping && base < nk;
+      if (!__ballot(inround)) break;
+      const int j = base + gl;
+      const int k2 = min_k + 2 * j;
+      int u = 0;
+      if (inround && j < nk) u = (nk <= 16) ? x + y : 2 * V[k2 & mask] - k2;
+      const uint32_t m = group_bits(__ballot(inround && j < nk && u >= thr), gbase);
+      if (m) {
+        new_min = min(new_min, min_k + 2 * (base + __builtin_ctz(m)));
+        new_max = max(new_max, min_k + 2 * (base + 31 - __builtin_clz(m)));
+      }
+    }
+    if (stepping) max_k = new_max + 1, min_k = new_min - 1, ++d;
+  }
+}
+
+void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out) {
+  if (n == 0) return;
+  KernelTimer tm("align", n);
+  int ring = 64;
+  while (ring < 2 * band + 8) ring <<= 1;
+  uint32_t *counter = ws<uint32_t>("align.counter", 1);
+  PGX_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), ctx().stream));
+  const size_t want = (n + 3) / 4;
+  const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * 32);
+  hipLaunchKernelGGL(k_align4, dim3(grid), dim3(64), 4 * ring * sizeof(int32_t), ctx().stream, db->d_seq.p, db->d_roff.p,
+                     db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter);
+  PGX_HIP(hipGetLastError());
+}
+
+}  // namespace pgx
