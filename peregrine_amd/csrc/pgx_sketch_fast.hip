@@ -29,7 +29,7 @@ namespace pgx {
 namespace {
 constexpr int W = 80, K = 16;
 constexpr int CH = 16;    // entries per chunk
-constexpr int CST = 20;   // dwords per chunk in LDS (16 + 4 pad)
+constexpr int CST = 20;   // dwords per chunk in LDS (16 + 4 pad: conflict-free ds_read_b128; unpadded measured 1.5x slower)
 constexpr int NB = 80;    // chunks in the buffer: <= 7 carried + 65 new + 6 zero pad (+ slack)
 constexpr int TILE = 1024;
 constexpr uint32_t INF = 0xFFFFFFFFu;
@@ -95,36 +95,45 @@ template <bool EDGE>
 __device__ __forceinline__ int phase_a_steps(Lds &s, int lane, int t, int lead, int len, int ebuf /* E - 16*qbase */) {
   const int o16 = lane & 15, g = lane >> 4;
   const int shF = 2 * (15 - o16), shR = (2 * (o16 + 1)) & 31;
+  const bool last16 = o16 == 15;
   const uint32_t *pf = &s.F[g], *pr = &s.R[g];
   int run = 0;  // entries appended so far in this tile (wave uniform)
   const int ibase = t * TILE + lane - lead;
-  const int lbase = ebuf + lane;
+  // while every step so far appended all 64 lanes, lane l's slot advances by exactly 4 chunks per step
+  int ad = chunk_addr(ebuf + lane);
+  int adH = ad * 4, adP = ad * 2;  // byte offsets into H (dwords) and P (halfwords)
+  uint32_t pz2 = ((uint32_t)ibase & 0x7FFFu) << 1;  // (position mod 2^15) << 1; the 16-bit store truncates the carry
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const uint32_t F0 = pf[4 * j], F1 = pf[4 * j + 1];
     const uint32_t R0 = pr[4 * j], R1 = pr[4 * j + 1];
     const uint32_t fw = __builtin_amdgcn_alignbit(F0, F1, shF);
     const uint32_t ra = __builtin_amdgcn_alignbit(R1, R0, shR);
-    const uint32_t rv = o16 == 15 ? R1 : ra;
-    const int i = ibase + 64 * j;
+    const uint32_t rv = last16 ? R1 : ra;
     bool valid = fw != rv;  // strand-ambiguous k-mers are not entries
-    if (EDGE) valid = valid && i >= K - 1 && i < len;
+    if (EDGE) {
+      const int i = ibase + 64 * j;
+      valid = valid && i >= K - 1 && i < len;
+    }
     const uint64_t vm = __ballot(valid);
     const uint32_t hh = mix32(min(fw, rv));
-    const uint32_t pz = (((uint32_t)i & 0x7FFFu) << 1) | (fw > rv ? 1u : 0u);
+    const uint32_t pz = pz2 + (fw > rv ? 1u : 0u);
+    pz2 += 128;
     if (vm == ~0ull) {  // nothing dropped: lane-linear address
-      const int ad = chunk_addr(lbase + run);
-      s.H[ad] = hh;
-      s.P[ad] = (uint16_t)pz;
+      *reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(s.H) + adH) = hh;
+      *reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(s.P) + adP) = (uint16_t)pz;
       run += 64;
+      adH += 4 * CST * 4, adP += 4 * CST * 2;
     } else {
       if (valid) {
         const int idx = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(vm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)vm, 0u));
-        const int ad = chunk_addr(ebuf + run + idx);
-        s.H[ad] = hh;
-        s.P[ad] = (uint16_t)pz;
+        const int ax = chunk_addr(ebuf + run + idx);
+        s.H[ax] = hh;
+        s.P[ax] = (uint16_t)pz;
       }
       run += __builtin_popcountll(vm);
+      ad = chunk_addr(ebuf + run + lane);
+      adH = ad * 4, adP = ad * 2;
     }
   }
   return run;
@@ -210,6 +219,8 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
   uint32_t bad = 0;
   uint32_t Fkeep = 0, Rkeep = 0;  // this lane's packs of the previous tile (lane 63's become block -1)
 
+  uint4 raw_next = make_uint4(0, 0, 0, 0);
+  if (lane * 16 < span) raw_next = *reinterpret_cast<const uint4 *>(base + lane * 16);
   for (int t = 0; t < ntiles; ++t) {
     // ---- compaction: move the live chunks [ddone, ceil(E/16)) to the front of the buffer -----------------------
     if (ddone > qbase) {
@@ -237,8 +248,9 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
     // ---- phase A: load, decode, pack ------------------------------------------------------------------------
     const int b0 = t * TILE + lane * 16;  // byte offset from `base` of this lane's 16-base block
     const int i0 = b0 - lead;             // read position of the block's first base
-    uint4 raw = make_uint4(0, 0, 0, 0);
-    if (b0 < span) raw = *reinterpret_cast<const uint4 *>(base + b0);
+    const uint4 raw = raw_next;           // loaded one tile ahead: the HBM latency hides behind the previous tile
+    raw_next = make_uint4(0, 0, 0, 0);
+    if (b0 + TILE < span) raw_next = *reinterpret_cast<const uint4 *>(base + b0 + TILE);
     const uint32_t dw[4] = {raw.x, raw.y, raw.z, raw.w};
     uint32_t F = 0;
     const bool inside = i0 >= 0 && i0 + 16 <= len;
@@ -312,13 +324,15 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
         sm[15] = wq[15];
 #pragma unroll
         for (int o = 14; o >= 0; --o) sm[o] = max(sm[o + 1], wq[o]);
-        uint32_t pm = 0;
+        uint32_t pm = 0, rmask = 0;  // rmask collects the decisions MSB-first (bit 15-o ... reversed below)
 #pragma unroll
         for (int o = 0; o < 16; ++o) {
           const uint32_t f = max(max(sm[o], m4), pm);  // pm = prefix max of chunk q+5 up to o-1
           pm = max(pm, wn[o]);
-          if (f >= v[o]) emask |= 1u << o;
+          // rmask = (rmask << 1) | (f >= v[o])   as v_cmp + v_addc
+          asm("v_cmp_ge_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rmask) : "v"(f), "v"(v[o]) : "vcc");
         }
+        emask = __builtin_bitreverse32(rmask) >> 16;
         if (last) {  // entries past the end are padding
           const int nvalid = E - q * CH;
           if (nvalid < 16) emask &= (1u << (nvalid < 0 ? 0 : nvalid)) - 1u;
