@@ -267,6 +267,9 @@ void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_cou
 bool sketch_wave_eligible(const ReadDesc &rd, int w, int k);  // pgx_sketch_fast.hip
 void launch_sketch_wave(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n_list, int w,
                         int k, pgx_mm128 *d_slab, const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags);
+bool sketch_fused_supported(int rs, int levels);
+void launch_sketch_fused(const pgx_seqdb *db, const ReadDesc *d_reads, uint32_t n, int rs, int levels, pgx_mm128 *d_slab,
+                         const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags);
 
 __global__ void k_gather_slabs(const pgx_mm128 *__restrict__ slab, const uint64_t *__restrict__ slab_off,
                                const uint32_t *__restrict__ list, uint32_t n_list, const uint32_t *__restrict__ counts,
@@ -443,6 +446,11 @@ __global__ __launch_bounds__(64) void k_reduce_read(pgx_mm128 *__restrict__ slab
   if (lane == 0) counts_top[slot] = (uint32_t)ncur;
 }
 
+__global__ void k_count_flags(const uint32_t *__restrict__ flags, uint32_t n, uint32_t *__restrict__ nbad) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flags[i]) atomicAdd(nbad, 1u);
+}
+
 bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, int rs, int levels,
                      const pgx_mm128 **d_top, size_t *n_top) {
   const uint32_t n = (uint32_t)reads.size();
@@ -464,11 +472,18 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
   PGX_HIP(hipMemcpyAsync(d_reads, reads.data(), n * sizeof(ReadDesc), hipMemcpyHostToDevice, st));
   PGX_HIP(hipMemcpyAsync(d_slab_off, slab_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
   PGX_HIP(hipMemsetAsync(d_cnt, 0, (3 * (size_t)n + 4) * sizeof(uint32_t), st));
-  {
+  // PGX_FUSE=1: one kernel (sketch + streaming reduce), HBM traffic == the algorithmic 1.04 B/base, measured 9 % slower
+  // than sketch + k_reduce_read because of the extra LDS (8 instead of 9 waves per CU); default: two kernels.
+  static const bool want_fuse = getenv("PGX_FUSE") && atoi(getenv("PGX_FUSE")) != 0;
+  if (want_fuse && sketch_fused_supported(rs, levels)) {
     KernelTimer tm("sketch", bases);
-    launch_sketch_wave(db, d_reads, nullptr, n, w, k, slab, d_slab_off, d_cnt, d_flags);
-  }
-  {
+    launch_sketch_fused(db, d_reads, n, rs, levels, slab, d_slab_off, d_ctop, d_flags);
+    hipLaunchKernelGGL(k_count_flags, dim3(cdiv(n, 256)), dim3(256), 0, st, d_flags, n, d_nbad);
+  } else {
+    {
+      KernelTimer tm("sketch", bases);
+      launch_sketch_wave(db, d_reads, nullptr, n, w, k, slab, d_slab_off, d_cnt, d_flags);
+    }
     KernelTimer tm("reduce", bases);
     hipLaunchKernelGGL(k_reduce_read, dim3(n), dim3(64), 0, st, slab, d_slab_off, d_reads, d_cnt, d_flags, n, rs, levels,
                        d_ctop, d_nbad);

@@ -85,8 +85,66 @@ struct Lds {
   uint16_t P[NB * CST];   // (lastPos & 0x7fff) << 1 | strand
   uint32_t C[NB];         // per chunk: min hash
   uint32_t M[NB];         // per chunk: max of Wm
-  uint32_t F[68], R[68];  // 2-bit packs of the tile's 16-base blocks; [0] = last block of the previous tile
+  uint32_t F[66], R[66];  // 2-bit packs of the tile's 16-base blocks; [0] = last block of the previous tile
 };
+
+// Streaming mm_reduce (src/shmr_reduce.c:53-90) of one read, fused behind the sketch: level 0 consumes the emitted L0
+// minimizers, level 1 consumes level 0's output.  Each level keeps the last rs-1 elements ("carry") in front of the newly
+// staged ones; hash = x>>8 (32 bits at k = 16), y = low word of mm128.y (position<<1 | strand).
+constexpr int RCARRY = 16, RSTAGE = 128, RBUF = RCARRY + RSTAGE;
+struct RedLds {
+  uint32_t h[2][RBUF];
+  uint32_t y[2][RBUF];
+};
+struct RedState {
+  int ncarry, nnew;   // elements in the buffer: [0, ncarry) carry, [ncarry, ncarry+nnew) staged
+  int cnt;            // elements of this read consumed before the staged ones (offset of the first staged element)
+  uint32_t lastw;     // y of the previous window's winner
+};
+
+// Process every staged element of level `lv`; winners go to `sink(hash, y)` in order.  rs <= RCARRY + 1.
+template <typename Sink>
+__device__ __forceinline__ void reduce_flush(RedLds &r, RedState &st, int lv, int rs, int lane, Sink sink) {
+  uint32_t *H = r.h[lv], *Y = r.y[lv];
+  for (int base = 0; base < st.nnew; base += 64) {
+    const int tl = base + lane;             // index among the staged elements
+    const int gidx = st.cnt + tl;            // offset of the element within the read's list
+    const bool valid = tl < st.nnew && gidx >= rs - 1;
+    uint32_t bh = 0, by = 0;
+    if (valid) {
+      int p = st.ncarry + tl - (rs - 1);     // buffer position of the window's first element (>= 0 by construction)
+      int sl = (gidx + 1) % rs;              // its ring slot: (gidx - rs + 1) % rs
+      bh = H[p], by = Y[p];
+      int bsl = sl;
+      for (int j = 1; j < rs; ++j) {
+        ++p;
+        if (++sl == rs) sl = 0;
+        const uint32_t hh = H[p];
+        if (hh < bh || (hh == bh && sl < bsl)) bh = hh, by = Y[p], bsl = sl;  // ties -> lowest slot index
+      }
+    }
+    uint32_t prevy = (uint32_t)__shfl_up((int)by, 1, 64);
+    if (lane == 0) prevy = st.lastw;
+    const bool emit = valid && (gidx == rs - 1 || by != prevy);
+    const uint64_t vm = __ballot(valid);
+    if (vm) st.lastw = (uint32_t)__builtin_amdgcn_readlane((int)by, 63 - __builtin_clzll(vm));
+    const uint64_t em = __ballot(emit);
+    const int idx = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+    sink(emit, idx, __builtin_popcountll(em), bh, by);
+  }
+  __syncthreads();
+  // new carry = the last min(rs-1, total) elements
+  const int total = st.ncarry + st.nnew;
+  const int keep = total < rs - 1 ? total : rs - 1;
+  uint32_t th = 0, ty = 0;
+  if (lane < keep) th = H[total - keep + lane], ty = Y[total - keep + lane];
+  __syncthreads();
+  if (lane < keep) H[lane] = th, Y[lane] = ty;
+  st.cnt += st.nnew;
+  st.ncarry = keep;
+  st.nnew = 0;
+  __syncthreads();
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // phase A step loop.  EDGE = the tile touches the first k-1 bases or the end of the read.
@@ -194,11 +252,17 @@ __device__ __forceinline__ void phase_b1(Lds &s, int lane, int q, int bq, bool a
 
 }  // namespace
 
+// FUSED = false: the read's L0 minimizers go to its slab.  FUSED = true: they are reduced `levels` times on the fly
+// (reduce_flush) and only the final level reaches the slab -- L0 never leaves the CU.
+template <bool FUSED>
 __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ seq, const ReadDesc *__restrict__ reads,
                                                     const uint32_t *__restrict__ list, uint32_t n_list,
                                                     pgx_mm128 *__restrict__ slab, const uint64_t *__restrict__ slab_off,
-                                                    uint32_t *__restrict__ counts, uint32_t *__restrict__ flags) {
+                                                    uint32_t *__restrict__ counts, uint32_t *__restrict__ flags, int rs,
+                                                    int levels) {
   __shared__ __attribute__((aligned(16))) Lds s;
+  __shared__ RedLds red;
+  RedState rst[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   const int lane = threadIdx.x;
   if (blockIdx.x >= n_list) return;
   const uint32_t slot = list ? list[blockIdx.x] : blockIdx.x;
@@ -219,6 +283,29 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
   uint32_t bad = 0;
   uint32_t Fkeep = 0, Rkeep = 0;  // this lane's packs of the previous tile (lane 63's become block -1)
 
+  // fused mode: push the staged L0 minimizers through level 0 (and level 1); final-level elements go to the slab
+  auto fused_flush = [&]() {
+    const uint64_t yhi = (uint64_t)rd.rid << 32;
+    auto to_slab = [&](bool emit, int idx, int tot, uint32_t hh, uint32_t yy) {
+      if (nout + (uint32_t)tot <= cap) {
+        if (emit) out[nout + (uint32_t)idx] = pgx_mm128{((uint64_t)hh << 8) | (uint64_t)K, yhi | yy};
+      } else {
+        bad |= 1;
+      }
+      nout += (uint32_t)tot;
+    };
+    if (levels == 1) {
+      reduce_flush(red, rst[0], 0, rs, lane, to_slab);
+    } else {
+      auto to_l1 = [&](bool emit, int idx, int tot, uint32_t hh, uint32_t yy) {
+        const int w = rst[1].ncarry + rst[1].nnew + idx;  // level-0 flushes stage at most RSTAGE elements: fits
+        if (emit) red.h[1][w] = hh, red.y[1][w] = yy;
+        rst[1].nnew += tot;
+      };
+      reduce_flush(red, rst[0], 0, rs, lane, to_l1);
+      reduce_flush(red, rst[1], 1, rs, lane, to_slab);
+    }
+  };
   uint4 raw_next = make_uint4(0, 0, 0, 0);
   if (lane * 16 < span) raw_next = *reinterpret_cast<const uint4 *>(base + lane * 16);
   for (int t = 0; t < ntiles; ++t) {
@@ -365,30 +452,53 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
       if (__ballot(ec != 0)) {
         const int einc = wave_incl_scan(ec, lane);
         const int etot = __shfl(einc, 63, 64);
-        uint32_t w = nout + (uint32_t)(einc - ec);
-        if (nout + (uint32_t)etot <= cap) {
-          // positions were stored modulo 2^15; the newest base seen so far bounds them from above
-          const int imax = (t + 1) * TILE - lead - 1;
-          uint32_t em = emask;
-          while (em) {
-            const int o = __builtin_ctz(em);
-            em &= em - 1;
-            const uint32_t pz = s.P[bq * CST + o];
-            const int i = imax - ((imax - (int)(pz >> 1)) & 0x7FFF);
-            pgx_mm128 e;
-            e.x = ((uint64_t)s.H[bq * CST + o] << 8) | (uint64_t)K;
-            e.y = ((uint64_t)rd.rid << 32) | ((uint64_t)(uint32_t)i << 1) | (uint64_t)(pz & 1u);
-            out[w++] = e;
+        // positions were stored modulo 2^15; the newest base seen so far bounds them from above
+        const int imax = (t + 1) * TILE - lead - 1;
+        if (!FUSED) {
+          uint32_t w = nout + (uint32_t)(einc - ec);
+          if (nout + (uint32_t)etot <= cap) {
+            uint32_t em = emask;
+            while (em) {
+              const int o = __builtin_ctz(em);
+              em &= em - 1;
+              const uint32_t pz = s.P[bq * CST + o];
+              const int i = imax - ((imax - (int)(pz >> 1)) & 0x7FFF);
+              pgx_mm128 e;
+              e.x = ((uint64_t)s.H[bq * CST + o] << 8) | (uint64_t)K;
+              e.y = ((uint64_t)rd.rid << 32) | ((uint64_t)(uint32_t)i << 1) | (uint64_t)(pz & 1u);
+              out[w++] = e;
+            }
+          } else {
+            bad |= 1;  // slab overflow: the literal kernel redoes this read
           }
+          nout += (uint32_t)etot;
         } else {
-          bad |= 1;  // slab overflow: the literal kernel redoes this read
+          if (etot > RSTAGE) {
+            bad |= 1;  // a burst of ties (low-complexity read): the general path redoes this read
+          } else {
+            if (rst[0].nnew + etot > RSTAGE) fused_flush();
+            int w = rst[0].ncarry + rst[0].nnew + (einc - ec);
+            uint32_t em = emask;
+            while (em) {
+              const int o = __builtin_ctz(em);
+              em &= em - 1;
+              const uint32_t pz = s.P[bq * CST + o];
+              const int i = imax - ((imax - (int)(pz >> 1)) & 0x7FFF);
+              red.h[0][w] = s.H[bq * CST + o];
+              red.y[0][w] = ((uint32_t)i << 1) | (pz & 1u);
+              ++w;
+            }
+            rst[0].nnew += etot;
+            __syncthreads();
+            if (rst[0].nnew >= 96) fused_flush();  // a flush costs ~300 wave instructions: amortise it over ~4 tiles
+          }
         }
-        nout += (uint32_t)etot;
       }
     }
     ddone = dlimit;
     __syncthreads();
   }
+  if (FUSED) fused_flush();
   const uint64_t anybad = __ballot(bad != 0);
   if (lane == 0) {
     counts[slot] = anybad ? 0u : nout;
@@ -403,8 +513,18 @@ void launch_sketch_wave(const pgx_seqdb *db, const ReadDesc *d_reads, const uint
                         int k, pgx_mm128 *d_slab, const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags) {
   (void)w, (void)k;
   if (!n_list) return;
-  hipLaunchKernelGGL(k_sketch_wave, dim3(n_list), dim3(64), 0, ctx().stream, db->d_seq.p, d_reads, d_list, n_list, d_slab,
-                     d_slab_off, d_counts, d_flags);
+  hipLaunchKernelGGL(k_sketch_wave<false>, dim3(n_list), dim3(64), 0, ctx().stream, db->d_seq.p, d_reads, d_list, n_list,
+                     d_slab, d_slab_off, d_counts, d_flags, 0, 0);
+  PGX_HIP(hipGetLastError());
+}
+
+// fused sketch + reduce x levels; requires rs <= RCARRY + 1 and levels in {1, 2}
+bool sketch_fused_supported(int rs, int levels) { return rs >= 1 && rs <= RCARRY + 1 && (levels == 1 || levels == 2); }
+void launch_sketch_fused(const pgx_seqdb *db, const ReadDesc *d_reads, uint32_t n, int rs, int levels, pgx_mm128 *d_slab,
+                         const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_sketch_wave<true>, dim3(n), dim3(64), 0, ctx().stream, db->d_seq.p, d_reads, (const uint32_t *)nullptr,
+                     n, d_slab, d_slab_off, d_counts, d_flags, rs, levels);
   PGX_HIP(hipGetLastError());
 }
 
