@@ -56,7 +56,7 @@ const char *pgx_version(void);
 void pgx_free(void *p);              /* releases any host array returned by this library */
 
 /* per-kernel device time (HIP events on the library's stream), accumulated since the last reset.
- * names: "sketch", "sketch_literal", "reduce", "count", "pairs", "align". */
+ * names: "sketch", "sketch_literal", "sketch_gather", "reduce", "count", "pairs", "align", "encode". */
 int pgx_timing_get(const char *kernel, double *total_ms, uint64_t *launches, uint64_t *units);
 void pgx_timing_reset(void);
 
@@ -95,6 +95,11 @@ void pgx_index_result_free(pgx_index_result *r);
 /* file level: same flags, same output file names/bytes as shmr_index (MC files: same (mer,count) multiset) */
 int pgx_index_chunk(const char *seqdb_prefix, const char *out_prefix, const pgx_index_params *p,
                     pgx_index_result *stats /* nullable; arrays are not returned */);
+
+/* ---- sequence database (replaces shmr_mkseqdb, src/shmr_mkseqdb.c:99-121) ----
+ * seq_dataset_path: text file with one FASTA/FASTQ(.gz) path per whitespace-separated token; writes <prefix>.seqdb and
+ * <prefix>.idx byte-identical to the reference's.  The two-strand encoding runs on the GPU. */
+int pgx_mkseqdb(const char *seq_dataset_path, const char *seqdb_prefix, uint64_t *n_reads, uint64_t *n_bases);
 
 /* ---- overlap stage (replaces shmr_overlap) ---- */
 typedef struct {

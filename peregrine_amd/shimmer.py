@@ -135,3 +135,12 @@ def shmr_overlap(seqdb_prefix: str, shimmer_prefix: str, out_path: str | None = 
     _lib.check(_lib.load().pgx_overlap_chunk(seqdb_prefix.encode(), shimmer_prefix.encode(), out_path.encode(),
                                              C.byref(p), C.byref(st)), "pgx_overlap_chunk")
     return st.asdict()
+
+
+def shmr_mkseqdb(seq_dataset_path: str = "seq_dataset.lst", seqdb_prefix: str = "seq_dataset", device=None) -> dict:
+    """shmr_mkseqdb -d -p   (defaults of src/shmr_mkseqdb.c:61-69): FASTA/FASTQ(.gz) list -> <prefix>.seqdb + <prefix>.idx."""
+    _lib.init(device)
+    nr, nb = C.c_uint64(0), C.c_uint64(0)
+    _lib.check(_lib.load().pgx_mkseqdb(seq_dataset_path.encode(), seqdb_prefix.encode(), C.byref(nr), C.byref(nb)),
+               "pgx_mkseqdb")
+    return dict(reads=int(nr.value), bases=int(nb.value))

@@ -194,3 +194,27 @@ def test_edge_cases(lib):
     with pytest.raises(_lib.PgxError):
         rdb.index(total_chunk=2, mychunk=3)
     rdb.close()
+
+
+def test_mkseqdb_matches_reference(tmp_path):
+    """row f1: FASTA / FASTQ / gz / CRLF / multi-line inputs -> seqdb + idx, byte-identical to the reference binary"""
+    from peregrine_amd.shimmer import shmr_mkseqdb
+    z = G.load("mkseqdb_cases.npz")
+    paths = []
+    for k in z["order"]:
+        p = tmp_path / str(k)
+        p.write_bytes(z["file_" + str(k)].tobytes())
+        paths.append(str(p))
+    (tmp_path / "seq.lst").write_text("\n".join(paths) + "\n")
+    st = shmr_mkseqdb(str(tmp_path / "seq.lst"), str(tmp_path / "out"))
+    assert (tmp_path / "out.seqdb").read_bytes() == z["seqdb"].tobytes()
+    assert (tmp_path / "out.idx").read_bytes() == z["idx"].tobytes()
+    assert st["bases"] == len(z["seqdb"])
+    # and a simulated read set round-trips: FASTA -> seqdb equals the simulator's own encoding
+    db = simreads.make_workload("tiny")
+    simreads.seqdb_to_fasta(db, str(tmp_path / "reads.fa"))
+    (tmp_path / "r.lst").write_text(str(tmp_path / "reads.fa") + "\n")
+    shmr_mkseqdb(str(tmp_path / "r.lst"), str(tmp_path / "sd"))
+    assert np.array_equal(np.fromfile(tmp_path / "sd.seqdb", np.uint8), db.seqdb)
+    with pytest.raises(_lib.PgxError):
+        shmr_mkseqdb(str(tmp_path / "missing.lst"), str(tmp_path / "x"))
