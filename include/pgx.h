@@ -56,7 +56,7 @@ const char *pgx_version(void);
 void pgx_free(void *p);              /* releases any host array returned by this library */
 
 /* per-kernel device time (HIP events on the library's stream), accumulated since the last reset.
- * names: "sketch", "sketch_literal", "sketch_gather", "reduce", "count", "pairs", "align", "encode". */
+ * names: "sketch", "sketch_literal", "sketch_gather", "reduce", "count", "pairs", "align", "encode", "dedup". */
 int pgx_timing_get(const char *kernel, double *total_ms, uint64_t *launches, uint64_t *units);
 void pgx_timing_reset(void);
 
@@ -129,6 +129,11 @@ int pgx_overlap_resident(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, con
 /* file level: globs <shimmer_prefix>-[0-9]*-of-[0-9]*.dat and -MC- twins like shmr_overlap.c:355-384 */
 int pgx_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, const char *out_path,
                       const pgx_overlap_params *p, pgx_overlap_stats *stats);
+
+/* ---- dedup (replaces shmr_dedup, src/shmr_dedup.c:32-101) ----
+ * recs: the concatenated ovlp_t streams (cat ovlp*.dat).  The first record of every read pair wins; *text receives the
+ * FALCON-style overlap lines (malloc'd, release with pgx_free), byte-identical to the reference's stdout. */
+int pgx_dedup(const pgx_ovlp *recs, size_t n, char **text, size_t *text_len, uint64_t *n_unique);
 
 /* ---- batch level ---- */
 int pgx_sketch_batch(pgx_seqdb *db, const uint32_t *read_slots, uint32_t n, int w, int k, pgx_mm128 **out,

@@ -735,3 +735,53 @@ int orc_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, cons
   free(out.a), free(mm.a), free(mc.a), free(rlen), free(roff), free(db), idx_free(&ix);
   return rc;
 }
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* row f2 -- src/shmr_dedup.c:32-101 (on a non-empty stream; the reference's feof loop re-reads the last   */
+/* record once, which the pair table then drops)                                                           */
+/* ------------------------------------------------------------------------------------------------------ */
+char *orc_dedup(const orc_ovlp_t *recs, size_t n, size_t *text_len, uint64_t *n_unique) {
+  otab_t seen = {0};
+  size_t cap = 1 << 16, len = 0;
+  char *out = (char *)malloc(cap);
+  uint64_t uniq = 0;
+  int absent;
+  for (size_t i = 0; i < n; ++i) {
+    const orc_ovlp_t *o = &recs[i];
+    const uint32_t rid0 = (uint32_t)(o->y0 >> 32), rid1 = (uint32_t)(o->y1 >> 32);
+    const uint64_t pair = rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0);
+    uint64_t dummy;
+    if (otab_get(&seen, pair, &dummy)) continue; /* :41-42 */
+    const uint32_t pos0 = pos_of(o->y0) + 1, pos1 = pos_of(o->y1) + 1, rlen0 = o->rl0, rlen1 = o->rl1;
+    int32_t q_bgn = o->match.q_bgn, q_end = o->match.q_end, t_bgn = o->match.t_bgn, t_end = o->match.t_end;
+    uint32_t a_bgn, a_end, b_bgn, b_end;
+    q_bgn -= t_bgn; /* :62-63 */
+    t_bgn = 0;
+    if (o->strand0 == 0) { /* :64-69 -- the variables are uint32_t in the reference: "< 0" never fires */
+      a_bgn = (uint32_t)((int32_t)(pos0 - pos1) + q_bgn);
+      a_end = (uint32_t)((int32_t)(pos0 - pos1) + q_end);
+    } else { /* :70-77 */
+      a_bgn = (uint32_t)((int32_t)rlen0 - (int32_t)(pos0 - pos1) - q_end);
+      a_end = (uint32_t)((int32_t)rlen0 - (int32_t)(pos0 - pos1) - q_bgn);
+    }
+    a_end = a_end >= rlen0 ? rlen0 : a_end;
+    if (o->strand1 == 0) { /* :78-82 */
+      b_bgn = (uint32_t)t_bgn, b_end = (uint32_t)t_end;
+    } else { /* :83-88 */
+      b_bgn = (uint32_t)((int32_t)rlen1 - t_end), b_end = (uint32_t)((int32_t)rlen1 - t_bgn);
+    }
+    b_end = b_end >= rlen1 ? rlen1 : b_end;
+    const double err_est = 100.0 - 100.0 * (double)o->match.dist / (double)o->match.m_size; /* :89-90 */
+    if (len + 256 > cap) out = (char *)realloc(out, cap *= 2);
+    len += (size_t)snprintf(out + len, 256, "%09d %09d %d %0.1f %u %d %d %u %u %d %d %u %s\n", (int)rid0, (int)rid1,
+                            -(o->match.m_size), err_est, 0u, (int)a_bgn, (int)a_end, rlen0,
+                            (unsigned)(o->strand0 == 0 ? o->strand1 : 1 - o->strand1), (int)b_bgn, (int)b_end, rlen1,
+                            o->ovlp_type == 0 ? "overlap" : (o->ovlp_type == 1 ? "contains" : "contained"));
+    otab_put(&seen, pair, &absent);
+    ++uniq;
+  }
+  otab_release(&seen);
+  if (text_len) *text_len = len;
+  if (n_unique) *n_unique = uniq;
+  return out;
+}

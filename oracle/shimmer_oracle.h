@@ -92,6 +92,9 @@ int orc_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, cons
                       int mychunk, int bestn, int mc_lower, int mc_upper, int band, int ovlp_upper,
                       orc_stats_t *stats, uint64_t *n_out);
 
+/* ---- row f2: first-wins dedup + FALCON text lines, src/shmr_dedup.c:32-101.  Returns malloc'd text (orc_free). ---- */
+char *orc_dedup(const orc_ovlp_t *recs, size_t n, size_t *text_len, uint64_t *n_unique);
+
 void orc_free(void *p);
 
 #ifdef __cplusplus

@@ -144,3 +144,20 @@ def shmr_mkseqdb(seq_dataset_path: str = "seq_dataset.lst", seqdb_prefix: str = 
     _lib.check(_lib.load().pgx_mkseqdb(seq_dataset_path.encode(), seqdb_prefix.encode(), C.byref(nr), C.byref(nb)),
                "pgx_mkseqdb")
     return dict(reads=int(nr.value), bases=int(nb.value))
+
+
+def shmr_dedup(ovlp_paths, out_path: str | None = None, device=None):
+    """cat ovlp*.dat | shmr_dedup > preads.ovl (pg_run.py:351-352): returns the text (bytes) and the number of unique pairs."""
+    _lib.init(device)
+    if isinstance(ovlp_paths, (str, bytes)):
+        ovlp_paths = [ovlp_paths]
+    recs = np.concatenate([np.fromfile(p, dtype=OVLP_DTYPE) for p in ovlp_paths]) if ovlp_paths else np.zeros(0, OVLP_DTYPE)
+    recs = np.ascontiguousarray(recs)
+    text, tl, nu = C.c_void_p(), C.c_size_t(0), C.c_uint64(0)
+    _lib.check(_lib.load().pgx_dedup(_ptr(recs), len(recs), C.byref(text), C.byref(tl), C.byref(nu)), "pgx_dedup")
+    data = C.string_at(text.value, tl.value)
+    _lib.load().pgx_free(text)
+    if out_path:
+        with open(out_path, "wb") as f:
+            f.write(data)
+    return data, int(nu.value)

@@ -147,6 +147,17 @@ def orc_overlap_chunk(seqdb_prefix, shimmer_prefix, out_path, total=1, mychunk=1
     return int(n.value), {f: getattr(st, f) for f, _ in Stats._fields_}
 
 
+def orc_dedup(recs):
+    recs = np.ascontiguousarray(recs, OVLP_DTYPE)
+    tl, nu = C.c_size_t(0), C.c_uint64(0)
+    fn = oracle().orc_dedup
+    fn.restype = C.c_void_p
+    p = fn(recs.ctypes.data_as(C.c_void_p), C.c_size_t(len(recs)), C.byref(tl), C.byref(nu))
+    data = C.string_at(p, tl.value)
+    oracle().orc_free(C.c_void_p(p))
+    return data, int(nu.value)
+
+
 # ------------------------------------------------------------------------------------------------------------
 # the real reference (oracle/_ref): present in the build container, prebuilt binaries on the GPU box
 # ------------------------------------------------------------------------------------------------------------

@@ -218,3 +218,20 @@ def test_mkseqdb_matches_reference(tmp_path):
     assert np.array_equal(np.fromfile(tmp_path / "sd.seqdb", np.uint8), db.seqdb)
     with pytest.raises(_lib.PgxError):
         shmr_mkseqdb(str(tmp_path / "missing.lst"), str(tmp_path / "x"))
+
+
+def test_dedup_matches_reference(tmp_path):
+    """row f2: cat ovlp*.dat | shmr_dedup -- GPU first-wins + coordinate transform, text byte-identical to the reference"""
+    from peregrine_amd.shimmer import shmr_dedup
+    z = G.load("tiny_stage.npz")
+    d = G.load("dedup_cases.npz")
+    for name in ("dd_t1", "dd_t2", "dd_t3", "dd_l1"):
+        paths = []
+        for k in d[name + "_keys"]:
+            p = tmp_path / f"{name}_{k}.dat"
+            z[str(k)].tofile(p)
+            paths.append(str(p))
+        text, nu = shmr_dedup(paths, str(tmp_path / f"{name}.ovl"))
+        assert text == d[name].tobytes(), name
+        assert (tmp_path / f"{name}.ovl").read_bytes() == text and nu == text.count(b"\n")
+    assert shmr_dedup([])[0] == b""

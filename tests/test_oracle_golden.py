@@ -76,3 +76,14 @@ def test_overlap_stage_matches_reference(tmp_path, name):
         want = z[f"{name}_{c}"]
         assert len(got) == n == len(want)
         assert formats.ovlp_fields_equal(got, want), name
+
+
+def test_dedup_matches_reference_text():
+    """row f2: oracle's shmr_dedup restatement against the reference binary's stdout on concatenated chunk streams"""
+    z = G.load("tiny_stage.npz")
+    d = G.load("dedup_cases.npz")
+    for name in ("dd_t1", "dd_t2", "dd_t3", "dd_l1"):
+        recs = np.concatenate([z[str(k)] for k in d[name + "_keys"]])
+        text, nu = U.orc_dedup(recs)
+        assert text == d[name].tobytes(), name
+        assert nu == text.count(b"\n")
