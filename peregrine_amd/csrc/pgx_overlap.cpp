@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 
 #include "pgx_internal.h"
 
@@ -315,31 +316,59 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
   SlotTable outer;
   for (uint32_t g : gord) outer.put(pt.gkey0[g], g, &absent);
   if ((size_t)pt.gfirst[gord.back()] + 1 < pt.n_rec) outer.put(pt.gkey0[gord[0]], 0, &absent);  // trailing repeat put
-  // level 2
-  ScratchTable in;
-  std::vector<uint32_t> bord;
-  for (uint32_t s0 = 0; s0 < outer.nb; ++s0) {
-    if (!outer.used[s0]) continue;
-    const uint32_t g = outer.ids[s0];
-    if (pt.gstart[g + 1] - pt.gstart[g] <= 2) continue;  // no bucket of this key0 can hold more than 2 records
-    const uint32_t b0 = pt.gbucket[g], b1 = pt.gbucket[g + 1];
-    bord.resize(b1 - b0);
-    for (uint32_t b = b0; b < b1; ++b) bord[b - b0] = b;
-    std::sort(bord.begin(), bord.end(), [&](uint32_t a, uint32_t b) { return pt.bfirst[a] < pt.bfirst[b]; });
-    in.reset();
-    for (uint32_t b : bord) in.put(pt.bkey1[b], b, &absent);
-    if (pt.bfirst[bord.back()] < pt.glast[g]) in.put(pt.bkey1[bord[0]], 0, &absent);  // trailing repeat put
-    for (uint32_t s1 = 0; s1 < in.nb; ++s1) {
-      if (!in.used[s1]) continue;
-      const uint32_t b = in.ids[s1];
-      const uint32_t bn = pt.bstart[b + 1] - pt.bstart[b];
-      if (bn <= 2 || bn > ovlp_upper) continue;  // shmr_overlap.c:216
-      for (uint32_t r = pt.bstart[b]; r < pt.bstart[b + 1]; ++r) {
-        const uint64_t y = pt.y0[r];
-        v.entries.push_back(Entry{(uint32_t)(y >> 32), pos_of(y) + 1, y, pt.dir[r]});
+  // level 2: the inner tables are independent, so the outer slots are split into contiguous ranges, one per thread;
+  // the fragments are concatenated in slot order afterwards
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned nthr = (unsigned)std::min<size_t>(std::min(16u, hw), std::max<size_t>(1, ng / 2048));
+  struct Frag {
+    std::vector<uint32_t> sizes;
+    std::vector<Entry> entries;
+  };
+  std::vector<Frag> frag(nthr);
+  auto work = [&](unsigned ti) {
+    const uint32_t lo = (uint32_t)((uint64_t)outer.nb * ti / nthr), hi = (uint32_t)((uint64_t)outer.nb * (ti + 1) / nthr);
+    Frag &f = frag[ti];
+    ScratchTable in;
+    std::vector<uint32_t> bord;
+    bool ab;
+    for (uint32_t s0 = lo; s0 < hi; ++s0) {
+      if (!outer.used[s0]) continue;
+      const uint32_t g = outer.ids[s0];
+      if (pt.gstart[g + 1] - pt.gstart[g] <= 2) continue;  // no bucket of this key0 can hold more than 2 records
+      const uint32_t b0 = pt.gbucket[g], b1 = pt.gbucket[g + 1];
+      bord.resize(b1 - b0);
+      for (uint32_t b = b0; b < b1; ++b) bord[b - b0] = b;
+      std::sort(bord.begin(), bord.end(), [&](uint32_t x, uint32_t y) { return pt.bfirst[x] < pt.bfirst[y]; });
+      in.reset();
+      for (uint32_t b : bord) in.put(pt.bkey1[b], b, &ab);
+      if (pt.bfirst[bord.back()] < pt.glast[g]) in.put(pt.bkey1[bord[0]], 0, &ab);  // trailing repeat put
+      for (uint32_t s1 = 0; s1 < in.nb; ++s1) {
+        if (!in.used[s1]) continue;
+        const uint32_t b = in.ids[s1];
+        const uint32_t bn = pt.bstart[b + 1] - pt.bstart[b];
+        if (bn <= 2 || bn > ovlp_upper) continue;  // shmr_overlap.c:216
+        for (uint32_t r = pt.bstart[b]; r < pt.bstart[b + 1]; ++r) {
+          const uint64_t y = pt.y0[r];
+          f.entries.push_back(Entry{(uint32_t)(y >> 32), pos_of(y) + 1, y, pt.dir[r]});
+        }
+        f.sizes.push_back(bn);
       }
-      v.start.push_back(v.entries.size());
     }
+  };
+  if (nthr == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned ti = 0; ti < nthr; ++ti) th.emplace_back(work, ti);
+    for (auto &t : th) t.join();
+  }
+  size_t ne = 0, nbk = 0;
+  for (const Frag &f : frag) ne += f.entries.size(), nbk += f.sizes.size();
+  v.entries.reserve(ne);
+  v.start.reserve(nbk + 1);
+  for (const Frag &f : frag) {
+    v.entries.insert(v.entries.end(), f.entries.begin(), f.entries.end());
+    for (uint32_t sz : f.sizes) v.start.push_back(v.start.back() + sz);
   }
 }
 
@@ -534,13 +563,13 @@ struct Replay {
     // what changed for later buckets?  (skipped while everything behind is dirty anyway: first sweep)
     if (!first_sweep) {
       for (const Own &o : old_own)
-        if (ps[o.pid].owner != b || ps[o.pid].type != o.type) mark_readers_after(o.pid, b);
+        if (ps[o.pid].owner != b || (ps[o.pid].type == T_OVERLAP) != (o.type == T_OVERLAP)) mark_readers_after(o.pid, b);
       for (uint32_t i = 0; i < st.nown; ++i) {
         const Own &o = owned[st.own0 + i];
         bool same = false;
         for (const Own &q : old_own)
-          if (q.pid == o.pid && q.type == o.type) {
-            same = true;
+          if (q.pid == o.pid && (q.type == T_OVERLAP) == (o.type == T_OVERLAP)) {  // readers only observe presence
+            same = true;                                                           // and "is a plain overlap"
             break;
           }
         if (!same) mark_readers_after(o.pid, b);
