@@ -235,3 +235,16 @@ def test_dedup_matches_reference(tmp_path):
         assert text == d[name].tobytes(), name
         assert (tmp_path / f"{name}.ovl").read_bytes() == text and nu == text.count(b"\n")
     assert shmr_dedup([])[0] == b""
+
+
+def test_parallel_replay_equals_oracle(small, monkeypatch):
+    """the multi-threaded replay (forced on for a small set) must reach the sequential fixed point, run after run"""
+    db, rdb = small
+    ix = rdb.index()
+    want, ost = U.orc_overlap(db, ix.top, ix.top_mc)
+    monkeypatch.setenv("PGX_PAR_MIN", "0")
+    for threads in (2, 8, 8, 32, 32):
+        monkeypatch.setenv("PGX_THREADS", str(threads))
+        got, st = rdb.overlap(ix.top, ix.top_mc)
+        assert formats.ovlp_fields_equal(got, want), threads
+        assert st["n_align_needed"] == ost["n_align"]

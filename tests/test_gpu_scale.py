@@ -79,7 +79,16 @@ def test_c3_scale_properties():
         assert q_bgn < 48 and t_bgn < 48 and (abs(len(q) - q_end) < 48 or abs(len(t) - t_end) < 48) and q_end > 500 and t_end > 500
         contain = abs(int(o["rl0"]) - (q_end - q_bgn)) < 96 or abs(int(o["rl1"]) - (t_end - t_bgn)) < 96
         assert int(o["ovlp_type"]) == ((1 if o["rl0"] >= o["rl1"] else 2) if contain else 0)
-    # (5) idempotence
-    ov2, _ = rdb.overlap(ix.top, ix.top_mc)
+    # (5) idempotence, and the multi-threaded replay reaches the same fixed point as the sequential one
+    import os
+    ov2, st2 = rdb.overlap(ix.top, ix.top_mc)
     assert formats.ovlp_fields_equal(ov, ov2)
+    os.environ["PGX_THREADS"] = "1"
+    try:
+        ov1, st1 = rdb.overlap(ix.top, ix.top_mc)
+    finally:
+        del os.environ["PGX_THREADS"]
+    assert formats.ovlp_fields_equal(ov, ov1)
+    assert st1["n_align_needed"] == st["n_align_needed"] == st2["n_align_needed"]
+    assert st1["n_seen_skip"] == st["n_seen_skip"]
     rdb.close()
