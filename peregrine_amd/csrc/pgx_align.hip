@@ -29,25 +29,32 @@ template <int CTRL>
 __device__ __forceinline__ int dpp_max(int v) {
   return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false));
 }
-// maximum over the 16 lanes of a row, result in every lane: xor-butterfly with quad_perm / row_half_mirror / row_mirror
-__device__ __forceinline__ int row_max_i32(int v) {
+// maximum over the GL (8 or 16) lanes of a group, result in every lane: xor-butterfly with quad_perm / row_half_mirror /
+// row_mirror
+template <int GL>
+__device__ __forceinline__ int group_max_i32(int v) {
   v = dpp_max<0xB1>(v);   // quad_perm [1,0,3,2]
   v = dpp_max<0x4E>(v);   // quad_perm [2,3,0,1]
-  v = dpp_max<0x141>(v);  // row_half_mirror
-  v = dpp_max<0x140>(v);  // row_mirror
+  v = dpp_max<0x141>(v);  // row_half_mirror: lanes i <-> 7-i of every 8
+  if (GL == 16) v = dpp_max<0x140>(v);  // row_mirror: lanes i <-> 15-i
   return v;
 }
-__device__ __forceinline__ uint32_t group_bits(uint64_t wave_mask, int gbase) { return (uint32_t)(wave_mask >> gbase) & 0xFFFFu; }
+template <int GL>
+__device__ __forceinline__ uint32_t group_bits(uint64_t wave_mask, int gbase) {
+  return (uint32_t)(wave_mask >> gbase) & ((1u << GL) - 1u);
+}
 
 }  // namespace
 
+// GL = lanes per candidate: 16 (four candidates per wavefront) or 8 (eight)
+template <int GL>
 __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
                                                const uint32_t *__restrict__ rlen,
                                                const pgx_align_key *__restrict__ keys, uint32_t n, int band, int ring,
                                                pgx_match *__restrict__ out, uint32_t *__restrict__ counter) {
   extern __shared__ int32_t Vall[];
-  const int lane = threadIdx.x, gl = lane & 15, gbase = lane & 48;
-  int32_t *V = Vall + (lane >> 4) * ring;
+  const int lane = threadIdx.x, gl = lane & (GL - 1), gbase = lane & ~(GL - 1);
+  int32_t *V = Vall + (lane / GL) * ring;
   const int mask = ring - 1, band_size = band * 2;
 
   // per-candidate state, uniform within a 16-lane group
@@ -102,7 +109,7 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
     // ---- one step: all diagonals of the current band, 16 per round -------------------------------------------
     const int nk = max_k >= min_k ? ((max_k - min_k) >> 1) + 1 : 0;
     int x = 0, y = 0;
-    for (int base = 0;; base += 16) {
+    for (int base = 0;; base += GL) {
       const bool inround = stepping && !matched && base < nk;
       if (!__ballot(inround)) break;
       const int j = base + gl;
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
       // long snakes: the group extends one diagonal at a time, 128 codes per iteration
       uint64_t mw = __ballot(more);
       while (mw) {
-        const uint32_t gm = group_bits(mw, gbase);
+        const uint32_t gm = group_bits<GL>(mw, gbase);
         const bool has = gm != 0;
         const int L = has ? __builtin_ctz(gm) : 0;
         const int xs = __shfl(x, gbase + L, 64), ys = __shfl(y, gbase + L, 64);
@@ -138,8 +145,8 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
           m = 0;
           if (off < rem) m = min(match8(load_u64_unaligned(q + xs + off), load_u64_unaligned(t + ys + off), qs, ts), rem - off);
         }
-        const uint32_t sg = group_bits(__ballot(has && m < 8), gbase);
-        int ext = 128;
+        const uint32_t sg = group_bits<GL>(__ballot(has && m < 8), gbase);
+        int ext = GL * 8;
         if (sg) {
           const int f = __builtin_ctz(sg);
           ext = 8 * f + __shfl(m, gbase + f, 64);
@@ -152,29 +159,37 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
       }
       const int ext = x - x1;
       const bool hit = active && (x >= q_len || y >= t_len);
-      const uint32_t hitm = group_bits(__ballot(hit), gbase);
-      const int hl = hitm ? __builtin_ctz(hitm) : 16;
+      const uint64_t hitw = __ballot(hit);  // rare (once per candidate): everything that depends on it sits behind the branch
+      int hl = GL;
+      if (hitw) {
+        const uint32_t hitm = group_bits<GL>(hitw, gbase);
+        if (hitm) hl = __builtin_ctz(hitm);
+      }
       const bool valid = active && gl <= hl;
       {  // first extension > 16 fixes q_bgn/t_bgn once (DWmatch.c:142-146)
-        const uint32_t m = group_bits(__ballot(valid && ext > 16 && !started), gbase);
-        const int l = m ? __builtin_ctz(m) : 0;
-        const int bx = __shfl(x1, gbase + l, 64), by = __shfl(y1, gbase + l, 64);
-        if (m) q_bgn = bx, t_bgn = by, started = true;
+        const uint64_t sw = __ballot(valid && ext > 16 && !started);
+        if (sw) {
+          const uint32_t m = group_bits<GL>(sw, gbase);
+          const int l = m ? __builtin_ctz(m) : 0;
+          const int bx = __shfl(x1, gbase + l, 64), by = __shfl(y1, gbase + l, 64);
+          if (m) q_bgn = bx, t_bgn = by, started = true;
+        }
       }
       if (__ballot(valid && (uint32_t)ext > longest)) {  // strictly longer extension (DWmatch.c:148-152)
-        const int mx = row_max_i32(valid ? ext : -1);
-        const uint32_t m = group_bits(__ballot(valid && ext == mx), gbase);
+        const int mx = group_max_i32<GL>(valid ? ext : -1);
+        const uint32_t m = group_bits<GL>(__ballot(valid && ext == mx), gbase);
         const int l = m ? __builtin_ctz(m) : 0;
         const int ex = __shfl(x, gbase + l, 64), ey = __shfl(y, gbase + l, 64);
         if (inround && mx >= 0 && (uint32_t)mx > longest) longest = (uint32_t)mx, q_m_end = ex, t_m_end = ey;
       }
       if (valid) V[k & mask] = x;
       {
-        const int s = row_max_i32(valid ? x + y : -1);
+        const int s = group_max_i32<GL>(valid ? x + y : -1);
         if (inround) best_m = max(best_m, s);
       }
-      {
-        const int ex = __shfl(x, gbase + (hl & 15), 64), ey = __shfl(y, gbase + (hl & 15), 64);
+      if (hitw) {
+        const uint32_t hitm = group_bits<GL>(hitw, gbase);
+        const int ex = __shfl(x, gbase + (hl & (GL - 1)), 64), ey = __shfl(y, gbase + (hl & (GL - 1)), 64);
         if (inround && hitm) matched = true, q_end = ex, t_end = ey;
       }
     }
@@ -193,14 +208,14 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
     // ---- band update (DWmatch.c:166-183) -------------------------------------------------------------------------
     int new_min = max_k, new_max = min_k;
     const int thr = best_m - band;
-    for (int base = 0;; base += 16) {
+    for (int base = 0;; base += GL) {
       const bool inround = stepping && base < nk;
       if (!__ballot(inround)) break;
       const int j = base + gl;
       const int k2 = min_k + 2 * j;
       int u = 0;
-      if (inround && j < nk) u = (nk <= 16) ? x + y : 2 * V[k2 & mask] - k2;
-      const uint32_t m = group_bits(__ballot(inround && j < nk && u >= thr), gbase);
+      if (inround && j < nk) u = (nk <= GL) ? x + y : 2 * V[k2 & mask] - k2;
+      const uint32_t m = group_bits<GL>(__ballot(inround && j < nk && u >= thr), gbase);
       if (m) {
         new_min = min(new_min, min_k + 2 * (base + __builtin_ctz(m)));
         new_max = max(new_max, min_k + 2 * (base + 31 - __builtin_clz(m)));
@@ -217,10 +232,18 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
   while (ring < 2 * band + 8) ring <<= 1;
   uint32_t *counter = ws<uint32_t>("align.counter", 1);
   PGX_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), ctx().stream));
-  const size_t want = (n + 3) / 4;
-  const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * 32);
-  hipLaunchKernelGGL(k_align4, dim3(grid), dim3(64), 4 * ring * sizeof(int32_t), ctx().stream, db->d_seq.p, db->d_roff.p,
-                     db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter);
+  static const int gl = getenv("PGX_ALIGN_GL") ? atoi(getenv("PGX_ALIGN_GL")) : 16;
+  if (gl == 8) {
+    const size_t want = (n + 7) / 8;
+    const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * 20);
+    hipLaunchKernelGGL(k_align4<8>, dim3(grid), dim3(64), 8 * ring * sizeof(int32_t), ctx().stream, db->d_seq.p,
+                       db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter);
+  } else {
+    const size_t want = (n + 3) / 4;
+    const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * 32);
+    hipLaunchKernelGGL(k_align4<16>, dim3(grid), dim3(64), 4 * ring * sizeof(int32_t), ctx().stream, db->d_seq.p,
+                       db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter);
+  }
   PGX_HIP(hipGetLastError());
 }
 
