@@ -248,3 +248,54 @@ def test_parallel_replay_equals_oracle(small, monkeypatch):
         got, st = rdb.overlap(ix.top, ix.top_mc)
         assert formats.ovlp_fields_equal(got, want), threads
         assert st["n_align_needed"] == ost["n_align"]
+
+
+def _enc(codes):
+    codes = np.asarray(codes, np.uint8)
+    return ((np.uint8(1) << codes) | ((np.uint8(8) >> codes[::-1]) << np.uint8(4))).astype(np.uint8)
+
+
+def test_adversarial_reads_all_paths():
+    """long contig-like reads (> 1024 minimizers), strand-ambiguous runs, homopolymers / tandem repeats (tie bursts, slab
+    overflow), tiny reads and ambiguous bases: every dispatch path of the index stage against the oracle"""
+    rng = np.random.default_rng(123)
+    rnd = lambda n: rng.integers(0, 4, n).astype(np.uint8)
+    at = lambda n: np.resize(np.array([0, 3], np.uint8), n)
+    reads = [
+        rnd(300_000),                                                  # contig-like: k_reduce_read cannot hold it
+        np.concatenate([rnd(4000), at(400), rnd(3000), at(39), rnd(800)]),   # long strand-ambiguous k-mer runs
+        np.concatenate([rnd(2000), np.zeros(600, np.uint8), rnd(2500)]),      # poly-A: every window ties
+        np.resize(rnd(3), 5000), np.resize(rnd(7), 6000), np.resize(rnd(16), 4000), np.resize(rnd(40), 9000),
+        rnd(1), rnd(15), rnd(16), rnd(17), rnd(94), rnd(95), rnd(96), rnd(110), rnd(1023), rnd(1024), rnd(1025), rnd(2049),
+        rnd(15000), rnd(15001),
+    ]
+    enc = [_enc(r) for r in reads]
+    amb = _enc(rnd(7000)).copy()
+    amb[[10, 3000, 6990]] &= 0xF0                                        # ambiguous forward bases -> literal kernel
+    enc.append(amb)
+    enc += [_enc(rnd(int(n))) for n in rng.integers(5000, 20000, 40)]
+    rlen = np.array([len(e) for e in enc], np.uint32)
+    roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
+    from peregrine_amd.formats import SeqDB
+    db = SeqDB(np.concatenate(enc), np.arange(len(enc), dtype=np.uint32), rlen, roff, None)
+    rdb = ResidentDB(db, 0)
+    l0 = np.concatenate([U.orc_sketch_seqdb(e, 80, 16, i) for i, e in enumerate(enc)])
+    l1 = U.orc_reduce(l0, 6)
+    l2 = U.orc_reduce(l1, 6)
+    a = rdb.index(want_l0=True)
+    assert a.reads_literal >= 1
+    assert np.array_equal(a.l0, l0) and np.array_equal(a.top, l2)
+    assert np.array_equal(rdb.index().top, l2)                          # fused attempt -> general path
+    assert np.array_equal(rdb.index(levels=1).top, l1)
+    assert np.array_equal(rdb.index(total_chunk=3, mychunk=1).top,
+                          U.orc_reduce(U.orc_reduce(np.concatenate([U.orc_sketch_seqdb(e, 80, 16, i) for i, e in enumerate(enc) if i % 3 == 1]), 6), 6))
+    import os
+    os.environ["PGX_FUSE"] = "1"   # read when the fused path is first consulted in this process; harmless if already cached
+    try:
+        assert np.array_equal(rdb.index().top, l2)
+    finally:
+        del os.environ["PGX_FUSE"]
+    ov, _ = rdb.overlap(a.top, a.top_mc)
+    want, _ = U.orc_overlap(db, l2, U.orc_count(l2))
+    assert formats.ovlp_fields_equal(ov, want)
+    rdb.close()
