@@ -267,7 +267,7 @@ void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_cou
 bool sketch_wave_eligible(const ReadDesc &rd, int w, int k);  // pgx_sketch_fast.hip
 void launch_sketch_wave(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n_list, int w,
                         int k, pgx_mm128 *d_slab, const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags);
-bool sketch_fused_supported(int rs, int levels);
+bool sketch_fused_supported(int w, int rs, int levels);
 void launch_sketch_fused(const pgx_seqdb *db, const ReadDesc *d_reads, uint32_t n, int rs, int levels, pgx_mm128 *d_slab,
                          const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags);
 
@@ -475,7 +475,7 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
   // PGX_FUSE=1: one kernel (sketch + streaming reduce), HBM traffic == the algorithmic 1.04 B/base, measured 9 % slower
   // than sketch + k_reduce_read because of the extra LDS (8 instead of 9 waves per CU); default: two kernels.
   static const bool want_fuse = getenv("PGX_FUSE") && atoi(getenv("PGX_FUSE")) != 0;
-  if (want_fuse && sketch_fused_supported(rs, levels)) {
+  if (want_fuse && sketch_fused_supported(w, rs, levels)) {
     KernelTimer tm("sketch", bases);
     launch_sketch_fused(db, d_reads, n, rs, levels, slab, d_slab_off, d_ctop, d_flags);
     hipLaunchKernelGGL(k_count_flags, dim3(cdiv(n, 256)), dim3(256), 0, st, d_flags, n, d_nbad);

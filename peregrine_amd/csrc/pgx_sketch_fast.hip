@@ -27,10 +27,12 @@
 namespace pgx {
 
 namespace {
-constexpr int W = 80, K = 16;
+constexpr int K = 16;    // k-mer size of the closed-form kernel (32-bit k-mers / hash)
+// window sizes handled by the closed form: w = 16 A with A in {4, 5, 6, 8} (the window is exactly A chunks of 16 entries)
 constexpr int CH = 16;    // entries per chunk
 constexpr int CST = 20;   // dwords per chunk in LDS (16 + 4 pad: conflict-free ds_read_b128; unpadded measured 1.5x slower)
-constexpr int NB = 80;    // chunks in the buffer: <= 7 carried + 65 new + 6 zero pad (+ slack)
+// chunks in the LDS buffer for window w = 16 A: <= A+2 carried + 65 new + A+1 zero pad (+1 slack)
+constexpr int nb_for(int A) { return 2 * A + 70; }
 constexpr int TILE = 1024;
 constexpr uint32_t INF = 0xFFFFFFFFu;
 
@@ -79,7 +81,8 @@ __device__ __forceinline__ void lds_write16(uint32_t *p, const uint32_t (&v)[16]
 }
 __device__ __forceinline__ int chunk_addr(int e) { return (int)__umul24((uint32_t)(e >> 4), CST) + (e & 15); }
 
-struct Lds {
+template <int NB>
+struct LdsT {
   uint32_t H[NB * CST];   // hash of entry e at (e/16 - qbase) * CST + e % 16
   uint32_t Wm[NB * CST];  // window minimum for the window ENDING at entry e
   uint16_t P[NB * CST];   // (lastPos & 0x7fff) << 1 | strand
@@ -149,7 +152,7 @@ __device__ __forceinline__ void reduce_flush(RedLds &r, RedState &st, int lv, in
 // ---------------------------------------------------------------------------------------------------------
 // phase A step loop.  EDGE = the tile touches the first k-1 bases or the end of the read.
 // ---------------------------------------------------------------------------------------------------------
-template <bool EDGE>
+template <bool EDGE, typename Lds>
 __device__ __forceinline__ int phase_a_steps(Lds &s, int lane, int t, int lead, int len, int ebuf /* E - 16*qbase */) {
   const int o16 = lane & 15, g = lane >> 4;
   const int shF = 2 * (15 - o16), shR = (2 * (o16 + 1)) & 31;
@@ -200,8 +203,9 @@ __device__ __forceinline__ int phase_a_steps(Lds &s, int lane, int t, int lead, 
 // ---------------------------------------------------------------------------------------------------------
 // phase B1: window minima of absolute chunk q (buffer chunk bq).  SPECIAL handles q < 5 and the read's end.
 // ---------------------------------------------------------------------------------------------------------
-template <bool SPECIAL>
+template <bool SPECIAL, int A, typename Lds>
 __device__ __forceinline__ void phase_b1(Lds &s, int lane, int q, int bq, bool active, int E) {
+  constexpr int W = 16 * A;
   uint32_t v[16], wm[16];
   uint32_t c = INF;
   if (active) {
@@ -213,7 +217,7 @@ __device__ __forceinline__ void phase_b1(Lds &s, int lane, int q, int bq, bool a
   // minima of the four preceding chunks: neighbours' registers, or LDS for chunks older than this round
   uint32_t m4 = INF;
 #pragma unroll
-  for (int d = 1; d <= 4; ++d) {
+  for (int d = 1; d <= A - 1; ++d) {
     uint32_t cd = (uint32_t)__shfl_up((int)c, d, 64);
     if (lane < d) cd = (bq - d >= 0) ? s.C[bq - d] : INF;
     if (SPECIAL && q - d < 0) cd = INF;
@@ -222,9 +226,9 @@ __device__ __forceinline__ void phase_b1(Lds &s, int lane, int q, int bq, bool a
   if (active) {
     uint32_t sfx[17];
     sfx[16] = INF;
-    if (!SPECIAL || q >= 5) {
+    if (!SPECIAL || q >= A) {
       uint32_t u[16];
-      lds_read16(&s.H[(bq - 5) * CST], u);
+      lds_read16(&s.H[(bq - A) * CST], u);
       sfx[15] = u[15];
 #pragma unroll
       for (int o = 14; o >= 1; --o) sfx[o] = min(sfx[o + 1], u[o]);
@@ -254,12 +258,14 @@ __device__ __forceinline__ void phase_b1(Lds &s, int lane, int q, int bq, bool a
 
 // FUSED = false: the read's L0 minimizers go to its slab.  FUSED = true: they are reduced `levels` times on the fly
 // (reduce_flush) and only the final level reaches the slab -- L0 never leaves the CU.
-template <bool FUSED>
+template <bool FUSED, int A>
 __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ seq, const ReadDesc *__restrict__ reads,
                                                     const uint32_t *__restrict__ list, uint32_t n_list,
                                                     pgx_mm128 *__restrict__ slab, const uint64_t *__restrict__ slab_off,
                                                     uint32_t *__restrict__ counts, uint32_t *__restrict__ flags, int rs,
                                                     int levels) {
+  constexpr int W = 16 * A;  // window size in entries = A chunks of 16
+  using Lds = LdsT<nb_for(A)>;
   __shared__ __attribute__((aligned(16))) Lds s;
   __shared__ RedLds red;
   RedState rst[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -312,11 +318,11 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
     // ---- compaction: move the live chunks [ddone, ceil(E/16)) to the front of the buffer -----------------------
     if (ddone > qbase) {
       const int shift = (ddone - qbase) * CST;
-      const int live = ((E + CH - 1) / CH - ddone) * CST;  // dwords to keep (<= 7 chunks)
-      uint32_t th[3], tw[3];
-      uint16_t tp[3];
+      const int live = ((E + CH - 1) / CH - ddone) * CST;  // dwords to keep (<= A + 2 <= 10 chunks = 200 dwords)
+      uint32_t th[4], tw[4];
+      uint16_t tp[4];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
+      for (int r = 0; r < 4; ++r) {
         const int d = lane + 64 * r;
         th[r] = tw[r] = 0, tp[r] = 0;
         if (d < live) th[r] = s.H[shift + d], tw[r] = s.Wm[shift + d], tp[r] = s.P[shift + d];
@@ -325,7 +331,7 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
       if (lane * CST < live) tc = s.C[ddone - qbase + lane], tm = s.M[ddone - qbase + lane];
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
+      for (int r = 0; r < 4; ++r) {
         const int d = lane + 64 * r;
         if (d < live) s.H[d] = th[r], s.Wm[d] = tw[r], s.P[d] = tp[r];
       }
@@ -370,7 +376,7 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
     const bool last = (t == ntiles - 1);
     const bool edge = (t * TILE - lead < K - 1) || ((t + 1) * TILE - lead > len);
     const int ebuf = E - qbase * CH;
-    E += edge ? phase_a_steps<true>(s, lane, t, lead, len, ebuf) : phase_a_steps<false>(s, lane, t, lead, len, ebuf);
+    E += edge ? phase_a_steps<true, Lds>(s, lane, t, lead, len, ebuf) : phase_a_steps<false, Lds>(s, lane, t, lead, len, ebuf);
     const int hch = last ? (E + CH - 1) / CH : E / CH;  // chunks whose hashes are final
     if (last) {                                          // pad the tail of the last chunk
       const int e = E + lane;
@@ -381,21 +387,22 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
     // ---- phase B1 -------------------------------------------------------------------------------------------
     for (int q0 = wdone; q0 < hch; q0 += 64) {
       const int q = q0 + lane;
-      if (q0 < 5 || last) phase_b1<true>(s, lane, q, q - qbase, q < hch, E);
-      else phase_b1<false>(s, lane, q, q - qbase, q < hch, E);
+      if (q0 < A || last) phase_b1<true, A, Lds>(s, lane, q, q - qbase, q < hch, E);
+      else phase_b1<false, A, Lds>(s, lane, q, q - qbase, q < hch, E);
       __syncthreads();
     }
     wdone = hch;
-    if (last) {  // windows past the end do not exist: six all-zero chunks
+    if (last) {  // windows past the end do not exist: A+1 all-zero chunks
       const int bz = hch - qbase;
-      s.Wm[(bz + (lane >> 4)) * CST + (lane & 15)] = 0;
-      if (lane < 32) s.Wm[(bz + 4 + (lane >> 4)) * CST + (lane & 15)] = 0;
-      if (lane < 6) s.M[bz + lane] = 0;
+#pragma unroll
+      for (int z = 0; z < A + 1; z += 4)
+        if (z + (lane >> 4) < A + 1) s.Wm[(bz + z + (lane >> 4)) * CST + (lane & 15)] = 0;
+      if (lane < A + 1) s.M[bz + lane] = 0;
       __syncthreads();
     }
 
     // ---- phase B2: decide and emit ----------------------------------------------------------------------------
-    const int dlimit = last ? hch : (wdone - 5 > 0 ? wdone - 5 : 0);
+    const int dlimit = last ? hch : (wdone - A > 0 ? wdone - A : 0);
     const bool short_read = last && E < W;  // fewer than w entries: emit only the rightmost smallest
     for (int q0 = ddone; q0 < dlimit; q0 += 64) {
       const int q = q0 + lane, bq = q - qbase;
@@ -405,8 +412,10 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
         uint32_t wq[16], wn[16];
         lds_read16(&s.H[bq * CST], v);
         lds_read16(&s.Wm[bq * CST], wq);
-        lds_read16(&s.Wm[(bq + 5) * CST], wn);
-        const uint32_t m4 = max(max(s.M[bq + 1], s.M[bq + 2]), max(s.M[bq + 3], s.M[bq + 4]));
+        lds_read16(&s.Wm[(bq + A) * CST], wn);
+        uint32_t m4 = 0;
+#pragma unroll
+        for (int d = 1; d <= A - 1; ++d) m4 = max(m4, s.M[bq + d]);
         uint32_t sm[16];
         sm[15] = wq[15];
 #pragma unroll
@@ -429,13 +438,13 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
       if (q0 == 0) {  // first-window correction / short-read rule; entries 0..79 are buffer chunks 0..4 (qbase == 0)
         const int lim = short_read ? E : W - 1;  // candidates are entries [0, lim)
         const uint32_t a = lane < lim ? s.H[(lane >> 4) * CST + (lane & 15)] : INF;
-        const uint32_t b = lane + 64 < lim ? s.H[(4 + (lane >> 4)) * CST + (lane & 15)] : INF;
+        const uint32_t b = lane + 64 < lim ? s.H[(4 + (lane >> 4)) * CST + (lane & 15)] : INF;  // W <= 128 = 2 x 64 lanes
         const uint32_t mv = wave_min_u32(min(a, b));
         const uint64_t mb = __ballot(lane + 64 < lim && b == mv), ma = __ballot(lane < lim && a == mv);
         const int m = mb ? 64 + (63 - __builtin_clzll(mb)) : (ma ? 63 - __builtin_clzll(ma) : -1);
         if (short_read) {
           if (m >= 0 && q == m / CH) emask = 1u << (m % CH);
-        } else if (q < 5 && q < dlimit) {
+        } else if (q < A && q < dlimit) {
           const uint32_t e79 = s.H[((W - 1) >> 4) * CST + ((W - 1) & 15)];
 #pragma unroll
           for (int o = 0; o < 16; ++o) {
@@ -507,24 +516,39 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
 }
 
 // host side ------------------------------------------------------------------------------------------------
-bool sketch_wave_eligible(const ReadDesc &rd, int w, int k) { return w == W && k == K && rd.len < (1u << 30); }
+bool sketch_wave_eligible(const ReadDesc &rd, int w, int k) {
+  return k == K && (w == 64 || w == 80 || w == 96 || w == 128) && rd.len < (1u << 30);
+}
+
+template <bool FUSED, int A>
+static void launch_w(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n, pgx_mm128 *d_slab,
+                     const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags, int rs, int levels) {
+  hipLaunchKernelGGL((k_sketch_wave<FUSED, A>), dim3(n), dim3(64), 0, ctx().stream, db->d_seq.p, d_reads, d_list, n, d_slab,
+                     d_slab_off, d_counts, d_flags, rs, levels);
+}
 
 void launch_sketch_wave(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n_list, int w,
                         int k, pgx_mm128 *d_slab, const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags) {
-  (void)w, (void)k;
+  (void)k;
   if (!n_list) return;
-  hipLaunchKernelGGL(k_sketch_wave<false>, dim3(n_list), dim3(64), 0, ctx().stream, db->d_seq.p, d_reads, d_list, n_list,
-                     d_slab, d_slab_off, d_counts, d_flags, 0, 0);
+  switch (w) {
+    case 64: launch_w<false, 4>(db, d_reads, d_list, n_list, d_slab, d_slab_off, d_counts, d_flags, 0, 0); break;
+    case 80: launch_w<false, 5>(db, d_reads, d_list, n_list, d_slab, d_slab_off, d_counts, d_flags, 0, 0); break;
+    case 96: launch_w<false, 6>(db, d_reads, d_list, n_list, d_slab, d_slab_off, d_counts, d_flags, 0, 0); break;
+    case 128: launch_w<false, 8>(db, d_reads, d_list, n_list, d_slab, d_slab_off, d_counts, d_flags, 0, 0); break;
+    default: PGX_REQUIRE(false, PGX_EARG, "window %d has no closed-form kernel", w);
+  }
   PGX_HIP(hipGetLastError());
 }
 
-// fused sketch + reduce x levels; requires rs <= RCARRY + 1 and levels in {1, 2}
-bool sketch_fused_supported(int rs, int levels) { return rs >= 1 && rs <= RCARRY + 1 && (levels == 1 || levels == 2); }
+// fused sketch + reduce x levels (w = 80 only); requires rs <= RCARRY + 1 and levels in {1, 2}
+bool sketch_fused_supported(int w, int rs, int levels) {
+  return w == 80 && rs >= 1 && rs <= RCARRY + 1 && (levels == 1 || levels == 2);
+}
 void launch_sketch_fused(const pgx_seqdb *db, const ReadDesc *d_reads, uint32_t n, int rs, int levels, pgx_mm128 *d_slab,
                          const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags) {
   if (!n) return;
-  hipLaunchKernelGGL(k_sketch_wave<true>, dim3(n), dim3(64), 0, ctx().stream, db->d_seq.p, d_reads, (const uint32_t *)nullptr,
-                     n, d_slab, d_slab_off, d_counts, d_flags, rs, levels);
+  launch_w<true, 5>(db, d_reads, nullptr, n, d_slab, d_slab_off, d_counts, d_flags, rs, levels);
   PGX_HIP(hipGetLastError());
 }
 
