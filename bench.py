@@ -32,7 +32,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="ecoli", help="ecoli (BASELINE configs[1]) | small | tiny | c3")
+    ap.add_argument("--workload", default="ecoli",
+                    help="ecoli (BASELINE configs[1], default) | small | tiny | c3 (configs[2]: 150 Mb x 30x, 4.5 Gbases, "
+                         "generated on the GPU; CPU baseline on a 10 Mb x 30x sample of the same recipe)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -98,8 +100,12 @@ def main():
 
     # ---- synthetic input (untimed): rank r simulates genome r; the union is the job's read set -----------------
     cfg = dict(simreads.WORKLOADS[a.workload])
-    g = simreads.make_genome(cfg.pop("genome_len"), cfg.pop("genome_seed") + 7919 * rank)
-    mine = simreads.simulate_reads(g, seed=42 + rank, **cfg)
+    if a.workload == "c3":   # multi-Gbase sets are generated with the torch recipe on the GPU (seconds instead of tens of minutes)
+        mine = simreads.simulate_reads_torch(cfg["genome_len"], cfg["genome_seed"] + 7919 * rank, cfg["coverage"], seed=42 + rank)
+        mine.names = None
+    else:
+        g = simreads.make_genome(cfg.pop("genome_len"), cfg.pop("genome_seed") + 7919 * rank)
+        mine = simreads.simulate_reads(g, seed=42 + rank, **cfg)
     if world > 1:
         parts = allgather_records(torch.from_numpy(mine.seqdb).to(xdev), world)
         lens = allgather_records(torch.from_numpy(mine.rlen.astype(np.int64)).to(xdev), world)
@@ -212,7 +218,14 @@ def main():
             "kernels": kern, "roofline": roof, "roofline_all": cands,
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(db, int(records))
+            if a.workload == "c3":  # bounded sample: the same recipe on a 10 Mb genome (~20 s of single-core reference time)
+                sample = simreads.simulate_reads_torch(10_000_000, 1003, 30.0, seed=42)
+                sample.names = [f"r{i:09d}" for i in range(sample.n_reads)]
+                cb = cpu_baseline(sample, -1)
+                cb["sample"] = "10 Mb x 30x sample of the c3 recipe: " + cb["sample"]
+                out["cpu_baseline"] = cb
+            else:
+                out["cpu_baseline"] = cpu_baseline(db, int(records))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
