@@ -159,6 +159,8 @@ struct PairTables {
   std::vector<uint32_t> gstart;    // ng+1 record offsets
   std::vector<uint32_t> gfirst, glast;  // first / last insertion of the group
   std::vector<uint32_t> gbucket;   // ng+1: first bucket of the group
+  std::vector<uint32_t> gord;      // groups in order of first insertion
+  std::vector<uint32_t> bord;      // buckets ordered by (group, first insertion): group g's slice is [gbucket[g], gbucket[g+1])
 };
 void dev_build_pairs(const pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts,
                      size_t n_counts, const pgx_overlap_params *p, PairTables &out);

@@ -11,6 +11,8 @@
 // alignments it asked for, runs them on the GPU, and replays with the true results until a replay asks for
 // nothing new.  That last replay used only true results, hence equals the reference's record sequence.
 #include <glob.h>
+#include <sched.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <chrono>
@@ -196,6 +198,10 @@ struct SlotTable {
     ids = (uint32_t *)realloc(ids, (size_t)nn * 4);
     const uint32_t m = nn - 1;
     for (uint32_t j = 0; j < nb; ++j) {
+      if (j + 16 < nb && used[j + 16]) {  // the destinations are random slots of a table that outgrew the caches
+        const uint32_t d = h32(keys[j + 16]) & m;
+        __builtin_prefetch(fresh + d, 1), __builtin_prefetch(keys + d, 1), __builtin_prefetch(ids + d, 1);
+      }
       if (!used[j]) continue;
       uint64_t key = keys[j];
       uint32_t id = ids[j];
@@ -230,6 +236,11 @@ struct SlotTable {
     *absent = true;
     return fresh_id;
   }
+  void prefetch(uint64_t key) const {  // start the miss a later put(key) will take
+    if (!nb) return;
+    const uint32_t i = h32(key) & (nb - 1);
+    __builtin_prefetch(used + i, 1), __builtin_prefetch(keys + i, 1);
+  }
 };
 
 static inline uint32_t pos_of(uint64_t y) { return (uint32_t)((y & 0xFFFFFFFFu) >> 1); }
@@ -243,9 +254,29 @@ struct Entry {
   uint64_t y0;
   uint8_t dir;
 };
+template <typename T>
+struct RawArray {  // malloc'd, never value-initialised (hundreds of MB that are about to be overwritten anyway)
+  T *p = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    free(p);
+    p = (T *)malloc(count ? count * sizeof(T) : 1);
+    if (!p) throw std::bad_alloc();
+    n = count;
+  }
+  void clear() { free(p), p = nullptr, n = 0; }
+  T *data() { return p; }
+  const T *data() const { return p; }
+  size_t size() const { return n; }
+  RawArray() = default;
+  RawArray(const RawArray &) = delete;
+  RawArray &operator=(const RawArray &) = delete;
+  ~RawArray() { free(p); }
+};
+
 struct Visit {
   std::vector<uint64_t> start;  // bucket b covers entries [start[b], start[b+1])
-  std::vector<Entry> entries;
+  RawArray<Entry> entries;
 };
 
 // A reusable inner table: same slot behaviour as SlotTable, but storage is recycled between key0 groups so the
@@ -307,20 +338,23 @@ struct ScratchTable {
 // inserted, plus one detail: a put of an already-present key still runs the load-factor check (khash.h:298-306), so if any
 // put follows the last first-insertion the table may grow once more.  Both levels are replayed on distinct keys only.
 void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
-  v.start.clear(), v.entries.clear();
-  v.start.push_back(0);
+  v.start.assign(1, 0), v.entries.clear();
   const size_t ng = pt.gkey0.size();
   if (!ng) return;
   bool absent;
+  const bool trace = getenv("PGX_TRACE") != nullptr;
+  const double tv0 = now_ms();
   // level 1: key0 groups in order of first insertion
-  std::vector<uint32_t> gord(ng);
-  for (size_t g = 0; g < ng; ++g) gord[g] = (uint32_t)g;
-  std::sort(gord.begin(), gord.end(), [&](uint32_t a, uint32_t b) { return pt.gfirst[a] < pt.gfirst[b]; });
+  const std::vector<uint32_t> &gord = pt.gord;  // (sorted on the GPU)
   SlotTable outer;
-  for (uint32_t g : gord) outer.put(pt.gkey0[g], g, &absent);
+  for (size_t i = 0; i < ng; ++i) {
+    if (i + 12 < ng) outer.prefetch(pt.gkey0[gord[i + 12]]);
+    outer.put(pt.gkey0[gord[i]], gord[i], &absent);
+  }
   if ((size_t)pt.gfirst[gord.back()] + 1 < pt.n_rec) outer.put(pt.gkey0[gord[0]], 0, &absent);  // trailing repeat put
   // level 2: the inner tables are independent, so the outer slots are split into contiguous ranges, one per thread;
   // the fragments are concatenated in slot order afterwards
+  const double tv1 = now_ms();
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const unsigned nthr = (unsigned)std::min<size_t>(std::min(16u, hw), std::max<size_t>(1, ng / 2048));
   struct Frag {
@@ -332,19 +366,16 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
     const uint32_t lo = (uint32_t)((uint64_t)outer.nb * ti / nthr), hi = (uint32_t)((uint64_t)outer.nb * (ti + 1) / nthr);
     Frag &f = frag[ti];
     ScratchTable in;
-    std::vector<uint32_t> bord;
     bool ab;
     for (uint32_t s0 = lo; s0 < hi; ++s0) {
       if (!outer.used[s0]) continue;
       const uint32_t g = outer.ids[s0];
       if (pt.gstart[g + 1] - pt.gstart[g] <= 2) continue;  // no bucket of this key0 can hold more than 2 records
       const uint32_t b0 = pt.gbucket[g], b1 = pt.gbucket[g + 1];
-      bord.resize(b1 - b0);
-      for (uint32_t b = b0; b < b1; ++b) bord[b - b0] = b;
-      std::sort(bord.begin(), bord.end(), [&](uint32_t x, uint32_t y) { return pt.bfirst[x] < pt.bfirst[y]; });
+      const uint32_t *bord = pt.bord.data() + b0;  // this group's buckets by first insertion (sorted on the GPU)
       in.reset();
-      for (uint32_t b : bord) in.put(pt.bkey1[b], b, &ab);
-      if (pt.bfirst[bord.back()] < pt.glast[g]) in.put(pt.bkey1[bord[0]], 0, &ab);  // trailing repeat put
+      for (uint32_t i = 0; i < b1 - b0; ++i) in.put(pt.bkey1[bord[i]], bord[i], &ab);
+      if (pt.bfirst[bord[b1 - b0 - 1]] < pt.glast[g]) in.put(pt.bkey1[bord[0]], 0, &ab);  // trailing repeat put
       for (uint32_t s1 = 0; s1 < in.nb; ++s1) {
         if (!in.used[s1]) continue;
         const uint32_t b = in.ids[s1];
@@ -365,14 +396,32 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
     for (unsigned ti = 0; ti < nthr; ++ti) th.emplace_back(work, ti);
     for (auto &t : th) t.join();
   }
+  const double tv2 = now_ms();
   size_t ne = 0, nbk = 0;
-  for (const Frag &f : frag) ne += f.entries.size(), nbk += f.sizes.size();
-  v.entries.reserve(ne);
-  v.start.reserve(nbk + 1);
-  for (const Frag &f : frag) {
-    v.entries.insert(v.entries.end(), f.entries.begin(), f.entries.end());
-    for (uint32_t sz : f.sizes) v.start.push_back(v.start.back() + sz);
+  std::vector<size_t> e0(nthr + 1, 0), b0(nthr + 1, 0);
+  for (unsigned ti = 0; ti < nthr; ++ti) {
+    e0[ti + 1] = (ne += frag[ti].entries.size());
+    b0[ti + 1] = (nbk += frag[ti].sizes.size());
   }
+  v.entries.alloc(ne);
+  v.start.resize(nbk + 1);
+  auto place = [&](unsigned ti) {  // every thread moves its own fragment to its final place
+    const Frag &f = frag[ti];
+    if (!f.entries.empty()) memcpy(v.entries.data() + e0[ti], f.entries.data(), f.entries.size() * sizeof(Entry));
+    uint64_t at = e0[ti];
+    for (size_t i = 0; i < f.sizes.size(); ++i) v.start[b0[ti] + i] = at, at += f.sizes[i];
+  };
+  if (nthr == 1) {
+    place(0);
+  } else {
+    std::vector<std::thread> th;
+    for (unsigned ti = 0; ti < nthr; ++ti) th.emplace_back(place, ti);
+    for (auto &t : th) t.join();
+  }
+  v.start[nbk] = ne;
+  if (trace)
+    fprintf(stderr, "[pgx]   visit: outer table %.2f ms, inner tables (%u threads) %.2f ms, concatenation %.2f ms\n", tv1 - tv0,
+            nthr, tv2 - tv1, now_ms() - tv2);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -398,6 +447,23 @@ struct Verdict {
 // the GPU batch a wrong guess makes its bucket dirty, a right guess only has its record patched.  At the fixed point every
 // bucket was last evaluated against final inputs, which is exactly the sequential process.
 // ---------------------------------------------------------------------------------------------------------
+struct OvOut {  // the stage's output: one malloc'd array handed to the caller as is
+  pgx_ovlp *a = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    free(a);
+    a = (pgx_ovlp *)malloc(count ? count * sizeof(pgx_ovlp) : 1);
+    if (!a) throw std::bad_alloc();
+    n = count;
+  }
+  pgx_ovlp *release() {
+    pgx_ovlp *p = a;
+    a = nullptr, n = 0;
+    return p;
+  }
+  ~OvOut() { free(a); }
+};
+
 struct Replay {
   static constexpr uint32_t NONE = 0xFFFFFFFFu;
   const Visit &v;
@@ -405,10 +471,10 @@ struct Replay {
   uint32_t bestn;
   bool predict = true;  // PGX_PREDICT=0: guess "plain overlap" always
 
-  AKeyMap memo;                     // alignment key -> result index, or PENDING_BIT | request index
-  std::vector<pgx_match> results;
-  std::vector<pgx_align_key> requests;
-  static constexpr uint32_t PENDING_BIT = 0x80000000u;
+  AKeyMap memo;                     // alignment key -> global request number (its result is pending while >= req_base)
+  std::vector<pgx_match> results;   // indexed by global request number
+  std::vector<pgx_align_key> requests;  // this sweep's requests: global number = req_base + index
+  uint32_t req_base = 0;
 
   PairMap pair_id;                  // read pair -> dense id
   struct PState {
@@ -528,17 +594,17 @@ struct Replay {
         Verdict vd;
         const pgx_match *mm = nullptr;
         if (fresh) {
-          *mv = PENDING_BIT | (uint32_t)requests.size();
+          *mv = req_base + (uint32_t)requests.size();
           requests.push_back(pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}});
         }
-        if (*mv & PENDING_BIT) {
+        if (*mv >= req_base) {
           // guess: accepted; the type follows from the geometry the shimmer pair implies (read1 starts q_off bases into
           // read0): if read1 fits inside the rest of read0, or read0 starts (almost) where read1 starts, a containment
           vd.accepted = true;
           vd.type = T_OVERLAP;
           if (predict && (rlen1 <= rlen0 - q_off || q_off < (uint32_t)(END_FUZZ * 2 - 8)))
             vd.type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
-          guesses.push_back(Guess{b, *mv & ~PENDING_BIT, (uint32_t)recs.size(), rlen0, rlen1, q_off, vd.type});
+          guesses.push_back(Guess{b, *mv, (uint32_t)recs.size(), rlen0, rlen1, q_off, vd.type});
         } else {
           mm = &results[*mv];
           vd = classify(*mm, rlen0, rlen1, q_off);
@@ -583,6 +649,7 @@ struct Replay {
 
   // one round: evaluate the dirty buckets in order; returns the number of alignments requested
   size_t sweep() {
+    req_base = (uint32_t)results.size();
     requests.clear();
     guesses.clear();
     const size_t nb = bs.size();
@@ -595,18 +662,16 @@ struct Replay {
     return requests.size();
   }
 
-  // store the GPU results; right guesses get their record patched, wrong ones make their bucket dirty
-  bool settle(const std::vector<pgx_match> &r) {
-    const uint32_t base = (uint32_t)results.size();
-    for (size_t i = 0; i < requests.size(); ++i) {
-      const pgx_align_key &k = requests[i];
-      const AKey key{(uint64_t)k.rid0 << 32 | k.rid1, (uint64_t)k.q_off << 2 | (uint64_t)k.dir0 << 1 | k.dir1};
-      *memo.slot(key, nullptr) = base + (uint32_t)i;
-      results.push_back(r[i]);
-    }
+  // room for this sweep's results (the GPU batch writes them in place)
+  pgx_match *result_slots() {
+    results.resize((size_t)req_base + requests.size());
+    return results.data() + req_base;
+  }
+  // after the GPU batch: right guesses get their record patched, wrong ones make their bucket dirty
+  bool settle() {
     bool any = false;
     for (const Guess &g : guesses) {
-      const pgx_match &m = results[base + g.req];
+      const pgx_match &m = results[g.req];
       const Verdict vd = classify(m, g.rlen0, g.rlen1, g.q_off);
       if (!vd.accepted || vd.type != g.type) dirty[g.bucket] = 1, any = true;
       else recs[g.rec].match = m;
@@ -614,14 +679,14 @@ struct Replay {
     return any;
   }
 
-  void collect(std::vector<pgx_ovlp> &out, uint64_t &lookups, uint64_t &skips) const {
+  void collect(OvOut &out, uint64_t &lookups, uint64_t &skips) const {
     size_t total = 0;
     for (const BState &b : bs) total += b.nrec;
-    out.clear();
-    out.reserve(total);
+    out.alloc(total);
     lookups = skips = 0;
+    pgx_ovlp *w = out.a;
     for (const BState &b : bs) {
-      out.insert(out.end(), recs.begin() + b.rec0, recs.begin() + b.rec0 + b.nrec);
+      if (b.nrec) memcpy(w, recs.data() + b.rec0, (size_t)b.nrec * sizeof(pgx_ovlp)), w += b.nrec;
       lookups += b.lookups, skips += b.skips;
     }
   }
@@ -656,42 +721,105 @@ struct BlockArena {  // append-only, never moves what it handed out (other threa
   }
 };
 
+// The replay threads hammer one shared table with locked operations: spread over both sockets they run ~1.7x slower than
+// on one (measured, 2 x EPYC 9575F).  NodePin keeps the caller and the threads it starts on the memory node the caller
+// is running on, for the lifetime of the object (PGX_PIN=0 disables it).
+struct NodePin {
+  cpu_set_t saved, node;
+  bool active = false;
+  NodePin() {
+    if (const char *e = getenv("PGX_PIN"))
+      if (atoi(e) == 0) return;
+    if (sched_getaffinity(0, sizeof(saved), &saved) != 0) return;
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return;
+    for (int nd = 0; nd < 64; ++nd) {
+      char path[96];
+      snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", nd);
+      FILE *f = fopen(path, "r");
+      if (!f) break;
+      char line[4096];
+      const bool ok = fgets(line, sizeof(line), f) != nullptr;
+      fclose(f);
+      if (!ok) continue;
+      CPU_ZERO(&node);
+      bool mine = false;
+      for (char *q = line; *q && *q != '\n';) {  // "0-63,128-191"
+        char *end;
+        const long a = strtol(q, &end, 10);
+        long b = a;
+        if (end == q) break;
+        if (*end == '-') b = strtol(end + 1, &end, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+          if (CPU_ISSET(c, &saved)) {
+            CPU_SET(c, &node);
+            mine |= c == cpu;
+          }
+        q = *end == ',' ? end + 1 : end;
+      }
+      if (mine && CPU_COUNT(&node) >= 2) {
+        active = sched_setaffinity(0, sizeof(node), &node) == 0;  // threads created from here on inherit the mask
+        return;
+      }
+    }
+  }
+  ~NodePin() {
+    if (active) sched_setaffinity(0, sizeof(saved), &saved);
+  }
+  NodePin(const NodePin &) = delete;
+  NodePin &operator=(const NodePin &) = delete;
+};
+
+template <typename F>
+void par_run(unsigned nthr, F &&fn) {  // fn(thread index) on nthr threads, the caller being thread 0
+  std::vector<std::thread> th;
+  for (unsigned ti = 1; ti < nthr; ++ti) th.emplace_back([&fn, ti] { fn(ti); });
+  fn(0);
+  for (auto &x : th) x.join();
+}
+
 struct ParReplay {
-  static constexpr uint64_t NOOWN = ~0ULL;
-  static constexpr uint64_t EMPTY = ~0ULL;
-  static constexpr uint32_t NIL = 0xFFFFFFFFu;
-  static constexpr uint32_t PENDING_BIT = 0x80000000u;
+  // every field of the shared pair table encodes "nothing" as 0, so the table is plain zero-filled pages
+  static constexpr uint64_t NOOWN = 0;
+  static constexpr uint64_t EMPTY = 0;
+  static constexpr uint32_t NIL = 0;
+  static constexpr uint32_t NIN = 10;
   struct Overflow {};
 
   const Visit &v;
   const std::vector<uint32_t> &rlen;
   uint32_t bestn;
   bool predict = true;
+  bool trace = false;
   unsigned nthr;
 
-  struct PSlot {
-    std::atomic<uint64_t> key;
-    std::atomic<uint64_t> own;   // owner bucket << 8 | type, or NOOWN
-    std::atomic<uint32_t> rhead; // reader list head (index into rlog) or NIL
-    uint32_t pad;
+  struct alignas(64) PSlot {       // one cache line per read pair
+    std::atomic<uint64_t> key;     // pair + 1, or EMPTY
+    std::atomic<uint64_t> own;     // (owner bucket << 8 | type) + 1, or NOOWN
+    std::atomic<uint32_t> rhead;   // overflow reader list: index into rlog, or NIL
+    std::atomic<uint32_t> nin;     // inline reader entries claimed (may run past NIN)
+    std::atomic<uint32_t> in[NIN]; // the first readers, bucket + 1 (0: claimed but not yet written)
   };
-  std::unique_ptr<PSlot[]> ptab;
+  static_assert(sizeof(PSlot) == 64, "pair slot must be one cache line");
+  PSlot *ptab = nullptr;           // mmap'd: zero pages, transparent huge pages where the kernel grants them
   size_t pcap = 0;
   std::atomic<size_t> pcount{0};
   struct RNode {
     uint32_t next, bucket;
   };
   std::unique_ptr<RNode[]> rlog;
-  std::atomic<uint32_t> rcount{0};
+  std::atomic<uint32_t> rcount{1};  // node 0 is NIL
   uint32_t rcap = 0;
 
-  static constexpr int NSHARD = 64;
-  struct Shard {
+  static constexpr int SHARD_BITS = 10, NSHARD = 1 << SHARD_BITS;
+  struct alignas(64) Shard {
     std::mutex mu;
     AKeyMap map;
   };
   std::unique_ptr<Shard[]> shards;
-  std::vector<pgx_match> results;  // read-only while threads run
+  // request r's result lives in results[r]; it is pending while r >= settled (settled only moves between sweeps)
+  std::unique_ptr<pgx_match[]> results;
+  size_t settled = 0;
   std::unique_ptr<pgx_align_key[]> requests;
   std::atomic<uint32_t> nreq{0};
   uint32_t reqcap = 0;
@@ -712,7 +840,7 @@ struct ParReplay {
   };
   std::vector<BState> bs;
   std::unique_ptr<std::atomic<uint8_t>[]> dirty;
-  struct TL {
+  struct alignas(128) TL {  // per-thread state on its own cache lines (no false sharing between neighbours)
     BlockArena<pgx_ovlp> recs;
     BlockArena<Own> owned;
     std::vector<Guess> guesses;
@@ -724,29 +852,29 @@ struct ParReplay {
     uint32_t qnext = 0, qend = 0;      // private chunk of request slots
   };
   static constexpr uint32_t RCHUNK = 4096, QCHUNK = 32;
+  static constexpr size_t PREFETCH = 3;
   std::vector<TL> tl;
   std::atomic<size_t> cursor{0};
   std::atomic<bool> overflow{false};
 
-  static uint64_t enc(uint32_t owner, uint8_t type) { return (uint64_t)owner << 8 | type; }
-  static uint32_t owner_of(uint64_t o) { return (uint32_t)(o >> 8); }
-  static uint8_t type_of(uint64_t o) { return (uint8_t)(o & 0xFF); }
+  static uint64_t enc(uint32_t owner, uint8_t type) { return ((uint64_t)owner << 8 | type) + 1; }
+  static uint32_t owner_of(uint64_t o) { return (uint32_t)((o - 1) >> 8); }
+  static uint8_t type_of(uint64_t o) { return (uint8_t)((o - 1) & 0xFF); }
 
   ParReplay(const Visit &vv, const std::vector<uint32_t> &rl, uint32_t bn, unsigned threads)
       : v(vv), rlen(rl), bestn(bn), nthr(threads) {
     const size_t ne = std::max<size_t>(v.entries.size(), 1024);
     pcap = 1024;
     while (pcap < ne - ne / 4) pcap <<= 1;  // distinct pairs ~ 0.25-0.3 x entries; > 70 % load -> Overflow -> sequential replay
-    ptab.reset(new PSlot[pcap]);
-    for (size_t i = 0; i < pcap; ++i) {
-      ptab[i].key.store(EMPTY, std::memory_order_relaxed);
-      ptab[i].own.store(NOOWN, std::memory_order_relaxed);
-      ptab[i].rhead.store(NIL, std::memory_order_relaxed);
-    }
+    void *m = mmap(nullptr, pcap * sizeof(PSlot), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m == MAP_FAILED) throw std::bad_alloc();
+    madvise(m, pcap * sizeof(PSlot), MADV_HUGEPAGE);  // random probes over a GB-sized table: fewer TLB misses
+    ptab = (PSlot *)m;
     rcap = (uint32_t)std::min<size_t>(ne * 10 + (size_t)nthr * RCHUNK, 0xFFFFFFF0u);
     rlog.reset(new RNode[rcap]);
     reqcap = (uint32_t)std::min<size_t>(ne * 2 + (size_t)nthr * QCHUNK * 8 + 1024, 0x7FFFFFF0u);
     requests.reset(new pgx_align_key[reqcap]);
+    results.reset(new pgx_match[reqcap]);  // untouched pages cost nothing
     shards.reset(new Shard[NSHARD]);
     for (int i = 0; i < NSHARD; ++i) shards[i].map.init(std::max<size_t>(256, ne / (NSHARD * 2)));
     const size_t nb = v.start.size() - 1;
@@ -755,16 +883,29 @@ struct ParReplay {
     for (size_t i = 0; i < nb; ++i) dirty[i].store(1, std::memory_order_relaxed);
     tl.resize(nthr);
   }
+  ~ParReplay() {
+    if (ptab) munmap((void *)ptab, pcap * sizeof(PSlot));
+  }
+  ParReplay(const ParReplay &) = delete;
+  ParReplay &operator=(const ParReplay &) = delete;
+
+  // A seq_cst load is a plain load on x86, a seq_cst store a locked exchange that drains the store buffer and ends all
+  // memory-level parallelism: most marks hit a flag that is already set, so look first.  (If the flag reads 1 the
+  // bucket's next evaluation starts after this point in the seq_cst order and therefore sees the caller's update.)
+  void mark_dirty(uint32_t b) {
+    if (dirty[b].load(std::memory_order_seq_cst) == 0) dirty[b].store(1, std::memory_order_seq_cst);
+  }
 
   uint32_t pid_of(uint64_t pair) {
     size_t i = mix(pair) & (pcap - 1);
+    const uint64_t want = pair + 1;
     unsigned probes = 0;
     for (;;) {
       uint64_t k = ptab[i].key.load(std::memory_order_acquire);
-      if (k == pair) return (uint32_t)i;
+      if (k == want) return (uint32_t)i;
       if (k == EMPTY) {
-        if (ptab[i].key.compare_exchange_strong(k, pair, std::memory_order_acq_rel)) return (uint32_t)i;
-        if (k == pair) return (uint32_t)i;
+        if (ptab[i].key.compare_exchange_strong(k, want, std::memory_order_acq_rel)) return (uint32_t)i;
+        if (k == want) return (uint32_t)i;
       }
       i = (i + 1) & (pcap - 1);
       if (++probes > 512) {  // the table is far fuller than sized for: give up (sequential replay takes over)
@@ -773,7 +914,21 @@ struct ParReplay {
       }
     }
   }
+  // Register bucket b as a reader of the pair BEFORE it loads the owner.  The first NIN readers live in the slot's own
+  // cache line; a bucket that is already listed (an earlier evaluation) is not added again.
   void add_reader(PSlot &ps, uint32_t b, TL &t) {
+    const uint32_t have = std::min(ps.nin.load(std::memory_order_relaxed), NIN);
+    for (uint32_t i = 0; i < have; ++i)
+      if (ps.in[i].load(std::memory_order_relaxed) == b + 1) return;  // listed by an earlier evaluation: the writer's
+                                                                      // scan finds it, and this run's owner load follows
+                                                                      // the seq_cst exchange that cleared dirty[b]
+    if (have < NIN) {
+      const uint32_t i = ps.nin.fetch_add(1, std::memory_order_relaxed);
+      if (i < NIN) {
+        ps.in[i].store(b + 1, std::memory_order_seq_cst);
+        return;
+      }
+    }
     if (t.rnext == t.rend) {  // a shared counter per node would serialise the threads on one cache line
       t.rnext = rcount.fetch_add(RCHUNK, std::memory_order_relaxed);
       t.rend = t.rnext + RCHUNK;
@@ -790,8 +945,28 @@ struct ParReplay {
     } while (!ps.rhead.compare_exchange_weak(h, n, std::memory_order_seq_cst));
   }
   void mark_readers_after(PSlot &ps, uint32_t b) {
+    const uint32_t have = std::min(ps.nin.load(std::memory_order_seq_cst), NIN);
+    for (uint32_t i = 0; i < have; ++i) {
+      const uint32_t x = ps.in[i].load(std::memory_order_seq_cst);  // 0: that reader has not loaded the owner yet
+      if (x > b + 1) mark_dirty(x - 1);
+    }
     for (uint32_t n = ps.rhead.load(std::memory_order_seq_cst); n != NIL; n = rlog[n].next)
-      if (rlog[n].bucket > b) dirty[rlog[n].bucket].store(1, std::memory_order_seq_cst);
+      if (rlog[n].bucket > b) mark_dirty(rlog[n].bucket);
+  }
+
+  // The pair table is far larger than the caches and every examination is a random probe into it: the worker starts
+  // the misses of the NEXT bucket's likely probes (the first PREFETCH partners of every row) before evaluating this one.
+  void prefetch_bucket(uint32_t b) const {
+    const Entry *e = v.entries.data() + v.start[b];
+    const size_t n = v.start[b + 1] - v.start[b];
+    for (size_t ai = 0; ai + 1 < n; ++ai) {
+      const uint32_t rid0 = e[ai].rid;
+      for (size_t pi = ai + 1, pe = std::min(n, ai + 1 + PREFETCH); pi < pe; ++pi) {
+        const uint32_t rid1 = e[pi].rid;
+        const uint64_t pair = rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0);
+        __builtin_prefetch(&ptab[mix(pair) & (pcap - 1)], 1);
+      }
+    }
   }
 
   void eval(uint32_t b, TL &t) {
@@ -843,7 +1018,7 @@ struct ParReplay {
         ++lookups;
         uint32_t mval;
         {
-          Shard &sh = shards[mix(key.a ^ mix(key.b)) >> 58];
+          Shard &sh = shards[mix(key.a ^ mix(key.b)) >> (64 - SHARD_BITS)];
           std::lock_guard<std::mutex> lk(sh.mu);
           bool fresh;
           uint32_t *mv = sh.map.slot(key, &fresh);
@@ -856,20 +1031,16 @@ struct ParReplay {
                 requests[z] = pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}};
             }
             const uint32_t r = t.qnext++;
-            if (r >= reqcap) {
-              overflow.store(true);
-              *mv = PENDING_BIT;
-            } else {
-              requests[r] = pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}};
-              *mv = PENDING_BIT | r;
-            }
+            if (r >= reqcap) overflow.store(true);
+            else requests[r] = pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}};
+            *mv = r;
           }
           mval = *mv;
         }
         Verdict vd;
         const pgx_match *mm = nullptr;
         bool guessed = false;
-        if (mval & PENDING_BIT) {
+        if (mval >= settled) {
           vd.accepted = true;
           vd.type = T_OVERLAP;
           if (predict && (rlen1 <= rlen0 - q_off || q_off < (uint32_t)(END_FUZZ * 2 - 8)))
@@ -887,11 +1058,11 @@ struct ParReplay {
           uint64_t c2 = ps.own.load(std::memory_order_seq_cst);
           for (;;) {
             if (c2 != NOOWN && owner_of(c2) < b) {
-              dirty[b].store(1, std::memory_order_seq_cst);
+              mark_dirty(b);
               break;
             }
             if (ps.own.compare_exchange_weak(c2, enc(b, vd.type), std::memory_order_seq_cst)) {
-              if (c2 != NOOWN && owner_of(c2) > b) dirty[owner_of(c2)].store(1, std::memory_order_seq_cst);
+              if (c2 != NOOWN && owner_of(c2) > b) mark_dirty(owner_of(c2));
               break;
             }
           }
@@ -902,7 +1073,7 @@ struct ParReplay {
           o.strand0 = e[ai].dir, o.strand1 = e[pi].dir, o.ovlp_type = vd.type;
           if (mm) o.match = *mm;
           if (guessed)
-            t.guesses.push_back(Guess{b, st.epoch, mval & ~PENDING_BIT, rlen0, rlen1, q_off,
+            t.guesses.push_back(Guess{b, st.epoch, mval, rlen0, rlen1, q_off,
                                       (pgx_ovlp *)(uintptr_t)t.tmp_recs.size(), vd.type});
           t.tmp_recs.push_back(o);
         }
@@ -951,8 +1122,11 @@ struct ParReplay {
       const size_t c0 = cursor.fetch_add(16, std::memory_order_relaxed);
       if (c0 >= nb || overflow.load(std::memory_order_relaxed)) return;
       const size_t c1 = std::min(nb, c0 + 16);
-      for (size_t b = c0; b < c1; ++b)
-        if (dirty[b].exchange(0, std::memory_order_seq_cst)) eval((uint32_t)b, t);
+      if (dirty[c0].load(std::memory_order_relaxed)) prefetch_bucket((uint32_t)c0);
+      for (size_t b = c0; b < c1; ++b) {
+        if (b + 1 < c1 && dirty[b + 1].load(std::memory_order_relaxed)) prefetch_bucket((uint32_t)(b + 1));
+        if (dirty[b].load(std::memory_order_relaxed) && dirty[b].exchange(0, std::memory_order_seq_cst)) eval((uint32_t)b, t);
+      }
     }
   }
 
@@ -964,14 +1138,10 @@ struct ParReplay {
       for (size_t b = 0; b < nb; ++b) nd += dirty[b].load(std::memory_order_relaxed);
       if (!nd) break;
       cursor.store(0);
-      if (nd < 512 || nthr == 1) {
-        worker(0);
-      } else {
-        std::vector<std::thread> th;
-        for (unsigned ti = 1; ti < nthr; ++ti) th.emplace_back(&ParReplay::worker, this, ti);
-        worker(0);
-        for (auto &x : th) x.join();
-      }
+      const double r0 = now_ms();
+      if (nd < 512 || nthr == 1) worker(0);
+      else par_run(nthr, [&](unsigned ti) { worker(ti); });
+      if (trace) fprintf(stderr, "[pgx]   round: %zu dirty buckets, %.2f ms\n", nd, now_ms() - r0);
       if (overflow.load()) throw Overflow();
       if (n_rounds) ++*n_rounds;
     }
@@ -983,39 +1153,49 @@ struct ParReplay {
     return std::min<size_t>(nreq.load(), reqcap);
   }
 
-  bool settle(const std::vector<pgx_match> &r, size_t first_req) {
-    const uint32_t base = (uint32_t)results.size();
-    const size_t n = r.size();
-    for (size_t i = 0; i < n; ++i) {
-      const pgx_align_key &k = requests[first_req + i];
-      const AKey key{(uint64_t)k.rid0 << 32 | k.rid1, (uint64_t)k.q_off << 2 | (uint64_t)k.dir0 << 1 | k.dir1};
-      *shards[mix(key.a ^ mix(key.b)) >> 58].map.slot(key, nullptr) = base + (uint32_t)i;
-      results.push_back(r[i]);
-    }
-    bool any = false;
-    for (TL &t : tl) {
+  // results[first_req, upto) have been written by the GPU batch: right guesses get their record patched, wrong ones
+  // make their bucket dirty.  Every thread settles the guesses it made itself.
+  bool settle(size_t first_req, size_t upto) {
+    settled = upto;
+    std::atomic<bool> any{false};
+    auto one = [&](unsigned ti) {
+      TL &t = tl[ti];
+      bool mine = false;
       for (const Guess &g : t.guesses) {
         if (g.req < first_req) continue;
-        const pgx_match &m = results[base + (g.req - first_req)];
+        const pgx_match &m = results[g.req];
         const Verdict vd = Replay::classify(m, g.rlen0, g.rlen1, g.q_off);
-        if (!vd.accepted || vd.type != g.type) dirty[g.bucket].store(1), any = true;
+        if (!vd.accepted || vd.type != g.type) dirty[g.bucket].store(1), mine = true;
         else if (bs[g.bucket].epoch == g.epoch) g.rec->match = m;  // (a newer evaluation has its own guesses)
       }
       t.guesses.clear();
-    }
-    return any;
+      if (mine) any.store(true);
+    };
+    size_t ng = 0;
+    for (const TL &t : tl) ng += t.guesses.size();
+    if (ng < 4096) for (unsigned ti = 0; ti < nthr; ++ti) one(ti);
+    else par_run(nthr, one);
+    return any.load();
   }
 
-  void collect(std::vector<pgx_ovlp> &out, uint64_t &lookups, uint64_t &skips) const {
-    size_t total = 0;
-    for (const BState &b : bs) total += b.nrec;
-    out.clear();
-    out.reserve(total);
+  void collect(OvOut &out, uint64_t &lookups, uint64_t &skips) const {
+    const size_t nb = bs.size();
+    std::vector<size_t> first(nthr + 1, 0);  // output offset of each thread's slice of the bucket order
     lookups = skips = 0;
-    for (const BState &b : bs) {
-      if (b.nrec) out.insert(out.end(), b.recs, b.recs + b.nrec);
-      lookups += b.lookups, skips += b.skips;
+    for (unsigned ti = 0; ti < nthr; ++ti) {
+      size_t c = 0;
+      for (size_t b = nb / nthr * ti, e = ti + 1 == nthr ? nb : nb / nthr * (ti + 1); b < e; ++b)
+        c += bs[b].nrec, lookups += bs[b].lookups, skips += bs[b].skips;
+      first[ti + 1] = first[ti] + c;
     }
+    out.alloc(first[nthr]);
+    auto one = [&](unsigned ti) {
+      pgx_ovlp *w = out.a + first[ti];
+      for (size_t b = nb / nthr * ti, e = ti + 1 == nthr ? nb : nb / nthr * (ti + 1); b < e; ++b)
+        if (bs[b].nrec) memcpy(w, bs[b].recs, (size_t)bs[b].nrec * sizeof(pgx_ovlp)), w += bs[b].nrec;
+    };
+    if (first[nthr] < (1u << 16)) for (unsigned ti = 0; ti < nthr; ++ti) one(ti);
+    else par_run(nthr, one);
   }
 };
 
@@ -1028,7 +1208,7 @@ void check_params(const pgx_overlap_params *p) {
 }
 
 void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
-                 const pgx_overlap_params *p, std::vector<pgx_ovlp> &out, pgx_overlap_stats *st) {
+                 const pgx_overlap_params *p, OvOut &out, pgx_overlap_stats *st) {
   pgx_overlap_stats s;
   memset(&s, 0, sizeof(s));
   const double t0 = now_ms();
@@ -1045,21 +1225,20 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   if (getenv("PGX_TRACE"))
     fprintf(stderr, "[pgx] GPU join: %zu records, %zu buckets, %zu key0 groups in %.2f ms; visit order (%llu buckets) in %.2f ms\n",
             pt.n_rec, pt.bkey1.size(), pt.gkey0.size(), t1 - t0, (unsigned long long)s.n_buckets, now_ms() - t1);
-  auto align_batch = [&](const pgx_align_key *keys, size_t nreq, std::vector<pgx_match> &res) {
+  auto align_batch = [&](const pgx_align_key *keys, size_t nreq, pgx_match *res) {  // results land in the replay's table
     const double g0 = now_ms();
     pgx_align_key *d_keys = ws<pgx_align_key>("ov.keys", nreq);
     pgx_match *d_res = ws<pgx_match>("ov.res", nreq);
     PGX_HIP(hipMemcpyAsync(d_keys, keys, nreq * sizeof(pgx_align_key), hipMemcpyHostToDevice, ctx().stream));
     dev_align(db, d_keys, nreq, p->align_bandwidth, d_res);
-    res.resize(nreq);
-    PGX_HIP(hipMemcpyAsync(res.data(), d_res, nreq * sizeof(pgx_match), hipMemcpyDeviceToHost, ctx().stream));
+    PGX_HIP(hipMemcpyAsync(res, d_res, nreq * sizeof(pgx_match), hipMemcpyDeviceToHost, ctx().stream));
     sync();
     gpu_ms += now_ms() - g0;
     s.n_align_gpu += nreq;
   };
   const bool trace = getenv("PGX_TRACE") != nullptr;
   const bool predict = !(getenv("PGX_PREDICT") && atoi(getenv("PGX_PREDICT")) == 0);
-  unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  unsigned threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
   if (const char *tv = getenv("PGX_THREADS")) threads = (unsigned)std::max(1, atoi(tv));
   // the shared-table protocol costs ~3 locked operations per examination: it pays once the pair table no longer fits the
   // caches (measured: 4.2 s -> 0.8 s for sweep 1 at 4.5 Gbases with 16 threads; slower than sequential at 75 Mbases)
@@ -1067,12 +1246,16 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   if (const char *pm = getenv("PGX_PAR_MIN")) par_min = (size_t)atoll(pm);
   if (visit.entries.size() < par_min) threads = 1;
   bool done = false;
-  std::vector<pgx_match> res;
   if (threads > 1) {
     try {
+      const double c0 = now_ms();
+      NodePin pin;
       ParReplay rp(visit, db->rlen_by_rid, (uint32_t)(uint8_t)p->bestn, threads);
       rp.predict = predict;
+      rp.trace = trace;
+      if (trace) fprintf(stderr, "[pgx] parallel replay tables set up in %.2f ms\n", now_ms() - c0);
       size_t first_req = 0;
+      double settle_ms = 0;
       for (;;) {
         const double p0 = now_ms();
         uint64_t ev = 0;
@@ -1083,12 +1266,16 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
           fprintf(stderr, "[pgx] parallel sweep %u (%u threads): %u rounds, %llu evaluations so far, %.2f ms, %zu requests\n",
                   s.rounds, threads, rounds, (unsigned long long)ev, now_ms() - p0, upto - first_req);
         if (upto == first_req) break;
-        align_batch(rp.requests.get() + first_req, upto - first_req, res);
-        const bool any = rp.settle(res, first_req);
+        align_batch(rp.requests.get() + first_req, upto - first_req, rp.results.get() + first_req);
+        const double s0 = now_ms();
+        const bool any = rp.settle(first_req, upto);
+        settle_ms += now_ms() - s0;
         first_req = upto;
         if (!any) break;
       }
+      const double k0 = now_ms();
       rp.collect(out, s.n_align_needed, s.n_seen_skip);
+      if (trace) fprintf(stderr, "[pgx] settle %.2f ms total, collect %.2f ms\n", settle_ms, now_ms() - k0);
       done = true;
     } catch (const ParReplay::Overflow &) {
       fprintf(stderr, "[pgx] note: parallel replay tables overflowed; falling back to the sequential replay\n");
@@ -1107,13 +1294,13 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
         fprintf(stderr, "[pgx] replay sweep %u: %llu buckets evaluated in %.2f ms, %zu requests\n", s.rounds,
                 (unsigned long long)(rp.n_eval - ev0), now_ms() - p0, nreq);
       if (nreq == 0) break;
-      align_batch(rp.requests.data(), nreq, res);
-      if (!rp.settle(res)) break;  // every guess was right: the replay is exact
+      align_batch(rp.requests.data(), nreq, rp.result_slots());
+      if (!rp.settle()) break;  // every guess was right: the replay is exact
     }
     rp.collect(out, s.n_align_needed, s.n_seen_skip);
   }
   timing_flush();
-  s.n_records = out.size();
+  s.n_records = out.n;
   s.gpu_ms = gpu_ms;
   s.host_ms = now_ms() - t0 - gpu_ms;
   if (st) *st = s;
@@ -1153,10 +1340,10 @@ int pgx_overlap_resident(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, con
     PGX_REQUIRE(db && out && n_out && (n_mm == 0 || mmers) && (n_counts == 0 || counts), PGX_EARG,
                 "pgx_overlap_resident: null argument");
     check_params(p);
-    std::vector<pgx_ovlp> v;
+    OvOut v;
     run_overlap(db, mmers, n_mm, counts, n_counts, p, v, stats);
-    *out = host_copy(v);
-    *n_out = v.size();
+    *n_out = v.n;
+    *out = v.release();
   } catch (const Fail &f) {
     return f.code;
   } catch (const std::bad_alloc &) {
@@ -1180,11 +1367,11 @@ int pgx_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, cons
     std::vector<pgx_mm_count> mc;
     read_counted_files(std::string(shimmer_prefix) + "-[0-9]*-of-[0-9]*.dat", mm);
     read_counted_files(std::string(shimmer_prefix) + "-MC-[0-9]*-of-[0-9]*.dat", mc);
-    std::vector<pgx_ovlp> v;
+    OvOut v;
     run_overlap(db, mm.data(), mm.size(), mc.data(), mc.size(), p, v, stats);
     FILE *f = fopen(out_path, "wb");
     PGX_REQUIRE(f, PGX_EIO, "file '%s' open error", out_path);
-    bool ok = v.empty() || fwrite(v.data(), sizeof(pgx_ovlp), v.size(), f) == v.size();
+    bool ok = v.n == 0 || fwrite(v.a, sizeof(pgx_ovlp), v.n, f) == v.n;
     ok = (fclose(f) == 0) && ok;
     PGX_REQUIRE(ok, PGX_EIO, "short write to '%s'", out_path);
   } catch (const Fail &f) {

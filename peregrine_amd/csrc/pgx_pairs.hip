@@ -161,6 +161,20 @@ __global__ void k_group_first_bucket(const uint32_t *__restrict__ gstart, uint32
   gb[g] = lo;
 }
 
+// sort key of a bucket for the host's table replay: (its key0 group, its first insertion)
+__global__ void k_bucket_order_key(const uint32_t *__restrict__ gbucket, uint32_t ng, const uint32_t *__restrict__ bfirst,
+                                   uint32_t nbk, uint64_t *__restrict__ key) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbk) return;
+  uint32_t lo = 0, hi = ng;  // last group whose first bucket is <= b
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (gbucket[mid] <= b) lo = mid;
+    else hi = mid;
+  }
+  key[b] = (uint64_t)lo << 32 | bfirst[b];
+}
+
 template <typename T>
 std::vector<T> to_host(const DevBuf<T> &d, size_t n) {
   std::vector<T> h(n);
@@ -285,8 +299,25 @@ void dev_build_pairs(const pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, c
   PGX_HIP(hipcub::DeviceSegmentedReduce::Max(tmp.get(bytes), bytes, perm_a.p, glast.p, (int)ng, gstart.p, gstart.p + 1, st));
   hipLaunchKernelGGL(k_group_first_bucket, dim3(cdiv(ng, 256)), dim3(256), 0, st, gstart.p, ng, bstart.p, nbk, gbucket.p);
 
+  // insertion orders the host replays the two khash levels in: groups by first insertion, buckets by (group, first insertion)
+  DevBuf<uint32_t> gord(ng), bord(nbk), iota_g(ng), iota_b(nbk), gf_sorted(ng);
+  DevBuf<uint64_t> bok(nbk), bok_sorted(nbk);
+  {
+    hipLaunchKernelGGL(k_iota, dim3(cdiv(ng, 256)), dim3(256), 0, st, iota_g.p, ng);
+    bytes = 0;
+    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, gfirst.p, gf_sorted.p, iota_g.p, gord.p, (int)ng, 0, 32, st));
+    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, gfirst.p, gf_sorted.p, iota_g.p, gord.p, (int)ng, 0, 32, st));
+    hipLaunchKernelGGL(k_iota, dim3(cdiv(nbk, 256)), dim3(256), 0, st, iota_b.p, nbk);
+    hipLaunchKernelGGL(k_bucket_order_key, dim3(cdiv(nbk, 256)), dim3(256), 0, st, gbucket.p, ng, bfirst.p, nbk, bok.p);
+    bytes = 0;
+    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, bok.p, bok_sorted.p, iota_b.p, bord.p, (int)nbk, 0, 64, st));
+    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, bok.p, bok_sorted.p, iota_b.p, bord.p, (int)nbk, 0, 64, st));
+  }
+
   out.y0 = to_host(sy0, nr);
   out.dir = to_host(sdir, nr);
+  out.gord = to_host(gord, ng);
+  out.bord = to_host(bord, nbk);
   DevBuf<uint64_t> bkey1(nbk), gkey0(ng);
   hipLaunchKernelGGL(k_gather_u64, dim3(cdiv(nbk, 256)), dim3(256), 0, st, sk1.p, bstart.p, nbk, bkey1.p);
   hipLaunchKernelGGL(k_gather_u64, dim3(cdiv(ng, 256)), dim3(256), 0, st, kgs.p, gstart.p, ng, gkey0.p);
