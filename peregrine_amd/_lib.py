@@ -64,6 +64,14 @@ def load():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise PgxError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # One HIP runtime per process.  A PyTorch-ROCm wheel bundles its own libamdhip64.so.7; if libpgx were loaded first
+        # it would bind /opt/rocm's copy, a later `import torch` would load the bundled one next to it, and the second
+        # runtime finds no device.  With torch imported first both resolve to the same copy (the loader matches SONAMEs).
+        # Without torch installed nothing changes.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         lib.pgx_last_error.restype = C.c_char_p
         lib.pgx_version.restype = C.c_char_p

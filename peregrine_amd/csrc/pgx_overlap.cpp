@@ -341,35 +341,49 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
   v.start.assign(1, 0), v.entries.clear();
   const size_t ng = pt.gkey0.size();
   if (!ng) return;
-  bool absent;
   const bool trace = getenv("PGX_TRACE") != nullptr;
   const double tv0 = now_ms();
-  // level 1: key0 groups in order of first insertion
-  const std::vector<uint32_t> &gord = pt.gord;  // (sorted on the GPU)
-  SlotTable outer;
-  for (size_t i = 0; i < ng; ++i) {
-    if (i + 12 < ng) outer.prefetch(pt.gkey0[gord[i + 12]]);
-    outer.put(pt.gkey0[gord[i]], gord[i], &absent);
-  }
-  if ((size_t)pt.gfirst[gord.back()] + 1 < pt.n_rec) outer.put(pt.gkey0[gord[0]], 0, &absent);  // trailing repeat put
-  // level 2: the inner tables are independent, so the outer slots are split into contiguous ranges, one per thread;
-  // the fragments are concatenated in slot order afterwards
-  const double tv1 = now_ms();
+  // The two levels are independent until the very end: the outer table only decides the ORDER in which the key0 groups
+  // are visited, an inner table only the order of one group's buckets.  So one thread replays the outer table (a
+  // sequential process with long probe chains: key0 = small hash << 8 | span is a poor input for khash's integer hash)
+  // while the others replay the inner tables, group range by group range; then the groups' fragments are moved to their
+  // final places in outer-slot order.
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const unsigned nthr = (unsigned)std::min<size_t>(std::min(16u, hw), std::max<size_t>(1, ng / 2048));
+  const unsigned nin = (unsigned)std::min<size_t>(std::min(16u, hw), std::max<size_t>(1, ng / 2048));  // inner workers
+  struct GroupOut {
+    uint64_t eoff;      // offset of the group's entries in its worker's fragment
+    uint32_t boff;      // offset of its bucket sizes
+    uint32_t ne, nb;    // entries, buckets (0: nothing to visit)
+    uint32_t worker;
+  };
+  std::vector<GroupOut> go(ng);
   struct Frag {
     std::vector<uint32_t> sizes;
     std::vector<Entry> entries;
   };
-  std::vector<Frag> frag(nthr);
-  auto work = [&](unsigned ti) {
-    const uint32_t lo = (uint32_t)((uint64_t)outer.nb * ti / nthr), hi = (uint32_t)((uint64_t)outer.nb * (ti + 1) / nthr);
+  std::vector<Frag> frag(nin);
+  SlotTable outer;
+  auto outer_work = [&] {
+    bool absent;
+    const std::vector<uint32_t> &gord = pt.gord;  // groups by first insertion (sorted on the GPU)
+    for (size_t i = 0; i < ng; ++i) outer.put(pt.gkey0[gord[i]], gord[i], &absent);
+    if ((size_t)pt.gfirst[gord.back()] + 1 < pt.n_rec) outer.put(pt.gkey0[gord[0]], 0, &absent);  // trailing repeat put
+  };
+  auto inner_work = [&](unsigned ti) {
+    // group range with ~1/nin of the records
+    auto split = [&](unsigned t) {
+      if (t == 0) return (size_t)0;
+      if (t >= nin) return ng;
+      const uint32_t want = (uint32_t)((uint64_t)pt.n_rec * t / nin);
+      return (size_t)(std::lower_bound(pt.gstart.begin(), pt.gstart.begin() + ng, want) - pt.gstart.begin());
+    };
+    const size_t g_lo = split(ti), g_hi = split(ti + 1);
     Frag &f = frag[ti];
     ScratchTable in;
     bool ab;
-    for (uint32_t s0 = lo; s0 < hi; ++s0) {
-      if (!outer.used[s0]) continue;
-      const uint32_t g = outer.ids[s0];
+    for (size_t g = g_lo; g < g_hi; ++g) {
+      GroupOut &o = go[g];
+      o = GroupOut{f.entries.size(), (uint32_t)f.sizes.size(), 0, 0, ti};
       if (pt.gstart[g + 1] - pt.gstart[g] <= 2) continue;  // no bucket of this key0 can hold more than 2 records
       const uint32_t b0 = pt.gbucket[g], b1 = pt.gbucket[g + 1];
       const uint32_t *bord = pt.bord.data() + b0;  // this group's buckets by first insertion (sorted on the GPU)
@@ -386,42 +400,56 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
           f.entries.push_back(Entry{(uint32_t)(y >> 32), pos_of(y) + 1, y, pt.dir[r]});
         }
         f.sizes.push_back(bn);
+        o.ne += bn, ++o.nb;
       }
     }
   };
-  if (nthr == 1) {
-    work(0);
+  double t_outer = 0, t_inner = 0;
+  if (nin == 1) {
+    outer_work();
+    t_outer = now_ms() - tv0;
+    inner_work(0);
+    t_inner = now_ms() - tv0 - t_outer;
   } else {
     std::vector<std::thread> th;
-    for (unsigned ti = 0; ti < nthr; ++ti) th.emplace_back(work, ti);
+    for (unsigned ti = 0; ti < nin; ++ti) th.emplace_back(inner_work, ti);
+    outer_work();
+    t_outer = now_ms() - tv0;
     for (auto &t : th) t.join();
+    t_inner = now_ms() - tv0;
   }
   const double tv2 = now_ms();
-  size_t ne = 0, nbk = 0;
-  std::vector<size_t> e0(nthr + 1, 0), b0(nthr + 1, 0);
-  for (unsigned ti = 0; ti < nthr; ++ti) {
-    e0[ti + 1] = (ne += frag[ti].entries.size());
-    b0[ti + 1] = (nbk += frag[ti].sizes.size());
-  }
+  // final places: groups in ascending outer slot order
+  std::vector<uint32_t> order;
+  order.reserve(ng);
+  for (uint32_t s0 = 0; s0 < outer.nb; ++s0)
+    if (outer.used[s0] && go[outer.ids[s0]].nb) order.push_back(outer.ids[s0]);
+  const size_t no = order.size();
+  std::vector<uint64_t> eat(no + 1, 0), bat(no + 1, 0);
+  for (size_t i = 0; i < no; ++i) eat[i + 1] = eat[i] + go[order[i]].ne, bat[i + 1] = bat[i] + go[order[i]].nb;
+  const uint64_t ne = eat[no], nbk = bat[no];
   v.entries.alloc(ne);
   v.start.resize(nbk + 1);
-  auto place = [&](unsigned ti) {  // every thread moves its own fragment to its final place
-    const Frag &f = frag[ti];
-    if (!f.entries.empty()) memcpy(v.entries.data() + e0[ti], f.entries.data(), f.entries.size() * sizeof(Entry));
-    uint64_t at = e0[ti];
-    for (size_t i = 0; i < f.sizes.size(); ++i) v.start[b0[ti] + i] = at, at += f.sizes[i];
+  auto place = [&](unsigned ti, unsigned nt) {
+    for (size_t i = no * ti / nt, ie = no * (ti + 1) / nt; i < ie; ++i) {
+      const GroupOut &o = go[order[i]];
+      const Frag &f = frag[o.worker];
+      memcpy(v.entries.data() + eat[i], f.entries.data() + o.eoff, (size_t)o.ne * sizeof(Entry));
+      uint64_t at = eat[i];
+      for (uint32_t j = 0; j < o.nb; ++j) v.start[bat[i] + j] = at, at += f.sizes[o.boff + j];
+    }
   };
-  if (nthr == 1) {
-    place(0);
+  if (nin == 1) {
+    place(0, 1);
   } else {
     std::vector<std::thread> th;
-    for (unsigned ti = 0; ti < nthr; ++ti) th.emplace_back(place, ti);
+    for (unsigned ti = 0; ti < nin; ++ti) th.emplace_back(place, ti, nin);
     for (auto &t : th) t.join();
   }
   v.start[nbk] = ne;
   if (trace)
-    fprintf(stderr, "[pgx]   visit: outer table %.2f ms, inner tables (%u threads) %.2f ms, concatenation %.2f ms\n", tv1 - tv0,
-            nthr, tv2 - tv1, now_ms() - tv2);
+    fprintf(stderr, "[pgx]   visit: outer table %.2f ms alongside %u inner-table workers (done at %.2f ms), placement %.2f ms\n",
+            t_outer, nin, t_inner, now_ms() - tv2);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -792,6 +820,9 @@ struct ParReplay {
   bool predict = true;
   bool trace = false;
   unsigned nthr;
+  size_t block = 64;  // buckets a worker takes at a time: neighbours in visit order share a key0 group, hence reads and
+                      // pairs, so they are best evaluated in order by one thread (measured: 16 -> 12.6 k conflicts in the
+                      // first round at 4.5 Gbases, 64 -> 4.6 k, 1024 -> 22 k because the in-flight window grows)
 
   struct alignas(64) PSlot {       // one cache line per read pair
     std::atomic<uint64_t> key;     // pair + 1, or EMPTY
@@ -803,25 +834,26 @@ struct ParReplay {
   static_assert(sizeof(PSlot) == 64, "pair slot must be one cache line");
   PSlot *ptab = nullptr;           // mmap'd: zero pages, transparent huge pages where the kernel grants them
   size_t pcap = 0;
-  std::atomic<size_t> pcount{0};
   struct RNode {
     uint32_t next, bucket;
   };
   std::unique_ptr<RNode[]> rlog;
-  std::atomic<uint32_t> rcount{1};  // node 0 is NIL
+  // (the shared counters live on cache lines of their own, below: a fetch_add next to the read-mostly pointers would
+  //  evict those from every other core each time)
   uint32_t rcap = 0;
 
-  static constexpr int SHARD_BITS = 10, NSHARD = 1 << SHARD_BITS;
-  struct alignas(64) Shard {
-    std::mutex mu;
-    AKeyMap map;
+  // alignment memo: insert-only, lock-free.  A slot is claimed by a CAS on `a` (rid0 << 32 | rid1, never 0 because the two
+  // reads differ); `bv` = (q_off << 2 | dir0 << 1 | dir1) << 32 | (request number + 1) follows with a release store, and
+  // a thread that meets a claimed slot whose `bv` is still 0 waits the few nanoseconds until it appears.
+  struct MSlot {
+    std::atomic<uint64_t> a, bv;
   };
-  std::unique_ptr<Shard[]> shards;
+  MSlot *mtab = nullptr;  // mmap'd zero pages
+  size_t mcap = 0;
   // request r's result lives in results[r]; it is pending while r >= settled (settled only moves between sweeps)
   std::unique_ptr<pgx_match[]> results;
   size_t settled = 0;
   std::unique_ptr<pgx_align_key[]> requests;
-  std::atomic<uint32_t> nreq{0};
   uint32_t reqcap = 0;
 
   struct Own {
@@ -854,8 +886,11 @@ struct ParReplay {
   static constexpr uint32_t RCHUNK = 4096, QCHUNK = 32;
   static constexpr size_t PREFETCH = 3;
   std::vector<TL> tl;
-  std::atomic<size_t> cursor{0};
-  std::atomic<bool> overflow{false};
+  alignas(128) std::atomic<size_t> cursor{0};
+  alignas(128) std::atomic<uint32_t> nreq{0};
+  alignas(128) std::atomic<uint32_t> rcount{1};  // node 0 is NIL
+  alignas(128) std::atomic<bool> overflow{false};
+  alignas(128) char tail_pad = 0;
 
   static uint64_t enc(uint32_t owner, uint8_t type) { return ((uint64_t)owner << 8 | type) + 1; }
   static uint32_t owner_of(uint64_t o) { return (uint32_t)((o - 1) >> 8); }
@@ -875,8 +910,12 @@ struct ParReplay {
     reqcap = (uint32_t)std::min<size_t>(ne * 2 + (size_t)nthr * QCHUNK * 8 + 1024, 0x7FFFFFF0u);
     requests.reset(new pgx_align_key[reqcap]);
     results.reset(new pgx_match[reqcap]);  // untouched pages cost nothing
-    shards.reset(new Shard[NSHARD]);
-    for (int i = 0; i < NSHARD; ++i) shards[i].map.init(std::max<size_t>(256, ne / (NSHARD * 2)));
+    mcap = 1024;
+    while (mcap < ne) mcap <<= 1;  // distinct alignments ~ 0.3 x entries
+    void *mm = mmap(nullptr, mcap * sizeof(MSlot), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (mm == MAP_FAILED) throw std::bad_alloc();
+    madvise(mm, mcap * sizeof(MSlot), MADV_HUGEPAGE);
+    mtab = (MSlot *)mm;
     const size_t nb = v.start.size() - 1;
     bs.assign(nb, BState());
     dirty.reset(new std::atomic<uint8_t>[nb ? nb : 1]);
@@ -885,6 +924,7 @@ struct ParReplay {
   }
   ~ParReplay() {
     if (ptab) munmap((void *)ptab, pcap * sizeof(PSlot));
+    if (mtab) munmap((void *)mtab, mcap * sizeof(MSlot));
   }
   ParReplay(const ParReplay &) = delete;
   ParReplay &operator=(const ParReplay &) = delete;
@@ -1016,26 +1056,46 @@ struct ParReplay {
         const uint32_t q_off = pos0 - pos1;
         const AKey key{(uint64_t)rid0 << 32 | rid1, (uint64_t)q_off << 2 | (uint64_t)e[ai].dir << 1 | e[pi].dir};
         ++lookups;
-        uint32_t mval;
+        if (q_off >= (1u << 30)) overflow.store(true);  // (a Gbase-long read: the sequential replay's wider keys take over)
+        const uint64_t b32 = (uint64_t)q_off << 2 | (uint64_t)e[ai].dir << 1 | e[pi].dir;
+        uint32_t mval = 0;
         {
-          Shard &sh = shards[mix(key.a ^ mix(key.b)) >> (64 - SHARD_BITS)];
-          std::lock_guard<std::mutex> lk(sh.mu);
-          bool fresh;
-          uint32_t *mv = sh.map.slot(key, &fresh);
-          if (fresh) {
-            if (t.qnext == t.qend) {
-              t.qnext = nreq.fetch_add(QCHUNK, std::memory_order_relaxed);
-              t.qend = t.qnext + QCHUNK;
-              // unused slots of a chunk must still hold a valid key: pre-fill with this one
-              for (uint32_t z = t.qnext; z < t.qend && z < reqcap; ++z)
-                requests[z] = pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}};
+          size_t i = mix(key.a ^ mix(key.b)) & (mcap - 1);
+          for (unsigned probes = 0;; i = (i + 1) & (mcap - 1)) {
+            MSlot &ms = mtab[i];
+            uint64_t a = ms.a.load(std::memory_order_acquire);
+            if (a == 0 && ms.a.compare_exchange_strong(a, key.a, std::memory_order_acq_rel)) {  // ours: file the request
+              if (t.qnext == t.qend) {
+                t.qnext = nreq.fetch_add(QCHUNK, std::memory_order_relaxed);
+                t.qend = t.qnext + QCHUNK;
+                // unused slots of a chunk must still hold a valid key: pre-fill with this one
+                for (uint32_t z = t.qnext; z < t.qend && z < reqcap; ++z)
+                  requests[z] = pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}};
+              }
+              const uint32_t r = t.qnext++;
+              if (r >= reqcap) overflow.store(true);
+              else requests[r] = pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}};
+              ms.bv.store(b32 << 32 | ((uint64_t)r + 1), std::memory_order_release);
+              mval = r;
+              break;
             }
-            const uint32_t r = t.qnext++;
-            if (r >= reqcap) overflow.store(true);
-            else requests[r] = pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}};
-            *mv = r;
+            if (a == key.a) {  // (after a lost CAS `a` holds the winner's key)
+              uint64_t bv = ms.bv.load(std::memory_order_acquire);
+              while (bv == 0) {
+                __builtin_ia32_pause();
+                bv = ms.bv.load(std::memory_order_acquire);
+              }
+              if (bv >> 32 == b32) {
+                mval = (uint32_t)bv - 1;
+                break;
+              }
+            }
+            if (++probes > 512) {
+              overflow.store(true);
+              mval = 0xFFFFFFFFu;
+              break;
+            }
           }
-          mval = *mv;
         }
         Verdict vd;
         const pgx_match *mm = nullptr;
@@ -1119,9 +1179,9 @@ struct ParReplay {
     const size_t nb = bs.size();
     TL &t = tl[ti];
     for (;;) {
-      const size_t c0 = cursor.fetch_add(16, std::memory_order_relaxed);
+      const size_t c0 = cursor.fetch_add(block, std::memory_order_relaxed);
       if (c0 >= nb || overflow.load(std::memory_order_relaxed)) return;
-      const size_t c1 = std::min(nb, c0 + 16);
+      const size_t c1 = std::min(nb, c0 + block);
       if (dirty[c0].load(std::memory_order_relaxed)) prefetch_bucket((uint32_t)c0);
       for (size_t b = c0; b < c1; ++b) {
         if (b + 1 < c1 && dirty[b + 1].load(std::memory_order_relaxed)) prefetch_bucket((uint32_t)(b + 1));
@@ -1253,6 +1313,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
       ParReplay rp(visit, db->rlen_by_rid, (uint32_t)(uint8_t)p->bestn, threads);
       rp.predict = predict;
       rp.trace = trace;
+      if (const char *bv = getenv("PGX_BLOCK")) rp.block = (size_t)std::max(1, atoi(bv));
       if (trace) fprintf(stderr, "[pgx] parallel replay tables set up in %.2f ms\n", now_ms() - c0);
       size_t first_req = 0;
       double settle_ms = 0;
