@@ -25,6 +25,52 @@ Context &ctx() {
 }
 void require_ready() { PGX_REQUIRE(ctx().ready, PGX_ESTATE, "pgx_init() has not been called (or failed)"); }
 
+// ---- device block cache ----------------------------------------------------------------------------------
+static std::mutex g_dev_mu;
+static std::multimap<size_t, void *> g_dev_free;  // size class -> cached blocks
+static std::map<void *, size_t> g_dev_live;       // block -> its size class
+static size_t size_class(size_t bytes) {           // powers of two up to 1 MiB, then eighths of a power of two (<= 12.5 % waste)
+  size_t c = 256;
+  while (c < bytes && c < (1u << 20)) c <<= 1;
+  if (c >= bytes) return c;
+  size_t p2 = (size_t)1 << 20;
+  while (p2 * 2 <= bytes) p2 <<= 1;
+  const size_t step = p2 >> 3;
+  return (bytes + step - 1) / step * step;
+}
+void *dev_alloc(size_t bytes) {
+  const size_t c = size_class(bytes);
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  auto it = g_dev_free.find(c);
+  void *p = nullptr;
+  if (it != g_dev_free.end()) {
+    p = it->second;
+    g_dev_free.erase(it);
+  } else {
+    hipError_t e = hipMalloc(&p, c);
+    if (e != hipSuccess) {  // make room: give the cached blocks back and retry once
+      for (auto &kv : g_dev_free) (void)hipFree(kv.second);
+      g_dev_free.clear();
+      (void)hipGetLastError();
+      PGX_HIP(hipMalloc(&p, c));
+    }
+  }
+  g_dev_live[p] = c;
+  return p;
+}
+void dev_release(void *p) {
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  auto it = g_dev_live.find(p);
+  if (it == g_dev_live.end()) return;
+  g_dev_free.emplace(it->second, p);
+  g_dev_live.erase(it);
+}
+void dev_cache_trim() {
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  for (auto &kv : g_dev_free) (void)hipFree(kv.second);
+  g_dev_free.clear();
+}
+
 // ---- persistent workspace --------------------------------------------------------------------------------
 static std::map<std::string, DevBuf<uint8_t>> g_ws;
 void *ws_raw(const char *name, size_t bytes) {
@@ -145,6 +191,8 @@ int pgx_init(int device) {
 void pgx_shutdown(void) {
   Context &c = ctx();
   g_ws.clear();
+  if (c.stream) (void)hipStreamSynchronize(c.stream);
+  dev_cache_trim();
   if (c.stream) (void)hipStreamDestroy(c.stream);
   c.stream = nullptr;
   c.ready = false;

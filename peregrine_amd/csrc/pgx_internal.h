@@ -50,6 +50,13 @@ Context &ctx();
 void require_ready();
 
 // device buffer (RAII, grow-only reuse is up to the caller)
+// Device blocks come from a size-class cache: hipMalloc / hipFree are synchronous and cost tens of microseconds each, and
+// the stages allocate dozens of temporaries per call.  All work is enqueued on ONE stream, so handing a released block to
+// the next user is stream-ordered and safe.  pgx_shutdown() returns everything to the driver.
+void *dev_alloc(size_t bytes);
+void dev_release(void *p);
+void dev_cache_trim();
+
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
@@ -71,10 +78,10 @@ struct DevBuf {
   void alloc(size_t count) {
     release();
     n = count;
-    if (count) PGX_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+    if (count) p = (T *)dev_alloc(count * sizeof(T));
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p) dev_release(p);
     p = nullptr, n = 0;
   }
   void upload(const T *src, size_t count) {

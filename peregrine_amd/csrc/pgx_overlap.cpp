@@ -1199,7 +1199,7 @@ struct ParReplay {
       if (!nd) break;
       cursor.store(0);
       const double r0 = now_ms();
-      if (nd < 512 || nthr == 1) worker(0);
+      if (nd < 48 || nthr == 1) worker(0);  // (a few dirty buckets still cascade into thousands of evaluations)
       else par_run(nthr, [&](unsigned ti) { worker(ti); });
       if (trace) fprintf(stderr, "[pgx]   round: %zu dirty buckets, %.2f ms\n", nd, now_ms() - r0);
       if (overflow.load()) throw Overflow();
@@ -1298,11 +1298,12 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   };
   const bool trace = getenv("PGX_TRACE") != nullptr;
   const bool predict = !(getenv("PGX_PREDICT") && atoi(getenv("PGX_PREDICT")) == 0);
-  unsigned threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+  unsigned threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
   if (const char *tv = getenv("PGX_THREADS")) threads = (unsigned)std::max(1, atoi(tv));
-  // the shared-table protocol costs ~3 locked operations per examination: it pays once the pair table no longer fits the
-  // caches (measured: 4.2 s -> 0.8 s for sweep 1 at 4.5 Gbases with 16 threads; slower than sequential at 75 Mbases)
-  size_t par_min = 1000000;
+  // the shared-table protocol costs two locked operations per examination and a thread team per round; measured against
+  // the sequential replay with 16 threads: 4.2 s -> 0.25 s for the first sweep at 4.5 Gbases, 11.9 -> 7 ms of sweeps at
+  // 75 Mbases (200 k entries); below ~50 k entries the team start-up dominates
+  size_t par_min = 50000;
   if (const char *pm = getenv("PGX_PAR_MIN")) par_min = (size_t)atoll(pm);
   if (visit.entries.size() < par_min) threads = 1;
   bool done = false;
