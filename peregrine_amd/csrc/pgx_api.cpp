@@ -1,9 +1,13 @@
 // pgx_api.cpp -- context, timing, resident seqdb, file formats, batch-level and shimmer4py entry points.
 #include <glob.h>
+#include <sys/mman.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include "pgx_internal.h"
 
@@ -24,6 +28,83 @@ Context &ctx() {
   return c;
 }
 void require_ready() { PGX_REQUIRE(ctx().ready, PGX_ESTATE, "pgx_init() has not been called (or failed)"); }
+
+// ---- large host arrays -------------------------------------------------------------------------------------
+static constexpr size_t HUGE = (size_t)2 << 20, BIG = (size_t)16 << 20;  // below BIG the allocator's free lists win
+void *big_alloc(size_t bytes) {
+  if (bytes < BIG) {
+    void *p = malloc(bytes ? bytes : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+  }
+  const size_t len = (bytes + HUGE - 1) / HUGE * HUGE;
+  void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (p == MAP_FAILED) throw std::bad_alloc();
+  (void)madvise(p, len, MADV_HUGEPAGE);
+  return p;
+}
+void big_free(void *p, size_t bytes) {
+  if (!p) return;
+  if (bytes < BIG) free(p);
+  else (void)munmap(p, (bytes + HUGE - 1) / HUGE * HUGE);
+}
+
+// ---- housekeeping thread -----------------------------------------------------------------------------------
+namespace {
+struct Reaper {
+  std::mutex mu;
+  std::condition_variable cv, idle;
+  std::deque<std::function<void()>> q;
+  bool busy = false, stop = false;
+  std::thread th;
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [&] { return stop || !q.empty(); });
+      if (q.empty()) return;
+      std::function<void()> fn = std::move(q.front());
+      q.pop_front();
+      busy = true;
+      lk.unlock();
+      fn();
+      fn = nullptr;
+      lk.lock();
+      busy = false;
+      idle.notify_all();
+    }
+  }
+  void push(std::function<void()> fn) {
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      if (q.size() < 4) {
+        if (!th.joinable()) th = std::thread([this] { loop(); });
+        q.push_back(std::move(fn));
+        cv.notify_one();
+        return;
+      }
+    }
+    fn();  // the thread is behind: do it here rather than pile up memory
+  }
+  void drain() {
+    std::unique_lock<std::mutex> lk(mu);
+    idle.wait(lk, [&] { return q.empty() && !busy; });
+  }
+  ~Reaper() {
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      stop = true;
+      cv.notify_all();
+    }
+    if (th.joinable()) th.join();
+  }
+};
+Reaper &reaper() {
+  static Reaper r;
+  return r;
+}
+}  // namespace
+void defer_destroy(std::function<void()> fn) { reaper().push(std::move(fn)); }
+void drain_deferred() { reaper().drain(); }
 
 // ---- device block cache ----------------------------------------------------------------------------------
 static std::mutex g_dev_mu;
@@ -190,6 +271,7 @@ int pgx_init(int device) {
 
 void pgx_shutdown(void) {
   Context &c = ctx();
+  drain_deferred();
   g_ws.clear();
   if (c.stream) (void)hipStreamSynchronize(c.stream);
   dev_cache_trim();

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -153,24 +154,74 @@ void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_cou
 // banded O(ND) confirmation of n candidate alignments (keys on device)
 void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out);
 
+// Large host arrays.  Never value-initialised (they are about to be overwritten); from 16 MiB up they are anonymous
+// mappings advised to use transparent huge pages, which the allocator would not do for us (THP is in "madvise" mode on
+// the target hosts): first-touch faults and the final munmap are ~500x fewer than with 4 KiB pages.
+void *big_alloc(size_t bytes);            // never returns nullptr (throws std::bad_alloc)
+void big_free(void *p, size_t bytes);
+template <typename T>
+struct HostArray {
+  T *p = nullptr;
+  size_t n = 0;
+  HostArray() = default;
+  explicit HostArray(size_t count) { alloc(count); }
+  HostArray(const HostArray &) = delete;
+  HostArray &operator=(const HostArray &) = delete;
+  HostArray(HostArray &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr, o.n = 0; }
+  HostArray &operator=(HostArray &&o) noexcept {
+    if (this != &o) {
+      clear();
+      p = o.p, n = o.n;
+      o.p = nullptr, o.n = 0;
+    }
+    return *this;
+  }
+  ~HostArray() { clear(); }
+  void alloc(size_t count) {
+    clear();
+    p = (T *)big_alloc((count ? count : 1) * sizeof(T));
+    n = count;
+  }
+  void clear() {
+    if (p) big_free(p, (n ? n : 1) * sizeof(T));
+    p = nullptr, n = 0;
+  }
+  T *data() { return p; }
+  const T *data() const { return p; }
+  size_t size() const { return n; }
+  bool empty() const { return n == 0; }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+  T *begin() { return p; }
+  T *end() { return p + n; }
+  const T *begin() const { return p; }
+  const T *end() const { return p + n; }
+  const T &back() const { return p[n - 1]; }
+};
+
 // shimmer-pair join (pgx_pairs.hip): records sorted by (key0, key1, position desc, insertion order) plus the bucket /
 // key0-group tables the host needs to replay the khash slot order on distinct keys
 struct PairTables {
   size_t n_rec = 0;
-  std::vector<uint64_t> y0;        // per record
-  std::vector<uint8_t> dir;        // per record
-  std::vector<uint64_t> bkey1;     // per bucket
-  std::vector<uint32_t> bstart;    // nb+1 record offsets
-  std::vector<uint32_t> bfirst;    // first insertion (record seq) of the bucket
-  std::vector<uint64_t> gkey0;     // per key0 group
-  std::vector<uint32_t> gstart;    // ng+1 record offsets
-  std::vector<uint32_t> gfirst, glast;  // first / last insertion of the group
-  std::vector<uint32_t> gbucket;   // ng+1: first bucket of the group
-  std::vector<uint32_t> gord;      // groups in order of first insertion
-  std::vector<uint32_t> bord;      // buckets ordered by (group, first insertion): group g's slice is [gbucket[g], gbucket[g+1])
+  HostArray<uint64_t> y0;        // per record
+  HostArray<uint8_t> dir;        // per record
+  HostArray<uint64_t> bkey1;     // per bucket
+  HostArray<uint32_t> bstart;    // nb+1 record offsets
+  HostArray<uint32_t> bfirst;    // first insertion (record seq) of the bucket
+  HostArray<uint64_t> gkey0;     // per key0 group
+  HostArray<uint32_t> gstart;    // ng+1 record offsets
+  HostArray<uint32_t> gfirst, glast;  // first / last insertion of the group
+  HostArray<uint32_t> gbucket;   // ng+1: first bucket of the group
+  HostArray<uint32_t> gord;      // groups in order of first insertion
+  HostArray<uint32_t> bord;      // buckets ordered by (group, first insertion): group g's slice is [gbucket[g], gbucket[g+1])
 };
 void dev_build_pairs(const pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts,
                      size_t n_counts, const pgx_overlap_params *p, PairTables &out);
+
+// Runs fn on the library's housekeeping thread: tearing down GB-sized host tables (munmap, free) takes tens of
+// milliseconds that the caller does not have to wait for.  At most a few jobs are queued; beyond that fn runs inline.
+void defer_destroy(std::function<void()> fn);
+void drain_deferred();  // waits until every queued job has run (pgx_shutdown)
 
 // host helpers (pgx_api.cpp)
 int load_idx(const char *path, std::vector<uint32_t> &rid, std::vector<uint32_t> &rlen, std::vector<uint64_t> &roff);

@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <atomic>
 #include <memory>
 #include <mutex>
@@ -254,29 +255,9 @@ struct Entry {
   uint64_t y0;
   uint8_t dir;
 };
-template <typename T>
-struct RawArray {  // malloc'd, never value-initialised (hundreds of MB that are about to be overwritten anyway)
-  T *p = nullptr;
-  size_t n = 0;
-  void alloc(size_t count) {
-    free(p);
-    p = (T *)malloc(count ? count * sizeof(T) : 1);
-    if (!p) throw std::bad_alloc();
-    n = count;
-  }
-  void clear() { free(p), p = nullptr, n = 0; }
-  T *data() { return p; }
-  const T *data() const { return p; }
-  size_t size() const { return n; }
-  RawArray() = default;
-  RawArray(const RawArray &) = delete;
-  RawArray &operator=(const RawArray &) = delete;
-  ~RawArray() { free(p); }
-};
-
 struct Visit {
   std::vector<uint64_t> start;  // bucket b covers entries [start[b], start[b+1])
-  RawArray<Entry> entries;
+  HostArray<Entry> entries;
 };
 
 // A reusable inner table: same slot behaviour as SlotTable, but storage is recycled between key0 groups so the
@@ -357,15 +338,16 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
     uint32_t worker;
   };
   std::vector<GroupOut> go(ng);
-  struct Frag {
-    std::vector<uint32_t> sizes;
-    std::vector<Entry> entries;
+  struct Frag {  // sized up front from the group range (no growth, no copies)
+    HostArray<uint32_t> sizes;
+    HostArray<Entry> entries;
+    size_t ns = 0, ne = 0;
   };
   std::vector<Frag> frag(nin);
   SlotTable outer;
   auto outer_work = [&] {
     bool absent;
-    const std::vector<uint32_t> &gord = pt.gord;  // groups by first insertion (sorted on the GPU)
+    const HostArray<uint32_t> &gord = pt.gord;  // groups by first insertion (sorted on the GPU)
     for (size_t i = 0; i < ng; ++i) outer.put(pt.gkey0[gord[i]], gord[i], &absent);
     if ((size_t)pt.gfirst[gord.back()] + 1 < pt.n_rec) outer.put(pt.gkey0[gord[0]], 0, &absent);  // trailing repeat put
   };
@@ -379,11 +361,14 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
     };
     const size_t g_lo = split(ti), g_hi = split(ti + 1);
     Frag &f = frag[ti];
+    if (g_lo >= g_hi) return;
+    f.entries.alloc(pt.gstart[g_hi] - pt.gstart[g_lo]);   // (gstart / gbucket carry an end sentinel)
+    f.sizes.alloc(pt.gbucket[g_hi] - pt.gbucket[g_lo]);
     ScratchTable in;
     bool ab;
     for (size_t g = g_lo; g < g_hi; ++g) {
       GroupOut &o = go[g];
-      o = GroupOut{f.entries.size(), (uint32_t)f.sizes.size(), 0, 0, ti};
+      o = GroupOut{f.ne, (uint32_t)f.ns, 0, 0, ti};
       if (pt.gstart[g + 1] - pt.gstart[g] <= 2) continue;  // no bucket of this key0 can hold more than 2 records
       const uint32_t b0 = pt.gbucket[g], b1 = pt.gbucket[g + 1];
       const uint32_t *bord = pt.bord.data() + b0;  // this group's buckets by first insertion (sorted on the GPU)
@@ -397,9 +382,9 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
         if (bn <= 2 || bn > ovlp_upper) continue;  // shmr_overlap.c:216
         for (uint32_t r = pt.bstart[b]; r < pt.bstart[b + 1]; ++r) {
           const uint64_t y = pt.y0[r];
-          f.entries.push_back(Entry{(uint32_t)(y >> 32), pos_of(y) + 1, y, pt.dir[r]});
+          f.entries[f.ne++] = Entry{(uint32_t)(y >> 32), pos_of(y) + 1, y, pt.dir[r]};
         }
-        f.sizes.push_back(bn);
+        f.sizes[f.ns++] = bn;
         o.ne += bn, ++o.nb;
       }
     }
@@ -734,16 +719,19 @@ struct Replay {
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
 struct BlockArena {  // append-only, never moves what it handed out (other threads may still read old ranges)
-  static constexpr size_t BLOCK = 1 << 15;
-  std::vector<std::unique_ptr<T[]>> blocks;
-  size_t used = BLOCK, cap = BLOCK;
+  size_t block = 1 << 12;  // elements per block; set_block() scales it with the job (big jobs: huge-page sized blocks)
+  std::vector<HostArray<T>> blocks;
+  size_t used = 0, cap = 0;
+  void set_block(size_t expected_elements) {
+    block = std::min<size_t>(std::max<size_t>(expected_elements / 4, 1 << 12), ((size_t)32 << 20) / sizeof(T));
+  }
   T *alloc(size_t n) {
     if (used + n > cap) {
-      cap = std::max(BLOCK, n);
-      blocks.emplace_back(new T[cap]);
+      cap = std::max(block, n);
+      blocks.emplace_back(cap);
       used = 0;
     }
-    T *p = blocks.back().get() + used;
+    T *p = blocks.back().data() + used;
     used += n;
     return p;
   }
@@ -812,6 +800,7 @@ struct ParReplay {
   static constexpr uint64_t EMPTY = 0;
   static constexpr uint32_t NIL = 0;
   static constexpr uint32_t NIN = 10;
+  static constexpr uint32_t NO_CHUNK = 0xFFFFFFFFu, ALLOCATING = 0xFFFFFFFEu;
   struct Overflow {};
 
   const Visit &v;
@@ -837,7 +826,7 @@ struct ParReplay {
   struct RNode {
     uint32_t next, bucket;
   };
-  std::unique_ptr<RNode[]> rlog;
+  HostArray<RNode> rlog;
   // (the shared counters live on cache lines of their own, below: a fetch_add next to the read-mostly pointers would
   //  evict those from every other core each time)
   uint32_t rcap = 0;
@@ -851,9 +840,9 @@ struct ParReplay {
   MSlot *mtab = nullptr;  // mmap'd zero pages
   size_t mcap = 0;
   // request r's result lives in results[r]; it is pending while r >= settled (settled only moves between sweeps)
-  std::unique_ptr<pgx_match[]> results;
+  HostArray<pgx_match> results;
   size_t settled = 0;
-  std::unique_ptr<pgx_align_key[]> requests;
+  HostArray<pgx_align_key> requests;
   uint32_t reqcap = 0;
 
   struct Own {
@@ -882,10 +871,22 @@ struct ParReplay {
     uint64_t n_eval = 0;
     uint32_t rnext = 0, rend = 0;      // private chunk of reader-node indices
     uint32_t qnext = 0, qend = 0;      // private chunk of request slots
+    std::atomic<uint32_t> cur_chunk{NO_CHUNK};  // first slot of the chunk being filled (what the submitter may not ship yet)
   };
   static constexpr uint32_t RCHUNK = 4096, QCHUNK = 32;
   static constexpr size_t PREFETCH = 3;
-  std::vector<TL> tl;
+  struct TLArray {  // (TL holds an atomic, so it cannot live in a std::vector)
+    std::unique_ptr<TL[]> p;
+    size_t n = 0;
+    void resize(size_t count) { p.reset(new TL[count]), n = count; }
+    TL &operator[](size_t i) { return p[i]; }
+    const TL &operator[](size_t i) const { return p[i]; }
+    TL *begin() { return p.get(); }
+    TL *end() { return p.get() + n; }
+    const TL *begin() const { return p.get(); }
+    const TL *end() const { return p.get() + n; }
+    size_t size() const { return n; }
+  } tl;
   alignas(128) std::atomic<size_t> cursor{0};
   alignas(128) std::atomic<uint32_t> nreq{0};
   alignas(128) std::atomic<uint32_t> rcount{1};  // node 0 is NIL
@@ -906,10 +907,10 @@ struct ParReplay {
     madvise(m, pcap * sizeof(PSlot), MADV_HUGEPAGE);  // random probes over a GB-sized table: fewer TLB misses
     ptab = (PSlot *)m;
     rcap = (uint32_t)std::min<size_t>(ne * 10 + (size_t)nthr * RCHUNK, 0xFFFFFFF0u);
-    rlog.reset(new RNode[rcap]);
+    rlog.alloc(rcap);
     reqcap = (uint32_t)std::min<size_t>(ne * 2 + (size_t)nthr * QCHUNK * 8 + 1024, 0x7FFFFFF0u);
-    requests.reset(new pgx_align_key[reqcap]);
-    results.reset(new pgx_match[reqcap]);  // untouched pages cost nothing
+    requests.alloc(reqcap);
+    results.alloc(reqcap);  // untouched pages cost nothing
     mcap = 1024;
     while (mcap < ne) mcap <<= 1;  // distinct alignments ~ 0.3 x entries
     void *mm = mmap(nullptr, mcap * sizeof(MSlot), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
@@ -921,6 +922,11 @@ struct ParReplay {
     dirty.reset(new std::atomic<uint8_t>[nb ? nb : 1]);
     for (size_t i = 0; i < nb; ++i) dirty[i].store(1, std::memory_order_relaxed);
     tl.resize(nthr);
+    for (TL &t : tl) {  // ~0.3 alignments (records, insertions, first-sweep guesses) per entry
+      t.guesses.reserve(ne / nthr / 3 + 1024);
+      t.recs.set_block(ne / nthr / 3);
+      t.owned.set_block(ne / nthr / 3);
+    }
   }
   ~ParReplay() {
     if (ptab) munmap((void *)ptab, pcap * sizeof(PSlot));
@@ -1066,15 +1072,18 @@ struct ParReplay {
             uint64_t a = ms.a.load(std::memory_order_acquire);
             if (a == 0 && ms.a.compare_exchange_strong(a, key.a, std::memory_order_acq_rel)) {  // ours: file the request
               if (t.qnext == t.qend) {
-                t.qnext = nreq.fetch_add(QCHUNK, std::memory_order_relaxed);
+                t.cur_chunk.store(ALLOCATING, std::memory_order_seq_cst);  // (between the fetch_add and the publication
+                t.qnext = nreq.fetch_add(QCHUNK, std::memory_order_seq_cst);  //  the submitter must not count the chunk)
                 t.qend = t.qnext + QCHUNK;
                 // unused slots of a chunk must still hold a valid key: pre-fill with this one
                 for (uint32_t z = t.qnext; z < t.qend && z < reqcap; ++z)
                   requests[z] = pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}};
+                t.cur_chunk.store(t.qnext, std::memory_order_seq_cst);
               }
               const uint32_t r = t.qnext++;
               if (r >= reqcap) overflow.store(true);
               else requests[r] = pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}};
+              if (t.qnext == t.qend) t.cur_chunk.store(NO_CHUNK, std::memory_order_release);  // chunk complete
               ms.bv.store(b32 << 32 | ((uint64_t)r + 1), std::memory_order_release);
               mval = r;
               break;
@@ -1175,10 +1184,32 @@ struct ParReplay {
     }
   }
 
+  // Requests below this index sit in completely filled chunks: they can go to the GPU while the sweep continues.
+  size_t complete_prefix() const {
+    size_t m = std::min<size_t>(nreq.load(std::memory_order_seq_cst), reqcap);
+    for (const TL &t : tl) {
+      const uint32_t c = t.cur_chunk.load(std::memory_order_seq_cst);
+      if (c == ALLOCATING) return 0;
+      if (c != NO_CHUNK) m = std::min<size_t>(m, c);
+    }
+    return m;
+  }
+  std::function<void(size_t, size_t)> submit;  // ships requests [first, upto) to the GPU without waiting (thread 0 only)
+  size_t submitted = 0;
+  void maybe_submit() {
+    const size_t p = complete_prefix();
+    if (p > submitted && p - submitted >= std::max<size_t>(16384, (submitted - sweep_first) / 2)) {
+      submit(submitted, p);
+      submitted = p;
+    }
+  }
+  size_t sweep_first = 0;
+
   void worker(unsigned ti) {
     const size_t nb = bs.size();
     TL &t = tl[ti];
     for (;;) {
+      if (ti == 0 && submit) maybe_submit();
       const size_t c0 = cursor.fetch_add(block, std::memory_order_relaxed);
       if (c0 >= nb || overflow.load(std::memory_order_relaxed)) return;
       const size_t c1 = std::min(nb, c0 + block);
@@ -1209,7 +1240,10 @@ struct ParReplay {
       *n_evals = 0;
       for (const TL &t : tl) *n_evals += t.n_eval;
     }
-    for (TL &t : tl) t.qnext = t.qend = 0;  // the rest of every private chunk stays filled with a duplicate key
+    for (TL &t : tl) {  // the rest of every private chunk stays filled with a duplicate key
+      t.qnext = t.qend = 0;
+      t.cur_chunk.store(NO_CHUNK, std::memory_order_relaxed);
+    }
     return std::min<size_t>(nreq.load(), reqcap);
   }
 
@@ -1273,13 +1307,26 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   memset(&s, 0, sizeof(s));
   const double t0 = now_ms();
   double gpu_ms = 0;
-  PairTables pt;
+  // the big host tables of this call are torn down on the housekeeping thread once the results are out
+  struct Scratch {
+    PairTables pt;
+    Visit visit;
+  };
+  Scratch *scratch = new Scratch;
+  struct Defer {
+    Scratch *s;
+    ~Defer() {
+      Scratch *z = s;
+      defer_destroy([z] { delete z; });
+    }
+  } defer_scratch{scratch};
+  PairTables &pt = scratch->pt;
   dev_build_pairs(db, mmers, n_mm, counts, n_counts, p, pt);
   sync();
   s.n_pair_records = pt.n_rec;
   const double t1 = now_ms();
   gpu_ms += t1 - t0;
-  Visit visit;
+  Visit &visit = scratch->visit;
   build_visit(pt, (uint32_t)p->ovlp_upper, visit);
   s.n_buckets = visit.start.size() - 1;
   if (getenv("PGX_TRACE"))
@@ -1311,24 +1358,59 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     try {
       const double c0 = now_ms();
       NodePin pin;
-      ParReplay rp(visit, db->rlen_by_rid, (uint32_t)(uint8_t)p->bestn, threads);
+      // (the replay tables too: but they refer to the visit list, so they go first)
+      ParReplay *rpp = new ParReplay(visit, db->rlen_by_rid, (uint32_t)(uint8_t)p->bestn, threads);
+      struct DeferReplay {
+        ParReplay *r;
+        ~DeferReplay() {
+          ParReplay *z = r;
+          defer_destroy([z] { delete z; });
+        }
+      } defer_replay{rpp};
+      ParReplay &rp = *rpp;
       rp.predict = predict;
       rp.trace = trace;
       if (const char *bv = getenv("PGX_BLOCK")) rp.block = (size_t)std::max(1, atoi(bv));
-      if (trace) fprintf(stderr, "[pgx] parallel replay tables set up in %.2f ms\n", now_ms() - c0);
+      if (trace) fprintf(stderr, "[pgx] parallel replay tables set up in %.2f ms; t = +%.2f ms\n", now_ms() - c0, now_ms() - t0);
       size_t first_req = 0;
       double settle_ms = 0;
+      // alignment batches go to the GPU while the sweep that files them is still running; the results come back once,
+      // after the sweep
+      struct Batch {
+        DevBuf<pgx_align_key> keys;
+        DevBuf<pgx_match> res;
+        size_t first, n;
+      };
+      std::vector<Batch> inflight;
+      rp.submit = [&](size_t first, size_t upto) {
+        const double g0 = now_ms();
+        Batch b{DevBuf<pgx_align_key>(upto - first), DevBuf<pgx_match>(upto - first), first, upto - first};
+        PGX_HIP(hipMemcpyAsync(b.keys.p, rp.requests.data() + first, b.n * sizeof(pgx_align_key), hipMemcpyHostToDevice,
+                               ctx().stream));
+        dev_align(db, b.keys.p, b.n, p->align_bandwidth, b.res.p);
+        inflight.push_back(std::move(b));
+        s.n_align_gpu += upto - first;
+        gpu_ms += now_ms() - g0;
+      };
       for (;;) {
         const double p0 = now_ms();
         uint64_t ev = 0;
         unsigned rounds = 0;
+        rp.sweep_first = rp.submitted = first_req;
         const size_t upto = rp.sweep(&ev, &rounds);
         ++s.rounds;
         if (trace)
-          fprintf(stderr, "[pgx] parallel sweep %u (%u threads): %u rounds, %llu evaluations so far, %.2f ms, %zu requests\n",
-                  s.rounds, threads, rounds, (unsigned long long)ev, now_ms() - p0, upto - first_req);
+          fprintf(stderr, "[pgx] parallel sweep %u (%u threads): %u rounds, %llu evaluations so far, %.2f ms, %zu requests (%zu already on the GPU)\n",
+                  s.rounds, threads, rounds, (unsigned long long)ev, now_ms() - p0, upto - first_req, rp.submitted - first_req);
         if (upto == first_req) break;
-        align_batch(rp.requests.get() + first_req, upto - first_req, rp.results.get() + first_req);
+        const double g0 = now_ms();
+        if (upto > rp.submitted) rp.submit(rp.submitted, upto);
+        for (Batch &b : inflight)
+          PGX_HIP(hipMemcpyAsync(rp.results.data() + b.first, b.res.p, b.n * sizeof(pgx_match), hipMemcpyDeviceToHost, ctx().stream));
+        sync();
+        inflight.clear();
+        gpu_ms += now_ms() - g0;
+        if (trace) fprintf(stderr, "[pgx]   waited %.2f ms for the GPU after the sweep\n", now_ms() - g0);
         const double s0 = now_ms();
         const bool any = rp.settle(first_req, upto);
         settle_ms += now_ms() - s0;
@@ -1337,7 +1419,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
       }
       const double k0 = now_ms();
       rp.collect(out, s.n_align_needed, s.n_seen_skip);
-      if (trace) fprintf(stderr, "[pgx] settle %.2f ms total, collect %.2f ms\n", settle_ms, now_ms() - k0);
+      if (trace) fprintf(stderr, "[pgx] settle %.2f ms total, collect %.2f ms; t = +%.2f ms\n", settle_ms, now_ms() - k0, now_ms() - t0);
       done = true;
     } catch (const ParReplay::Overflow &) {
       fprintf(stderr, "[pgx] note: parallel replay tables overflowed; falling back to the sequential replay\n");
@@ -1361,7 +1443,9 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     }
     rp.collect(out, s.n_align_needed, s.n_seen_skip);
   }
+  const double tf0 = now_ms();
   timing_flush();
+  if (trace) fprintf(stderr, "[pgx] stage total %.2f ms (timing flush %.2f ms)\n", now_ms() - t0, now_ms() - tf0);
   s.n_records = out.n;
   s.gpu_ms = gpu_ms;
   s.host_ms = now_ms() - t0 - gpu_ms;

@@ -176,8 +176,8 @@ __global__ void k_bucket_order_key(const uint32_t *__restrict__ gbucket, uint32_
 }
 
 template <typename T>
-std::vector<T> to_host(const DevBuf<T> &d, size_t n) {
-  std::vector<T> h(n);
+HostArray<T> to_host(const DevBuf<T> &d, size_t n, size_t extra = 0) {  // (extra: room for a sentinel the caller appends)
+  HostArray<T> h(n + extra);
   d.download(h.data(), n);
   return h;
 }
@@ -328,9 +328,9 @@ void dev_build_pairs(const pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, c
   out.gstart = to_host(gstart, (size_t)ng + 1);
   out.gfirst = to_host(gfirst, ng);
   out.glast = to_host(glast, ng);
-  out.gbucket = to_host(gbucket, ng);
+  out.gbucket = to_host(gbucket, ng, 1);
   sync();
-  out.gbucket.push_back(nbk);
+  out.gbucket[ng] = nbk;
 }
 
 }  // namespace pgx
