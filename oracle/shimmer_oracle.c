@@ -785,3 +785,120 @@ char *orc_dedup(const orc_ovlp_t *recs, size_t n, size_t *text_len, uint64_t *n_
   if (n_unique) *n_unique = uniq;
   return out;
 }
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* row f4 -- the shimmer4py query helpers, src/shimmer4py.c:44-196 (build_shimmer_map4py, get_shimmers_for_read, */
+/* get_mmer_count, get_shimmer_hits) over the same pair map as the overlap stage                            */
+/* ------------------------------------------------------------------------------------------------------ */
+struct orc_map {
+  otab_t mc;
+  pairmap_t pm;
+  uint64_t n_rec;
+};
+
+orc_map_t *orc_map_build(const orc_mm_t *mmers, size_t n_mm, const orc_mc_t *counts, size_t n_counts, const uint32_t *rlen,
+                         uint32_t mychunk, uint32_t total_chunk, uint32_t lower, uint32_t upper) {
+  orc_map_t *m = (orc_map_t *)calloc(1, sizeof(*m));
+  int absent;
+  for (size_t i = 0; i < n_counts; ++i) { /* aggregate_mm_count, shmr_utils.c:162-176 (shimmer4py.c:109-116) */
+    uint32_t s = otab_put(&m->mc, counts[i].mer, &absent);
+    m->mc.vals[s] += counts[i].count;
+  }
+  m->n_rec = build_pairmap(&m->pm, mmers, n_mm, &m->mc, rlen, mychunk, total_chunk, lower, upper); /* :122-123 */
+  return m;
+}
+
+void orc_map_free(orc_map_t *m) {
+  if (!m) return;
+  for (size_t i = 0; i < m->pm.buckets.n; ++i) free(m->pm.buckets.a[i].a);
+  for (size_t i = 0; i < m->pm.inner.n; ++i) otab_release(&m->pm.inner.a[i]);
+  free(m->pm.buckets.a), free(m->pm.inner.a);
+  otab_release(&m->pm.outer), otab_release(&m->mc);
+  free(m);
+}
+
+/* get_mmer_count, shimmer4py.c:148-156 */
+uint32_t orc_map_count(const orc_map_t *m, uint64_t mhash) {
+  uint64_t v;
+  return otab_get(&m->mc, mhash, &v) ? (uint32_t)v : 0;
+}
+
+/* get_shimmer_hits, shimmer4py.c:158-196: the key0's inner table in ascending slot order, every bucket sorted (stably, */
+/* position descending: the comparator of :38-42 under glibc's merge sort) and appended                                */
+size_t orc_map_hits(orc_map_t *m, uint64_t mhash0, uint32_t span, orc_mp256_t **out) {
+  const uint64_t key0 = mhash0 << 8 | span;
+  uint64_t v;
+  size_t n = 0, cap = 0;
+  orc_mp256_t *a = NULL;
+  if (otab_get(&m->pm.outer, key0, &v)) {
+    otab_t *in = &m->pm.inner.a[v];
+    for (uint32_t s1 = 0; s1 < in->nb; ++s1) {
+      if (!in->used[s1]) continue;
+      precv_t *b = &m->pm.buckets.a[in->vals[s1]];
+      sort_bucket(b);
+      for (size_t j = 0; j < b->n; ++j) {
+        if (n == cap) a = (orc_mp256_t *)realloc(a, (cap = cap ? cap * 2 : 16) * sizeof(*a));
+        memset(&a[n], 0, sizeof(a[n]));
+        a[n].x0 = key0, a[n].x1 = in->keys[s1], a[n].y0 = b->a[j].y0, a[n].y1 = b->a[j].y1, a[n].direction = b->a[j].dir;
+        ++n;
+      }
+    }
+  }
+  *out = a;
+  return n;
+}
+
+/* get_ridmm + get_shimmers_for_read, shmr_utils.c:415-443, shimmer4py.c:134-146: a read's shimmers are the run that */
+/* starts at its first occurrence and is as long as its number of occurrences in the whole list                       */
+void orc_read_shimmers(const orc_mm_t *mmers, size_t n_mm, uint32_t rid, size_t *first, size_t *count) {
+  size_t f = 0, c = 0;
+  for (size_t s = 0; s < n_mm; ++s)
+    if ((uint32_t)(mmers[s].y >> 32) == rid) {
+      if (!c) f = s;
+      ++c;
+    }
+  *first = f, *count = c;
+}
+
+/* ------------------------------------------------------------------------------------------------------ */
+/* row f3 -- shmr_map, src/shmr_map.c:48-161 (process_map) after the build_map of :350-351                  */
+/* ------------------------------------------------------------------------------------------------------ */
+char *orc_map_reads_to_ref(const orc_mm_t *ref, size_t n_ref, const orc_mm_t *mmers, size_t n_mm, const orc_mc_t *counts,
+                           size_t n_counts, const uint32_t *rlen, uint32_t mychunk, uint32_t total_chunk, uint32_t lower,
+                           uint32_t upper, size_t *text_len, uint64_t *n_lines) {
+  orc_map_t *m = orc_map_build(mmers, n_mm, counts, n_counts, rlen, mychunk, total_chunk, lower, upper);
+  size_t cap = 1 << 16, len = 0;
+  char *out = (char *)malloc(cap);
+  uint64_t lines = 0, v, c0, c1;
+  size_t s = 0;
+  for (; s < n_ref; ++s) /* :84-90 first reference shimmer that is a key0 of the map */
+    if (otab_get(&m->pm.outer, ref[s].x, &v)) break;
+  if (s < n_ref) {
+    orc_mm_t a = ref[s], b;
+    for (size_t i = s + 1; i < n_ref; ++i) {
+      b = ref[i];
+      if (!otab_get(&m->mc, b.x >> 8, &c1)) continue;              /* :96 unknown to the reads: anchor kept */
+      if (c1 < lower || c1 > upper) continue;                       /* :98 */
+      if ((a.y >> 32) != (b.y >> 32)) { a = b; continue; }          /* :100-103 different contigs */
+      if (!otab_get(&m->pm.outer, a.x, &v)) { a = b; continue; }    /* :105-109 */
+      otab_t *in = &m->pm.inner.a[v];
+      if (!otab_get(in, b.x, &v)) { a = b; continue; }              /* :111-116 */
+      /* :118 64-bit difference of the positions masked to 28 bits; a negative gap wraps to a huge value */
+      if ((((b.y >> 1) & 0xFFFFFFF) - ((a.y >> 1) & 0xFFFFFFF)) < 100) { a = b; continue; }
+      const precv_t *bk = &m->pm.buckets.a[v];                      /* insertion order: no sort here */
+      if (!otab_get(&m->mc, a.x >> 8, &c0)) abort();                /* :147 */
+      for (size_t j = 0; j < bk->n; ++j) {
+        if (len + 160 > cap) out = (char *)realloc(out, cap *= 2);
+        len += (size_t)snprintf(out + len, 160, "%u %u %u %u %u %u %d %u %u\n", (uint32_t)(a.y >> 32), pos_of(a.y), pos_of(b.y),
+                                (uint32_t)(bk->a[j].y0 >> 32), pos_of(bk->a[j].y0), pos_of(bk->a[j].y1), (int)bk->a[j].dir,
+                                (uint32_t)c0, (uint32_t)c1);
+        ++lines;
+      }
+      a = b;
+    }
+  }
+  orc_map_free(m);
+  if (text_len) *text_len = len;
+  if (n_lines) *n_lines = lines;
+  return out;
+}

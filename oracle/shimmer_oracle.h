@@ -95,6 +95,21 @@ int orc_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, cons
 /* ---- row f2: first-wins dedup + FALCON text lines, src/shmr_dedup.c:32-101.  Returns malloc'd text (orc_free). ---- */
 char *orc_dedup(const orc_ovlp_t *recs, size_t n, size_t *text_len, uint64_t *n_unique);
 
+/* ---- row f4: query helpers of src/shimmer4py.c:44-196 over the pair map of build_map ---- */
+typedef struct { uint64_t x0, x1, y0, y1; uint8_t direction; uint8_t pad[7]; } orc_mp256_t; /* mp256_t, shimmer.h:122-126 */
+typedef struct orc_map orc_map_t;
+orc_map_t *orc_map_build(const orc_mm_t *mmers, size_t n_mm, const orc_mc_t *counts, size_t n_counts, const uint32_t *rlen,
+                         uint32_t mychunk, uint32_t total_chunk, uint32_t lower, uint32_t upper);
+void orc_map_free(orc_map_t *m);
+uint32_t orc_map_count(const orc_map_t *m, uint64_t mhash);
+size_t orc_map_hits(orc_map_t *m, uint64_t mhash0, uint32_t span, orc_mp256_t **out); /* *out malloc'd (orc_free) */
+void orc_read_shimmers(const orc_mm_t *mmers, size_t n_mm, uint32_t rid, size_t *first, size_t *count);
+
+/* ---- row f3: shmr_map, src/shmr_map.c:48-161.  Returns the stdout text (malloc'd, orc_free). ---- */
+char *orc_map_reads_to_ref(const orc_mm_t *ref, size_t n_ref, const orc_mm_t *mmers, size_t n_mm, const orc_mc_t *counts,
+                           size_t n_counts, const uint32_t *rlen, uint32_t mychunk, uint32_t total_chunk, uint32_t lower,
+                           uint32_t upper, size_t *text_len, uint64_t *n_lines);
+
 void orc_free(void *p);
 
 #ifdef __cplusplus

@@ -49,3 +49,14 @@ OVERLAP_RUNS = {  # name: (index chunks, level, overlap chunks, kwargs)  -- mirr
     "ov_l1_t1": (2, 1, 1, {}),
     "ov_par_t2": (2, 2, 2, dict(bestn=2, mc_upper=30, band=60, ovlp_upper=40, mc_lower=2)),
 }
+
+
+def query_fixture():
+    """rows f3/f4: the tiny set's two-chunk level-2 index (inputs) + query_cases.npz (the reference's answers)"""
+    from peregrine_amd import formats
+    q, t = load("query_cases.npz"), load("tiny_stage.npz")
+    mmers = np.concatenate([t["ix2l2_L2_1"], t["ix2l2_L2_2"]])
+    pairs = np.concatenate([t["ix2l2_L2MC_1"], t["ix2l2_L2MC_2"]])
+    mc = np.zeros(len(pairs), formats.MC_DTYPE)
+    mc["mer"], mc["count"] = pairs[:, 0], pairs[:, 1]
+    return q, mmers, mc, t["rlen"].astype(np.uint32)

@@ -158,6 +158,64 @@ def orc_dedup(recs):
     return data, int(nu.value)
 
 
+MP256_DTYPE = np.dtype([("x0", "<u8"), ("x1", "<u8"), ("y0", "<u8"), ("y1", "<u8"), ("direction", "u1"), ("pad", "u1", 7)])
+
+
+class OrcMap:
+    """rows f4: the oracle's pair map + query helpers (orc_map_*)"""
+
+    def __init__(self, mmers, counts, rlen_by_rid, mychunk=1, total=1, lower=2, upper=240):
+        self.mm = np.ascontiguousarray(mmers, MM_DTYPE)
+        mc = np.ascontiguousarray(counts, MC_DTYPE)
+        rl = np.ascontiguousarray(rlen_by_rid, np.uint32)
+        fn = oracle().orc_map_build
+        fn.restype = C.c_void_p
+        self.h = fn(self.mm.ctypes.data_as(C.c_void_p), C.c_size_t(len(self.mm)), mc.ctypes.data_as(C.c_void_p), C.c_size_t(len(mc)),
+                    rl.ctypes.data_as(C.c_void_p), C.c_uint32(mychunk), C.c_uint32(total), C.c_uint32(lower), C.c_uint32(upper))
+
+    def count(self, mhash):
+        fn = oracle().orc_map_count
+        fn.restype = C.c_uint32
+        return int(fn(C.c_void_p(self.h), C.c_uint64(int(mhash))))
+
+    def hits(self, mhash0, span):
+        fn = oracle().orc_map_hits
+        fn.restype = C.c_size_t
+        p = C.c_void_p()
+        n = fn(C.c_void_p(self.h), C.c_uint64(int(mhash0)), C.c_uint32(int(span)), C.byref(p))
+        out = np.frombuffer(C.string_at(p, n * MP256_DTYPE.itemsize), MP256_DTYPE).copy() if n else np.zeros(0, MP256_DTYPE)
+        if p:
+            oracle().orc_free(p)
+        return out
+
+    def read_shimmers(self, rid):
+        f, c = C.c_size_t(0), C.c_size_t(0)
+        oracle().orc_read_shimmers(self.mm.ctypes.data_as(C.c_void_p), C.c_size_t(len(self.mm)), C.c_uint32(int(rid)), C.byref(f), C.byref(c))
+        return int(f.value), int(c.value)
+
+    def close(self):
+        if self.h:
+            oracle().orc_map_free(C.c_void_p(self.h))
+            self.h = None
+
+
+def orc_map_reads_to_ref(ref_mmers, mmers, counts, rlen_by_rid, mychunk=1, total=1, lower=1, upper=240):
+    """row f3: the oracle's shmr_map text"""
+    rf = np.ascontiguousarray(ref_mmers, MM_DTYPE)
+    mm = np.ascontiguousarray(mmers, MM_DTYPE)
+    mc = np.ascontiguousarray(counts, MC_DTYPE)
+    rl = np.ascontiguousarray(rlen_by_rid, np.uint32)
+    tl, nl = C.c_size_t(0), C.c_uint64(0)
+    fn = oracle().orc_map_reads_to_ref
+    fn.restype = C.c_void_p
+    p = fn(rf.ctypes.data_as(C.c_void_p), C.c_size_t(len(rf)), mm.ctypes.data_as(C.c_void_p), C.c_size_t(len(mm)),
+           mc.ctypes.data_as(C.c_void_p), C.c_size_t(len(mc)), rl.ctypes.data_as(C.c_void_p), C.c_uint32(mychunk), C.c_uint32(total),
+           C.c_uint32(lower), C.c_uint32(upper), C.byref(tl), C.byref(nl))
+    data = C.string_at(p, tl.value)
+    oracle().orc_free(C.c_void_p(p))
+    return data, int(nl.value)
+
+
 # ------------------------------------------------------------------------------------------------------------
 # the real reference (oracle/_ref): present in the build container, prebuilt binaries on the GPU box
 # ------------------------------------------------------------------------------------------------------------

@@ -245,11 +245,15 @@ def test_parallel_replay_equals_oracle(small, monkeypatch):
     ix = rdb.index()
     want, ost = U.orc_overlap(db, ix.top, ix.top_mc)
     monkeypatch.setenv("PGX_PAR_MIN", "0")
-    for threads in (2, 8, 8, 32, 32):
+    rng = np.random.default_rng(3)
+    for it in range(60):   # (tools/replay_stress.py is the long version of this loop)
+        threads, block = int(rng.choice([2, 3, 8, 16, 32, 64])), int(rng.choice([1, 3, 16, 64]))
         monkeypatch.setenv("PGX_THREADS", str(threads))
+        monkeypatch.setenv("PGX_BLOCK", str(block))       # work-block size: 1 maximises the cross-thread conflicts
+        monkeypatch.setenv("PGX_PIN", str(it & 1))
         got, st = rdb.overlap(ix.top, ix.top_mc)
-        assert formats.ovlp_fields_equal(got, want), threads
-        assert st["n_align_needed"] == ost["n_align"]
+        assert formats.ovlp_fields_equal(got, want), (threads, block)
+        assert st["n_align_needed"] == ost["n_align"] and st["n_seen_skip"] == ost["n_seen_skip"]
 
 
 def _enc(codes):

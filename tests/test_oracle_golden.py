@@ -87,3 +87,30 @@ def test_dedup_matches_reference_text():
         text, nu = U.orc_dedup(recs)
         assert text == d[name].tobytes(), name
         assert nu == text.count(b"\n")
+
+
+def test_query_helpers_match_reference():
+    """row f4: get_shimmer_hits / get_mmer_count / get_shimmers_for_read of the compiled reference (shimmer4py.c)"""
+    q, mmers, mc, rlen = G.query_fixture()
+    for (c, T, lo, hi) in ((1, 1, 2, 240), (1, 2, 2, 240), (2, 2, 2, 240), (1, 1, 1, 3), (2, 3, 2, 30)):
+        tag = f"c{c}t{T}lo{lo}hi{hi}"
+        m = U.OrcMap(mmers, mc, rlen, c, T, lo, hi)
+        want, off = q[f"hits_{tag}"], q[f"hoff_{tag}"]
+        for i, k in enumerate(q["qkeys"]):
+            got = m.hits(int(k) >> 8, int(k) & 0xFF)
+            assert got.tobytes() == want[off[i]:off[i + 1]].tobytes(), (tag, i)
+        if tag == "c1t1lo2hi240":
+            assert [m.count(int(k) >> 8) for k in q["qkeys"]] == q["counts"].tolist()
+            for r, f, n in zip(q["qrids"], q["read_first"], q["read_count"]):
+                gf, gn = m.read_shimmers(r)
+                assert gn == n and (n == 0 or gf == f)
+        m.close()
+
+
+def test_map_matches_reference_text():
+    """row f3: stdout of the compiled reference's shmr_map for contigs cut from the reads' genome"""
+    q, mmers, mc, rlen = G.query_fixture()
+    for (c, T, lo, hi) in ((1, 1, 1, 240), (2, 2, 1, 240), (1, 1, 2, 4)):
+        text, n = U.orc_map_reads_to_ref(q["ref_l2"], mmers, mc, rlen, c, T, lo, hi)
+        want = q[f"map_c{c}t{T}lo{lo}hi{hi}"].tobytes()
+        assert text == want and n == want.count(b"\n"), (c, T, lo, hi)
