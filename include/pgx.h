@@ -56,7 +56,7 @@ const char *pgx_version(void);
 void pgx_free(void *p);              /* releases any host array returned by this library */
 
 /* per-kernel device time (HIP events on the library's stream), accumulated since the last reset.
- * names: "sketch", "sketch_literal", "sketch_gather", "reduce", "count", "pairs", "align", "encode", "dedup". */
+ * names: "sketch", "sketch_literal", "sketch_gather", "reduce", "count", "pairs", "align", "encode", "dedup", "map". */
 int pgx_timing_get(const char *kernel, double *total_ms, uint64_t *launches, uint64_t *units);
 void pgx_timing_reset(void);
 
@@ -135,6 +135,22 @@ int pgx_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, cons
  * FALCON-style overlap lines (malloc'd, release with pgx_free), byte-identical to the reference's stdout. */
 int pgx_dedup(const pgx_ovlp *recs, size_t n, char **text, size_t *text_len, uint64_t *n_unique);
 
+/* ---- reads -> contigs mapping (replaces shmr_map, src/shmr_map.c:48-161,163-373) ----
+ * The reads' shimmer-pair map is built exactly as in the overlap stage (build_map with -t/-c/-n/-M); the reference
+ * shimmers are chained the same way and every hit bucket is reported, one line per record in insertion order:
+ * "ref_id ref_bgn ref_end read_id read_bgn read_end direction mcount0 mcount1\n" (shmr_map.c:152-153).  *text is malloc'd
+ * (pgx_free) and byte-identical to the reference's stdout. */
+typedef struct {
+  int total_chunk, mychunk;  /* -t -c */
+  int mc_lower, mc_upper;    /* -n -M (defaults 1, 240: shmr_map.c:28-29) */
+} pgx_map_params;
+int pgx_map(const pgx_mm128 *ref_mmers, size_t n_ref, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts,
+            size_t n_counts, const uint32_t *rlen_by_rid, uint32_t n_rid, const pgx_map_params *p, char **text,
+            size_t *text_len, uint64_t *n_lines);
+/* file level: -r refdb_prefix (unused, as in the reference) -m ref_shimmer_prefix -p seqdb_prefix -l shimmer_prefix */
+int pgx_map_chunk(const char *refdb_prefix, const char *ref_shimmer_prefix, const char *seqdb_prefix,
+                  const char *shimmer_prefix, const pgx_map_params *p, char **text, size_t *text_len, uint64_t *n_lines);
+
 /* ---- batch level ---- */
 int pgx_sketch_batch(pgx_seqdb *db, const uint32_t *read_slots, uint32_t n, int w, int k, pgx_mm128 **out,
                      size_t *n_out);  /* read_slots index the idx-file order; output in that order */
@@ -154,6 +170,21 @@ ovlp_match_t *ovlp_match(uint8_t *query_seq, int32_t q_len, uint8_t q_strand, ui
 void free_ovlp_match(ovlp_match_t *m);
 mm128_v read_mmlist(char *fn);
 void write_mmlist(char *fn, mm128_v *p);
+
+/* query helpers (src/shimmer4py.c:44-196, cdef py/peregrine/build_shimmer4py.py:44-62).  The map is
+ * built on the GPU by build_shimmer_map4py; the three getters are host lookups over its sorted tables.  On failure
+ * build_shimmer_map4py leaves every field of *py_mmer NULL (the reference exit(1)s / asserts) and the getters then return
+ * nothing.  get_shimmers_for_read returns a VIEW into py_mmer->mmers (do not free); get_shimmer_hits appends to a
+ * caller-owned kvec whose .a is realloc'd (free it with free / pgx_free). */
+typedef struct { uint64_t x0, x1, y0, y1; uint8_t direction; } mp256_t;   /* src/shimmer.h:122-126 */
+typedef struct { size_t n, m; mp256_t *a; } mp256_v;
+typedef struct { mm128_v *mmers; void *mmer0_map; void *rlmap; void *mcmap; void *ridmm; } py_mmer_t; /* shimmer.h:132-138 */
+void build_shimmer_map4py(py_mmer_t *py_mmer, char *seqdb_prefix, char *shimmer_prefix, uint32_t mychunk,
+                          uint32_t total_chunk, uint32_t lowerbound, uint32_t upperbound);
+void get_shimmers_for_read(mm128_v *out, py_mmer_t *py_mmer, uint32_t rid);
+uint32_t get_mmer_count(py_mmer_t *py_mmer, uint64_t mhash);
+void get_shimmer_hits(mp256_v *out, py_mmer_t *py_mmer, uint64_t mhash0, uint32_t span);
+void pgx_shimmer_map_free(py_mmer_t *py_mmer); /* extension: the reference never releases the map */
 
 #ifdef __cplusplus
 }

@@ -35,6 +35,22 @@ class OverlapParams(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("total_chunk", "mychunk", "bestn", "mc_lower", "mc_upper", "align_bandwidth", "ovlp_upper")]
 
 
+class MapParams(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("total_chunk", "mychunk", "mc_lower", "mc_upper")]
+
+
+class KVec(C.Structure):  # klib kvec {size_t n, m; T *a} (mm128_v, mp256_v)
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.c_void_p)]
+
+
+class PyMmer(C.Structure):  # py_mmer_t (src/shimmer.h:132-138)
+    _fields_ = [("mmers", C.POINTER(KVec)), ("mmer0_map", C.c_void_p), ("rlmap", C.c_void_p), ("mcmap", C.c_void_p),
+                ("ridmm", C.c_void_p)]
+
+
+MP256_DTYPE = np.dtype([("x0", "<u8"), ("x1", "<u8"), ("y0", "<u8"), ("y1", "<u8"), ("direction", "u1"), ("pad", "u1", 7)])
+
+
 class OverlapStats(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("n_pair_records", C.c_uint64), ("n_buckets", C.c_uint64),
                 ("n_align_needed", C.c_uint64), ("n_align_gpu", C.c_uint64), ("n_seen_skip", C.c_uint64),
@@ -53,6 +69,8 @@ EXPORTS = [
     "pgx_overlap_resident", "pgx_overlap_chunk", "pgx_mkseqdb", "pgx_dedup",
     "pgx_sketch_batch", "pgx_reduce_batch", "pgx_count_batch", "pgx_align_batch",
     "decode_biseq", "encode_biseq", "mm_sketch", "mm_reduce", "ovlp_match", "free_ovlp_match", "read_mmlist", "write_mmlist",
+    "pgx_map", "pgx_map_chunk",
+    "build_shimmer_map4py", "get_shimmers_for_read", "get_mmer_count", "get_shimmer_hits", "pgx_shimmer_map_free",
 ]
 
 _lib = None
@@ -95,6 +113,19 @@ def load():
         lib.pgx_count_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         lib.pgx_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         lib.pgx_timing_get.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pgx_map.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pgx_map_chunk.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.build_shimmer_map4py.restype = None
+        lib.build_shimmer_map4py.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.get_shimmers_for_read.restype = None
+        lib.get_shimmers_for_read.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        lib.get_mmer_count.restype = C.c_uint32
+        lib.get_mmer_count.argtypes = [C.c_void_p, C.c_uint64]
+        lib.get_shimmer_hits.restype = None
+        lib.get_shimmer_hits.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32]
+        lib.pgx_shimmer_map_free.restype = None
+        lib.pgx_shimmer_map_free.argtypes = [C.c_void_p]
         _lib = lib
     return _lib
 

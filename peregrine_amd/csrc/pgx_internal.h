@@ -214,9 +214,21 @@ struct PairTables {
   HostArray<uint32_t> gbucket;   // ng+1: first bucket of the group
   HostArray<uint32_t> gord;      // groups in order of first insertion
   HostArray<uint32_t> bord;      // buckets ordered by (group, first insertion): group g's slice is [gbucket[g], gbucket[g+1])
+  HostArray<uint64_t> y1;        // per record, only with PAIRS_Y1
+  HostArray<uint64_t> umer;      // aggregated multiplicities, sorted by mer: only with PAIRS_COUNTS
+  HostArray<uint32_t> ucnt;
 };
-void dev_build_pairs(const pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts,
-                     size_t n_counts, const pgx_overlap_params *p, PairTables &out);
+struct PairParams {
+  uint32_t total, mychunk, lower, upper;  // bucket ownership (x>>8) % total == mychunk % total; multiplicity bounds
+};
+enum : unsigned {
+  PAIRS_Y1 = 1,               // also return the second coordinate of every record (mp128_t.y1)
+  PAIRS_INSERTION_ORDER = 2,  // records of a bucket in insertion order instead of position-descending
+  PAIRS_COUNTS = 4,           // also return the aggregated multiplicity table
+};
+// d_rlen: read length by rid, on the device
+void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts,
+                     size_t n_counts, const PairParams &pp, PairTables &out, unsigned flags = 0);
 
 // Runs fn on the library's housekeeping thread: tearing down GB-sized host tables (munmap, free) takes tens of
 // milliseconds that the caller does not have to wait for.  At most a few jobs are queued; beyond that fn runs inline.

@@ -23,6 +23,7 @@
 #include <thread>
 
 #include "pgx_internal.h"
+#include "pgx_khash.h"
 
 using namespace pgx;
 
@@ -169,81 +170,6 @@ struct PairMap {
   }
 };
 
-// ---------------------------------------------------------------------------------------------------------
-// klib khash slot-order emulation, keys + a dense id payload (contract: SURVEY.md 8a-11 / Appendix A1;
-// behaviour of src/khash.h:232-336 with no deletions; hash src/khash.h:373; load factor 0.77 src/khash.h:180).
-// ---------------------------------------------------------------------------------------------------------
-struct SlotTable {
-  uint32_t nb = 0, size = 0, upper = 0;
-  uint64_t *keys = nullptr;
-  uint32_t *ids = nullptr;
-  uint8_t *used = nullptr;
-  SlotTable() = default;
-  SlotTable(const SlotTable &) = delete;
-  SlotTable &operator=(const SlotTable &) = delete;
-  SlotTable(SlotTable &&o) noexcept { *this = std::move(o); }
-  SlotTable &operator=(SlotTable &&o) noexcept {
-    std::swap(nb, o.nb), std::swap(size, o.size), std::swap(upper, o.upper);
-    std::swap(keys, o.keys), std::swap(ids, o.ids), std::swap(used, o.used);
-    return *this;
-  }
-  ~SlotTable() { free(keys), free(ids), free(used); }
-  static uint32_t h32(uint64_t k) { return (uint32_t)(k >> 33 ^ k ^ k << 11); }
-
-  void enlarge() {
-    const uint32_t nn = nb ? nb * 2 : 4;
-    const uint32_t thr = (uint32_t)(nn * 0.77 + 0.5);
-    if (size >= thr) return;
-    uint8_t *fresh = (uint8_t *)calloc(nn, 1);
-    keys = (uint64_t *)realloc(keys, (size_t)nn * 8);
-    ids = (uint32_t *)realloc(ids, (size_t)nn * 4);
-    const uint32_t m = nn - 1;
-    for (uint32_t j = 0; j < nb; ++j) {
-      if (j + 16 < nb && used[j + 16]) {  // the destinations are random slots of a table that outgrew the caches
-        const uint32_t d = h32(keys[j + 16]) & m;
-        __builtin_prefetch(fresh + d, 1), __builtin_prefetch(keys + d, 1), __builtin_prefetch(ids + d, 1);
-      }
-      if (!used[j]) continue;
-      uint64_t key = keys[j];
-      uint32_t id = ids[j];
-      used[j] = 0;
-      for (;;) {  // move the element; an occupied, not yet moved destination is evicted and carried on
-        uint32_t i = h32(key) & m, step = 0;
-        while (fresh[i]) i = (i + (++step)) & m;
-        fresh[i] = 1;
-        if (i < nb && used[i]) {
-          std::swap(key, keys[i]), std::swap(id, ids[i]);
-          used[i] = 0;
-        } else {
-          keys[i] = key, ids[i] = id;
-          break;
-        }
-      }
-    }
-    free(used);
-    used = fresh, nb = nn, upper = thr;
-  }
-  // the load check precedes the lookup, so a put of an existing key can still trigger the resize
-  uint32_t put(uint64_t key, uint32_t fresh_id, bool *absent) {
-    if (size >= upper) enlarge();
-    const uint32_t m = nb - 1;
-    uint32_t i = h32(key) & m, step = 0;
-    while (used[i] && keys[i] != key) i = (i + (++step)) & m;
-    if (used[i]) {
-      *absent = false;
-      return ids[i];
-    }
-    used[i] = 1, keys[i] = key, ids[i] = fresh_id, ++size;
-    *absent = true;
-    return fresh_id;
-  }
-  void prefetch(uint64_t key) const {  // start the miss a later put(key) will take
-    if (!nb) return;
-    const uint32_t i = h32(key) & (nb - 1);
-    __builtin_prefetch(used + i, 1), __builtin_prefetch(keys + i, 1);
-  }
-};
-
 static inline uint32_t pos_of(uint64_t y) { return (uint32_t)((y & 0xFFFFFFFFu) >> 1); }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -258,60 +184,6 @@ struct Entry {
 struct Visit {
   std::vector<uint64_t> start;  // bucket b covers entries [start[b], start[b+1])
   HostArray<Entry> entries;
-};
-
-// A reusable inner table: same slot behaviour as SlotTable, but storage is recycled between key0 groups so the
-// ~10^5..10^6 tiny second-level tables cost no allocation.
-struct ScratchTable {
-  std::vector<uint64_t> keys;
-  std::vector<uint32_t> ids;
-  std::vector<uint8_t> used, fresh;
-  uint32_t nb = 0, size = 0, upper = 0;
-  void reset() {
-    if (nb) std::fill(used.begin(), used.begin() + nb, 0);
-    nb = size = upper = 0;
-  }
-  void enlarge() {
-    const uint32_t nn = nb ? nb * 2 : 4;
-    const uint32_t thr = (uint32_t)(nn * 0.77 + 0.5);
-    if (size >= thr) return;
-    if (keys.size() < nn) keys.resize(nn), ids.resize(nn), used.resize(nn, 0), fresh.resize(nn, 0);
-    std::fill(fresh.begin(), fresh.begin() + nn, 0);
-    const uint32_t m = nn - 1;
-    for (uint32_t j = 0; j < nb; ++j) {
-      if (!used[j]) continue;
-      uint64_t key = keys[j];
-      uint32_t id = ids[j];
-      used[j] = 0;
-      for (;;) {
-        uint32_t i = SlotTable::h32(key) & m, step = 0;
-        while (fresh[i]) i = (i + (++step)) & m;
-        fresh[i] = 1;
-        if (i < nb && used[i]) {
-          std::swap(key, keys[i]), std::swap(id, ids[i]);
-          used[i] = 0;
-        } else {
-          keys[i] = key, ids[i] = id;
-          break;
-        }
-      }
-    }
-    std::copy(fresh.begin(), fresh.begin() + nn, used.begin());
-    nb = nn, upper = thr;
-  }
-  uint32_t put(uint64_t key, uint32_t fresh_id, bool *absent) {
-    if (size >= upper) enlarge();
-    const uint32_t m = nb - 1;
-    uint32_t i = SlotTable::h32(key) & m, step = 0;
-    while (used[i] && keys[i] != key) i = (i + (++step)) & m;
-    if (used[i]) {
-      *absent = false;
-      return ids[i];
-    }
-    used[i] = 1, keys[i] = key, ids[i] = fresh_id, ++size;
-    *absent = true;
-    return fresh_id;
-  }
 };
 
 // The GPU join delivers every (key0,key1) bucket contiguous and internally ordered, plus the first/last insertion of every
@@ -1321,7 +1193,8 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     }
   } defer_scratch{scratch};
   PairTables &pt = scratch->pt;
-  dev_build_pairs(db, mmers, n_mm, counts, n_counts, p, pt);
+  dev_build_pairs(db->d_rlen.p, mmers, n_mm, counts, n_counts,
+                  PairParams{(uint32_t)p->total_chunk, (uint32_t)p->mychunk, (uint32_t)p->mc_lower, (uint32_t)p->mc_upper}, pt);
   sync();
   s.n_pair_records = pt.n_rec;
   const double t1 = now_ms();

@@ -91,7 +91,8 @@ template <int MODE>
 __global__ void k_records(const pgx_mm128 *__restrict__ mm, uint32_t n, const int32_t *__restrict__ chain,
                           uint32_t T, uint32_t c, const uint32_t *__restrict__ rlen, uint32_t *__restrict__ nrec,
                           const uint32_t *__restrict__ off, uint64_t *__restrict__ key0, uint64_t *__restrict__ key1,
-                          uint64_t *__restrict__ y0, uint8_t *__restrict__ dir, uint32_t *__restrict__ npos) {
+                          uint64_t *__restrict__ y0, uint8_t *__restrict__ dir, uint32_t *__restrict__ npos,
+                          uint64_t *__restrict__ y1) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t cnt = 0;
@@ -114,11 +115,13 @@ __global__ void k_records(const pgx_mm128 *__restrict__ mm, uint32_t n, const in
     uint32_t o = off[i];
     if (fwd) {
       key0[o] = a.x, key1[o] = b.x, y0[o] = a.y, dir[o] = 0, npos[o] = ~pos_of(a.y);
+      if (y1) y1[o] = b.y;
       ++o;
     }
     if (rev) {
       const uint64_t fy = flip_y(b.y, b.x, rlen);
       key0[o] = b.x, key1[o] = a.x, y0[o] = fy, dir[o] = 1, npos[o] = ~pos_of(fy);
+      if (y1) y1[o] = flip_y(a.y, a.x, rlen);  // shmr_utils.c:388-396
     }
   }
 }
@@ -183,8 +186,8 @@ HostArray<T> to_host(const DevBuf<T> &d, size_t n, size_t extra = 0) {  // (extr
 }
 }  // namespace
 
-void dev_build_pairs(const pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
-                     const pgx_overlap_params *p, PairTables &out) {
+void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
+                     const PairParams &pp, PairTables &out, unsigned flags) {
   out = PairTables();
   if (n_mm == 0) return;
   PGX_REQUIRE(n_mm < (1ULL << 31) && n_counts < (1ULL << 31), PGX_EARG, "shimmer list too long for one chunk");
@@ -220,19 +223,19 @@ void dev_build_pairs(const pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, c
   DevBuf<uint32_t> d_misc(2);  // [0] first strict index, [1] missing hashes
   const uint32_t init[2] = {0xFFFFFFFFu, 0u};
   d_misc.upload(init, 2);
-  hipLaunchKernelGGL(k_keep, dim3(cdiv(n, 256)), dim3(256), 0, st, d_mm.p, n, umer.p, ucnt.p, nu, (uint32_t)p->mc_lower,
-                     (uint32_t)p->mc_upper, keep.p, d_misc.p, d_misc.p + 1);
+  hipLaunchKernelGGL(k_keep, dim3(cdiv(n, 256)), dim3(256), 0, st, d_mm.p, n, umer.p, ucnt.p, nu, pp.lower, pp.upper, keep.p,
+                     d_misc.p, d_misc.p + 1);
   DevBuf<int32_t> chain_in(n), chain(n);
   hipLaunchKernelGGL(k_chain_in, dim3(cdiv(n, 256)), dim3(256), 0, st, keep.p, n, d_misc.p, chain_in.p);
   bytes = 0;
   PGX_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, bytes, chain_in.p, chain.p, MaxOp(), (int)n, st));
   PGX_HIP(hipcub::DeviceScan::InclusiveScan(tmp.get(bytes), bytes, chain_in.p, chain.p, MaxOp(), (int)n, st));
   // chain[i] == i  <=> i is kept ; chain[i-1] = previous kept shimmer (or -1)
-  const uint32_t T = (uint32_t)p->total_chunk, c = (uint32_t)p->mychunk % T;
+  const uint32_t T = pp.total, c = pp.mychunk % T;
   DevBuf<uint32_t> nrec(n), off(n + 1);
-  hipLaunchKernelGGL(k_records<0>, dim3(cdiv(n, 256)), dim3(256), 0, st, d_mm.p, n, chain.p, T, c, db->d_rlen.p, nrec.p,
+  hipLaunchKernelGGL(k_records<0>, dim3(cdiv(n, 256)), dim3(256), 0, st, d_mm.p, n, chain.p, T, c, d_rlen, nrec.p,
                      (const uint32_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr,
-                     (uint8_t *)nullptr, (uint32_t *)nullptr);
+                     (uint8_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr);
   PGX_HIP(hipMemsetAsync(off.p, 0, sizeof(uint32_t), st));
   bytes = 0;
   PGX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, bytes, nrec.p, off.p + 1, (int)n, st));
@@ -243,21 +246,30 @@ void dev_build_pairs(const pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, c
   sync();
   PGX_REQUIRE(misc[1] == 0, PGX_EARG, "%u shimmer hashes are missing from the MC files", misc[1]);
   out.n_rec = nr;
+  if (flags & PAIRS_COUNTS) {  // the aggregated multiplicity table, sorted by mer
+    out.umer = to_host(umer, nu);
+    out.ucnt = to_host(ucnt, nu);
+    sync();
+  }
   if (nr == 0) return;
-  DevBuf<uint64_t> key0(nr), key1(nr), y0(nr);
+  DevBuf<uint64_t> key0(nr), key1(nr), y0(nr), y1((flags & PAIRS_Y1) ? nr : 0);
   DevBuf<uint8_t> dir(nr);
   DevBuf<uint32_t> npos(nr);
-  hipLaunchKernelGGL(k_records<1>, dim3(cdiv(n, 256)), dim3(256), 0, st, d_mm.p, n, chain.p, T, c, db->d_rlen.p,
-                     (uint32_t *)nullptr, off.p, key0.p, key1.p, y0.p, dir.p, npos.p);
+  hipLaunchKernelGGL(k_records<1>, dim3(cdiv(n, 256)), dim3(256), 0, st, d_mm.p, n, chain.p, T, c, d_rlen, (uint32_t *)nullptr,
+                     off.p, key0.p, key1.p, y0.p, dir.p, npos.p, y1.p);
 
   // ---- bucket order: stable LSD sorts (position desc, key1, key0) carrying the record index --------------------
   DevBuf<uint32_t> idx(nr), perm_a(nr), perm_b(nr), k32s(nr);
   DevBuf<uint64_t> kg(nr), kgs(nr);
   {
-    hipLaunchKernelGGL(k_iota, dim3(cdiv(nr, 256)), dim3(256), 0, st, idx.p, nr);
-    bytes = 0;
-    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, npos.p, k32s.p, idx.p, perm_a.p, (int)nr, 0, 32, st));
-    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, npos.p, k32s.p, idx.p, perm_a.p, (int)nr, 0, 32, st));
+    if (flags & PAIRS_INSERTION_ORDER) {  // buckets keep their records in insertion order (shmr_map never sorts them)
+      hipLaunchKernelGGL(k_iota, dim3(cdiv(nr, 256)), dim3(256), 0, st, perm_a.p, nr);
+    } else {
+      hipLaunchKernelGGL(k_iota, dim3(cdiv(nr, 256)), dim3(256), 0, st, idx.p, nr);
+      bytes = 0;
+      PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, npos.p, k32s.p, idx.p, perm_a.p, (int)nr, 0, 32, st));
+      PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, npos.p, k32s.p, idx.p, perm_a.p, (int)nr, 0, 32, st));
+    }
     hipLaunchKernelGGL(k_gather_u64, dim3(cdiv(nr, 256)), dim3(256), 0, st, key1.p, perm_a.p, nr, kg.p);
     bytes = 0;
     PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kg.p, kgs.p, perm_a.p, perm_b.p, (int)nr, 0, 64, st));
@@ -316,6 +328,11 @@ void dev_build_pairs(const pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, c
 
   out.y0 = to_host(sy0, nr);
   out.dir = to_host(sdir, nr);
+  DevBuf<uint64_t> sy1((flags & PAIRS_Y1) ? nr : 0);
+  if (flags & PAIRS_Y1) {
+    hipLaunchKernelGGL(k_gather_u64, dim3(cdiv(nr, 256)), dim3(256), 0, st, y1.p, perm_a.p, nr, sy1.p);
+    out.y1 = to_host(sy1, nr);
+  }
   out.gord = to_host(gord, ng);
   out.bord = to_host(bord, nbk);
   DevBuf<uint64_t> bkey1(nbk), gkey0(ng);

@@ -161,3 +161,87 @@ def shmr_dedup(ovlp_paths, out_path: str | None = None, device=None):
         with open(out_path, "wb") as f:
             f.write(data)
     return data, int(nu.value)
+
+
+def shmr_map(ref_shimmer_prefix: str = "ref-L2", seqdb_prefix: str = "seq_dataset", shimmer_prefix: str = "shimmer-L2",
+             refdb_prefix: str = "ref", total_chunk=1, mychunk=1, mc_lower=1, mc_upper=240, out_path: str | None = None, device=None):
+    """shmr_map -r -m -p -l -t -c -n -M (src/shmr_map.c:163-373): the reads' shimmer pairs located on the contigs.  Returns the
+    reference's stdout text (bytes) and the number of lines."""
+    _lib.init(device)
+    p = _lib.MapParams(total_chunk, mychunk, mc_lower, mc_upper)
+    text, tl, nl = C.c_void_p(), C.c_size_t(0), C.c_uint64(0)
+    _lib.check(_lib.load().pgx_map_chunk(refdb_prefix.encode(), ref_shimmer_prefix.encode(), seqdb_prefix.encode(),
+                                         shimmer_prefix.encode(), C.byref(p), C.byref(text), C.byref(tl), C.byref(nl)), "pgx_map_chunk")
+    data = C.string_at(text.value, tl.value)
+    _lib.load().pgx_free(text)
+    if out_path:
+        with open(out_path, "wb") as f:
+            f.write(data)
+    return data, int(nl.value)
+
+
+def map_reads_to_ref(ref_mmers, mmers, counts, rlen_by_rid, total_chunk=1, mychunk=1, mc_lower=1, mc_upper=240, device=None):
+    """in-memory form of shmr_map (pgx_map): arrays in, text out"""
+    _lib.init(device)
+    rf = np.ascontiguousarray(ref_mmers, MM_DTYPE)
+    mm = np.ascontiguousarray(mmers, MM_DTYPE)
+    mc = np.ascontiguousarray(counts, MC_DTYPE)
+    rl = np.ascontiguousarray(rlen_by_rid, np.uint32)
+    p = _lib.MapParams(total_chunk, mychunk, mc_lower, mc_upper)
+    text, tl, nl = C.c_void_p(), C.c_size_t(0), C.c_uint64(0)
+    _lib.check(_lib.load().pgx_map(_ptr(rf), len(rf), _ptr(mm), len(mm), _ptr(mc), len(mc), _ptr(rl), len(rl), C.byref(p),
+                                   C.byref(text), C.byref(tl), C.byref(nl)), "pgx_map")
+    data = C.string_at(text.value, tl.value)
+    _lib.load().pgx_free(text)
+    return data, int(nl.value)
+
+
+class ShimmerMap:
+    """The shimmer4py query object (py_mmer_t + build_shimmer_map4py / get_* of src/shimmer4py.c:44-196), as the reference's
+    notebooks and py/peregrine/utils.py use it: built once on the GPU, queried from the host."""
+
+    def __init__(self, seqdb_prefix: str, shimmer_prefix: str, mychunk=1, total_chunk=1, lowerbound=2, upperbound=240, device=None):
+        _lib.init(device)
+        self._lib = _lib.load()
+        self.h = _lib.PyMmer()
+        self._lib.build_shimmer_map4py(C.byref(self.h), seqdb_prefix.encode(), shimmer_prefix.encode(), mychunk, total_chunk,
+                                       lowerbound, upperbound)
+        if not self.h.mmer0_map:
+            raise _lib.PgxError("build_shimmer_map4py failed: " + self._lib.pgx_last_error().decode(errors="replace"))
+
+    @property
+    def mmers(self) -> np.ndarray:
+        v = self.h.mmers.contents
+        return np.frombuffer((C.c_uint8 * (v.n * 16)).from_address(v.a), MM_DTYPE) if v.n else np.zeros(0, MM_DTYPE)
+
+    def shimmers_for_read(self, rid: int) -> np.ndarray:
+        v = _lib.KVec()
+        self._lib.get_shimmers_for_read(C.byref(v), C.byref(self.h), int(rid))
+        return np.frombuffer((C.c_uint8 * (v.n * 16)).from_address(v.a), MM_DTYPE).copy() if v.n else np.zeros(0, MM_DTYPE)
+
+    def read_range(self, rid: int):
+        """(first index, count) of the read's run inside .mmers"""
+        v = _lib.KVec()
+        self._lib.get_shimmers_for_read(C.byref(v), C.byref(self.h), int(rid))
+        return ((v.a - self.h.mmers.contents.a) // 16 if v.n else 0), int(v.n)
+
+    def mmer_count(self, mhash: int) -> int:
+        return int(self._lib.get_mmer_count(C.byref(self.h), int(mhash)))
+
+    def hits(self, mhash0: int, span: int) -> np.ndarray:
+        v = _lib.KVec()
+        self._lib.get_shimmer_hits(C.byref(v), C.byref(self.h), int(mhash0), int(span))
+        out = np.frombuffer(C.string_at(v.a, v.n * _lib.MP256_DTYPE.itemsize), _lib.MP256_DTYPE).copy() if v.n else np.zeros(0, _lib.MP256_DTYPE)
+        if v.a:
+            self._lib.pgx_free(C.c_void_p(v.a))
+        return out
+
+    def close(self):
+        if self.h.mmer0_map:
+            self._lib.pgx_shimmer_map_free(C.byref(self.h))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

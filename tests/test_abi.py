@@ -24,7 +24,8 @@ def test_header_symbols_are_exported(lib):
     hdr = open(os.path.join(ROOT, "include", "pgx.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = set(re.findall(r"\b(pgx_[a-z0-9_]+)\s*\(", hdr))
-    names |= set(re.findall(r"\b(decode_biseq|encode_biseq|mm_sketch|mm_reduce|ovlp_match|free_ovlp_match|read_mmlist|write_mmlist)\s*\(", hdr))
+    names |= set(re.findall(r"\b(decode_biseq|encode_biseq|mm_sketch|mm_reduce|ovlp_match|free_ovlp_match|read_mmlist|write_mmlist|"
+                            r"build_shimmer_map4py|get_shimmers_for_read|get_mmer_count|get_shimmer_hits)\s*\(", hdr))
     assert names == set(_lib.EXPORTS), names ^ set(_lib.EXPORTS)
     for n in names:
         assert hasattr(lib, n), n

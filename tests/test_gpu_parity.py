@@ -11,6 +11,7 @@ import oracle_util as U
 from peregrine_amd import _lib, formats, simreads
 from peregrine_amd.shimmer import ResidentDB, mm_count, mm_reduce, shmr_index, shmr_overlap
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
@@ -305,3 +306,104 @@ def test_adversarial_reads_all_paths():
     want, _ = U.orc_overlap(db, l2, U.orc_count(l2))
     assert formats.ovlp_fields_equal(ov, want)
     rdb.close()
+
+
+def _write_query_files(tmp_path):
+    """the tiny set's seqdb / idx / two-chunk level-2 index as files (inputs of query_cases.npz)"""
+    q, mmers, mc, rlen = G.query_fixture()
+    t = G.load("tiny_stage.npz")
+    pre, sp = str(tmp_path / "sd"), str(tmp_path / "ix-L2")
+    (tmp_path / "sd.seqdb").write_bytes(t["seqdb"].tobytes())
+    (tmp_path / "sd.idx").write_bytes(t["idx_text"].tobytes())
+    for c in (1, 2):
+        formats.write_mmlist(f"{sp}-{c:02d}-of-02.dat", t[f"ix2l2_L2_{c}"])
+        m = np.zeros(len(t[f"ix2l2_L2MC_{c}"]), formats.MC_DTYPE)
+        m["mer"], m["count"] = t[f"ix2l2_L2MC_{c}"][:, 0], t[f"ix2l2_L2MC_{c}"][:, 1]
+        formats.write_mm_count(f"{sp}-MC-{c:02d}-of-02.dat", m)
+    return q, mmers, mc, rlen, pre, sp
+
+
+def test_query_helpers_match_reference(tmp_path):
+    """row f4: build_shimmer_map4py + get_shimmer_hits / get_mmer_count / get_shimmers_for_read vs the compiled reference's
+    answers (tests/golden/query_cases.npz) on every key of the tiny set, 5 chunk / bound settings"""
+    from peregrine_amd.shimmer import ShimmerMap
+    q, mmers, mc, rlen, pre, sp = _write_query_files(tmp_path)
+    for (c, T, lo, hi) in ((1, 1, 2, 240), (1, 2, 2, 240), (2, 2, 2, 240), (1, 1, 1, 3), (2, 3, 2, 30)):
+        tag = f"c{c}t{T}lo{lo}hi{hi}"
+        m = ShimmerMap(pre, sp, c, T, lo, hi)
+        assert np.array_equal(m.mmers, mmers)
+        want, off = q[f"hits_{tag}"], q[f"hoff_{tag}"]
+        for i, k in enumerate(q["qkeys"]):
+            got = m.hits(int(k) >> 8, int(k) & 0xFF)
+            assert got.tobytes() == want[off[i]:off[i + 1]].tobytes(), (tag, i)
+        if tag == "c1t1lo2hi240":
+            assert [m.mmer_count(int(k) >> 8) for k in q["qkeys"]] == q["counts"].tolist()
+            for r, f, n in zip(q["qrids"], q["read_first"], q["read_count"]):
+                gf, gn = m.read_range(int(r))
+                assert gn == n and (n == 0 or gf == f)
+                assert np.array_equal(m.shimmers_for_read(int(r)), mmers[f:f + n] if n else mmers[:0])
+        m.close()
+    with pytest.raises(_lib.PgxError):
+        ShimmerMap(str(tmp_path / "missing"), sp)
+
+
+def test_query_helpers_match_oracle_on_small_set(small, tmp_path):
+    """row f4 on a larger set against the oracle: every hit list of 400 sampled keys (+ absent ones), chunked ownership"""
+    from peregrine_amd.shimmer import ShimmerMap
+    db, rdb = small
+    formats.write_seqdb(str(tmp_path / "sd"), db)
+    for c in (1, 2, 3):
+        ix = rdb.index(total_chunk=3, mychunk=c)
+        formats.write_mmlist(str(tmp_path / f"ix-L2-{c:02d}-of-03.dat"), ix.top)
+        formats.write_mm_count(str(tmp_path / f"ix-L2-MC-{c:02d}-of-03.dat"), ix.top_mc)
+    mm = np.concatenate([formats.read_mmlist(str(tmp_path / f"ix-L2-{c:02d}-of-03.dat")) for c in (1, 2, 3)])
+    mcs = np.concatenate([formats.read_mm_count(str(tmp_path / f"ix-L2-MC-{c:02d}-of-03.dat")) for c in (1, 2, 3)])
+    rl, _ = db.by_rid()
+    rng = np.random.default_rng(8)
+    keys = np.concatenate([rng.choice(np.unique(mm["x"]), 400, replace=False), np.array([12345 << 8 | 16], np.uint64)])
+    for (c, T) in ((1, 1), (2, 2)):
+        m, o = ShimmerMap(str(tmp_path / "sd"), str(tmp_path / "ix-L2"), c, T), U.OrcMap(mm, mcs, rl, c, T)
+        nhit = 0
+        for k in keys:
+            got, want = m.hits(int(k) >> 8, int(k) & 0xFF), o.hits(int(k) >> 8, int(k) & 0xFF)
+            assert got.tobytes() == want.tobytes(), (c, T, int(k))
+            assert m.mmer_count(int(k) >> 8) == o.count(int(k) >> 8)
+            nhit += len(got)
+        assert nhit > 1000
+        for r in rng.integers(0, db.n_reads, 50):
+            assert m.read_range(int(r)) == o.read_shimmers(int(r))
+        m.close(), o.close()
+
+
+def test_map_matches_reference(tmp_path):
+    """row f3: pgx_map_chunk / bin/shmr_map vs the compiled reference's shmr_map stdout (contigs cut from the reads' genome,
+    one of them reverse-complemented), 3 chunk / bound settings"""
+    import subprocess
+    import sys
+    from peregrine_amd.shimmer import map_reads_to_ref, shmr_map
+    q, mmers, mc, rlen, pre, sp = _write_query_files(tmp_path)
+    formats.write_mmlist(str(tmp_path / "ref-L2-01-of-01.dat"), q["ref_l2"])
+    for (c, T, lo, hi) in ((1, 1, 1, 240), (2, 2, 1, 240), (1, 1, 2, 4)):
+        want = q[f"map_c{c}t{T}lo{lo}hi{hi}"].tobytes()
+        text, n = shmr_map(str(tmp_path / "ref-L2"), pre, sp, str(tmp_path / "ref"), T, c, lo, hi)
+        assert text == want and n == want.count(b"\n"), (c, T, lo, hi)
+        text2, _ = map_reads_to_ref(q["ref_l2"], mmers, mc, rlen, T, c, lo, hi)
+        assert text2 == want
+    cli = subprocess.run([sys.executable, os.path.join(ROOT, "bin", "shmr_map"), "-r", str(tmp_path / "ref"), "-m", str(tmp_path / "ref-L2"),
+                          "-p", pre, "-l", sp, "-t", "2", "-c", "2"], check=True, stdout=subprocess.PIPE).stdout
+    assert cli == q["map_c2t2lo1hi240"].tobytes()
+
+
+def test_map_matches_oracle_on_small_set(small):
+    """row f3 at a larger size against the oracle: the reads' own genome as contigs is not available here, so the reads
+    themselves (every 7th, as 'contigs') are mapped against all reads"""
+    from peregrine_amd.shimmer import map_reads_to_ref
+    db, rdb = small
+    ix = rdb.index()
+    rl, _ = db.by_rid()
+    rid = (ix.top["y"] >> np.uint64(32)).astype(np.int64)
+    ref = ix.top[rid % 7 == 0]
+    for (c, T, lo, hi) in ((1, 1, 1, 240), (2, 3, 2, 30)):
+        text, n = map_reads_to_ref(ref, ix.top, ix.top_mc, rl, T, c, lo, hi)
+        want, wn = U.orc_map_reads_to_ref(ref, ix.top, ix.top_mc, rl, c, T, lo, hi)
+        assert n == wn and text == want and n > 1000, (c, T, n, wn)
