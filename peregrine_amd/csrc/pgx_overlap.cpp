@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <functional>
 #include <atomic>
 #include <memory>
@@ -186,6 +187,152 @@ struct Visit {
   HostArray<Entry> entries;
 };
 
+// The replay threads hammer one shared table with locked operations: spread over both sockets they run ~1.7x slower than
+// on one (measured, 2 x EPYC 9575F).  NodePin keeps the caller and the threads it starts on the memory node the caller
+// is running on, for the lifetime of the object (PGX_PIN=0 disables it).
+struct NodePin {
+  cpu_set_t saved, node;
+  bool active = false;
+  NodePin() {
+    if (const char *e = getenv("PGX_PIN"))
+      if (atoi(e) == 0) return;
+    if (sched_getaffinity(0, sizeof(saved), &saved) != 0) return;
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return;
+    for (int nd = 0; nd < 64; ++nd) {
+      char path[96];
+      snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", nd);
+      FILE *f = fopen(path, "r");
+      if (!f) break;
+      char line[4096];
+      const bool ok = fgets(line, sizeof(line), f) != nullptr;
+      fclose(f);
+      if (!ok) continue;
+      CPU_ZERO(&node);
+      bool mine = false;
+      for (char *q = line; *q && *q != '\n';) {  // "0-63,128-191"
+        char *end;
+        const long a = strtol(q, &end, 10);
+        long b = a;
+        if (end == q) break;
+        if (*end == '-') b = strtol(end + 1, &end, 10);
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+          if (CPU_ISSET(c, &saved)) {
+            CPU_SET(c, &node);
+            mine |= c == cpu;
+          }
+        q = *end == ',' ? end + 1 : end;
+      }
+      if (mine && CPU_COUNT(&node) >= 2) {
+        active = sched_setaffinity(0, sizeof(node), &node) == 0;  // threads created from here on inherit the mask
+        return;
+      }
+    }
+  }
+  ~NodePin() {
+    if (active) sched_setaffinity(0, sizeof(saved), &saved);
+  }
+  NodePin(const NodePin &) = delete;
+  NodePin &operator=(const NodePin &) = delete;
+};
+
+// A persistent team of host threads.  The stage runs dozens of short parallel regions per call (replay rounds of a
+// fraction of a millisecond, settle, collect, the table replays); creating 15 threads for each costs more than the work
+// at the small end.  Workers spin briefly for the next region and then sleep; every region starts by adopting the
+// caller's CPU affinity (see NodePin).
+class WorkTeam {
+ public:
+  template <typename F>
+  void run(unsigned nthr, F &&fn) {  // fn(thread index) on nthr threads, the caller being thread 0
+    if (nthr <= 1) {
+      fn(0);
+      return;
+    }
+    std::lock_guard<std::mutex> serial(run_mu_);
+    cpu_set_t mask;
+    const bool have_mask = sched_getaffinity(0, sizeof(mask), &mask) == 0;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      while (th_.size() < nthr - 1) {
+        const unsigned id = (unsigned)th_.size();
+        th_.emplace_back([this, id] { worker(id); });
+      }
+      job_.call = [](void *c, unsigned ti) { (*static_cast<std::remove_reference_t<F> *>(c))(ti); };
+      job_.ctx = (void *)&fn;
+      job_.workers = nthr - 1;
+      job_.mask = mask, job_.have_mask = have_mask;
+      remaining_.store(nthr - 1, std::memory_order_relaxed);
+      gen_.fetch_add(1, std::memory_order_release);
+      if (sleepers_) cv_.notify_all();
+    }
+    fn(0);
+    for (unsigned spins = 0; remaining_.load(std::memory_order_acquire); ++spins)
+      if (spins < 4096) __builtin_ia32_pause();
+      else std::this_thread::yield();
+  }
+  ~WorkTeam() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+      gen_.fetch_add(1, std::memory_order_release);
+      cv_.notify_all();
+    }
+    for (auto &t : th_) t.join();
+  }
+
+ private:
+  struct Job {
+    void (*call)(void *, unsigned) = nullptr;
+    void *ctx = nullptr;
+    unsigned workers = 0;
+    cpu_set_t mask;
+    bool have_mask = false;
+  };
+  void worker(unsigned id) {
+    uint64_t seen = 0;
+    cpu_set_t mine;
+    CPU_ZERO(&mine);
+    for (;;) {
+      for (unsigned spins = 0; gen_.load(std::memory_order_acquire) == seen && spins < 20000; ++spins) __builtin_ia32_pause();
+      Job j;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (gen_.load(std::memory_order_acquire) == seen) {
+          ++sleepers_;
+          cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+          --sleepers_;
+        }
+        if (stop_) return;
+        seen = gen_.load(std::memory_order_acquire);
+        j = job_;
+      }
+      if (id >= j.workers) continue;
+      if (j.have_mask && !CPU_EQUAL(&j.mask, &mine)) {
+        (void)sched_setaffinity(0, sizeof(j.mask), &j.mask);
+        mine = j.mask;
+      }
+      j.call(j.ctx, id + 1);
+      remaining_.fetch_sub(1, std::memory_order_release);
+    }
+  }
+  std::mutex run_mu_, mu_;
+  std::condition_variable cv_;
+  std::vector<std::thread> th_;
+  Job job_;
+  std::atomic<uint64_t> gen_{0};
+  std::atomic<unsigned> remaining_{0};
+  unsigned sleepers_ = 0;
+  bool stop_ = false;
+};
+WorkTeam &team() {
+  static WorkTeam t;
+  return t;
+}
+template <typename F>
+void par_run(unsigned nthr, F &&fn) {
+  team().run(nthr, std::forward<F>(fn));
+}
+
 // The GPU join delivers every (key0,key1) bucket contiguous and internally ordered, plus the first/last insertion of every
 // bucket and key0 group.  klib-khash's final slot layout depends only on the order in which DISTINCT keys are first
 // inserted, plus one detail: a put of an already-present key still runs the load-factor check (khash.h:298-306), so if any
@@ -268,11 +415,10 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
     inner_work(0);
     t_inner = now_ms() - tv0 - t_outer;
   } else {
-    std::vector<std::thread> th;
-    for (unsigned ti = 0; ti < nin; ++ti) th.emplace_back(inner_work, ti);
-    outer_work();
-    t_outer = now_ms() - tv0;
-    for (auto &t : th) t.join();
+    par_run(nin + 1, [&](unsigned ti) {
+      if (ti == 0) outer_work(), t_outer = now_ms() - tv0;
+      else inner_work(ti - 1);
+    });
     t_inner = now_ms() - tv0;
   }
   const double tv2 = now_ms();
@@ -299,9 +445,7 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
   if (nin == 1) {
     place(0, 1);
   } else {
-    std::vector<std::thread> th;
-    for (unsigned ti = 0; ti < nin; ++ti) th.emplace_back(place, ti, nin);
-    for (auto &t : th) t.join();
+    par_run(nin, [&](unsigned ti) { place(ti, nin); });
   }
   v.start[nbk] = ne;
   if (trace)
@@ -608,63 +752,6 @@ struct BlockArena {  // append-only, never moves what it handed out (other threa
     return p;
   }
 };
-
-// The replay threads hammer one shared table with locked operations: spread over both sockets they run ~1.7x slower than
-// on one (measured, 2 x EPYC 9575F).  NodePin keeps the caller and the threads it starts on the memory node the caller
-// is running on, for the lifetime of the object (PGX_PIN=0 disables it).
-struct NodePin {
-  cpu_set_t saved, node;
-  bool active = false;
-  NodePin() {
-    if (const char *e = getenv("PGX_PIN"))
-      if (atoi(e) == 0) return;
-    if (sched_getaffinity(0, sizeof(saved), &saved) != 0) return;
-    const int cpu = sched_getcpu();
-    if (cpu < 0) return;
-    for (int nd = 0; nd < 64; ++nd) {
-      char path[96];
-      snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", nd);
-      FILE *f = fopen(path, "r");
-      if (!f) break;
-      char line[4096];
-      const bool ok = fgets(line, sizeof(line), f) != nullptr;
-      fclose(f);
-      if (!ok) continue;
-      CPU_ZERO(&node);
-      bool mine = false;
-      for (char *q = line; *q && *q != '\n';) {  // "0-63,128-191"
-        char *end;
-        const long a = strtol(q, &end, 10);
-        long b = a;
-        if (end == q) break;
-        if (*end == '-') b = strtol(end + 1, &end, 10);
-        for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
-          if (CPU_ISSET(c, &saved)) {
-            CPU_SET(c, &node);
-            mine |= c == cpu;
-          }
-        q = *end == ',' ? end + 1 : end;
-      }
-      if (mine && CPU_COUNT(&node) >= 2) {
-        active = sched_setaffinity(0, sizeof(node), &node) == 0;  // threads created from here on inherit the mask
-        return;
-      }
-    }
-  }
-  ~NodePin() {
-    if (active) sched_setaffinity(0, sizeof(saved), &saved);
-  }
-  NodePin(const NodePin &) = delete;
-  NodePin &operator=(const NodePin &) = delete;
-};
-
-template <typename F>
-void par_run(unsigned nthr, F &&fn) {  // fn(thread index) on nthr threads, the caller being thread 0
-  std::vector<std::thread> th;
-  for (unsigned ti = 1; ti < nthr; ++ti) th.emplace_back([&fn, ti] { fn(ti); });
-  fn(0);
-  for (auto &x : th) x.join();
-}
 
 struct ParReplay {
   // every field of the shared pair table encodes "nothing" as 0, so the table is plain zero-filled pages
@@ -1199,6 +1286,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   s.n_pair_records = pt.n_rec;
   const double t1 = now_ms();
   gpu_ms += t1 - t0;
+  NodePin pin;  // from here on the caller and its helper threads stay on one memory node
   Visit &visit = scratch->visit;
   build_visit(pt, (uint32_t)p->ovlp_upper, visit);
   s.n_buckets = visit.start.size() - 1;
@@ -1230,7 +1318,6 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   if (threads > 1) {
     try {
       const double c0 = now_ms();
-      NodePin pin;
       // (the replay tables too: but they refer to the visit list, so they go first)
       ParReplay *rpp = new ParReplay(visit, db->rlen_by_rid, (uint32_t)(uint8_t)p->bestn, threads);
       struct DeferReplay {
