@@ -199,6 +199,9 @@ struct NodePin {
     if (sched_getaffinity(0, sizeof(saved), &saved) != 0) return;
     const int cpu = sched_getcpu();
     if (cpu < 0) return;
+    // the memory nodes and the CPUs of each that this process may use
+    std::vector<cpu_set_t> nodes;
+    int mine = -1;
     for (int nd = 0; nd < 64; ++nd) {
       char path[96];
       snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", nd);
@@ -208,8 +211,8 @@ struct NodePin {
       const bool ok = fgets(line, sizeof(line), f) != nullptr;
       fclose(f);
       if (!ok) continue;
-      CPU_ZERO(&node);
-      bool mine = false;
+      cpu_set_t set;
+      CPU_ZERO(&set);
       for (char *q = line; *q && *q != '\n';) {  // "0-63,128-191"
         char *end;
         const long a = strtol(q, &end, 10);
@@ -218,16 +221,23 @@ struct NodePin {
         if (*end == '-') b = strtol(end + 1, &end, 10);
         for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
           if (CPU_ISSET(c, &saved)) {
-            CPU_SET(c, &node);
-            mine |= c == cpu;
+            CPU_SET(c, &set);
+            if (c == cpu) mine = (int)nodes.size();
           }
         q = *end == ',' ? end + 1 : end;
       }
-      if (mine && CPU_COUNT(&node) >= 2) {
-        active = sched_setaffinity(0, sizeof(node), &node) == 0;  // threads created from here on inherit the mask
-        return;
-      }
+      if (CPU_COUNT(&set) >= 2) nodes.push_back(set);
+      else if (mine == (int)nodes.size()) mine = -1;
     }
+    if (nodes.empty()) return;
+    // one process per GPU (torchrun exports LOCAL_RANK / LOCAL_WORLD_SIZE): spread the ranks over the nodes evenly instead
+    // of wherever their main threads happen to run; a single process stays where it is
+    int pick = mine;
+    const char *lr = getenv("LOCAL_RANK"), *lw = getenv("LOCAL_WORLD_SIZE");
+    if (lr && lw && atoi(lw) > 1) pick = (int)((long)atoi(lr) * (long)nodes.size() / std::max(1, atoi(lw))) % (int)nodes.size();
+    if (pick < 0) return;
+    node = nodes[(size_t)pick];
+    active = sched_setaffinity(0, sizeof(node), &node) == 0;  // threads created from here on inherit the mask
   }
   ~NodePin() {
     if (active) sched_setaffinity(0, sizeof(saved), &saved);
@@ -974,6 +984,56 @@ struct ParReplay {
     }
   }
 
+  // The alignment memo: the request number of (rid0, rid1, q_off, dir0, dir1), filing the request if it is new.
+  uint32_t request_of(TL &t, uint32_t rid0, uint32_t rid1, uint32_t q_off, uint8_t dir0, uint8_t dir1) {
+    if (q_off >= (1u << 30)) overflow.store(true);  // (a Gbase-long read: the sequential replay's wider keys take over)
+    const AKey key{(uint64_t)rid0 << 32 | rid1, (uint64_t)q_off << 2 | (uint64_t)dir0 << 1 | dir1};
+    const uint64_t b32 = (uint64_t)q_off << 2 | (uint64_t)dir0 << 1 | dir1;
+    uint32_t mval = 0;
+    {
+      size_t i = mix(key.a ^ mix(key.b)) & (mcap - 1);
+      for (unsigned probes = 0;; i = (i + 1) & (mcap - 1)) {
+        MSlot &ms = mtab[i];
+        uint64_t a = ms.a.load(std::memory_order_acquire);
+        if (a == 0 && ms.a.compare_exchange_strong(a, key.a, std::memory_order_acq_rel)) {  // ours: file the request
+          if (t.qnext == t.qend) {
+            t.cur_chunk.store(ALLOCATING, std::memory_order_seq_cst);  // (between the fetch_add and the publication
+            t.qnext = nreq.fetch_add(QCHUNK, std::memory_order_seq_cst);  //  the submitter must not count the chunk)
+            t.qend = t.qnext + QCHUNK;
+            // unused slots of a chunk must still hold a valid key: pre-fill with this one
+            for (uint32_t z = t.qnext; z < t.qend && z < reqcap; ++z)
+              requests[z] = pgx_align_key{rid0, rid1, q_off, dir0, dir1, {0, 0}};
+            t.cur_chunk.store(t.qnext, std::memory_order_seq_cst);
+          }
+          const uint32_t r = t.qnext++;
+          if (r >= reqcap) overflow.store(true);
+          else requests[r] = pgx_align_key{rid0, rid1, q_off, dir0, dir1, {0, 0}};
+          if (t.qnext == t.qend) t.cur_chunk.store(NO_CHUNK, std::memory_order_release);  // chunk complete
+          ms.bv.store(b32 << 32 | ((uint64_t)r + 1), std::memory_order_release);
+          mval = r;
+          break;
+        }
+        if (a == key.a) {  // (after a lost CAS `a` holds the winner's key)
+          uint64_t bv = ms.bv.load(std::memory_order_acquire);
+          while (bv == 0) {
+            __builtin_ia32_pause();
+            bv = ms.bv.load(std::memory_order_acquire);
+          }
+          if (bv >> 32 == b32) {
+            mval = (uint32_t)bv - 1;
+            break;
+          }
+        }
+        if (++probes > 512) {
+          overflow.store(true);
+          mval = 0xFFFFFFFFu;
+          break;
+        }
+      }
+    }
+    return mval;
+  }
+
   void eval(uint32_t b, TL &t) {
     ++t.n_eval;
     BState &st = bs[b];
@@ -1019,52 +1079,8 @@ struct ParReplay {
         }
         const uint32_t pos1 = e[pi].pos1, rlen1 = rlen[rid1];
         const uint32_t q_off = pos0 - pos1;
-        const AKey key{(uint64_t)rid0 << 32 | rid1, (uint64_t)q_off << 2 | (uint64_t)e[ai].dir << 1 | e[pi].dir};
         ++lookups;
-        if (q_off >= (1u << 30)) overflow.store(true);  // (a Gbase-long read: the sequential replay's wider keys take over)
-        const uint64_t b32 = (uint64_t)q_off << 2 | (uint64_t)e[ai].dir << 1 | e[pi].dir;
-        uint32_t mval = 0;
-        {
-          size_t i = mix(key.a ^ mix(key.b)) & (mcap - 1);
-          for (unsigned probes = 0;; i = (i + 1) & (mcap - 1)) {
-            MSlot &ms = mtab[i];
-            uint64_t a = ms.a.load(std::memory_order_acquire);
-            if (a == 0 && ms.a.compare_exchange_strong(a, key.a, std::memory_order_acq_rel)) {  // ours: file the request
-              if (t.qnext == t.qend) {
-                t.cur_chunk.store(ALLOCATING, std::memory_order_seq_cst);  // (between the fetch_add and the publication
-                t.qnext = nreq.fetch_add(QCHUNK, std::memory_order_seq_cst);  //  the submitter must not count the chunk)
-                t.qend = t.qnext + QCHUNK;
-                // unused slots of a chunk must still hold a valid key: pre-fill with this one
-                for (uint32_t z = t.qnext; z < t.qend && z < reqcap; ++z)
-                  requests[z] = pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}};
-                t.cur_chunk.store(t.qnext, std::memory_order_seq_cst);
-              }
-              const uint32_t r = t.qnext++;
-              if (r >= reqcap) overflow.store(true);
-              else requests[r] = pgx_align_key{rid0, rid1, q_off, e[ai].dir, e[pi].dir, {0, 0}};
-              if (t.qnext == t.qend) t.cur_chunk.store(NO_CHUNK, std::memory_order_release);  // chunk complete
-              ms.bv.store(b32 << 32 | ((uint64_t)r + 1), std::memory_order_release);
-              mval = r;
-              break;
-            }
-            if (a == key.a) {  // (after a lost CAS `a` holds the winner's key)
-              uint64_t bv = ms.bv.load(std::memory_order_acquire);
-              while (bv == 0) {
-                __builtin_ia32_pause();
-                bv = ms.bv.load(std::memory_order_acquire);
-              }
-              if (bv >> 32 == b32) {
-                mval = (uint32_t)bv - 1;
-                break;
-              }
-            }
-            if (++probes > 512) {
-              overflow.store(true);
-              mval = 0xFFFFFFFFu;
-              break;
-            }
-          }
-        }
+        const uint32_t mval = request_of(t, rid0, rid1, q_off, e[ai].dir, e[pi].dir);
         Verdict vd;
         const pgx_match *mm = nullptr;
         bool guessed = false;
