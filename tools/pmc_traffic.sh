@@ -7,12 +7,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o p -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
 python - <<PY
-import csv, collections, json
+import csv, collections, json, re
 res = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f"$OUT/{c}/p_counter_collection.csv")):
-        acc[r["Kernel_Name"].split("(")[0].replace("pgx::", "")].append(float(r["Counter_Value"]))
+        m = re.search(r"\b(k_[a-z0-9_]+)", r["Kernel_Name"])   # "void pgx::k_align4<16>(...)" -> k_align4
+        if m:
+            acc[m.group(1)].append(float(r["Counter_Value"]))
     for k, v in acc.items():
         if k in ("k_align4", "k_sketch_wave", "k_reduce_read"):
             res.setdefault(k, {})[c + "_KB_per_launch"] = sum(v) / len(v)
