@@ -407,3 +407,24 @@ def test_map_matches_oracle_on_small_set(small):
         text, n = map_reads_to_ref(ref, ix.top, ix.top_mc, rl, T, c, lo, hi)
         want, wn = U.orc_map_reads_to_ref(ref, ix.top, ix.top_mc, rl, c, T, lo, hi)
         assert n == wn and text == want and n > 1000, (c, T, n, wn)
+
+
+def test_repeat_rich_set_parallel_replay_vs_oracle():
+    """a genome with planted repeat families and tandem arrays (deep buckets, multiplicity cut-offs, best-n saturation,
+    many rejected candidates => long correction cascades), large enough for the multi-threaded replay by default; several
+    parameter sets, every record compared with the oracle"""
+    g = simreads.make_genome(2_000_000, 31, repeat_families=6, repeat_len=5000, repeat_copies=12, divergence=0.02, tandem=8)
+    db = simreads.simulate_reads(g, coverage=24.0, seed=5, mean_len=9000, sd_len=2500, err=0.012)
+    rdb = ResidentDB(db, 0)
+    ix = rdb.index()
+    for kw in (dict(), dict(bestn=2, mc_upper=40, ovlp_upper=60), dict(total_chunk=2, mychunk=2, bestn=8, align_bandwidth=60),
+               dict(mc_lower=1, mc_upper=1000, ovlp_upper=400)):
+        got, st = rdb.overlap(ix.top, ix.top_mc, **kw)
+        okw = dict(mychunk=kw.get("mychunk", 1), total=kw.get("total_chunk", 1), mc_lower=kw.get("mc_lower", 2),
+                   mc_upper=kw.get("mc_upper", 240), bestn=kw.get("bestn", 4), ovlp_upper=kw.get("ovlp_upper", 120),
+                   band=kw.get("align_bandwidth", 100))
+        want, ost = U.orc_overlap(db, ix.top, ix.top_mc, **okw)
+        assert len(want) > 5000 and formats.ovlp_fields_equal(got, want), kw
+        assert st["n_align_needed"] == ost["n_align"] and st["n_seen_skip"] == ost["n_seen_skip"], kw
+        assert st["n_align_needed"] > st["n_records"]          # the set does produce rejected candidates
+    rdb.close()
