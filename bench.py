@@ -185,7 +185,7 @@ def main():
         if "align" in kern:
             k = kern["align"]
             gbs = ALIGN_BYTES_PER_PAIR * k["units"] / (k["ms_total"] * 1e-3) / 1e9
-            cands["align"] = {"kernel": "k_align4", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            cands["align"] = {"kernel": "k_align4 (launches > 8 k alignments) + k_align1 (smaller ones)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
                               "bytes_per_unit": ALIGN_BYTES_PER_PAIR, "unit_name": "alignment",
                               "alignments_per_s": k["units"] / (k["ms_total"] * 1e-3)}

@@ -44,7 +44,159 @@ __device__ __forceinline__ uint32_t group_bits(uint64_t wave_mask, int gbase) {
   return (uint32_t)(wave_mask >> gbase) & ((1u << GL) - 1u);
 }
 
+// ---- one candidate per wavefront: all per-candidate state is wave-uniform (scalar registers, readlane instead of
+// cross-lane permutes, no predicated bookkeeping), so a d-step costs roughly half the instructions of the grouped kernel.
+// A lone alignment is a chain of 300-600 dependent steps bound by instruction issue, hence this form for SMALL launches
+// (the replay's tail rounds), where latency is everything and idle lanes cost nothing.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_max_step(int v) {  // v = max(v, v from the DPP-selected lane); lanes without a source keep v
+  return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ int wave_max_i32(int v) {  // DPP tree: 6 VALU ops, result broadcast from lane 63
+  v = dpp_max_step<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_max_step<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_max_step<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_max_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row maximum
+  v = dpp_max_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1,3
+  v = dpp_max_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2,3 -> lane 63 holds the wave maximum
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+
 }  // namespace
+
+__global__ __launch_bounds__(64) void k_align1(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
+                                              const uint32_t *__restrict__ rlen,
+                                              const pgx_align_key *__restrict__ keys, uint32_t n, int band,
+                                              int ring, pgx_match *__restrict__ out) {
+  extern __shared__ int32_t V[];
+  const int lane = threadIdx.x;
+  const uint32_t a = blockIdx.x;
+  if (a >= n) return;
+  const pgx_align_key key = keys[a];
+  const uint8_t *q = seq + roff[key.rid0] + key.q_off;
+  const uint8_t *t = seq + roff[key.rid1];
+  const int q_len = (int)(rlen[key.rid0] - key.q_off);
+  const int t_len = (int)rlen[key.rid1];
+  const int qs = key.dir0 ? 4 : 0, ts = key.dir1 ? 4 : 0;
+  const int max_d = (int)(0.3 * (double)(q_len + t_len));  // DWmatch.c:96, one IEEE double multiply
+  const int band_size = band * 2;
+  const int mask = ring - 1;
+  for (int i = lane; i < ring; i += 64) V[i] = 0;
+  __syncthreads();
+
+  int best_m = -1, min_k = 0, max_k = 0;
+  uint32_t longest = 0;
+  bool started = false, matched = false;
+  int q_bgn = 0, t_bgn = 0, q_m_end = 0, t_m_end = 0, q_end = 0, t_end = 0, dist = 0;
+
+  for (int d = 0; d < max_d; ++d) {
+    if (max_k - min_k > band_size) break;
+    const int nk = max_k >= min_k ? ((max_k - min_k) >> 1) + 1 : 0;
+    int x = 0, y = 0;
+    for (int base = 0; base < nk && !matched; base += 64) {
+      const int j = base + lane;
+      const bool active = j < nk;
+      const int k = min_k + 2 * j;
+      int x1 = 0, y1 = 0;
+      x = 0, y = 0;
+      bool more = false;
+      if (active) {
+        const int va = V[(k - 1) & mask], vb = V[(k + 1) & mask];
+        x = (k == min_k || (k != max_k && va < vb)) ? vb : va + 1;
+        y = x - k;
+        x1 = x, y1 = y;
+        // probe: the first 8 codes.  Off-diagonal fronts almost always stop here.
+        const int rem = min(q_len - x, t_len - y);
+        if (rem > 0) {
+          int m = match8(load_u64_unaligned(q + x), load_u64_unaligned(t + y), qs, ts);
+          m = min(m, rem);
+          x += m, y += m;
+          more = (m == 8) && (rem > 8);
+        }
+      }
+      // long snakes (normally one per step): the whole wavefront extends one diagonal, 512 codes per iteration
+      uint64_t mm = __ballot(more);
+      while (mm) {
+        const int L = __builtin_ctzll(mm);
+        const int xs = __builtin_amdgcn_readlane(x, L), ys = __builtin_amdgcn_readlane(y, L);
+        const int rem = min(q_len - xs, t_len - ys);  // > 0 by construction
+        const int off = lane * 8;
+        int m = 0;
+        if (off < rem) m = min(match8(load_u64_unaligned(q + xs + off), load_u64_unaligned(t + ys + off), qs, ts), rem - off);
+        const uint64_t stop = __ballot(m < 8);
+        int ext;
+        if (stop) {
+          const int f = __builtin_ctzll(stop);
+          ext = 8 * f + __builtin_amdgcn_readlane(m, f);
+        } else {
+          ext = 512;
+        }
+        if (lane == L) x += ext, y += ext;
+        if (stop || ext >= rem) mm &= mm - 1;  // this diagonal is done (mismatch found or an end reached)
+      }
+      const int ext = x - x1;
+      const bool hit = active && (x >= q_len || y >= t_len);
+      const uint64_t hitmask = __ballot(hit);
+      const int hl = hitmask ? __builtin_ctzll(hitmask) : 64;
+      const bool valid = active && lane <= hl;
+      if (!started) {
+        const uint64_t m = __ballot(valid && ext > 16);
+        if (m) {
+          const int l = __builtin_ctzll(m);
+          q_bgn = __builtin_amdgcn_readlane(x1, l), t_bgn = __builtin_amdgcn_readlane(y1, l);
+          started = true;
+        }
+      }
+      if (__ballot(valid && (uint32_t)ext > longest)) {
+        const int mx = wave_max_i32(valid ? ext : -1);
+        const int l = __builtin_ctzll(__ballot(valid && ext == mx));
+        longest = (uint32_t)mx;
+        q_m_end = __builtin_amdgcn_readlane(x, l), t_m_end = __builtin_amdgcn_readlane(y, l);
+      }
+      if (valid) V[k & mask] = x;
+      best_m = max(best_m, wave_max_i32(valid ? x + y : -1));
+      if (hitmask) {
+        matched = true;
+        q_end = __builtin_amdgcn_readlane(x, hl), t_end = __builtin_amdgcn_readlane(y, hl);
+      }
+    }
+    __syncthreads();
+    if (matched) {
+      dist = d;
+      break;
+    }
+    // band update (DWmatch.c:166-183)
+    int new_min = max_k, new_max = min_k;
+    const int thr = best_m - band;
+    for (int base = 0; base < nk; base += 64) {
+      const int j = base + lane;
+      const int k2 = min_k + 2 * j;
+      int u;
+      if (nk <= 64) u = x + y;  // still in registers
+      else u = j < nk ? 2 * V[k2 & mask] - k2 : 0;
+      const uint64_t m = __ballot(j < nk && u >= thr);
+      if (m) {
+        new_min = min(new_min, min_k + 2 * (base + __builtin_ctzll(m)));
+        new_max = max(new_max, min_k + 2 * (base + 63 - __builtin_clzll(m)));
+      }
+    }
+    max_k = new_max + 1;
+    min_k = new_min - 1;
+  }
+  if (lane == 0) {
+    pgx_match r;
+    if (matched) {
+      r.q_bgn = q_bgn, r.t_bgn = t_bgn, r.q_end = q_end, r.t_end = t_end, r.dist = dist;
+      r.m_size = (q_end - q_bgn + t_end - t_bgn + 2 * dist) / 2;
+    } else {
+      r.q_bgn = 0, r.t_bgn = 0, r.q_end = 0, r.t_end = 0, r.dist = 0, r.m_size = 0;
+    }
+    r.q_m_end = q_m_end, r.t_m_end = t_m_end;
+    out[a] = r;
+  }
+}
+
 
 // GL = lanes per candidate: 16 (four candidates per wavefront) or 8 (eight)
 template <int GL>
@@ -233,7 +385,11 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
   uint32_t *counter = ws<uint32_t>("align.counter", 1);
   PGX_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), ctx().stream));
   static const int gl = getenv("PGX_ALIGN_GL") ? atoi(getenv("PGX_ALIGN_GL")) : 16;
-  if (gl == 8) {
+  static const long small_max = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : 8192;  // measured crossover ~12 k (tools/alignlat.py)
+  if ((long)n <= small_max) {
+    hipLaunchKernelGGL(k_align1, dim3((unsigned)n), dim3(64), ring * sizeof(int32_t), ctx().stream, db->d_seq.p, db->d_roff.p,
+                       db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out);
+  } else if (gl == 8) {
     const size_t want = (n + 7) / 8;
     const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * 20);
     hipLaunchKernelGGL(k_align4<8>, dim3(grid), dim3(64), 8 * ring * sizeof(int32_t), ctx().stream, db->d_seq.p,
