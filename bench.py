@@ -169,7 +169,7 @@ def main():
 
     if rank == 0:
         kern = {}
-        for name in ("sketch", "sketch_literal", "sketch_gather", "reduce", "count", "align"):
+        for name in ("sketch", "sketch_literal", "sketch_gather", "reduce", "count", "align", "align1"):
             ms, launches, units = _lib.timing(name)
             if launches:
                 kern[name] = {"ms_total": ms, "launches": launches, "units": units, "avg_ms": ms / launches}
@@ -185,15 +185,22 @@ def main():
         if "align" in kern:
             k = kern["align"]
             gbs = ALIGN_BYTES_PER_PAIR * k["units"] / (k["ms_total"] * 1e-3) / 1e9
-            cands["align"] = {"kernel": "k_align4 (launches > 8 k alignments) + k_align1 (smaller ones)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            cands["align"] = {"kernel": "k_align4", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
                               "bytes_per_unit": ALIGN_BYTES_PER_PAIR, "unit_name": "alignment",
                               "alignments_per_s": k["units"] / (k["ms_total"] * 1e-3)}
+        if "align1" in kern:   # the one-candidate-per-wavefront form used for launches of at most 8 k alignments (tail rounds)
+            k = kern["align1"]
+            gbs = ALIGN_BYTES_PER_PAIR * k["units"] / (k["ms_total"] * 1e-3) / 1e9
+            cands["align1"] = {"kernel": "k_align1", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
+                               "bytes_per_unit": ALIGN_BYTES_PER_PAIR, "unit_name": "alignment",
+                               "alignments_per_s": k["units"] / (k["ms_total"] * 1e-3)}
         # HBM traffic from the PMC counters: collected in separate rocprofv3 passes of this same command
         # (tools/pmc_traffic.sh) and committed under profiles/; bench.py itself cannot run under two profilers
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            for nm, kk in (("sketch", "k_sketch_wave"), ("align", "k_align4")):
+            for nm, kk in (("sketch", "k_sketch_wave"), ("align", "k_align4"), ("align1", "k_align1")):
                 if nm in cands and kk in tr:
                     cands[nm]["traffic"] = tr[kk]["hbm_bytes_per_launch"]
                     cands[nm]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"

@@ -379,13 +379,13 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
 
 void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out) {
   if (n == 0) return;
-  KernelTimer tm("align", n);
+  static const long small_max = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : 8192;  // measured crossover ~12 k (tools/alignlat.py)
+  KernelTimer tm((long)n <= small_max ? "align1" : "align", n);
   int ring = 64;
   while (ring < 2 * band + 8) ring <<= 1;
   uint32_t *counter = ws<uint32_t>("align.counter", 1);
   PGX_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), ctx().stream));
   static const int gl = getenv("PGX_ALIGN_GL") ? atoi(getenv("PGX_ALIGN_GL")) : 16;
-  static const long small_max = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : 8192;  // measured crossover ~12 k (tools/alignlat.py)
   if ((long)n <= small_max) {
     hipLaunchKernelGGL(k_align1, dim3((unsigned)n), dim3(64), ring * sizeof(int32_t), ctx().stream, db->d_seq.p, db->d_roff.p,
                        db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out);

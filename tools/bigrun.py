@@ -21,6 +21,8 @@ for it in range(2):
 os.environ["PGX_TRACE"] = "1"
 t = time.perf_counter(); ov, st = rdb.overlap(ix.top, ix.top_mc); to = time.perf_counter() - t
 ms, n, u = _lib.timing("align")
+ms1, n1, u1 = _lib.timing("align1")
+ms, n, u = ms + ms1, n + n1, u + u1
 print(f"overlap: {to:.2f}s wall, {len(ov)} records = {len(ov)/to/1e3:.1f} k rec/s; align kernel {ms:.1f} ms / {u} aln = {u/ms/1e3:.2f} M aln/s; stats {st}", flush=True)
 pair = np.minimum(ov['y0'] >> 32, ov['y1'] >> 32) << 32 | np.maximum(ov['y0'] >> 32, ov['y1'] >> 32)
 print("unique pairs:", len(np.unique(pair)) == len(pair), "types", np.bincount(ov['ovlp_type']))
