@@ -83,6 +83,82 @@ struct SlotTable {
 };
 
 
+// ---------------------------------------------------------------------------------------------------------
+// The same slot layout for a sequence of DISTINCT keys, computed without walking the probe chains again and again.
+//
+// khash probes h, h+1, h+3, h+6, ... (triangular steps) and nothing is ever deleted, so for a given home slot h the
+// leading positions of its sequence that were found occupied stay occupied: a put that starts where the previous put with
+// the same home left off finds exactly the slot khash would find.  `skip[h]` = number of leading sequence positions of
+// home h known to be occupied.  This matters because the outer key, (small hash) << 8 | span, is a terrible input for
+// khash's integer hash: its low 8 index bits are the span, so ~1/256 of the slots are the home of ALL keys, chains are
+// hundreds of probes long, and the literal replay of 2.7 M keys took 1.1 s (15 Gbases) where this form takes a fraction.
+// The rehash of a resize (khash.h:258-284, kick-out order preserved) uses the same trick on its `fresh` bitmap, and its
+// skip counts stay valid for the resized table.  Keys MUST be distinct; a put of a present key -- which in khash still
+// runs the load-factor check and may resize -- is `touch()`.
+// ---------------------------------------------------------------------------------------------------------
+struct DistinctSlotTable {
+  uint32_t nb = 0, size = 0, upper = 0;
+  uint64_t *keys = nullptr;
+  uint32_t *ids = nullptr, *skip = nullptr;
+  uint8_t *used = nullptr;
+  DistinctSlotTable() = default;
+  DistinctSlotTable(const DistinctSlotTable &) = delete;
+  DistinctSlotTable &operator=(const DistinctSlotTable &) = delete;
+  ~DistinctSlotTable() { free(keys), free(ids), free(used), free(skip); }
+  static inline uint32_t at(uint32_t home, uint32_t step, uint32_t m) {  // position after `step` triangular increments
+    return (uint32_t)((uint64_t)home + (uint64_t)step * (step + 1) / 2) & m;
+  }
+  void enlarge() {
+    const uint32_t nn = nb ? nb * 2 : 4;
+    const uint32_t thr = (uint32_t)(nn * 0.77 + 0.5);
+    if (size >= thr) return;
+    uint8_t *fresh = (uint8_t *)calloc(nn, 1);
+    uint32_t *fskip = (uint32_t *)calloc(nn, sizeof(uint32_t));
+    keys = (uint64_t *)realloc(keys, (size_t)nn * 8);
+    ids = (uint32_t *)realloc(ids, (size_t)nn * 4);
+    const uint32_t m = nn - 1;
+    for (uint32_t j = 0; j < nb; ++j) {
+      if (!used[j]) continue;
+      uint64_t key = keys[j];
+      uint32_t id = ids[j];
+      used[j] = 0;
+      for (;;) {  // move the element; an occupied, not yet moved destination is evicted and carried on
+        const uint32_t h = SlotTable::h32(key) & m;
+        uint32_t step = fskip[h], i = at(h, step, m);
+        while (fresh[i]) i = (i + (++step)) & m;
+        fskip[h] = step + 1;
+        fresh[i] = 1;
+        if (i < nb && used[i]) {
+          std::swap(key, keys[i]), std::swap(id, ids[i]);
+          used[i] = 0;
+        } else {
+          keys[i] = key, ids[i] = id;
+          break;
+        }
+      }
+    }
+    free(used), free(skip);
+    used = fresh, skip = fskip, nb = nn, upper = thr;
+  }
+  void touch() {  // a put of a key that is already present: only the load-factor check has an effect
+    if (size >= upper) enlarge();
+  }
+  void put_new(uint64_t key, uint32_t id) {  // key must not be present
+    if (size >= upper) enlarge();
+    const uint32_t m = nb - 1, h = SlotTable::h32(key) & m;
+    uint32_t step = skip[h], i = at(h, step, m);
+    while (used[i]) i = (i + (++step)) & m;
+    skip[h] = step + 1;
+    used[i] = 1, keys[i] = key, ids[i] = id, ++size;
+  }
+  void prefetch(uint64_t key) const {  // start the misses a later put_new(key) will take
+    if (!nb) return;
+    const uint32_t m = nb - 1, h = SlotTable::h32(key) & m;
+    const uint32_t i = at(h, skip[h], m);
+    __builtin_prefetch(used + i, 1), __builtin_prefetch(keys + i, 1), __builtin_prefetch(ids + i, 1);
+  }
+};
+
 // A reusable inner table: same slot behaviour as SlotTable, but storage is recycled between key0 groups so the
 // ~10^5..10^6 tiny second-level tables cost no allocation.
 struct ScratchTable {

@@ -373,12 +373,14 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
     size_t ns = 0, ne = 0;
   };
   std::vector<Frag> frag(nin);
-  SlotTable outer;
+  DistinctSlotTable outer;
   auto outer_work = [&] {
-    bool absent;
     const HostArray<uint32_t> &gord = pt.gord;  // groups by first insertion (sorted on the GPU)
-    for (size_t i = 0; i < ng; ++i) outer.put(pt.gkey0[gord[i]], gord[i], &absent);
-    if ((size_t)pt.gfirst[gord.back()] + 1 < pt.n_rec) outer.put(pt.gkey0[gord[0]], 0, &absent);  // trailing repeat put
+    for (size_t i = 0; i < ng; ++i) {
+      if (i + 8 < ng) outer.prefetch(pt.gkey0[gord[i + 8]]);
+      outer.put_new(pt.gkey0[gord[i]], gord[i]);
+    }
+    if ((size_t)pt.gfirst[gord.back()] + 1 < pt.n_rec) outer.touch();  // a put after the last first-insertion (khash.h:298-306)
   };
   auto inner_work = [&](unsigned ti) {
     // group range with ~1/nin of the records
