@@ -159,6 +159,11 @@ int pgx_reduce_batch(const pgx_mm128 *in, size_t n, int rs, pgx_mm128 **out, siz
 int pgx_count_batch(const pgx_mm128 *in, size_t n, pgx_mm_count **out, size_t *n_out);
 int pgx_align_batch(pgx_seqdb *db, const pgx_align_key *keys, size_t n, int band, pgx_match *out);
 
+/* host utility: the order in which klib khash (src/khash.h:232-336, integer hash :373) iterates n DISTINCT 64-bit keys
+ * inserted in the given order -- the order shmr_overlap visits its tables in (src/shmr_overlap.c:206-215).  out receives
+ * the n keys in ascending slot order.  Runs on the host (it is the routine the overlap stage uses for its outer table). */
+int pgx_khash_slot_order(const uint64_t *keys, size_t n, uint64_t *out);
+
 /* ---- shimmer4py surface (py/peregrine/build_shimmer4py.py:8-84), GPU-backed single-call forms ---- */
 typedef struct { size_t n, m; pgx_mm128 *a; } mm128_v; /* kvec layout, src/shimmer.h:27-30; .a is malloc'd, caller frees */
 typedef pgx_match ovlp_match_t;

@@ -69,7 +69,7 @@ EXPORTS = [
     "pgx_overlap_resident", "pgx_overlap_chunk", "pgx_mkseqdb", "pgx_dedup",
     "pgx_sketch_batch", "pgx_reduce_batch", "pgx_count_batch", "pgx_align_batch",
     "decode_biseq", "encode_biseq", "mm_sketch", "mm_reduce", "ovlp_match", "free_ovlp_match", "read_mmlist", "write_mmlist",
-    "pgx_map", "pgx_map_chunk",
+    "pgx_map", "pgx_map_chunk", "pgx_khash_slot_order",
     "build_shimmer_map4py", "get_shimmers_for_read", "get_mmer_count", "get_shimmer_hits", "pgx_shimmer_map_free",
 ]
 
@@ -113,6 +113,7 @@ def load():
         lib.pgx_count_batch.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         lib.pgx_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         lib.pgx_timing_get.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pgx_khash_slot_order.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         lib.pgx_map.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pgx_map_chunk.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

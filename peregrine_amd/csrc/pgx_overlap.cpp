@@ -1456,6 +1456,24 @@ void read_counted_files(const std::string &pattern, std::vector<T> &out) {
 
 extern "C" {
 
+int pgx_khash_slot_order(const uint64_t *keys, size_t n, uint64_t *out) {
+  try {
+    PGX_REQUIRE((keys && out) || n == 0, PGX_EARG, "pgx_khash_slot_order: null argument");
+    PGX_REQUIRE(n < (1ULL << 31), PGX_EARG, "pgx_khash_slot_order: too many keys");
+    DistinctSlotTable t;
+    for (size_t i = 0; i < n; ++i) {
+      if (i + 8 < n) t.prefetch(keys[i + 8]);
+      t.put_new(keys[i], (uint32_t)i);
+    }
+    size_t m = 0;
+    for (uint32_t s0 = 0; s0 < t.nb; ++s0)
+      if (t.used[s0]) out[m++] = t.keys[s0];
+  } catch (const Fail &f) {
+    return f.code;
+  }
+  return PGX_OK;
+}
+
 int pgx_overlap_resident(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts,
                          size_t n_counts, const pgx_overlap_params *p, pgx_ovlp **out, size_t *n_out,
                          pgx_overlap_stats *stats) {

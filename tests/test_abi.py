@@ -58,3 +58,21 @@ def test_no_cpu_fallback_without_gpu(lib):
         from peregrine_amd.shimmer import mm_count
         _lib._inited = None
         mm_count(np.zeros(4, dtype=[("x", "<u8"), ("y", "<u8")]))
+
+
+def test_khash_slot_order_equals_the_literal_replay(lib):
+    """the chain-skipping replay of khash's slot layout (DistinctSlotTable, used for the overlap stage's outer table) against
+    the oracle's literal put-by-put emulation: random keys, and keys shaped like the real ones -- (small hash) << 8 | span,
+    whose low index bits are nearly constant, the worst case for khash's integer hash -- through many resizes"""
+    import oracle_util as U
+    rng = np.random.default_rng(12)
+    cases = [np.zeros(0, np.uint64), np.array([5], np.uint64), rng.integers(0, 1 << 63, 100_000, dtype=np.uint64)]
+    for n, hbits in ((3, 20), (4, 20), (1000, 16), (50_000, 22), (700_000, 24)):
+        h = rng.choice(1 << hbits, n, replace=False).astype(np.uint64)
+        span = rng.choice(np.array([16, 16, 16, 17, 19], np.uint64), n)
+        cases.append((h << np.uint64(8)) | span)
+    for keys in cases:
+        keys = np.unique(keys)[rng.permutation(len(np.unique(keys)))]      # distinct, arbitrary insertion order
+        got = np.zeros(len(keys), np.uint64)
+        assert lib.pgx_khash_slot_order(keys.ctypes.data_as(C.c_void_p), len(keys), got.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(got, U.orc_khash_order(keys)), len(keys)
