@@ -31,23 +31,95 @@ void require_ready() { PGX_REQUIRE(ctx().ready, PGX_ESTATE, "pgx_init() has not 
 
 // ---- large host arrays -------------------------------------------------------------------------------------
 static constexpr size_t HUGE = (size_t)2 << 20, BIG = (size_t)16 << 20;  // below BIG the allocator's free lists win
+// Mappings are pooled by size class instead of unmapped: munmap takes the address-space lock exclusively and stalls
+// every page fault of the process for its duration -- freeing one call's tables in the background used to slow the NEXT
+// stage's host side 2-3x.  Two pools: blocks with arbitrary content, and blocks known to be all zero (the lock-free
+// tables need zero pages; they are cleared by whoever frees them, normally the housekeeping thread).
+namespace {
+struct BigPool {
+  std::mutex mu;
+  std::multimap<size_t, void *> any, zero;
+  size_t held = 0;
+  static size_t cls(size_t bytes) {  // eighths of a power of two, multiples of the huge page size
+    size_t p2 = HUGE;
+    while (p2 * 2 <= bytes) p2 <<= 1;
+    const size_t step = std::max(p2 >> 3, HUGE);
+    return (bytes + step - 1) / step * step;
+  }
+  static size_t cap() {
+    static const size_t c = getenv("PGX_HOST_POOL_GB") ? (size_t)atol(getenv("PGX_HOST_POOL_GB")) << 30 : (size_t)16 << 30;
+    return c;
+  }
+  void *take(std::multimap<size_t, void *> &pool, size_t len) {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = pool.find(len);
+    if (it == pool.end()) return nullptr;
+    void *p = it->second;
+    pool.erase(it);
+    held -= len;
+    return p;
+  }
+  bool give(std::multimap<size_t, void *> &pool, void *p, size_t len) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (held + len > cap()) return false;
+    pool.emplace(len, p);
+    held += len;
+    return true;
+  }
+  void trim() {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &kv : any) (void)munmap(kv.second, kv.first);
+    for (auto &kv : zero) (void)munmap(kv.second, kv.first);
+    any.clear(), zero.clear();
+    held = 0;
+  }
+};
+BigPool &big_pool() {
+  static BigPool p;
+  return p;
+}
+void *map_fresh(size_t len) {
+  void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (p == MAP_FAILED) throw std::bad_alloc();
+  (void)madvise(p, len, MADV_HUGEPAGE);
+  return p;
+}
+}  // namespace
 void *big_alloc(size_t bytes) {
   if (bytes < BIG) {
     void *p = malloc(bytes ? bytes : 1);
     if (!p) throw std::bad_alloc();
     return p;
   }
-  const size_t len = (bytes + HUGE - 1) / HUGE * HUGE;
-  void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-  if (p == MAP_FAILED) throw std::bad_alloc();
-  (void)madvise(p, len, MADV_HUGEPAGE);
-  return p;
+  const size_t len = BigPool::cls(bytes);
+  if (void *p = big_pool().take(big_pool().any, len)) return p;
+  return map_fresh(len);
 }
 void big_free(void *p, size_t bytes) {
   if (!p) return;
-  if (bytes < BIG) free(p);
-  else (void)munmap(p, (bytes + HUGE - 1) / HUGE * HUGE);
+  if (bytes < BIG) {
+    free(p);
+    return;
+  }
+  const size_t len = BigPool::cls(bytes);
+  if (!big_pool().give(big_pool().any, p, len)) (void)munmap(p, len);
 }
+void *big_alloc_zero(size_t bytes) {  // zero-filled, always a mapping
+  const size_t len = BigPool::cls(std::max(bytes, HUGE));
+  if (void *p = big_pool().take(big_pool().zero, len)) return p;
+  return map_fresh(len);
+}
+void big_free_zero(void *p, size_t bytes) {
+  if (!p) return;
+  const size_t len = BigPool::cls(std::max(bytes, HUGE));
+  if (big_pool().held + len > BigPool::cap()) {
+    (void)munmap(p, len);
+    return;
+  }
+  memset(p, 0, len);  // (plain stores: no address-space lock, unlike munmap / MADV_DONTNEED)
+  if (!big_pool().give(big_pool().zero, p, len)) (void)munmap(p, len);
+}
+void big_pool_trim() { big_pool().trim(); }
 
 // ---- housekeeping thread -----------------------------------------------------------------------------------
 namespace {
@@ -103,7 +175,11 @@ Reaper &reaper() {
   return r;
 }
 }  // namespace
-void defer_destroy(std::function<void()> fn) { reaper().push(std::move(fn)); }
+void defer_destroy(std::function<void()> fn) {
+  static const bool inline_only = getenv("PGX_DEFER") && atoi(getenv("PGX_DEFER")) == 0;
+  if (inline_only) fn();
+  else reaper().push(std::move(fn));
+}
 void drain_deferred() { reaper().drain(); }
 
 // ---- device block cache ----------------------------------------------------------------------------------
@@ -272,6 +348,7 @@ int pgx_init(int device) {
 void pgx_shutdown(void) {
   Context &c = ctx();
   drain_deferred();
+  big_pool_trim();
   g_ws.clear();
   if (c.stream) (void)hipStreamSynchronize(c.stream);
   dev_cache_trim();

@@ -154,11 +154,14 @@ void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_cou
 // banded O(ND) confirmation of n candidate alignments (keys on device)
 void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out);
 
-// Large host arrays.  Never value-initialised (they are about to be overwritten); from 16 MiB up they are anonymous
+// Large host arrays.  Never value-initialised (they are about to be overwritten); from 16 MiB up they are pooled anonymous
 // mappings advised to use transparent huge pages, which the allocator would not do for us (THP is in "madvise" mode on
 // the target hosts): first-touch faults and the final munmap are ~500x fewer than with 4 KiB pages.
-void *big_alloc(size_t bytes);            // never returns nullptr (throws std::bad_alloc)
+void *big_alloc(size_t bytes);            // never returns nullptr (throws std::bad_alloc); content arbitrary
 void big_free(void *p, size_t bytes);
+void *big_alloc_zero(size_t bytes);       // all-zero mapping (fresh, or one that big_free_zero cleared)
+void big_free_zero(void *p, size_t bytes);
+void big_pool_trim();                     // unmap everything pooled (pgx_shutdown)
 template <typename T>
 struct HostArray {
   T *p = nullptr;

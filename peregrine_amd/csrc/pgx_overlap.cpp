@@ -873,10 +873,7 @@ struct ParReplay {
     const size_t ne = std::max<size_t>(v.entries.size(), 1024);
     pcap = 1024;
     while (pcap < ne - ne / 4) pcap <<= 1;  // distinct pairs ~ 0.25-0.3 x entries; > 70 % load -> Overflow -> sequential replay
-    void *m = mmap(nullptr, pcap * sizeof(PSlot), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-    if (m == MAP_FAILED) throw std::bad_alloc();
-    madvise(m, pcap * sizeof(PSlot), MADV_HUGEPAGE);  // random probes over a GB-sized table: fewer TLB misses
-    ptab = (PSlot *)m;
+    ptab = (PSlot *)big_alloc_zero(pcap * sizeof(PSlot));  // huge pages: random probes over a GB-sized table
     rcap = (uint32_t)std::min<size_t>(ne * 10 + (size_t)nthr * RCHUNK, 0xFFFFFFF0u);
     rlog.alloc(rcap);
     reqcap = (uint32_t)std::min<size_t>(ne * 2 + (size_t)nthr * QCHUNK * 8 + 1024, 0x7FFFFFF0u);
@@ -884,10 +881,7 @@ struct ParReplay {
     results.alloc(reqcap);  // untouched pages cost nothing
     mcap = 1024;
     while (mcap < ne) mcap <<= 1;  // distinct alignments ~ 0.3 x entries
-    void *mm = mmap(nullptr, mcap * sizeof(MSlot), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-    if (mm == MAP_FAILED) throw std::bad_alloc();
-    madvise(mm, mcap * sizeof(MSlot), MADV_HUGEPAGE);
-    mtab = (MSlot *)mm;
+    mtab = (MSlot *)big_alloc_zero(mcap * sizeof(MSlot));
     const size_t nb = v.start.size() - 1;
     bs.assign(nb, BState());
     dirty.reset(new std::atomic<uint8_t>[nb ? nb : 1]);
@@ -900,8 +894,8 @@ struct ParReplay {
     }
   }
   ~ParReplay() {
-    if (ptab) munmap((void *)ptab, pcap * sizeof(PSlot));
-    if (mtab) munmap((void *)mtab, mcap * sizeof(MSlot));
+    big_free_zero((void *)ptab, pcap * sizeof(PSlot));  // (cleared here, i.e. on the housekeeping thread)
+    big_free_zero((void *)mtab, mcap * sizeof(MSlot));
   }
   ParReplay(const ParReplay &) = delete;
   ParReplay &operator=(const ParReplay &) = delete;
