@@ -1193,16 +1193,49 @@ struct ParReplay {
   }
 
   // evaluate until no bucket is dirty; returns the number of alignments requested since the last settle()
-  size_t sweep(uint64_t *n_evals, unsigned *n_rounds) {
+  // dirty buckets, found eight flags at a time (the tail rounds of a GB-scale job have a handful of dirty buckets among
+  // millions); at most `keep` of them are listed
+  size_t scan_dirty(std::vector<uint32_t> &list, size_t keep) const {
     const size_t nb = bs.size();
+    const uint8_t *f = reinterpret_cast<const uint8_t *>(dirty.get());  // (std::atomic<uint8_t> is one plain byte)
+    size_t nd = 0, b = 0;
+    list.clear();
+    for (; b + 8 <= nb; b += 8) {
+      uint64_t w;
+      memcpy(&w, f + b, 8);
+      if (!w) continue;
+      for (size_t j = b; j < b + 8; ++j)
+        if (f[j]) {
+          if (nd < keep) list.push_back((uint32_t)j);
+          ++nd;
+        }
+    }
+    for (; b < nb; ++b)
+      if (f[b]) {
+        if (nd < keep) list.push_back((uint32_t)b);
+        ++nd;
+      }
+    return nd;
+  }
+
+  size_t sweep(uint64_t *n_evals, unsigned *n_rounds) {
+    std::vector<uint32_t> few;
     for (;;) {
-      size_t nd = 0;
-      for (size_t b = 0; b < nb; ++b) nd += dirty[b].load(std::memory_order_relaxed);
+      const size_t nd = scan_dirty(few, 48);
       if (!nd) break;
-      cursor.store(0);
       const double r0 = now_ms();
-      if (nd < 48 || nthr == 1) worker(0);  // (a few dirty buckets still cascade into thousands of evaluations)
-      else par_run(nthr, [&](unsigned ti) { worker(ti); });
+      if (nd < 48 && nthr > 1) {
+        // a handful of buckets: one thread, straight from the list (what they dirty in turn is found by the next scan)
+        TL &t = tl[0];
+        for (uint32_t b : few) {
+          if (submit) maybe_submit();
+          if (dirty[b].exchange(0, std::memory_order_seq_cst)) eval(b, t);
+        }
+      } else {
+        cursor.store(0);
+        if (nthr == 1) worker(0);
+        else par_run(nthr, [&](unsigned ti) { worker(ti); });
+      }
       if (trace) fprintf(stderr, "[pgx]   round: %zu dirty buckets, %.2f ms\n", nd, now_ms() - r0);
       if (overflow.load()) throw Overflow();
       if (n_rounds) ++*n_rounds;
