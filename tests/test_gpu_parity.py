@@ -428,3 +428,37 @@ def test_repeat_rich_set_parallel_replay_vs_oracle():
         assert st["n_align_needed"] == ost["n_align"] and st["n_seen_skip"] == ost["n_seen_skip"], kw
         assert st["n_align_needed"] > st["n_records"]          # the set does produce rejected candidates
     rdb.close()
+
+
+def test_query_and_map_edge_cases(tmp_path):
+    """rows f3/f4 at the edges: unrelated contigs (no line), a chunk that owns nothing, reads unknown to the index (error, not a
+    crash), an empty shimmer list, repeated / interleaved queries on one map"""
+    from peregrine_amd.shimmer import ShimmerMap, map_reads_to_ref
+    q, mmers, mc, rlen, pre, sp = _write_query_files(tmp_path)
+    rng = np.random.default_rng(3)
+    alien = np.zeros(500, formats.MM_DTYPE)                     # shimmers whose hashes the reads never produced
+    alien["x"] = (rng.integers(1 << 40, 1 << 41, 500).astype(np.uint64) << np.uint64(8)) | np.uint64(16)
+    alien["y"] = (np.uint64(7) << np.uint64(32)) | (np.arange(500, dtype=np.uint64) * np.uint64(400) << np.uint64(1))
+    assert map_reads_to_ref(alien, mmers, mc, rlen) == (b"", 0)
+    text, n = map_reads_to_ref(q["ref_l2"], mmers[:0], mc, rlen)  # no read shimmers at all
+    assert (text, n) == (b"", 0)
+    with pytest.raises(_lib.PgxError):                            # a shimmer of read 10^6 with 160 known reads
+        bad = mmers.copy()
+        bad["y"][5] = (np.uint64(1_000_000) << np.uint64(32)) | np.uint64(10)
+        map_reads_to_ref(q["ref_l2"], bad, mc, rlen)
+    with pytest.raises(_lib.PgxError):                            # a hash that is missing from the MC files
+        map_reads_to_ref(q["ref_l2"], mmers, mc[: len(mc) // 2], rlen)
+    m = ShimmerMap(pre, sp, 1, 1, 2, 240)
+    keys = q["qkeys"][:40]
+    first = [m.hits(int(k) >> 8, int(k) & 0xFF).tobytes() for k in keys]
+    for _ in range(3):                                            # the per-map scratch table is reused across queries
+        for i in rng.permutation(len(keys)):
+            assert m.hits(int(keys[i]) >> 8, int(keys[i]) & 0xFF).tobytes() == first[i]
+    assert m.mmer_count(0) == 0 and m.read_range(4_000_000_000) == (0, 0)
+    m.close()
+    m.close()                                                     # idempotent
+    (tmp_path / "e-L2-01-of-01.dat").write_bytes(np.uint64(0).tobytes())
+    (tmp_path / "e-L2-MC-01-of-01.dat").write_bytes(np.uint64(0).tobytes())
+    e = ShimmerMap(pre, str(tmp_path / "e-L2"))
+    assert len(e.mmers) == 0 and len(e.hits(123, 16)) == 0 and e.mmer_count(5) == 0 and e.read_range(1) == (0, 0)
+    e.close()
