@@ -127,6 +127,13 @@ typedef struct {
 int pgx_overlap_resident(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts,
                          size_t n_counts, const pgx_overlap_params *p, pgx_ovlp **out, size_t *n_out,
                          pgx_overlap_stats *stats);
+/* index + overlap of a single-chunk job in one call: the final-level list and its counts stay in HBM between the two
+ * stages (the reference hands them over through files).  ip must name chunk 1 of 1.  want_index_arrays == 0: index_out
+ * carries the sizes / statistics only (top, top_mc stay NULL).  Results are those of pgx_index_resident followed by
+ * pgx_overlap_resident. */
+int pgx_index_overlap_resident(pgx_seqdb *db, const pgx_index_params *ip, const pgx_overlap_params *op,
+                               int want_index_arrays, pgx_index_result *index_out, pgx_ovlp **out, size_t *n_out,
+                               pgx_overlap_stats *stats);
 /* file level: globs <shimmer_prefix>-[0-9]*-of-[0-9]*.dat and -MC- twins like shmr_overlap.c:355-384 */
 int pgx_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, const char *out_path,
                       const pgx_overlap_params *p, pgx_overlap_stats *stats);

@@ -66,7 +66,7 @@ EXPORTS = [
     "pgx_timing_get", "pgx_timing_reset",
     "pgx_seqdb_upload", "pgx_seqdb_load", "pgx_seqdb_free", "pgx_seqdb_bases", "pgx_seqdb_reads",
     "pgx_index_resident", "pgx_index_result_free", "pgx_index_chunk",
-    "pgx_overlap_resident", "pgx_overlap_chunk", "pgx_mkseqdb", "pgx_dedup",
+    "pgx_overlap_resident", "pgx_overlap_chunk", "pgx_index_overlap_resident", "pgx_mkseqdb", "pgx_dedup",
     "pgx_sketch_batch", "pgx_reduce_batch", "pgx_count_batch", "pgx_align_batch",
     "decode_biseq", "encode_biseq", "mm_sketch", "mm_reduce", "ovlp_match", "free_ovlp_match", "read_mmlist", "write_mmlist",
     "pgx_map", "pgx_map_chunk", "pgx_khash_slot_order",
@@ -106,6 +106,8 @@ def load():
         lib.pgx_overlap_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pgx_overlap_chunk.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p]
+        lib.pgx_index_overlap_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.c_void_p]
         lib.pgx_mkseqdb.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p]
         lib.pgx_dedup.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pgx_sketch_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]

@@ -30,8 +30,9 @@ T *download_list(const DevBuf<T> &d, size_t n) {
   return h;
 }
 
-void run_index(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out) {
+void run_index(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out, DeviceIndex *keep = nullptr, bool host_arrays = true) {
   memset(out, 0, sizeof(*out));
+  if (keep) keep->valid = false;
   const double t0 = now_ms();
   // read selection: rid % total == mychunk % total, in idx-file order (shmr_index.c:155-157)
   std::vector<ReadDesc> reads;
@@ -54,11 +55,14 @@ void run_index(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out) 
       DevBuf<pgx_mm_count> mc;
       size_t nmc = 0;
       dev_count(d_top, ntop, kbits, mc, nmc);
-      out->top = (pgx_mm128 *)malloc(ntop ? ntop * sizeof(pgx_mm128) : 1);
-      if (ntop) PGX_HIP(hipMemcpyAsync(out->top, d_top, ntop * sizeof(pgx_mm128), hipMemcpyDeviceToHost, ctx().stream));
-      out->n_top = ntop;
-      out->top_mc = download_list(mc, nmc), out->n_top_mc = nmc;
+      out->n_top = ntop, out->n_top_mc = nmc;
+      if (host_arrays) {
+        out->top = (pgx_mm128 *)malloc(ntop ? ntop * sizeof(pgx_mm128) : 1);
+        if (ntop) PGX_HIP(hipMemcpyAsync(out->top, d_top, ntop * sizeof(pgx_mm128), hipMemcpyDeviceToHost, ctx().stream));
+        out->top_mc = download_list(mc, nmc);
+      }
       sync();
+      if (keep) keep->d_top = d_top, keep->n_top = ntop, keep->mc = std::move(mc), keep->n_mc = nmc, keep->valid = true;
       timing_flush();
       out->gpu_ms = now_ms() - t0;
       return;
@@ -113,6 +117,12 @@ std::string level_path(const char *prefix, int level, bool mc, int chunk, int to
 }
 
 }  // namespace
+
+namespace pgx {
+void index_stage(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out, DeviceIndex *keep, bool host_arrays) {
+  run_index(db, p, out, keep, host_arrays);
+}
+}  // namespace pgx
 
 extern "C" {
 

@@ -231,7 +231,19 @@ enum : unsigned {
 };
 // d_rlen: read length by rid, on the device
 void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts,
-                     size_t n_counts, const PairParams &pp, PairTables &out, unsigned flags = 0);
+                     size_t n_counts, const PairParams &pp, PairTables &out, unsigned flags = 0,
+                     const pgx_mm128 *d_mmers = nullptr, const pgx_mm_count *d_counts = nullptr);  // d_*: the same lists, already on the device
+
+// what the index stage leaves in HBM for a following overlap stage of the same process (pgx_index_overlap_resident)
+struct DeviceIndex {
+  const pgx_mm128 *d_top = nullptr;  // lives in the index workspace: valid until the next index call
+  size_t n_top = 0;
+  DevBuf<pgx_mm_count> mc;
+  size_t n_mc = 0;
+  bool valid = false;
+};
+// the index stage; keep != nullptr: leave the final list + counts on the device too; host_arrays == false: do not download them
+void index_stage(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out, DeviceIndex *keep, bool host_arrays);
 
 // Runs fn on the library's housekeeping thread: tearing down GB-sized host tables (munmap, free) takes tens of
 // milliseconds that the caller does not have to wait for.  At most a few jobs are queued; beyond that fn runs inline.

@@ -1306,7 +1306,7 @@ void check_params(const pgx_overlap_params *p) {
 }
 
 void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
-                 const pgx_overlap_params *p, OvOut &out, pgx_overlap_stats *st) {
+                 const pgx_overlap_params *p, OvOut &out, pgx_overlap_stats *st, const DeviceIndex *dev = nullptr) {
   pgx_overlap_stats s;
   memset(&s, 0, sizeof(s));
   const double t0 = now_ms();
@@ -1326,7 +1326,8 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   } defer_scratch{scratch};
   PairTables &pt = scratch->pt;
   dev_build_pairs(db->d_rlen.p, mmers, n_mm, counts, n_counts,
-                  PairParams{(uint32_t)p->total_chunk, (uint32_t)p->mychunk, (uint32_t)p->mc_lower, (uint32_t)p->mc_upper}, pt);
+                  PairParams{(uint32_t)p->total_chunk, (uint32_t)p->mychunk, (uint32_t)p->mc_lower, (uint32_t)p->mc_upper}, pt, 0,
+                  dev ? dev->d_top : nullptr, dev ? dev->mc.p : nullptr);
   sync();
   s.n_pair_records = pt.n_rec;
   const double t1 = now_ms();
@@ -1515,6 +1516,35 @@ int pgx_overlap_resident(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, con
     check_params(p);
     OvOut v;
     run_overlap(db, mmers, n_mm, counts, n_counts, p, v, stats);
+    *n_out = v.n;
+    *out = v.release();
+  } catch (const Fail &f) {
+    return f.code;
+  } catch (const std::bad_alloc &) {
+    set_error("out of host memory");
+    return PGX_ENOMEM;
+  }
+  return PGX_OK;
+}
+
+// index + overlap of ONE chunk with the shimmer list and the counts handed over in HBM (no download + upload between the
+// stages); anything the fused index path does not cover falls back to the two-stage hand-over through host arrays
+int pgx_index_overlap_resident(pgx_seqdb *db, const pgx_index_params *ip, const pgx_overlap_params *op, int want_index_arrays,
+                               pgx_index_result *index_out, pgx_ovlp **out, size_t *n_out, pgx_overlap_stats *stats) {
+  try {
+    require_ready();
+    PGX_REQUIRE(db && ip && op && index_out && out && n_out, PGX_EARG, "pgx_index_overlap_resident: null argument");
+    PGX_REQUIRE(ip->total_chunk == 1 && ip->mychunk == 1, PGX_EARG,
+                "pgx_index_overlap_resident is the single-index-chunk pipeline (other chunks' lists would be missing)");
+    check_params(op);
+    DeviceIndex dev;
+    index_stage(db, ip, index_out, &dev, want_index_arrays != 0);
+    OvOut v;
+    if (dev.valid) {
+      run_overlap(db, nullptr, dev.n_top, nullptr, dev.n_mc, op, v, stats, &dev);
+    } else {  // (want_l0, ambiguous parameters ...: the general index path has already produced host arrays)
+      run_overlap(db, index_out->top, index_out->n_top, index_out->top_mc, index_out->n_top_mc, op, v, stats);
+    }
     *n_out = v.n;
     *out = v.release();
   } catch (const Fail &f) {

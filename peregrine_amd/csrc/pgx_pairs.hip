@@ -187,7 +187,7 @@ HostArray<T> to_host(const DevBuf<T> &d, size_t n, size_t extra = 0) {  // (extr
 }  // namespace
 
 void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
-                     const PairParams &pp, PairTables &out, unsigned flags) {
+                     const PairParams &pp, PairTables &out, unsigned flags, const pgx_mm128 *d_mmers, const pgx_mm_count *d_counts) {
   out = PairTables();
   if (n_mm == 0) return;
   PGX_REQUIRE(n_mm < (1ULL << 31) && n_counts < (1ULL << 31), PGX_EARG, "shimmer list too long for one chunk");
@@ -198,13 +198,14 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
   const uint32_t n = (uint32_t)n_mm;
 
   // ---- aggregated counts ----------------------------------------------------------------------------------
-  DevBuf<pgx_mm_count> d_cin(n_counts);
-  d_cin.upload(counts, n_counts);
+  DevBuf<pgx_mm_count> cin_own(d_counts ? 0 : n_counts);  // (lists that are already on the device are used in place)
+  if (!d_counts) cin_own.upload(counts, n_counts);
+  const pgx_mm_count *cin = d_counts ? d_counts : cin_own.p;
   DevBuf<uint64_t> mer(n_counts), mer_s(n_counts), umer(n_counts);
   DevBuf<uint32_t> cnt(n_counts), cnt_s(n_counts), ucnt(n_counts), d_nu(1);
   uint32_t nu = 0;
   if (n_counts) {
-    hipLaunchKernelGGL(k_split_counts, dim3(cdiv(n_counts, 256)), dim3(256), 0, st, d_cin.p, n_counts, mer.p, cnt.p);
+    hipLaunchKernelGGL(k_split_counts, dim3(cdiv(n_counts, 256)), dim3(256), 0, st, cin, n_counts, mer.p, cnt.p);
     PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, mer.p, mer_s.p, cnt.p, cnt_s.p, (int)n_counts, 0, 56, st));
     PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, mer.p, mer_s.p, cnt.p, cnt_s.p, (int)n_counts, 0, 56, st));
     bytes = 0;
@@ -217,13 +218,14 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
   }
 
   // ---- keep flags, chain, records -------------------------------------------------------------------------
-  DevBuf<pgx_mm128> d_mm(n);
-  d_mm.upload(mmers, n);
+  DevBuf<pgx_mm128> mm_own(d_mmers ? 0 : n);
+  if (!d_mmers) mm_own.upload(mmers, n);
+  const pgx_mm128 *mm_dev = d_mmers ? d_mmers : mm_own.p;
   DevBuf<uint8_t> keep(n);
   DevBuf<uint32_t> d_misc(2);  // [0] first strict index, [1] missing hashes
   const uint32_t init[2] = {0xFFFFFFFFu, 0u};
   d_misc.upload(init, 2);
-  hipLaunchKernelGGL(k_keep, dim3(cdiv(n, 256)), dim3(256), 0, st, d_mm.p, n, umer.p, ucnt.p, nu, pp.lower, pp.upper, keep.p,
+  hipLaunchKernelGGL(k_keep, dim3(cdiv(n, 256)), dim3(256), 0, st, mm_dev, n, umer.p, ucnt.p, nu, pp.lower, pp.upper, keep.p,
                      d_misc.p, d_misc.p + 1);
   DevBuf<int32_t> chain_in(n), chain(n);
   hipLaunchKernelGGL(k_chain_in, dim3(cdiv(n, 256)), dim3(256), 0, st, keep.p, n, d_misc.p, chain_in.p);
@@ -233,7 +235,7 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
   // chain[i] == i  <=> i is kept ; chain[i-1] = previous kept shimmer (or -1)
   const uint32_t T = pp.total, c = pp.mychunk % T;
   DevBuf<uint32_t> nrec(n), off(n + 1);
-  hipLaunchKernelGGL(k_records<0>, dim3(cdiv(n, 256)), dim3(256), 0, st, d_mm.p, n, chain.p, T, c, d_rlen, nrec.p,
+  hipLaunchKernelGGL(k_records<0>, dim3(cdiv(n, 256)), dim3(256), 0, st, mm_dev, n, chain.p, T, c, d_rlen, nrec.p,
                      (const uint32_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr,
                      (uint8_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr);
   PGX_HIP(hipMemsetAsync(off.p, 0, sizeof(uint32_t), st));
@@ -255,7 +257,7 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
   DevBuf<uint64_t> key0(nr), key1(nr), y0(nr), y1((flags & PAIRS_Y1) ? nr : 0);
   DevBuf<uint8_t> dir(nr);
   DevBuf<uint32_t> npos(nr);
-  hipLaunchKernelGGL(k_records<1>, dim3(cdiv(n, 256)), dim3(256), 0, st, d_mm.p, n, chain.p, T, c, d_rlen, (uint32_t *)nullptr,
+  hipLaunchKernelGGL(k_records<1>, dim3(cdiv(n, 256)), dim3(256), 0, st, mm_dev, n, chain.p, T, c, d_rlen, (uint32_t *)nullptr,
                      off.p, key0.p, key1.p, y0.p, dir.p, npos.p, y1.p);
 
   // ---- bucket order: stable LSD sorts (position desc, key1, key0) carrying the record index --------------------

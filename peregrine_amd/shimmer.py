@@ -79,6 +79,21 @@ class ResidentDB:
                                                   C.byref(out), C.byref(n), C.byref(st)), "pgx_overlap_resident")
         return _lib.take(out.value, n.value, OVLP_DTYPE), st.asdict()
 
+    def index_overlap(self, want_index_arrays=False, levels=2, reduction=6, window=80, kmer=16, bestn=4, mc_lower=2,
+                      mc_upper=240, align_bandwidth=100, ovlp_upper=120):
+        """single-chunk index + overlap in one call; the shimmer list and its counts never leave HBM between the stages.
+        Returns (IndexOut — arrays None unless want_index_arrays —, ovlp records, stats)."""
+        ip = _lib.IndexParams(1, 1, levels, reduction, window, kmer, 0)
+        op = _lib.OverlapParams(1, 1, bestn, mc_lower, mc_upper, align_bandwidth, ovlp_upper)
+        r, out, n, st = _lib.IndexResult(), C.c_void_p(), C.c_size_t(0), _lib.OverlapStats()
+        _lib.check(self._lib.pgx_index_overlap_resident(self.h, C.byref(ip), C.byref(op), 1 if want_index_arrays else 0,
+                                                        C.byref(r), C.byref(out), C.byref(n), C.byref(st)),
+                   "pgx_index_overlap_resident")
+        ix = IndexOut(top=_lib.take(r.top, r.n_top, MM_DTYPE) if r.top else None,
+                      top_mc=_lib.take(r.top_mc, r.n_top_mc, MC_DTYPE) if r.top_mc else None, l0=None, l0_mc=None,
+                      bases=int(r.bases), reads=int(r.reads), reads_literal=int(r.reads_literal), ms=float(r.gpu_ms))
+        return ix, _lib.take(out.value, n.value, OVLP_DTYPE), st.asdict()
+
     # ---- batch level -------------------------------------------------------------------------------------
     def sketch(self, read_slots, w=80, k=16) -> np.ndarray:
         slots = np.ascontiguousarray(read_slots, np.uint32)

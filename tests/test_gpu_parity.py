@@ -462,3 +462,21 @@ def test_query_and_map_edge_cases(tmp_path):
     e = ShimmerMap(pre, str(tmp_path / "e-L2"))
     assert len(e.mmers) == 0 and len(e.hits(123, 16)) == 0 and e.mmer_count(5) == 0 and e.read_range(1) == (0, 0)
     e.close()
+
+
+def test_fused_index_overlap_equals_the_two_stages(small):
+    """pgx_index_overlap_resident (list and counts handed over in HBM) == pgx_index_resident + pgx_overlap_resident"""
+    db, rdb = small
+    ix = rdb.index()
+    ov, st = rdb.overlap(ix.top, ix.top_mc)
+    for want in (False, True):
+        ix2, ov2, st2 = rdb.index_overlap(want_index_arrays=want)
+        assert formats.ovlp_fields_equal(ov, ov2) and st2["n_align_needed"] == st["n_align_needed"]
+        assert ix2.bases == ix.bases and ix2.reads == ix.reads
+        if want:
+            assert np.array_equal(ix2.top, ix.top) and np.array_equal(ix2.top_mc, ix.top_mc)
+        else:
+            assert ix2.top is None and ix2.top_mc is None
+    ov3, _ = rdb.overlap(ix.top, ix.top_mc, bestn=2, mc_upper=60)
+    _, ov4, _ = rdb.index_overlap(bestn=2, mc_upper=60)
+    assert formats.ovlp_fields_equal(ov3, ov4)
