@@ -12,6 +12,8 @@
 //              already in the order the reference's qsort produces (descending position, ties in insertion order,
 //              shmr_overlap.c:46-50,217); segmented min/max of seq give the first/last insertion of every bucket and
 //              key0 group, which is all the host needs to replay klib-khash's slot order on DISTINCT keys only.
+#include <chrono>
+
 #include <hipcub/hipcub.hpp>
 
 #include "pgx_internal.h"
@@ -328,6 +330,12 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
     PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, bok.p, bok_sorted.p, iota_b.p, bord.p, (int)nbk, 0, 64, st));
   }
 
+  const bool trace = getenv("PGX_TRACE") != nullptr;
+  double tj0 = 0;
+  if (trace) {
+    sync();
+    tj0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
   out.y0 = to_host(sy0, nr);
   out.dir = to_host(sdir, nr);
   DevBuf<uint64_t> sy1((flags & PAIRS_Y1) ? nr : 0);
@@ -350,6 +358,9 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
   out.gbucket = to_host(gbucket, ng, 1);
   sync();
   out.gbucket[ng] = nbk;
+  if (trace)
+    fprintf(stderr, "[pgx]   join: tables downloaded in %.2f ms\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tj0);
 }
 
 }  // namespace pgx
