@@ -384,7 +384,7 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
   int ring = 64;
   while (ring < 2 * band + 8) ring <<= 1;
   uint32_t *counter = ws<uint32_t>("align.counter", 1);
-  PGX_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), ctx().stream));
+  if ((long)n > small_max) PGX_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), ctx().stream));  // (k_align1 has no work counter)
   static const int gl = getenv("PGX_ALIGN_GL") ? atoi(getenv("PGX_ALIGN_GL")) : 16;
   if ((long)n <= small_max) {
     hipLaunchKernelGGL(k_align1, dim3((unsigned)n), dim3(64), ring * sizeof(int32_t), ctx().stream, db->d_seq.p, db->d_roff.p,
