@@ -1,0 +1,83 @@
+"""The reference's own pipeline test (test/ecoli_K12/run_test.sh, test/genome_mapping/run_test.sh), step for step, with the
+drop-in executables of bin/ next to the REAL reference binaries (oracle/_ref, prebuilt): FASTA files -> shmr_mkseqdb ->
+shmr_index (several chunks) -> shmr_overlap (several chunks) -> cat | shmr_dedup -> shmr_map reads->contigs and
+contigs->contigs.  Every output file must be byte-identical (MC files: same multiset of (mer, count))."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_util as U
+from peregrine_amd import formats, simreads
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _mine(tool, *args, cwd=None, stdin=None):
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bin", tool), *map(str, args)], cwd=cwd, check=True, input=stdin,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
+
+
+def _ref(tool, *args, cwd=None, stdin=None):
+    return subprocess.run([os.path.join(U.REF_DIR, tool), *map(str, args)], cwd=cwd, check=True, input=stdin,
+                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout
+
+
+@pytest.mark.skipif(not (U.have_ref() and os.path.exists(os.path.join(U.REF_DIR, "shmr_map"))), reason="needs the prebuilt reference binaries (oracle/_ref)")
+def test_pipeline_like_the_reference_test_scripts(tmp_path):
+    g = simreads.make_genome(300_000, 21, repeat_families=2, repeat_len=3000, repeat_copies=4, divergence=0.02, tandem=2)
+    db = simreads.simulate_reads(g, coverage=14.0, seed=3, mean_len=7000, sd_len=1500, err=0.01, n_files=1)
+    # reads in three FASTA files, contigs = two pieces of the genome (one reverse-complemented) in a fourth
+    third = -(-db.n_reads // 3)
+    paths = []
+    lut = np.full(16, ord("N"), np.uint8)
+    lut[[1, 2, 4, 8]] = [ord(c) for c in "ACGT"]
+    for i in range(3):
+        p = tmp_path / f"reads_{i}.fa"
+        with open(p, "wb") as f:
+            for r in range(i * third, min(db.n_reads, (i + 1) * third)):
+                o, n = int(db.roff[r]), int(db.rlen[r])
+                f.write(b">read%06d\n" % r + lut[db.seqdb[o:o + n] & 0x0F].tobytes() + b"\n")
+        paths.append(str(p))
+    (tmp_path / "seq_dataset.lst").write_text("\n".join(paths) + "\n")
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    with open(tmp_path / "ctg.fa", "wb") as f:
+        f.write(b">ctg0\n" + acgt[g[:180_000]].tobytes() + b"\n>ctg1\n" + acgt[(3 - g[150_000:])[::-1]].tobytes() + b"\n")
+    (tmp_path / "ctg.lst").write_text(str(tmp_path / "ctg.fa") + "\n")
+
+    out = {}
+    for who, run in (("ref", _ref), ("mine", _mine)):
+        d = tmp_path / who
+        (d / "index").mkdir(parents=True)
+        (d / "ovlp").mkdir()
+        ix = str(d / "index")
+        run("shmr_mkseqdb", "-p", f"{ix}/seq_dataset", "-d", tmp_path / "seq_dataset.lst")
+        run("shmr_mkseqdb", "-p", f"{ix}/p_ctg", "-d", tmp_path / "ctg.lst")
+        for c in (1, 2, 3):
+            run("shmr_index", "-p", f"{ix}/seq_dataset", "-r", 6, "-t", 3, "-c", c, "-o", f"{ix}/shmr")
+        run("shmr_index", "-p", f"{ix}/p_ctg", "-r", 6, "-t", 1, "-c", 1, "-o", f"{ix}/p_ctg")
+        for c in (1, 2):
+            run("shmr_overlap", "-p", f"{ix}/seq_dataset", "-l", f"{ix}/shmr-L2", "-t", 2, "-c", f"{c:02d}", "-o", d / "ovlp" / f"ovlp.{c:02d}")
+        cat = b"".join((d / "ovlp" / f"ovlp.{c:02d}").read_bytes() for c in (1, 2))
+        out[who, "preads.ovl"] = run("shmr_dedup", stdin=cat)
+        out[who, "read_map.txt"] = run("shmr_map", "-r", f"{ix}/p_ctg", "-m", f"{ix}/p_ctg-L2", "-p", f"{ix}/seq_dataset", "-l",
+                                       f"{ix}/shmr-L2", "-t", 1, "-c", 1)
+        out[who, "ref2ref.out"] = run("shmr_map", "-r", f"{ix}/p_ctg", "-m", f"{ix}/p_ctg-L2", "-p", f"{ix}/p_ctg", "-l", f"{ix}/p_ctg-L2",
+                                      "-t", 1, "-c", 1)
+    names = sorted(os.listdir(tmp_path / "ref" / "index")) + [os.path.join("..", "ovlp", f) for f in sorted(os.listdir(tmp_path / "ref" / "ovlp"))]
+    assert sorted(os.listdir(tmp_path / "mine" / "index")) == sorted(os.listdir(tmp_path / "ref" / "index"))
+    for n in names:
+        a = (tmp_path / "ref" / "index" / n).read_bytes()
+        b = (tmp_path / "mine" / "index" / n).read_bytes()
+        if "-MC-" in n:   # khash slot order in the reference, sorted here: same (mer, count) multiset
+            pa = formats.mc_as_sorted_pairs(formats.read_mm_count(str(tmp_path / "ref" / "index" / n)))
+            pb = formats.mc_as_sorted_pairs(formats.read_mm_count(str(tmp_path / "mine" / "index" / n)))
+            assert np.array_equal(pa, pb), n
+        else:
+            assert a == b, n
+    for k in ("preads.ovl", "read_map.txt", "ref2ref.out"):
+        assert out["ref", k] == out["mine", k], k
+    assert out["ref", "preads.ovl"].count(b"\n") > 500 and out["ref", "read_map.txt"].count(b"\n") > 500
