@@ -121,6 +121,35 @@ void big_free_zero(void *p, size_t bytes) {
 }
 void big_pool_trim() { big_pool().trim(); }
 
+// Arrays handed to the caller (released with pgx_free): large ones come from the pooled huge-page mappings too, so that
+// filling a 300 MB result does not start with 73,000 first-touch page faults; the registry tells pgx_free which is which.
+namespace {
+std::mutex g_out_mu;
+std::map<void *, size_t> g_out_big;
+}  // namespace
+void *out_alloc(size_t bytes) {
+  if (bytes < BIG) {
+    void *p = malloc(bytes ? bytes : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+  }
+  void *p = big_alloc(bytes);
+  std::lock_guard<std::mutex> lk(g_out_mu);
+  g_out_big[p] = bytes;
+  return p;
+}
+void out_free(void *p) {
+  if (!p) return;
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_out_mu);
+    auto it = g_out_big.find(p);
+    if (it != g_out_big.end()) bytes = it->second, g_out_big.erase(it);
+  }
+  if (bytes) big_free(p, bytes);
+  else free(p);
+}
+
 // ---- housekeeping thread -----------------------------------------------------------------------------------
 namespace {
 struct Reaper {
@@ -318,7 +347,7 @@ extern "C" {
 
 const char *pgx_last_error(void) { return pgx::g_err.c_str(); }
 const char *pgx_version(void) { return "pgx 0.1 (gfx950)"; }
-void pgx_free(void *p) { free(p); }
+void pgx_free(void *p) { pgx::out_free(p); }
 
 int pgx_device_count(void) {
   int n = 0;

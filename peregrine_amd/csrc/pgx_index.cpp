@@ -25,7 +25,7 @@ void check_params(const pgx_index_params *p) {
 
 template <typename T>
 T *download_list(const DevBuf<T> &d, size_t n) {
-  T *h = (T *)malloc(n ? n * sizeof(T) : 1);
+  T *h = (T *)out_alloc(n ? n * sizeof(T) : 1);
   d.download(h, n);
   return h;
 }
@@ -57,7 +57,7 @@ void run_index(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out, 
       dev_count(d_top, ntop, kbits, mc, nmc);
       out->n_top = ntop, out->n_top_mc = nmc;
       if (host_arrays) {
-        out->top = (pgx_mm128 *)malloc(ntop ? ntop * sizeof(pgx_mm128) : 1);
+        out->top = (pgx_mm128 *)out_alloc(ntop ? ntop * sizeof(pgx_mm128) : 1);
         if (ntop) PGX_HIP(hipMemcpyAsync(out->top, d_top, ntop * sizeof(pgx_mm128), hipMemcpyDeviceToHost, ctx().stream));
         out->top_mc = download_list(mc, nmc);
       }
@@ -128,7 +128,7 @@ extern "C" {
 
 void pgx_index_result_free(pgx_index_result *r) {
   if (!r) return;
-  free(r->l0), free(r->l0_mc), free(r->top), free(r->top_mc);
+  out_free(r->l0), out_free(r->l0_mc), out_free(r->top), out_free(r->top_mc);
   r->l0 = r->top = nullptr;
   r->l0_mc = r->top_mc = nullptr;
   r->n_l0 = r->n_l0_mc = r->n_top = r->n_top_mc = 0;

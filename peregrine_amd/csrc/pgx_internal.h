@@ -162,6 +162,8 @@ void big_free(void *p, size_t bytes);
 void *big_alloc_zero(size_t bytes);       // all-zero mapping (fresh, or one that big_free_zero cleared)
 void big_free_zero(void *p, size_t bytes);
 void big_pool_trim();                     // unmap everything pooled (pgx_shutdown)
+void *out_alloc(size_t bytes);            // an array for the caller (pgx_free): malloc, or a pooled mapping when large
+void out_free(void *p);
 template <typename T>
 struct HostArray {
   T *p = nullptr;

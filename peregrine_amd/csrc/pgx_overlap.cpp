@@ -492,9 +492,8 @@ struct OvOut {  // the stage's output: one malloc'd array handed to the caller a
   pgx_ovlp *a = nullptr;
   size_t n = 0;
   void alloc(size_t count) {
-    free(a);
-    a = (pgx_ovlp *)malloc(count ? count * sizeof(pgx_ovlp) : 1);
-    if (!a) throw std::bad_alloc();
+    out_free(a);
+    a = (pgx_ovlp *)out_alloc(count ? count * sizeof(pgx_ovlp) : 1);
     n = count;
   }
   pgx_ovlp *release() {
@@ -502,7 +501,7 @@ struct OvOut {  // the stage's output: one malloc'd array handed to the caller a
     a = nullptr, n = 0;
     return p;
   }
-  ~OvOut() { free(a); }
+  ~OvOut() { out_free(a); }
 };
 
 struct Replay {
