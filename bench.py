@@ -83,7 +83,7 @@ def main():
     import torch.distributed as dist
     from peregrine_amd import _lib, simreads
     from peregrine_amd.formats import MC_DTYPE, MM_DTYPE, SeqDB
-    from peregrine_amd.parallel import allgather_records
+    from peregrine_amd.parallel import allgather_many, allgather_records
     from peregrine_amd.shimmer import ResidentDB
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
@@ -125,10 +125,9 @@ def main():
             return rdb.index_overlap()
         ix = rdb.index(total_chunk=world, mychunk=rank + 1, levels=2, reduction=6, window=80, kmer=16)
         if world > 1:  # the path's one exchange step: every overlap chunk needs every index chunk's L2 + counts
-            mm = np.concatenate([p.cpu().numpy().view(MM_DTYPE) for p in
-                                 allgather_records(torch.from_numpy(ix.top.view(np.uint8)).to(xdev), world)])
-            mc = np.concatenate([p.cpu().numpy().view(MC_DTYPE) for p in
-                                 allgather_records(torch.from_numpy(ix.top_mc.view(np.uint8)).to(xdev), world)])
+            got = allgather_many([torch.from_numpy(ix.top.view(np.uint8)).to(xdev), torch.from_numpy(ix.top_mc.view(np.uint8)).to(xdev)], world)
+            mm = np.concatenate([p.cpu().numpy().view(MM_DTYPE) for p in got[0]])
+            mc = np.concatenate([p.cpu().numpy().view(MC_DTYPE) for p in got[1]])
         else:
             mm, mc = ix.top, ix.top_mc
         ov, st = rdb.overlap(mm, mc, total_chunk=world, mychunk=rank + 1)
@@ -156,10 +155,9 @@ def main():
         ix = rdb.index(total_chunk=world, mychunk=rank + 1)
         s1 = time.perf_counter()
         if world > 1:
-            mm = np.concatenate([p.cpu().numpy().view(MM_DTYPE) for p in
-                                 allgather_records(torch.from_numpy(ix.top.view(np.uint8)).to(xdev), world)])
-            mc = np.concatenate([p.cpu().numpy().view(MC_DTYPE) for p in
-                                 allgather_records(torch.from_numpy(ix.top_mc.view(np.uint8)).to(xdev), world)])
+            got = allgather_many([torch.from_numpy(ix.top.view(np.uint8)).to(xdev), torch.from_numpy(ix.top_mc.view(np.uint8)).to(xdev)], world)
+            mm = np.concatenate([p.cpu().numpy().view(MM_DTYPE) for p in got[0]])
+            mc = np.concatenate([p.cpu().numpy().view(MC_DTYPE) for p in got[1]])
         else:
             mm, mc = ix.top, ix.top_mc
         ov, st = rdb.overlap(mm, mc, total_chunk=world, mychunk=rank + 1)
