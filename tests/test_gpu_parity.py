@@ -480,3 +480,18 @@ def test_fused_index_overlap_equals_the_two_stages(small):
     ov3, _ = rdb.overlap(ix.top, ix.top_mc, bestn=2, mc_upper=60)
     _, ov4, _ = rdb.index_overlap(bestn=2, mc_upper=60)
     assert formats.ovlp_fields_equal(ov3, ov4)
+
+
+def test_one_level_index_through_both_stages(small):
+    """-l 1 (run_test_one_level.sh): the three-times denser L1 list through the join and the multi-threaded replay, two overlap
+    chunks, against the oracle"""
+    db, rdb = small
+    ix = rdb.index(levels=1)
+    l1 = np.concatenate([U.orc_reduce(U.orc_sketch_seqdb(db.seqdb[int(db.roff[r]):int(db.roff[r]) + int(db.rlen[r])], 80, 16, r), 6)
+                         for r in range(db.n_reads)])
+    assert np.array_equal(ix.top, l1) and len(l1) > 3 * len(rdb.index().top)
+    for c in (1, 2):
+        got, st = rdb.overlap(ix.top, ix.top_mc, total_chunk=2, mychunk=c)
+        want, ost = U.orc_overlap(db, ix.top, ix.top_mc, mychunk=c, total=2)
+        assert len(want) > 5000 and formats.ovlp_fields_equal(got, want), c
+        assert st["n_align_needed"] == ost["n_align"]
