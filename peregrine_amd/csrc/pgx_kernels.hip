@@ -1,8 +1,9 @@
 // pgx_kernels.hip -- gfx950 device code of libpgx.so (index stage + banded O(ND) confirmation).
 //
 // Kernels (each cites the reference routine whose results it must reproduce bit-for-bit):
-//   k_sketch_literal : mm_sketch      src/mm_sketch.c:70-151   general state machine, one lane per read
-//                                     (reads with ambiguous bases, k > 16, reads shorter than a window ...)
+//   k_sketch_literal : mm_sketch      src/mm_sketch.c:70-151   the literal state machine, one lane per read
+//                                     (reads with ambiguous bases, slab overflow)
+//   k_sketch_general : mm_sketch      closed form for any (w, k), one wavefront per read, entries in global scratch
 //   k_sketch_wave    : mm_sketch      closed form, one wavefront per read            (pgx_sketch_fast.hip)
 //   k_reduce_*       : mm_reduce      src/shmr_reduce.c:53-90
 //   count            : mm_count       src/shmr_utils.c:131-160  radix sort + run-length
@@ -282,6 +283,135 @@ __global__ void k_gather_slabs(const pgx_mm128 *__restrict__ slab, const uint64_
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
+// =========================================================================================================
+// k_sketch_general: the closed form of pgx_sketch_fast.hip (see its header) for ANY window and k-mer size
+// (0 < w < 256, 0 < k <= 28; pg_run.py exposes both as --shimmer-w / --shimmer-k), one wavefront per read, three
+// passes over the read's ENTRIES (non strand-ambiguous k-mers, numbered in position order) kept in global scratch:
+//   1. entries: every lane builds the k-mer ending at its base, canonical strand, 64-bit hash (mm_sketch.c:23-32);
+//      ballot-compacted to H[] (hash) and PY[] (position << 1 | strand);
+//   2. WM[s] = minimum hash of the full window of w entries starting at s;
+//   3. entry p is emitted iff some full window containing it has WM == H[p], corrected for the first window
+//      (m = rightmost smallest of entries 0..w-2: its ties are always emitted, m itself iff H[w-1] > H[m]); a read with
+//      fewer than w entries emits only its rightmost smallest entry.
+// O(w) work per entry and pass -- ~50x slower than the w = 16 A, k = 16 kernel, ~50x faster than one lane per read.
+// Reads with an ambiguous base (the state machine restarts there) or more minimizers than their slab holds are
+// flagged and redone by k_sketch_literal.
+// =========================================================================================================
+__global__ __launch_bounds__(64) void k_sketch_general(const uint8_t *__restrict__ seq, const ReadDesc *__restrict__ reads,
+                                                       const uint32_t *__restrict__ list, uint32_t n_list, int w, int k,
+                                                       const uint64_t *__restrict__ scr_off, uint64_t *__restrict__ Hs,
+                                                       uint32_t *__restrict__ PYs, uint64_t *__restrict__ WMs,
+                                                       pgx_mm128 *__restrict__ slab, const uint64_t *__restrict__ slab_off,
+                                                       uint32_t *__restrict__ counts, uint32_t *__restrict__ flags) {
+  const int lane = threadIdx.x;
+  const uint64_t mask = (1ULL << (2 * k)) - 1, top = 2ULL * (uint64_t)(k - 1);
+  for (uint32_t it = blockIdx.x; it < n_list; it += gridDim.x) {
+    const uint32_t slot = list[it];
+    const ReadDesc rd = reads[slot];
+    const uint8_t *s = seq + rd.off;
+    const int len = (int)rd.len;
+    uint64_t *H = Hs + scr_off[it], *WM = WMs + scr_off[it];
+    uint32_t *PY = PYs + scr_off[it];
+    // ---- pass 1 ----------------------------------------------------------------------------------------------
+    int n = 0;
+    bool bad = false;
+    for (int b0 = 0; b0 < len; b0 += 64) {
+      const int i = b0 + lane;
+      bool entry = false;
+      uint64_t h = 0;
+      uint32_t py = 0;
+      if (i < len) {
+        if (code_of_nibble(s[i]) > 3) bad = true;
+        if (i >= k - 1) {
+          uint64_t fwd = 0, rev = 0;
+          for (int j = i - k + 1; j <= i; ++j) {
+            const uint64_t c = (uint64_t)(code_of_nibble(s[j]) & 3);
+            fwd = (fwd << 2 | c) & mask;
+            rev = (rev >> 2) | (3ULL ^ c) << top;
+          }
+          if (fwd != rev) {
+            const uint32_t strand = fwd < rev ? 0u : 1u;
+            entry = true;
+            h = mix64(strand ? rev : fwd, mask);
+            py = (uint32_t)i << 1 | strand;
+          }
+        }
+      }
+      const uint64_t em = __ballot(entry);
+      if (entry) {
+        const int r = n + __builtin_popcountll(em & ((1ULL << lane) - 1));
+        H[r] = h, PY[r] = py;
+      }
+      n += __builtin_popcountll(em);
+    }
+    if (__ballot(bad)) {
+      if (lane == 0) counts[slot] = 0, flags[slot] = 1;
+      continue;
+    }
+    __syncthreads();  // (one wavefront per block: orders this wave's global writes before its reads below)
+    // ---- pass 2 ----------------------------------------------------------------------------------------------
+    const int nwin = n - w + 1;  // number of full windows (<= 0: short read)
+    for (int v0 = 0; v0 < nwin; v0 += 64) {
+      const int v = v0 + lane;
+      if (v < nwin) {
+        uint64_t m = H[v];
+        for (int j = 1; j < w; ++j) m = min(m, H[v + j]);
+        WM[v] = m;
+      }
+    }
+    // rightmost smallest of the first min(n, w - 1) entries (all n entries for a short read)
+    const int lim = nwin > 0 ? w - 1 : n;
+    uint64_t bh = ~0ULL;
+    int bi = -1;
+    for (int v = lane; v < lim; v += 64) {
+      const uint64_t x = H[v];
+      if (x <= bh) bh = x, bi = v;  // ascending v per lane: <= keeps the rightmost
+    }
+    for (int d = 32; d; d >>= 1) {
+      const uint64_t oh = (uint64_t)__shfl_xor((int)(bh >> 32), d, 64) << 32 | (uint32_t)__shfl_xor((int)bh, d, 64);
+      const int oi = __shfl_xor(bi, d, 64);
+      if (oi >= 0 && (bi < 0 || oh < bh || (oh == bh && oi > bi))) bh = oh, bi = oi;
+    }
+    const int m_idx = bi;
+    const uint64_t m_h = bh;
+    const uint64_t h_last = nwin > 0 ? H[w - 1] : 0;
+    __syncthreads();
+    // ---- pass 3 ----------------------------------------------------------------------------------------------
+    const uint64_t cap = slab_off[slot + 1] - slab_off[slot];
+    pgx_mm128 *dst = slab + slab_off[slot];
+    uint32_t nout = 0;
+    bool over = false;
+    for (int p0 = 0; p0 < n; p0 += 64) {
+      const int p = p0 + lane;
+      bool emit = false;
+      uint64_t hp = 0;
+      if (p < n) {
+        hp = H[p];
+        if (nwin > 0) {
+          const int s0 = p - w + 1 > 0 ? p - w + 1 : 0, s1 = p < nwin - 1 ? p : nwin - 1;
+          for (int sidx = s0; sidx <= s1; ++sidx) emit |= WM[sidx] == hp;
+          if (p <= w - 2 && hp == m_h) emit = p != m_idx ? true : h_last > m_h;
+        } else {
+          emit = p == m_idx;
+        }
+      }
+      const uint64_t em = __ballot(emit);
+      if (emit) {
+        const uint32_t r = nout + (uint32_t)__builtin_popcountll(em & ((1ULL << lane) - 1));
+        if (r < cap) dst[r] = pgx_mm128{hp << 8 | (uint64_t)k, (uint64_t)rd.rid << 32 | PY[p]};
+        else over = true;
+      }
+      nout += (uint32_t)__builtin_popcountll(em);
+    }
+    const bool anyover = __ballot(over) != 0;
+    if (lane == 0) {
+      counts[slot] = anyover ? 0u : nout;
+      if (anyover) flags[slot] = 1;
+    }
+    __syncthreads();
+  }
+}
+
 void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, DevBuf<pgx_mm128> &out,
                 size_t &n_out, uint32_t *n_literal) {
   n_out = 0;
@@ -299,8 +429,10 @@ void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, 
   std::vector<uint32_t> fast, slow;
   std::vector<uint64_t> slab_off(n + 1, 0);
   uint64_t fast_bases = 0, slow_bases = 0;
+  // (w, k) outside the specialised kernel's set: the general closed-form kernel takes the wave kernel's place
+  const bool general = !(k == 16 && (w == 64 || w == 80 || w == 96 || w == 128));
   for (uint32_t i = 0; i < n; ++i) {
-    const bool f = sketch_wave_eligible(reads[i], w, k);
+    const bool f = general ? reads[i].len < (1u << 30) : sketch_wave_eligible(reads[i], w, k);
     // slab capacity: 5x the expected density 2/(w+1); overflow (low-complexity reads) falls back to the literal kernel
     slab_off[i + 1] = slab_off[i] + (f ? (uint64_t)reads[i].len / 8 + 64 : 0);
     if (f) fast.push_back(i), fast_bases += reads[i].len;
@@ -313,9 +445,29 @@ void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, 
     d_fast.upload(fast.data(), fast.size());
     d_slab_off.upload(slab_off.data(), n + 1);
     slab.alloc(slab_off[n]);
-    {
+    if (!general) {
       KernelTimer tm("sketch", fast_bases);
       launch_sketch_wave(db, d_reads.p, d_fast.p, (uint32_t)fast.size(), w, k, slab.p, d_slab_off.p, counts.p, d_flag.p);
+    } else {
+      // entry scratch (hash, position|strand, window minimum: 20 B per base), in batches of at most ~256 Mbases
+      KernelTimer tm("sketch_general", fast_bases);
+      const uint64_t batch_bases = 256ull << 20;
+      for (size_t b0 = 0; b0 < fast.size();) {
+        std::vector<uint64_t> so;
+        uint64_t acc = 0;
+        size_t b1 = b0;
+        while (b1 < fast.size() && (b1 == b0 || acc + reads[fast[b1]].len <= batch_bases)) so.push_back(acc), acc += reads[fast[b1]].len, ++b1;
+        uint64_t *d_so = ws<uint64_t>("sk.gen_off", so.size());
+        uint64_t *H = ws<uint64_t>("sk.gen_h", acc), *WMv = ws<uint64_t>("sk.gen_wm", acc);
+        uint32_t *PY = ws<uint32_t>("sk.gen_py", acc);
+        PGX_HIP(hipMemcpyAsync(d_so, so.data(), so.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        const unsigned grid = (unsigned)std::min<size_t>(b1 - b0, (size_t)ctx().num_cu * 16);
+        hipLaunchKernelGGL(k_sketch_general, dim3(grid), dim3(64), 0, st, db->d_seq.p, d_reads.p, d_fast.p + b0, (uint32_t)(b1 - b0), w, k,
+                           d_so, H, PY, WMv, slab.p, d_slab_off.p, counts.p, d_flag.p);
+        PGX_HIP(hipGetLastError());
+        sync();  // (so[] is reused by the next batch)
+        b0 = b1;
+      }
     }
     std::vector<uint32_t> flag(n);
     d_flag.download(flag.data(), n);
