@@ -1,14 +1,16 @@
 // pgx_align.hip -- banded O(ND) furthest-reaching confirmation (ovlp_match, /root/reference/src/DWmatch.c:66-204),
-// FOUR candidate alignments per wavefront.
+// EIGHT (default) or four candidate alignments per wavefront.
 //
-// A candidate keeps on average ~4 diagonals alive (at most band+1 = 101), so one wavefront per candidate leaves most
-// lanes idle.  Here a wavefront is four independent 16-lane groups; each group runs the reference's d-loop for its own
+// A candidate keeps on average 3.6 diagonals alive (<= 8 in 98.7 % of the steps, at most band+1 = 101), so one wavefront
+// per candidate leaves most lanes idle -- and the kernel is bound by VALU issue (profiles/r01_pmc_align.txt), so lane
+// utilisation is throughput.  Here a wavefront is eight independent 8-lane groups (GL = 8; or four 16-lane groups, the
+// description below uses 16); each group runs the reference's d-loop for its own
 // candidate, in lock-step with the other three, and pulls the next candidate from a device-wide counter the moment it
 // finishes (persistent groups: no tail inside the wave).  Lane j of a group owns diagonal k = min_k + 2*(base+j) of the
 // current step; wider bands take several rounds of 16.  V lives in a per-group LDS ring indexed by k (only the previous
 // step's values are ever read, so 2*band+8 slots never alias live data; only V[1] needs to start at 0).
 // Per step: start point from V[k-1], V[k+1]; an 8-code probe per lane (off-diagonal fronts stop there); long snakes are
-// extended by the whole group, 128 codes per iteration, with coalesced loads; the order-dependent side results (first
+// extended by the whole group, 128 codes per iteration (8 per lane with 16 lanes, 16 per lane with 8), with coalesced loads; the order-dependent side results (first
 // diagonal reaching an end, first extension > 16, first occurrence of the strictly longest extension) are resolved
 // lowest-k-first with ballots restricted to the group; band update by ballot of U >= best - band.
 #include "pgx_internal.h"
@@ -291,17 +293,24 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
         const int L = has ? __builtin_ctz(gm) : 0;
         const int xs = __shfl(x, gbase + L, 64), ys = __shfl(y, gbase + L, 64);
         const int rem = min(q_len - xs, t_len - ys);
-        const int off = gl * 8;
-        int m = 8;
+        // codes per lane and iteration: 8 with 16-lane groups, 16 with 8-lane groups (128 per group either way)
+        constexpr int SL = GL == 16 ? 8 : 16;
+        const int off = gl * SL;
+        int m = SL;
         if (has) {
           m = 0;
-          if (off < rem) m = min(match8(load_u64_unaligned(q + xs + off), load_u64_unaligned(t + ys + off), qs, ts), rem - off);
+          if (off < rem) {
+            m = match8(load_u64_unaligned(q + xs + off), load_u64_unaligned(t + ys + off), qs, ts);
+            if (SL == 16 && m == 8 && off + 8 < rem)
+              m += match8(load_u64_unaligned(q + xs + off + 8), load_u64_unaligned(t + ys + off + 8), qs, ts);
+            m = min(m, rem - off);
+          }
         }
-        const uint32_t sg = group_bits<GL>(__ballot(has && m < 8), gbase);
-        int ext = GL * 8;
+        const uint32_t sg = group_bits<GL>(__ballot(has && m < SL), gbase);
+        int ext = GL * SL;
         if (sg) {
           const int f = __builtin_ctz(sg);
-          ext = 8 * f + __shfl(m, gbase + f, 64);
+          ext = SL * f + __shfl(m, gbase + f, 64);
         }
         if (has && gl == L) {
           x += ext, y += ext;
@@ -385,13 +394,13 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
   while (ring < 2 * band + 8) ring <<= 1;
   uint32_t *counter = ws<uint32_t>("align.counter", 1);
   if ((long)n > small_max) PGX_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), ctx().stream));  // (k_align1 has no work counter)
-  static const int gl = getenv("PGX_ALIGN_GL") ? atoi(getenv("PGX_ALIGN_GL")) : 16;
+  static const int gl = getenv("PGX_ALIGN_GL") ? atoi(getenv("PGX_ALIGN_GL")) : 8;  // measured: 8 lanes per candidate (avg 3.6 live diagonals, <= 8 in 98.7 % of the steps) 45.6 vs 42.1 M aln/s
   if ((long)n <= small_max) {
     hipLaunchKernelGGL(k_align1, dim3((unsigned)n), dim3(64), ring * sizeof(int32_t), ctx().stream, db->d_seq.p, db->d_roff.p,
                        db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out);
   } else if (gl == 8) {
     const size_t want = (n + 7) / 8;
-    const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * 20);
+    const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * (getenv("PGX_ALIGN_WG8") ? atoi(getenv("PGX_ALIGN_WG8")) : 20));
     hipLaunchKernelGGL(k_align4<8>, dim3(grid), dim3(64), 8 * ring * sizeof(int32_t), ctx().stream, db->d_seq.p,
                        db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter);
   } else {
