@@ -200,15 +200,17 @@ __global__ __launch_bounds__(64) void k_align1(const uint8_t *__restrict__ seq, 
 }
 
 
-// GL = lanes per candidate: 16 (four candidates per wavefront) or 8 (eight)
-template <int GL>
+// GL = lanes per candidate: 16 (four candidates per wavefront) or 8 (eight).
+// VT = storage type of the V ring: uint16_t when no read is longer than 65,535 bases (x <= q_len fits), which halves the LDS of
+// a workgroup and lets 32 instead of 20 eight-candidate wavefronts share a CU; int32_t otherwise.
+template <int GL, typename VT>
 __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
                                                const uint32_t *__restrict__ rlen,
                                                const pgx_align_key *__restrict__ keys, uint32_t n, int band, int ring,
                                                pgx_match *__restrict__ out, uint32_t *__restrict__ counter) {
   extern __shared__ int32_t Vall[];
   const int lane = threadIdx.x, gl = lane & (GL - 1), gbase = lane & ~(GL - 1);
-  int32_t *V = Vall + (lane / GL) * ring;
+  VT *V = reinterpret_cast<VT *>(Vall) + (lane / GL) * ring;
   const int mask = ring - 1, band_size = band * 2;
 
   // per-candidate state, uniform within a 16-lane group
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
         d = 0, best_m = -1, min_k = 0, max_k = 0, longest = 0;
         started = matched = false;
         q_bgn = t_bgn = q_m_end = t_m_end = q_end = t_end = 0;
-        if (gl == 0) V[1 & mask] = 0;  // the only slot read before it is written (d = 0 reads V[k+1] = V[1])
+        if (gl == 0) V[1 & mask] = (VT)0;  // the only slot read before it is written (d = 0 reads V[k+1] = V[1])
         alive = true;
       }
     }
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
       bool more = false;
       if (inround) x = 0, y = 0;
       if (active) {
-        const int va = V[(k - 1) & mask], vb = V[(k + 1) & mask];
+        const int va = (int)V[(k - 1) & mask], vb = (int)V[(k + 1) & mask];
         x = (k == min_k || (k != max_k && va < vb)) ? vb : va + 1;
         y = x - k;
         x1 = x, y1 = y;
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
         const int ex = __shfl(x, gbase + l, 64), ey = __shfl(y, gbase + l, 64);
         if (inround && mx >= 0 && (uint32_t)mx > longest) longest = (uint32_t)mx, q_m_end = ex, t_m_end = ey;
       }
-      if (valid) V[k & mask] = x;
+      if (valid) V[k & mask] = (VT)x;
       {
         const int s = group_max_i32<GL>(valid ? x + y : -1);
         if (inround) best_m = max(best_m, s);
@@ -375,7 +377,7 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
       const int j = base + gl;
       const int k2 = min_k + 2 * j;
       int u = 0;
-      if (inround && j < nk) u = (nk <= GL) ? x + y : 2 * V[k2 & mask] - k2;
+      if (inround && j < nk) u = (nk <= GL) ? x + y : 2 * (int)V[k2 & mask] - k2;
       const uint32_t m = group_bits<GL>(__ballot(inround && j < nk && u >= thr), gbase);
       if (m) {
         new_min = min(new_min, min_k + 2 * (base + __builtin_ctz(m)));
@@ -400,13 +402,19 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
                        db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out);
   } else if (gl == 8) {
     const size_t want = (n + 7) / 8;
-    const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * (getenv("PGX_ALIGN_WG8") ? atoi(getenv("PGX_ALIGN_WG8")) : 20));
-    hipLaunchKernelGGL(k_align4<8>, dim3(grid), dim3(64), 8 * ring * sizeof(int32_t), ctx().stream, db->d_seq.p,
-                       db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter);
+    if (db->max_rlen <= 65535u) {
+      const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * 32);
+      hipLaunchKernelGGL((k_align4<8, uint16_t>), dim3(grid), dim3(64), 8 * ring * sizeof(uint16_t), ctx().stream, db->d_seq.p,
+                         db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter);
+    } else {
+      const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * 20);
+      hipLaunchKernelGGL((k_align4<8, int32_t>), dim3(grid), dim3(64), 8 * ring * sizeof(int32_t), ctx().stream, db->d_seq.p,
+                         db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter);
+    }
   } else {
     const size_t want = (n + 3) / 4;
     const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * 32);
-    hipLaunchKernelGGL(k_align4<16>, dim3(grid), dim3(64), 4 * ring * sizeof(int32_t), ctx().stream, db->d_seq.p,
+    hipLaunchKernelGGL((k_align4<16, int32_t>), dim3(grid), dim3(64), 4 * ring * sizeof(int32_t), ctx().stream, db->d_seq.p,
                        db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter);
   }
   PGX_HIP(hipGetLastError());

@@ -427,7 +427,8 @@ int pgx_seqdb_upload(const uint8_t *seqdb, size_t nbytes, const uint32_t *rid, c
   const size_t nr = nreads ? (size_t)max_rid + 1 : 0;
   db->rlen_by_rid.assign(nr, 0);
   db->roff_by_rid.assign(nr, 0);
-  for (uint32_t i = 0; i < nreads; ++i) db->rlen_by_rid[rid[i]] = rlen[i], db->roff_by_rid[rid[i]] = roff[i];
+  for (uint32_t i = 0; i < nreads; ++i)
+    db->rlen_by_rid[rid[i]] = rlen[i], db->roff_by_rid[rid[i]] = roff[i], db->max_rlen = std::max(db->max_rlen, rlen[i]);
   db->nbytes = nbytes;
   try {
     db->d_seq.alloc(nbytes + 1024);

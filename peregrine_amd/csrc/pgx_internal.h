@@ -130,6 +130,7 @@ struct pgx_seqdb {
   std::vector<uint32_t> rid, rlen; // idx-file order
   std::vector<uint64_t> roff;
   std::vector<uint32_t> rlen_by_rid;
+  uint32_t max_rlen = 0;  // longest read (chooses the 16-bit V ring of the alignment kernel)
   std::vector<uint64_t> roff_by_rid;
   size_t nbytes = 0;
   uint64_t bases = 0;
