@@ -283,17 +283,50 @@ __global__ void k_gather_slabs(const pgx_mm128 *__restrict__ slab, const uint64_
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
 }
 
+// Running extremum within blocks of w consecutive elements (block b = [b w, (b+1) w)), the whole wavefront walking the array 64
+// elements at a time with coalesced accesses: a segmented Hillis-Steele scan (segment heads at multiples of w) plus a carry
+// between the 64-element slices.  FWD: dst[i] = op(src[block start .. i]);  !FWD: dst[i] = op(src[i .. block end]).
+template <bool MIN, bool FWD>
+__device__ __forceinline__ void block_running_extremum(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, int count, int w,
+                                                       int lane) {
+  const uint64_t neutral = MIN ? ~0ULL : 0ULL;
+  auto op = [](uint64_t a, uint64_t b) { return MIN ? (a < b ? a : b) : (a > b ? a : b); };
+  const int nslice = (count + 63) / 64;
+  uint64_t carry = neutral;
+  for (int sl = 0; sl < nslice; ++sl) {
+    const int c0 = (FWD ? sl : nslice - 1 - sl) * 64;
+    const int i = c0 + (FWD ? lane : 63 - lane);  // scan order: ascending i when FWD, descending otherwise
+    uint64_t v = i < count ? src[i] : neutral;
+    // a segment starts at this lane (in scan order) when i is the first (FWD) / last (!FWD) element of its block
+    int f = i < count && (FWD ? (i % w == 0) : (i % w == w - 1 || i == count - 1)) ? 1 : 0;
+    const int head = f;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t vu = (uint64_t)__shfl_up((int)(v >> 32), d, 64) << 32 | (uint32_t)__shfl_up((int)v, d, 64);
+      const int fu = __shfl_up(f, d, 64);
+      if (lane >= d) {
+        if (!f) v = op(v, vu);
+        f |= fu;
+      }
+    }
+    if (!f) v = op(v, carry);  // no segment head at or before this lane inside the slice: the open segment continues
+    if (i < count) dst[i] = v;
+    (void)head;
+    carry = (uint64_t)__shfl((int)(v >> 32), 63, 64) << 32 | (uint32_t)__shfl((int)v, 63, 64);
+  }
+}
+
 // =========================================================================================================
 // k_sketch_general: the closed form of pgx_sketch_fast.hip (see its header) for ANY window and k-mer size
 // (0 < w < 256, 0 < k <= 28; pg_run.py exposes both as --shimmer-w / --shimmer-k), one wavefront per read, three
 // passes over the read's ENTRIES (non strand-ambiguous k-mers, numbered in position order) kept in global scratch:
 //   1. entries: every lane builds the k-mer ending at its base, canonical strand, 64-bit hash (mm_sketch.c:23-32);
 //      ballot-compacted to H[] (hash) and PY[] (position << 1 | strand);
-//   2. WM[s] = minimum hash of the full window of w entries starting at s;
-//   3. entry p is emitted iff some full window containing it has WM == H[p], corrected for the first window
+//   2. WM[s] = minimum hash of the full window of w entries starting at s, and GX[p] = maximum of WM over the windows that
+//      contain p, both in O(1) per entry from running extrema over blocks of w (van Herk / Gil-Werman);
+//   3. entry p is emitted iff GX[p] == H[p] (some full window containing it has its hash as minimum), corrected for the first window
 //      (m = rightmost smallest of entries 0..w-2: its ties are always emitted, m itself iff H[w-1] > H[m]); a read with
 //      fewer than w entries emits only its rightmost smallest entry.
-// O(w) work per entry and pass -- ~50x slower than the w = 16 A, k = 16 kernel, ~50x faster than one lane per read.
+// O(k) work per base for the k-mers, O(1) per entry for the windows.
 // Reads with an ambiguous base (the state machine restarts there) or more minimizers than their slab holds are
 // flagged and redone by k_sketch_literal.
 // =========================================================================================================
@@ -301,6 +334,7 @@ __global__ __launch_bounds__(64) void k_sketch_general(const uint8_t *__restrict
                                                        const uint32_t *__restrict__ list, uint32_t n_list, int w, int k,
                                                        const uint64_t *__restrict__ scr_off, uint64_t *__restrict__ Hs,
                                                        uint32_t *__restrict__ PYs, uint64_t *__restrict__ WMs,
+                                                       uint64_t *__restrict__ T1s, uint64_t *__restrict__ T2s,
                                                        pgx_mm128 *__restrict__ slab, const uint64_t *__restrict__ slab_off,
                                                        uint32_t *__restrict__ counts, uint32_t *__restrict__ flags) {
   const int lane = threadIdx.x;
@@ -310,54 +344,77 @@ __global__ __launch_bounds__(64) void k_sketch_general(const uint8_t *__restrict
     const ReadDesc rd = reads[slot];
     const uint8_t *s = seq + rd.off;
     const int len = (int)rd.len;
-    uint64_t *H = Hs + scr_off[it], *WM = WMs + scr_off[it];
+    uint64_t *H = Hs + scr_off[it], *WM = WMs + scr_off[it], *T1 = T1s + scr_off[it], *T2 = T2s + scr_off[it];
     uint32_t *PY = PYs + scr_off[it];
-    // ---- pass 1 ----------------------------------------------------------------------------------------------
+    // ---- pass 1: every lane rolls the two k-mers over 16 consecutive bases (k-1 bases of run-in per lane) -----------
     int n = 0;
     bool bad = false;
-    for (int b0 = 0; b0 < len; b0 += 64) {
-      const int i = b0 + lane;
-      bool entry = false;
-      uint64_t h = 0;
-      uint32_t py = 0;
-      if (i < len) {
-        if (code_of_nibble(s[i]) > 3) bad = true;
-        if (i >= k - 1) {
-          uint64_t fwd = 0, rev = 0;
-          for (int j = i - k + 1; j <= i; ++j) {
-            const uint64_t c = (uint64_t)(code_of_nibble(s[j]) & 3);
+    for (int t0 = 0; t0 < len; t0 += 64 * 16) {
+      const int start = t0 + lane * 16;
+      uint64_t hh[16];
+      uint32_t vmask = 0, smask = 0;
+      if (start < len) {
+        uint64_t fwd = 0, rev = 0;
+        for (int j = start - (k - 1) > 0 ? start - (k - 1) : 0; j < start; ++j) {
+          const uint64_t c = (uint64_t)(code_of_nibble(s[j]) & 3);
+          fwd = (fwd << 2 | c) & mask;
+          rev = (rev >> 2) | (3ULL ^ c) << top;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int i = start + u;
+          hh[u] = 0;
+          if (i < len) {
+            const int cc = code_of_nibble(s[i]);
+            if (cc > 3) bad = true;
+            const uint64_t c = (uint64_t)(cc & 3);
             fwd = (fwd << 2 | c) & mask;
             rev = (rev >> 2) | (3ULL ^ c) << top;
-          }
-          if (fwd != rev) {
-            const uint32_t strand = fwd < rev ? 0u : 1u;
-            entry = true;
-            h = mix64(strand ? rev : fwd, mask);
-            py = (uint32_t)i << 1 | strand;
+            if (i >= k - 1 && fwd != rev) {
+              const uint32_t strand = fwd < rev ? 0u : 1u;
+              hh[u] = mix64(strand ? rev : fwd, mask);
+              vmask |= 1u << u, smask |= strand << u;
+            }
           }
         }
       }
-      const uint64_t em = __ballot(entry);
-      if (entry) {
-        const int r = n + __builtin_popcountll(em & ((1ULL << lane) - 1));
-        H[r] = h, PY[r] = py;
+      const int cnt = __builtin_popcount(vmask);
+      int incl = cnt;  // wave inclusive scan of the per-lane entry counts
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
       }
-      n += __builtin_popcountll(em);
+      int r = n + incl - cnt;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (vmask >> u & 1u) {
+          H[r] = hh[u];
+          PY[r] = (uint32_t)(start + u) << 1 | (smask >> u & 1u);
+          ++r;
+        }
+      n += __shfl(incl, 63, 64);
     }
     if (__ballot(bad)) {
       if (lane == 0) counts[slot] = 0, flags[slot] = 1;
       continue;
     }
     __syncthreads();  // (one wavefront per block: orders this wave's global writes before its reads below)
-    // ---- pass 2 ----------------------------------------------------------------------------------------------
+    // ---- pass 2: window minima in O(1) per entry (van Herk / Gil-Werman over blocks of w entries) ---------------------
+    // T1 = running minimum from the start of the entry's block, T2 = running minimum from the end of its block;
+    // the window [s, s+w) is the tail of block(s) plus the head of the next block: WM[s] = min(T2[s], T1[s+w-1]).
     const int nwin = n - w + 1;  // number of full windows (<= 0: short read)
-    for (int v0 = 0; v0 < nwin; v0 += 64) {
-      const int v = v0 + lane;
-      if (v < nwin) {
-        uint64_t m = H[v];
-        for (int j = 1; j < w; ++j) m = min(m, H[v + j]);
-        WM[v] = m;
+    if (nwin > 0) {
+      block_running_extremum<true, true>(H, T1, n, w, lane);
+      block_running_extremum<true, false>(H, T2, n, w, lane);
+      __syncthreads();
+      for (int v0 = 0; v0 < nwin; v0 += 64) {
+        const int v = v0 + lane;
+        if (v < nwin) WM[v] = (v % w == 0) ? T1[v + w - 1] : min(T2[v], T1[v + w - 1]);
       }
+      __syncthreads();
+      // the same over WM with maxima: GX(p) = max of WM over the (up to w) windows that contain entry p
+      block_running_extremum<false, true>(WM, T1, nwin, w, lane);
+      block_running_extremum<false, false>(WM, T2, nwin, w, lane);
     }
     // rightmost smallest of the first min(n, w - 1) entries (all n entries for a short read)
     const int lim = nwin > 0 ? w - 1 : n;
@@ -389,7 +446,13 @@ __global__ __launch_bounds__(64) void k_sketch_general(const uint8_t *__restrict
         hp = H[p];
         if (nwin > 0) {
           const int s0 = p - w + 1 > 0 ? p - w + 1 : 0, s1 = p < nwin - 1 ? p : nwin - 1;
-          for (int sidx = s0; sidx <= s1; ++sidx) emit |= WM[sidx] == hp;
+          uint64_t gx = 0;
+          if (s1 - s0 + 1 == w) {  // all w windows exist: tail of block(s0) + head of the next block
+            gx = (s0 % w == 0) ? T1[s1] : max(T2[s0], T1[s1]);
+          } else {  // the first / last w-1 entries of the read: fewer windows, scanned directly
+            for (int sidx = s0; sidx <= s1; ++sidx) gx = max(gx, WM[sidx]);
+          }
+          emit = gx == hp;  // (a window that contains p has minimum <= hash(p))
           if (p <= w - 2 && hp == m_h) emit = p != m_idx ? true : h_last > m_h;
         } else {
           emit = p == m_idx;
@@ -449,7 +512,8 @@ void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, 
       KernelTimer tm("sketch", fast_bases);
       launch_sketch_wave(db, d_reads.p, d_fast.p, (uint32_t)fast.size(), w, k, slab.p, d_slab_off.p, counts.p, d_flag.p);
     } else {
-      // entry scratch (hash, position|strand, window minimum: 20 B per base), in batches of at most ~256 Mbases
+      // entry scratch (hash, position|strand, window minimum, two running-extremum arrays: 36 B per base), in batches of
+      // at most ~256 Mbases
       KernelTimer tm("sketch_general", fast_bases);
       const uint64_t batch_bases = 256ull << 20;
       for (size_t b0 = 0; b0 < fast.size();) {
@@ -459,11 +523,12 @@ void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, 
         while (b1 < fast.size() && (b1 == b0 || acc + reads[fast[b1]].len <= batch_bases)) so.push_back(acc), acc += reads[fast[b1]].len, ++b1;
         uint64_t *d_so = ws<uint64_t>("sk.gen_off", so.size());
         uint64_t *H = ws<uint64_t>("sk.gen_h", acc), *WMv = ws<uint64_t>("sk.gen_wm", acc);
+        uint64_t *T1 = ws<uint64_t>("sk.gen_t1", acc), *T2 = ws<uint64_t>("sk.gen_t2", acc);
         uint32_t *PY = ws<uint32_t>("sk.gen_py", acc);
         PGX_HIP(hipMemcpyAsync(d_so, so.data(), so.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         const unsigned grid = (unsigned)std::min<size_t>(b1 - b0, (size_t)ctx().num_cu * 16);
         hipLaunchKernelGGL(k_sketch_general, dim3(grid), dim3(64), 0, st, db->d_seq.p, d_reads.p, d_fast.p + b0, (uint32_t)(b1 - b0), w, k,
-                           d_so, H, PY, WMv, slab.p, d_slab_off.p, counts.p, d_flag.p);
+                           d_so, H, PY, WMv, T1, T2, slab.p, d_slab_off.p, counts.p, d_flag.p);
         PGX_HIP(hipGetLastError());
         sync();  // (so[] is reused by the next batch)
         b0 = b1;
