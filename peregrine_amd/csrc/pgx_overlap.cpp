@@ -1354,6 +1354,11 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   // 24 threads measured best on a 64-core node at both ends (E. coli set: 8 -> 15.1 ms, 16 -> 12.3, 24 -> 10.3, 48 -> 10.0,
   // 64 -> 16.6 per step; 4.5 Gbases: 16 -> 620 ms, 24 -> 539, 32 -> 571); the ranks of a multi-process job share the host
   unsigned threads = std::max(1u, std::thread::hardware_concurrency());
+  {
+    cpu_set_t allowed;  // (a container may grant far fewer CPUs than the machine has)
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0 && CPU_COUNT(&allowed) > 0)
+      threads = std::min(threads, (unsigned)CPU_COUNT(&allowed));
+  }
   if (const char *lw = getenv("LOCAL_WORLD_SIZE")) threads = std::max(4u, threads / (2u * (unsigned)std::max(1, atoi(lw))));
   threads = std::min(24u, threads);
   if (const char *tv = getenv("PGX_THREADS")) threads = (unsigned)std::max(1, atoi(tv));
