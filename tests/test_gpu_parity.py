@@ -496,3 +496,32 @@ def test_one_level_index_through_both_stages(small):
         want, ost = U.orc_overlap(db, ix.top, ix.top_mc, mychunk=c, total=2)
         assert len(want) > 5000 and formats.ovlp_fields_equal(got, want), c
         assert st["n_align_needed"] == ost["n_align"]
+
+
+def test_overlap_argument_edges(small):
+    """degenerate overlap-stage arguments through the C-ABI: nothing to do, hostile lists, parameter corners (the reference
+    asserts / exits on most of these; here they are errors or empty results, never a crash), each compared with the oracle where
+    the oracle defines a result"""
+    db, rdb = small
+    ix = rdb.index()
+    empty_mm, empty_mc = np.zeros(0, formats.MM_DTYPE), np.zeros(0, formats.MC_DTYPE)
+    ov, st = rdb.overlap(empty_mm, empty_mc)
+    assert len(ov) == 0 and st["n_records"] == 0
+    ov, st = rdb.overlap(ix.top[:1], ix.top_mc)                       # a single shimmer: no pair
+    assert len(ov) == 0
+    with pytest.raises(_lib.PgxError):                                # a hash without a count (the reference asserts)
+        rdb.overlap(ix.top, ix.top_mc[:10])
+    with pytest.raises(_lib.PgxError):
+        rdb.overlap(ix.top, ix.top_mc, total_chunk=2, mychunk=3)
+    for kw in (dict(bestn=0), dict(ovlp_upper=2), dict(mc_lower=5, mc_upper=4), dict(mc_lower=0, mc_upper=1), dict(bestn=255, ovlp_upper=30),
+               dict(align_bandwidth=1), dict(align_bandwidth=400)):
+        got, st = rdb.overlap(ix.top, ix.top_mc, **kw)
+        want, ost = U.orc_overlap(db, ix.top, ix.top_mc, mc_lower=kw.get("mc_lower", 2), mc_upper=kw.get("mc_upper", 240),
+                                  bestn=kw.get("bestn", 4), ovlp_upper=kw.get("ovlp_upper", 120), band=kw.get("align_bandwidth", 100))
+        assert formats.ovlp_fields_equal(got, want), (kw, len(got), len(want))
+        assert st["n_align_needed"] == ost["n_align"], kw
+    dup = np.concatenate([ix.top, ix.top])                            # the same list twice (two copies of every read's run)
+    dmc = np.concatenate([ix.top_mc, ix.top_mc])
+    got, st = rdb.overlap(dup, dmc)
+    want, ost = U.orc_overlap(db, dup, dmc)
+    assert formats.ovlp_fields_equal(got, want) and st["n_align_needed"] == ost["n_align"]
