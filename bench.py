@@ -198,7 +198,7 @@ def main():
                               "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
                               "bytes_per_unit": ALIGN_BYTES_PER_PAIR, "unit_name": "alignment",
                               "alignments_per_s": k["units"] / (k["ms_total"] * 1e-3)}
-        if "align1" in kern:   # the one-candidate-per-wavefront form used for launches of at most 8 k alignments (tail rounds)
+        if "align1" in kern:   # the one-candidate-per-wavefront form used for launches of at most 13 k alignments (tail rounds)
             k = kern["align1"]
             gbs = ALIGN_BYTES_PER_PAIR * k["units"] / (k["ms_total"] * 1e-3) / 1e9
             cands["align1"] = {"kernel": "k_align1", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

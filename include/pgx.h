@@ -57,7 +57,7 @@ void pgx_free(void *p);              /* releases any host array returned by this
 
 /* per-kernel device time (HIP events on the library's stream), accumulated since the last reset.
  * names: "sketch", "sketch_general", "sketch_literal", "sketch_gather", "reduce", "count", "pairs", "align" (k_align4), "align1" (k_align1: launches of
- * at most 8 k alignments), "encode", "dedup", "map". */
+ * at most 13 k alignments), "encode", "dedup", "map". */
 int pgx_timing_get(const char *kernel, double *total_ms, uint64_t *launches, uint64_t *units);
 void pgx_timing_reset(void);
 

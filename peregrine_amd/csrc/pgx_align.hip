@@ -390,7 +390,7 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
 
 void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out) {
   if (n == 0) return;
-  static const long small_max = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : 8192;  // measured crossover ~12 k (tools/alignlat.py)
+  static const long small_max = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : 13000;  // measured crossover ~14 k (tools/alignlat.py)
   KernelTimer tm((long)n <= small_max ? "align1" : "align", n);
   int ring = 64;
   while (ring < 2 * band + 8) ring <<= 1;

@@ -16,7 +16,7 @@ keys["rid0"] = ov["y0"] >> np.uint64(32); keys["rid1"] = ov["y1"] >> np.uint64(3
 p0 = ((ov["y0"] & np.uint64(0xFFFFFFFF)) >> np.uint64(1)); p1 = ((ov["y1"] & np.uint64(0xFFFFFFFF)) >> np.uint64(1))
 keys["q_off"] = (p0 - p1).astype(np.uint32); keys["dir0"] = ov["strand0"]; keys["dir1"] = ov["strand1"]
 rng = np.random.default_rng(2)
-for n in (1, 32, 512, 2048, 8192, 16384, len(keys)):
+for n in [int(a) for a in sys.argv[1:]] or (1, 32, 512, 2048, 8192, 16384, len(keys)):
     sel = keys[rng.choice(len(keys), n, replace=False)] if n < len(keys) else keys
     rdb.align(sel, 100)
     _lib.timing_reset()
