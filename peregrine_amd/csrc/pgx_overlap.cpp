@@ -359,7 +359,7 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
   // while the others replay the inner tables, group range by group range; then the groups' fragments are moved to their
   // final places in outer-slot order.
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const unsigned nin = (unsigned)std::min<size_t>(std::min(16u, hw), std::max<size_t>(1, ng / 2048));  // inner workers
+  const unsigned nin = (unsigned)std::min<size_t>(std::min(24u, hw), std::max<size_t>(1, ng / 2048));  // inner workers
   struct GroupOut {
     uint64_t eoff;      // offset of the group's entries in its worker's fragment
     uint32_t boff;      // offset of its bucket sizes
