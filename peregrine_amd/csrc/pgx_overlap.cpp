@@ -975,9 +975,15 @@ struct ParReplay {
         const uint32_t rid1 = e[pi].rid;
         const uint64_t pair = rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0);
         __builtin_prefetch(&ptab[mix(pair) & (pcap - 1)], 1);
+        if (memo_prefetch && pi == ai + 1 && rid0 != rid1) {  // the row's first partner is the likeliest memo lookup
+          const uint64_t ka = (uint64_t)rid0 << 32 | rid1;
+          const uint64_t kb = (uint64_t)(e[ai].pos1 - e[pi].pos1) << 2 | (uint64_t)e[ai].dir << 1 | e[pi].dir;
+          __builtin_prefetch(&mtab[mix(ka ^ mix(kb)) & (mcap - 1)], 1);
+        }
       }
     }
   }
+  bool memo_prefetch = !(getenv("PGX_MEMO_PF") && atoi(getenv("PGX_MEMO_PF")) == 0);  // (measured: first round 160 -> 156 ms at 4.5 Gbases)
 
   // The alignment memo: the request number of (rid0, rid1, q_off, dir0, dir1), filing the request if it is new.
   uint32_t request_of(TL &t, uint32_t rid0, uint32_t rid1, uint32_t q_off, uint8_t dir0, uint8_t dir1) {
