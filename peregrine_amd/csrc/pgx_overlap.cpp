@@ -769,7 +769,7 @@ struct ParReplay {
   static constexpr uint64_t NOOWN = 0;
   static constexpr uint64_t EMPTY = 0;
   static constexpr uint32_t NIL = 0;
-  static constexpr uint32_t NIN = 10;
+  static constexpr uint32_t NIN = 11;
   static constexpr uint32_t NO_CHUNK = 0xFFFFFFFFu, ALLOCATING = 0xFFFFFFFEu;
   struct Overflow {};
 
@@ -787,8 +787,7 @@ struct ParReplay {
     std::atomic<uint64_t> key;     // pair + 1, or EMPTY
     std::atomic<uint64_t> own;     // (owner bucket << 8 | type) + 1, or NOOWN
     std::atomic<uint32_t> rhead;   // overflow reader list: index into rlog, or NIL
-    std::atomic<uint32_t> nin;     // inline reader entries claimed (may run past NIN)
-    std::atomic<uint32_t> in[NIN]; // the first readers, bucket + 1 (0: claimed but not yet written)
+    std::atomic<uint32_t> in[NIN]; // the first readers, bucket + 1, filled front to back (0: free)
   };
   static_assert(sizeof(PSlot) == 64, "pair slot must be one cache line");
   PSlot *ptab = nullptr;           // mmap'd: zero pages, transparent huge pages where the kernel grants them
@@ -927,16 +926,15 @@ struct ParReplay {
   // Register bucket b as a reader of the pair BEFORE it loads the owner.  The first NIN readers live in the slot's own
   // cache line; a bucket that is already listed (an earlier evaluation) is not added again.
   void add_reader(PSlot &ps, uint32_t b, TL &t) {
-    const uint32_t have = std::min(ps.nin.load(std::memory_order_relaxed), NIN);
-    for (uint32_t i = 0; i < have; ++i)
-      if (ps.in[i].load(std::memory_order_relaxed) == b + 1) return;  // listed by an earlier evaluation: the writer's
-                                                                      // scan finds it, and this run's owner load follows
-                                                                      // the seq_cst exchange that cleared dirty[b]
-    if (have < NIN) {
-      const uint32_t i = ps.nin.fetch_add(1, std::memory_order_relaxed);
-      if (i < NIN) {
-        ps.in[i].store(b + 1, std::memory_order_seq_cst);
-        return;
+    // ONE locked operation: a compare-exchange on the first free inline entry both publishes the reader and orders the
+    // publication before the owner load that follows (a listing by an earlier evaluation needs nothing: the writer's scan
+    // finds it, and this run's owner load follows the seq_cst exchange that cleared dirty[b])
+    for (uint32_t i = 0; i < NIN; ++i) {
+      uint32_t cur = ps.in[i].load(std::memory_order_relaxed);
+      if (cur == b + 1) return;
+      if (cur == 0) {
+        if (ps.in[i].compare_exchange_strong(cur, b + 1, std::memory_order_seq_cst)) return;
+        if (cur == b + 1) return;  // (cannot happen: a bucket is evaluated by one thread at a time)
       }
     }
     if (t.rnext == t.rend) {  // a shared counter per node would serialise the threads on one cache line
@@ -955,9 +953,9 @@ struct ParReplay {
     } while (!ps.rhead.compare_exchange_weak(h, n, std::memory_order_seq_cst));
   }
   void mark_readers_after(PSlot &ps, uint32_t b) {
-    const uint32_t have = std::min(ps.nin.load(std::memory_order_seq_cst), NIN);
-    for (uint32_t i = 0; i < have; ++i) {
-      const uint32_t x = ps.in[i].load(std::memory_order_seq_cst);  // 0: that reader has not loaded the owner yet
+    for (uint32_t i = 0; i < NIN; ++i) {
+      const uint32_t x = ps.in[i].load(std::memory_order_seq_cst);
+      if (x == 0) break;  // entries fill front to back; a reader that lists itself later loads the owner after this point
       if (x > b + 1) mark_dirty(x - 1);
     }
     for (uint32_t n = ps.rhead.load(std::memory_order_seq_cst); n != NIL; n = rlog[n].next)
