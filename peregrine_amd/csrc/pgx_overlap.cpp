@@ -1366,7 +1366,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   if (const char *lw = getenv("LOCAL_WORLD_SIZE")) threads = std::max(4u, threads / (2u * (unsigned)std::max(1, atoi(lw))));
   threads = std::min(24u, threads);
   if (const char *tv = getenv("PGX_THREADS")) threads = (unsigned)std::max(1, atoi(tv));
-  // the shared-table protocol costs two locked operations per examination and a thread team per round; measured against
+  // the shared-table protocol costs a locked operation per examination (plus one per insertion) and a thread team per round; measured against
   // the sequential replay with 16 threads: 4.2 s -> 0.25 s for the first sweep at 4.5 Gbases, 11.9 -> 7 ms of sweeps at
   // 75 Mbases (200 k entries); below ~50 k entries the team start-up dominates
   size_t par_min = 50000;
