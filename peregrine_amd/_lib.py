@@ -86,10 +86,13 @@ def load():
         # it would bind /opt/rocm's copy, a later `import torch` would load the bundled one next to it, and the second
         # runtime finds no device.  With torch imported first both resolve to the same copy (the loader matches SONAMEs).
         # Without torch installed nothing changes.
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        # (PGX_NO_TORCH=1: the caller promises that torch is never imported in this process -- the bin/ drop-ins do, and
+        # save its ~2 s import)
+        if os.environ.get("PGX_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         lib = C.CDLL(LIB_PATH)
         lib.pgx_last_error.restype = C.c_char_p
         lib.pgx_version.restype = C.c_char_p
