@@ -1,5 +1,5 @@
 """The reference's own pipeline test (test/ecoli_K12/run_test.sh, test/genome_mapping/run_test.sh), step for step, with the
-drop-in executables of bin/ next to the REAL reference binaries (oracle/_ref, prebuilt): FASTA files -> shmr_mkseqdb ->
+drop-in executables of bin/ (Python) and bin/native/ (one C binary against the C-ABI) next to the REAL reference binaries (oracle/_ref, prebuilt): FASTA files -> shmr_mkseqdb ->
 shmr_index (several chunks) -> shmr_overlap (several chunks) -> cat | shmr_dedup -> shmr_map reads->contigs and
 contigs->contigs.  Every output file must be byte-identical (MC files: same multiset of (mer, count))."""
 import os
@@ -19,6 +19,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _mine(tool, *args, cwd=None, stdin=None):
     return subprocess.run([sys.executable, os.path.join(ROOT, "bin", tool), *map(str, args)], cwd=cwd, check=True, input=stdin,
                           stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
+
+
+def _native(tool, *args, cwd=None, stdin=None):
+    """the native multi-call binary (peregrine_amd/csrc/pgx_cli.c), through its per-tool link when the link survived the copy"""
+    exe = os.path.join(ROOT, "bin", "native", tool)
+    cmd = [exe] if os.path.exists(exe) else [os.path.join(ROOT, "bin", "native", "pgx_cli"), tool]
+    return subprocess.run([*cmd, *map(str, args)], cwd=cwd, check=True, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE).stdout
 
 
 def _ref(tool, *args, cwd=None, stdin=None):
@@ -49,7 +56,7 @@ def test_pipeline_like_the_reference_test_scripts(tmp_path):
     (tmp_path / "ctg.lst").write_text(str(tmp_path / "ctg.fa") + "\n")
 
     out = {}
-    for who, run in (("ref", _ref), ("mine", _mine)):
+    for who, run in (("ref", _ref), ("mine", _mine), ("native", _native)):
         d = tmp_path / who
         (d / "index").mkdir(parents=True)
         (d / "ovlp").mkdir()
@@ -68,16 +75,17 @@ def test_pipeline_like_the_reference_test_scripts(tmp_path):
         out[who, "ref2ref.out"] = run("shmr_map", "-r", f"{ix}/p_ctg", "-m", f"{ix}/p_ctg-L2", "-p", f"{ix}/p_ctg", "-l", f"{ix}/p_ctg-L2",
                                       "-t", 1, "-c", 1)
     names = sorted(os.listdir(tmp_path / "ref" / "index")) + [os.path.join("..", "ovlp", f) for f in sorted(os.listdir(tmp_path / "ref" / "ovlp"))]
-    assert sorted(os.listdir(tmp_path / "mine" / "index")) == sorted(os.listdir(tmp_path / "ref" / "index"))
-    for n in names:
-        a = (tmp_path / "ref" / "index" / n).read_bytes()
-        b = (tmp_path / "mine" / "index" / n).read_bytes()
-        if "-MC-" in n:   # khash slot order in the reference, sorted here: same (mer, count) multiset
-            pa = formats.mc_as_sorted_pairs(formats.read_mm_count(str(tmp_path / "ref" / "index" / n)))
-            pb = formats.mc_as_sorted_pairs(formats.read_mm_count(str(tmp_path / "mine" / "index" / n)))
-            assert np.array_equal(pa, pb), n
-        else:
-            assert a == b, n
-    for k in ("preads.ovl", "read_map.txt", "ref2ref.out"):
-        assert out["ref", k] == out["mine", k], k
+    for who in ("mine", "native"):   # the Python drop-ins of bin/ and the native multi-call binary of bin/native/
+        assert sorted(os.listdir(tmp_path / who / "index")) == sorted(os.listdir(tmp_path / "ref" / "index"))
+        for n in names:
+            a = (tmp_path / "ref" / "index" / n).read_bytes()
+            b = (tmp_path / who / "index" / n).read_bytes()
+            if "-MC-" in n:   # khash slot order in the reference, sorted here: same (mer, count) multiset
+                pa = formats.mc_as_sorted_pairs(formats.read_mm_count(str(tmp_path / "ref" / "index" / n)))
+                pb = formats.mc_as_sorted_pairs(formats.read_mm_count(str(tmp_path / who / "index" / n)))
+                assert np.array_equal(pa, pb), (who, n)
+            else:
+                assert a == b, (who, n)
+        for k in ("preads.ovl", "read_map.txt", "ref2ref.out"):
+            assert out["ref", k] == out[who, k], (who, k)
     assert out["ref", "preads.ovl"].count(b"\n") > 500 and out["ref", "read_map.txt"].count(b"\n") > 500
