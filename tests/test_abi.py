@@ -76,3 +76,17 @@ def test_khash_slot_order_equals_the_literal_replay(lib):
         got = np.zeros(len(keys), np.uint64)
         assert lib.pgx_khash_slot_order(keys.ctypes.data_as(C.c_void_p), len(keys), got.ctypes.data_as(C.c_void_p)) == 0
         assert np.array_equal(got, U.orc_khash_order(keys)), len(keys)
+
+
+def test_native_drop_ins_exist_and_fail_loudly_without_a_gpu(lib, tmp_path):
+    """bin/native/pgx_cli (plain C against the C-ABI) is built with the library, dispatches on the tool name, and -- there is
+    no CPU fallback -- exits 1 with the library's message when no GPU is visible"""
+    import subprocess
+    exe = os.path.join(ROOT, "bin", "native", "pgx_cli")
+    assert os.path.exists(exe), "build() did not produce bin/native/pgx_cli"
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 2 and b"shmr_index" in r.stderr
+    if lib.pgx_device_count() == 0:
+        for tool, args in (("shmr_index", ["-p", str(tmp_path / "nothing")]), ("shmr_overlap", ["-p", str(tmp_path / "nothing")])):
+            r = subprocess.run([exe, tool, *args], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 1 and b"failed" in r.stderr, (tool, r.stderr)
