@@ -232,10 +232,25 @@ enum : unsigned {
   PAIRS_INSERTION_ORDER = 2,  // records of a bucket in insertion order instead of position-descending
   PAIRS_COUNTS = 4,           // also return the aggregated multiplicity table
 };
+// what the join leaves in HBM for the device replay (pgx_replay.hip): the bucket-sorted records
+struct DevicePairs {
+  DevBuf<uint64_t> y0;       // per record: rid << 32 | lastPos << 1 | strand
+  DevBuf<uint8_t> dir;       // per record
+  DevBuf<uint32_t> bstart;   // n_buckets + 1 record offsets
+  size_t n_rec = 0, n_buckets = 0;
+  bool valid = false;
+};
 // d_rlen: read length by rid, on the device
 void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts,
                      size_t n_counts, const PairParams &pp, PairTables &out, unsigned flags = 0,
-                     const pgx_mm128 *d_mmers = nullptr, const pgx_mm_count *d_counts = nullptr);  // d_*: the same lists, already on the device
+                     const pgx_mm128 *d_mmers = nullptr, const pgx_mm_count *d_counts = nullptr,  // d_*: the same lists, already on the device
+                     DevicePairs *keep = nullptr);  // keep: the sorted records stay on the device too
+// The greedy walk over the visit list (visit_bids: the join's bucket ids in visit order) on the GPU; the records go to the
+// array alloc_out(n) returns.  false: the job does not fit the device tables' encodings or they overflowed -- nothing was
+// produced and the caller runs the host replay.
+bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, size_t nb, size_t n_entries,
+                uint32_t bestn, int band, bool predict, uint32_t ovlp_upper, const std::function<pgx_ovlp *(size_t)> &alloc_out,
+                size_t *n_out, pgx_overlap_stats *st, bool trace);
 
 // what the index stage leaves in HBM for a following overlap stage of the same process (pgx_index_overlap_resident)
 struct DeviceIndex {

@@ -185,6 +185,9 @@ struct Entry {
 struct Visit {
   std::vector<uint64_t> start;  // bucket b covers entries [start[b], start[b+1])
   HostArray<Entry> entries;
+  // the ids-only form (device replay): the join's bucket id of every visited bucket, in visit order
+  HostArray<uint32_t> bids;
+  size_t n_buckets = 0, n_entries = 0;
 };
 
 // The replay threads hammer one shared table with locked operations: spread over both sockets they run ~1.7x slower than
@@ -347,8 +350,10 @@ void par_run(unsigned nthr, F &&fn) {
 // bucket and key0 group.  klib-khash's final slot layout depends only on the order in which DISTINCT keys are first
 // inserted, plus one detail: a put of an already-present key still runs the load-factor check (khash.h:298-306), so if any
 // put follows the last first-insertion the table may grow once more.  Both levels are replayed on distinct keys only.
-void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
-  v.start.assign(1, 0), v.entries.clear();
+// ids_only: leave the visit list as bucket ids (the device replay reads the records where the join left them)
+void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_only = false) {
+  v.start.assign(1, 0), v.entries.clear(), v.bids.clear();
+  v.n_buckets = v.n_entries = 0;
   const size_t ng = pt.gkey0.size();
   if (!ng) return;
   const bool trace = getenv("PGX_TRACE") != nullptr;
@@ -368,7 +373,7 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
   };
   std::vector<GroupOut> go(ng);
   struct Frag {  // sized up front from the group range (no growth, no copies)
-    HostArray<uint32_t> sizes;
+    HostArray<uint32_t> sizes;  // (ids_only: the bucket ids instead)
     HostArray<Entry> entries;
     size_t ns = 0, ne = 0;
   };
@@ -393,7 +398,7 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
     const size_t g_lo = split(ti), g_hi = split(ti + 1);
     Frag &f = frag[ti];
     if (g_lo >= g_hi) return;
-    f.entries.alloc(pt.gstart[g_hi] - pt.gstart[g_lo]);   // (gstart / gbucket carry an end sentinel)
+    if (!ids_only) f.entries.alloc(pt.gstart[g_hi] - pt.gstart[g_lo]);   // (gstart / gbucket carry an end sentinel)
     f.sizes.alloc(pt.gbucket[g_hi] - pt.gbucket[g_lo]);
     ScratchTable in;
     bool ab;
@@ -411,11 +416,15 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
         const uint32_t b = in.ids[s1];
         const uint32_t bn = pt.bstart[b + 1] - pt.bstart[b];
         if (bn <= 2 || bn > ovlp_upper) continue;  // shmr_overlap.c:216
-        for (uint32_t r = pt.bstart[b]; r < pt.bstart[b + 1]; ++r) {
-          const uint64_t y = pt.y0[r];
-          f.entries[f.ne++] = Entry{(uint32_t)(y >> 32), pos_of(y) + 1, y, pt.dir[r]};
+        if (ids_only) {
+          f.sizes[f.ns++] = b, f.ne += bn;
+        } else {
+          for (uint32_t r = pt.bstart[b]; r < pt.bstart[b + 1]; ++r) {
+            const uint64_t y = pt.y0[r];
+            f.entries[f.ne++] = Entry{(uint32_t)(y >> 32), pos_of(y) + 1, y, pt.dir[r]};
+          }
+          f.sizes[f.ns++] = bn;
         }
-        f.sizes[f.ns++] = bn;
         o.ne += bn, ++o.nb;
       }
     }
@@ -443,12 +452,17 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
   std::vector<uint64_t> eat(no + 1, 0), bat(no + 1, 0);
   for (size_t i = 0; i < no; ++i) eat[i + 1] = eat[i] + go[order[i]].ne, bat[i + 1] = bat[i] + go[order[i]].nb;
   const uint64_t ne = eat[no], nbk = bat[no];
-  v.entries.alloc(ne);
-  v.start.resize(nbk + 1);
+  v.n_buckets = nbk, v.n_entries = ne;
+  if (ids_only) v.bids.alloc(nbk);
+  else v.entries.alloc(ne), v.start.resize(nbk + 1);
   auto place = [&](unsigned ti, unsigned nt) {
     for (size_t i = no * ti / nt, ie = no * (ti + 1) / nt; i < ie; ++i) {
       const GroupOut &o = go[order[i]];
       const Frag &f = frag[o.worker];
+      if (ids_only) {
+        memcpy(v.bids.data() + bat[i], f.sizes.data() + o.boff, (size_t)o.nb * sizeof(uint32_t));
+        continue;
+      }
       memcpy(v.entries.data() + eat[i], f.entries.data() + o.eoff, (size_t)o.ne * sizeof(Entry));
       uint64_t at = eat[i];
       for (uint32_t j = 0; j < o.nb; ++j) v.start[bat[i] + j] = at, at += f.sizes[o.boff + j];
@@ -459,7 +473,7 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v) {
   } else {
     par_run(nin, [&](unsigned ti) { place(ti, nin); });
   }
-  v.start[nbk] = ne;
+  if (!ids_only) v.start[nbk] = ne;
   if (trace)
     fprintf(stderr, "[pgx]   visit: outer table %.2f ms alongside %u inner-table workers (done at %.2f ms), placement %.2f ms\n",
             t_outer, nin, t_inner, now_ms() - tv2);
@@ -1328,18 +1342,48 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     }
   } defer_scratch{scratch};
   PairTables &pt = scratch->pt;
+  // PGX_GPU_REPLAY=1: the greedy walk itself runs on the GPU (pgx_replay.hip); the host replay below is the fallback
+  static const bool gpu_replay = getenv("PGX_GPU_REPLAY") && atoi(getenv("PGX_GPU_REPLAY")) != 0;
+  const bool trace = getenv("PGX_TRACE") != nullptr;
+  const bool predict = !(getenv("PGX_PREDICT") && atoi(getenv("PGX_PREDICT")) == 0);
+  DevicePairs dpairs;
   dev_build_pairs(db->d_rlen.p, mmers, n_mm, counts, n_counts,
                   PairParams{(uint32_t)p->total_chunk, (uint32_t)p->mychunk, (uint32_t)p->mc_lower, (uint32_t)p->mc_upper}, pt, 0,
-                  dev ? dev->d_top : nullptr, dev ? dev->mc.p : nullptr);
+                  dev ? dev->d_top : nullptr, dev ? dev->mc.p : nullptr, gpu_replay ? &dpairs : nullptr);
   sync();
   s.n_pair_records = pt.n_rec;
   const double t1 = now_ms();
   gpu_ms += t1 - t0;
   NodePin pin;  // from here on the caller and its helper threads stay on one memory node
   Visit &visit = scratch->visit;
+  if (gpu_replay && dpairs.valid) {
+    build_visit(pt, (uint32_t)p->ovlp_upper, visit, true);
+    s.n_buckets = visit.n_buckets;
+    if (trace)
+      fprintf(stderr, "[pgx] GPU join: %zu records, %zu buckets, %zu key0 groups in %.2f ms; visit order (%llu buckets, ids only) in %.2f ms\n",
+              pt.n_rec, pt.bkey1.size(), pt.gkey0.size(), t1 - t0, (unsigned long long)s.n_buckets, now_ms() - t1);
+    const double r0 = now_ms();
+    size_t nrec = 0;
+    pgx_overlap_stats rs;
+    memset(&rs, 0, sizeof(rs));
+    if (dev_replay(db, dpairs, visit.bids.data(), visit.n_buckets, visit.n_entries, (uint32_t)(uint8_t)p->bestn,
+                   p->align_bandwidth, predict, (uint32_t)p->ovlp_upper,
+                   [&](size_t n) { out.alloc(n); return out.a; }, &nrec, &rs, trace)) {
+      s.n_align_needed = rs.n_align_needed, s.n_seen_skip = rs.n_seen_skip, s.n_align_gpu = rs.n_align_gpu, s.rounds = rs.rounds;
+      gpu_ms += now_ms() - r0;
+      timing_flush();
+      if (trace) fprintf(stderr, "[pgx] stage total %.2f ms\n", now_ms() - t0);
+      s.n_records = out.n;
+      s.gpu_ms = gpu_ms;
+      s.host_ms = now_ms() - t0 - gpu_ms;
+      if (st) *st = s;
+      return;
+    }
+    dpairs = DevicePairs();
+  }
   build_visit(pt, (uint32_t)p->ovlp_upper, visit);
   s.n_buckets = visit.start.size() - 1;
-  if (getenv("PGX_TRACE"))
+  if (trace)
     fprintf(stderr, "[pgx] GPU join: %zu records, %zu buckets, %zu key0 groups in %.2f ms; visit order (%llu buckets) in %.2f ms\n",
             pt.n_rec, pt.bkey1.size(), pt.gkey0.size(), t1 - t0, (unsigned long long)s.n_buckets, now_ms() - t1);
   auto align_batch = [&](const pgx_align_key *keys, size_t nreq, pgx_match *res) {  // results land in the replay's table
@@ -1353,8 +1397,6 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     gpu_ms += now_ms() - g0;
     s.n_align_gpu += nreq;
   };
-  const bool trace = getenv("PGX_TRACE") != nullptr;
-  const bool predict = !(getenv("PGX_PREDICT") && atoi(getenv("PGX_PREDICT")) == 0);
   // 24 threads measured best on a 64-core node at both ends (E. coli set: 8 -> 15.1 ms, 16 -> 12.3, 24 -> 10.3, 48 -> 10.0,
   // 64 -> 16.6 per step; 4.5 Gbases: 16 -> 620 ms, 24 -> 539, 32 -> 571); the ranks of a multi-process job share the host
   unsigned threads = std::max(1u, std::thread::hardware_concurrency());
@@ -1409,6 +1451,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
         inflight.push_back(std::move(b));
         s.n_align_gpu += upto - first;
         gpu_ms += now_ms() - g0;
+        if (trace) fprintf(stderr, "[pgx]   submitted %zu requests in %.2f ms at t = +%.2f ms\n", upto - first, now_ms() - g0, now_ms() - t0);
       };
       for (;;) {
         const double p0 = now_ms();

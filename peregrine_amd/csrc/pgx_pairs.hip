@@ -189,8 +189,10 @@ HostArray<T> to_host(const DevBuf<T> &d, size_t n, size_t extra = 0) {  // (extr
 }  // namespace
 
 void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
-                     const PairParams &pp, PairTables &out, unsigned flags, const pgx_mm128 *d_mmers, const pgx_mm_count *d_counts) {
+                     const PairParams &pp, PairTables &out, unsigned flags, const pgx_mm128 *d_mmers, const pgx_mm_count *d_counts,
+                     DevicePairs *keep_dev) {
   out = PairTables();
+  if (keep_dev) *keep_dev = DevicePairs();
   if (n_mm == 0) return;
   PGX_REQUIRE(n_mm < (1ULL << 31) && n_counts < (1ULL << 31), PGX_EARG, "shimmer list too long for one chunk");
   hipStream_t st = ctx().stream;
@@ -358,6 +360,10 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
   out.gbucket = to_host(gbucket, ng, 1);
   sync();
   out.gbucket[ng] = nbk;
+  if (keep_dev) {  // the device replay reads the sorted records where they are
+    keep_dev->y0 = std::move(sy0), keep_dev->dir = std::move(sdir), keep_dev->bstart = std::move(bstart);
+    keep_dev->n_rec = nr, keep_dev->n_buckets = nbk, keep_dev->valid = true;
+  }
   if (trace)
     fprintf(stderr, "[pgx]   join: tables downloaded in %.2f ms\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - tj0);

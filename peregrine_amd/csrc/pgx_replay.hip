@@ -1,0 +1,761 @@
+// pgx_replay.hip -- the greedy best-n walk over the shimmer-pair buckets (shimmer_to_overlap + the seen-pair table of
+// build_ovlp, /root/reference/src/shmr_overlap.c:52-228) on the GPU, one lane per bucket.
+//
+// The reference visits the buckets once, in order, sharing one seen-pair table.  A bucket's evaluation is a pure function of
+// (a) which of the pairs it examines were inserted by EARLIER buckets (and with which type) and (b) the alignment results it
+// looks up.  So the walk is solved as a fixed point (the same formulation as the host replay in pgx_overlap.cpp, which stays
+// as the fallback), in phases separated by kernel boundaries -- no intra-kernel ordering is needed anywhere:
+//
+//   k_eval    every dirty bucket of a window re-runs shimmer_to_overlap against the pair table AS IT STANDS (read-only in
+//             this kernel): pair present <=> owner < bucket.  It registers itself as a reader of every pair it examines
+//             (lock-free push), guesses unknown alignments (accepted; type predicted from the geometry) and leaves the
+//             list of pairs it would insert.
+//   k_update  applies the evaluated buckets' lists to the table (compare-and-swap, lowest bucket wins), withdraws what a
+//             bucket no longer inserts, and marks dirty every later reader of a pair whose state changed, the displaced
+//             owner, and the bucket itself when an earlier bucket got in first.
+//   ... repeated window by window until no bucket is dirty; then
+//   k_file    files the alignments the lists still need in the memo table (insert-only) and numbers the requests,
+//   dev_align the banded O(ND) kernel (pgx_align.hip) on the new requests,
+//   k_settle  checks every guess against its result; a wrong guess makes the bucket dirty again
+//   ... until a sweep files nothing or every guess was right; k_emit writes the ovlp_t records in bucket order.
+//
+// At the fixed point every bucket was last evaluated against a table that has not changed since in any way it could
+// observe, and the owner of a pair is the lowest bucket inserting it: by induction over the bucket order that is the
+// sequential walk.  Changes only ever propagate to LATER buckets, so the lowest unstable bucket rises monotonically.
+#include <chrono>
+
+#include <hipcub/hipcub.hpp>
+
+#include "pgx_internal.h"
+
+namespace pgx {
+namespace {
+
+constexpr uint32_t NIL = 0;  // list links and reader heads are stored +1
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr int END_FUZZ = 48;  // READ_END_FUZZINESS, shmr_overlap.c:36
+enum { T_OVERLAP = 0, T_CONTAINS = 1, T_CONTAINED = 2 };
+
+constexpr uint32_t NIN = 26;
+struct alignas(128) PSlot {  // one read pair: key = (min rid << 32 | max rid) + 1, own = (bucket << 3 | parity << 2 | type) + 1
+  unsigned long long key;
+  uint32_t own;
+  uint32_t rhead;     // readers beyond the inline ones: linked nodes
+  uint32_t cnt;       // registrations so far; the first NIN sit in in[] (bucket + 1)
+  uint32_t pad;
+  uint32_t in[NIN];
+};
+static_assert(sizeof(PSlot) == 128, "pair slot = two cache lines");
+struct MSlot {  // one alignment: a = rid0 << 32 | rid1 (never 0), b = (q_off << 2 | dir0 << 1 | dir1) + 1, req = request number
+  unsigned long long a;
+  uint32_t b;
+  uint32_t req;
+};
+struct Item {  // one insertion of a bucket's latest evaluation
+  uint32_t pslot;
+  uint32_t info;  // ai | pi << 8 | type << 16 | I_GUESS | I_UNFILED
+  uint32_t mslot;
+  uint32_t next;
+};
+struct RNode {
+  uint32_t next, bucket;
+};
+constexpr uint32_t I_GUESS = 1u << 18, I_UNFILED = 1u << 19;
+constexpr uint8_t F_DUP = 1, F_GUESS = 2, F_UNFILED = 4;
+
+struct Counters {
+  uint32_t item_top, rnode_top, nreq, overflow;
+  uint32_t ndirty, min_dirty, max_dirty, pad;
+  unsigned long long lookups, skips, evals, records;
+};
+
+struct R {
+  uint32_t nb;
+  const uint32_t *bid, *bstart;
+  const uint64_t *y0;
+  const uint8_t *dir;
+  const uint32_t *rlen;
+  PSlot *pt;
+  uint32_t pmask;
+  MSlot *mt;
+  uint32_t mmask;
+  Item *items;
+  uint32_t item_cap;
+  RNode *rn;
+  uint32_t rn_cap;
+  pgx_align_key *rq_key;
+  pgx_match *rq_res;
+  uint32_t req_cap, settled;
+  uint8_t *dirty, *evaluated, *parity, *bflags;
+  uint32_t *ihead, *inum, *ohead, *lookups, *skips;
+  uint4 *wcur;  // per wavefront of k_eval: the unused rest of its arena chunks {node cur, node end, item cur, item end}, kept across launches
+  Counters *c;
+  uint32_t bestn;
+  int predict;
+};
+
+__device__ __forceinline__ uint64_t mix64(uint64_t h) {
+  h ^= h >> 33, h *= 0xff51afd7ed558ccdULL, h ^= h >> 33, h *= 0xc4ceb9fe1a85ec53ULL, h ^= h >> 33;
+  return h;
+}
+__device__ __forceinline__ uint32_t own_enc(uint32_t j, uint32_t par, uint32_t type) { return ((j << 3) | (par << 2) | type) + 1; }
+__device__ __forceinline__ uint32_t own_bucket(uint32_t v) { return (v - 1) >> 3; }
+__device__ __forceinline__ uint32_t own_parity(uint32_t v) { return ((v - 1) >> 2) & 1; }
+__device__ __forceinline__ uint32_t own_type(uint32_t v) { return (v - 1) & 3; }
+__device__ __forceinline__ uint32_t lane_rank(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ long iabs64(long x) { return x < 0 ? -x : x; }
+
+// acceptance test and classification of shimmer_to_overlap (shmr_overlap.c:134-160)
+__device__ __forceinline__ bool classify(const pgx_match &m, uint32_t rlen0, uint32_t rlen1, uint32_t q_off, uint32_t *type) {
+  const uint32_t slen0 = rlen0 - q_off, slen1 = rlen1;
+  *type = T_OVERLAP;
+  if (m.q_bgn < END_FUZZ && m.t_bgn < END_FUZZ &&
+      (iabs64((long)slen0 - m.q_end) < END_FUZZ || iabs64((long)slen1 - m.t_end) < END_FUZZ) && m.q_end > 500 &&
+      m.t_end > 500) {
+    if (iabs64((long)rlen0 - ((long)m.q_end - m.q_bgn)) < END_FUZZ * 2 ||
+        iabs64((long)rlen1 - ((long)m.t_end - m.t_bgn)) < END_FUZZ * 2)
+      *type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
+    return true;
+  }
+  return false;
+}
+
+// the slot of a read pair, inserting the key if it is new (keys never change once set, so a stale "empty" only costs a
+// failed compare-and-swap)
+__device__ __forceinline__ uint32_t pair_slot(const R &r, uint64_t pair) {
+  const unsigned long long want = pair + 1;
+  uint32_t i = (uint32_t)mix64(pair) & r.pmask;
+  for (int probes = 0; probes < 1024; ++probes) {
+    unsigned long long k = r.pt[i].key;
+    if (k == want) return i;
+    if (k == 0) {
+      k = atomicCAS(&r.pt[i].key, 0ULL, want);
+      if (k == 0 || k == want) return i;
+    }
+    i = (i + 1) & r.pmask;
+  }
+  r.c->overflow = 1;
+  return i;
+}
+
+// read-only lookup of an alignment in the memo (nothing inserts while k_eval / k_settle / k_emit run)
+__device__ __forceinline__ uint32_t memo_find(const R &r, unsigned long long a, uint32_t b) {
+  uint32_t i = (uint32_t)mix64(a ^ mix64(b)) & r.mmask;
+  for (int probes = 0; probes < 1024; ++probes) {
+    const unsigned long long cur = r.mt[i].a;
+    if (cur == 0) return NONE;
+    if (cur == a && r.mt[i].b == b + 1) return i;
+    i = (i + 1) & r.mmask;
+  }
+  return NONE;
+}
+
+struct Ent {
+  uint32_t rid, pos1;
+};
+__device__ __forceinline__ Ent entry_of(uint64_t y) { return Ent{(uint32_t)(y >> 32), (((uint32_t)y) >> 1) + 1}; }
+
+// ---- flags: buckets holding a read more than once (only those can meet a pair twice within one evaluation) ----------
+__global__ __launch_bounds__(256) void k_setup(R r) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= r.nb) return;
+  const uint32_t b = r.bid[j], s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
+  bool dup = false;
+  for (uint32_t i = 0; i + 1 < n && !dup; ++i) {
+    const uint32_t ri = (uint32_t)(r.y0[s0 + i] >> 32);
+    for (uint32_t k = i + 1; k < n; ++k)
+      if ((uint32_t)(r.y0[s0 + k] >> 32) == ri) {
+        dup = true;
+        break;
+      }
+  }
+  r.bflags[j] = dup ? F_DUP : 0;
+  r.dirty[j] = 1;
+}
+
+// ---- shimmer_to_overlap (shmr_overlap.c:52-180) for every dirty bucket in [lo, hi) -------------------------------------
+// A group of GL lanes per bucket.  The rows (ai, descending) are sequential -- they communicate through the "contained"
+// flags -- but the partners of one row are examined GL at a time, speculatively: lane l takes partner pbase + l, and the
+// sequential semantics (stop once bestn overlaps are counted, or when the row's own read turns out contained) are then
+// resolved with ballots.  What a lane beyond the stop did is harmless: a pair key, a reader registration (only ever costs a
+// spurious re-evaluation), loads.  Buckets that hold a read twice can meet a pair twice within one evaluation: they run one
+// partner at a time.  A single evaluation is a chain of dependent memory round trips, so the group form is what bounds
+// the latency of a pass: rows x ~4 round trips instead of examinations x ~4.
+constexpr uint32_t NCH = 256, ICHW = 64;  // arena chunks of a wavefront: reader nodes, items
+template <int GL>
+__device__ __forceinline__ uint64_t gbits(uint64_t wave_mask, int gbase) {
+  return GL == 64 ? wave_mask : ((wave_mask >> gbase) & ((1ULL << (GL & 63)) - 1ULL));
+}
+template <int GL>
+__global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
+  constexpr uint32_t GPW = 64 / GL;
+  const int lane = threadIdx.x & 63, gl = lane & (GL - 1), gbase = lane & ~(GL - 1);
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t jj = (uint64_t)lo + (uint64_t)wave * GPW + (uint32_t)(lane / GL);
+  const uint32_t j = (uint32_t)jj;
+  bool alive = jj < hi && r.dirty[j] && !r.c->overflow;
+  {
+    const uint64_t am = __ballot(alive);
+    if (!am) return;
+    if (lane == (int)__builtin_ctzll(am)) atomicAdd(&r.c->evals, (unsigned long long)(__popcll(am) / GL));
+  }
+  // wave-uniform arena cursors; the wavefront that evaluates these buckets next time continues where this one stops
+  const uint32_t wave_id = (uint32_t)(((uint64_t)lo + (uint64_t)wave * GPW) / GPW);
+  const uint4 wc = r.wcur[wave_id];
+  uint32_t rcur = wc.x, rend = wc.y, icur = wc.z, iend = wc.w;
+  uint32_t s0 = 0, n = 0;
+  bool dup = false;
+  if (alive) {
+    const uint32_t b = r.bid[j];
+    s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
+    dup = (r.bflags[j] & F_DUP) != 0;
+    if (gl == 0) {
+      r.dirty[j] = 0;
+      r.evaluated[j] = 1;
+      r.parity[j] ^= 1;
+      r.ohead[j] = r.ihead[j];
+    }
+  }
+  uint64_t clo = 0, chi = 0;  // "contained" flags of the bucket's entries (n <= 128)
+  auto cget = [&](uint32_t i) { return (((i < 64 ? clo : chi) >> (i & 63)) & 1) != 0; };
+  uint32_t head = NIL, num = 0, lookups = 0, skips = 0;
+  bool any_guess = false, any_unfiled = false;
+  int ai = (int)n - 1;  // (the first row opened is n - 2)
+  bool row_open = false;
+  uint32_t pbase = 0, got = 0, rid0 = 0, pos0 = 0, rlen0 = 0, dir0 = 0;
+  for (;;) {
+    if (alive && !row_open) {
+      do --ai;
+      while (ai >= 0 && cget((uint32_t)ai));
+      if (ai < 0 || r.bestn == 0) {  // the bucket is done
+        if (gl == 0) {
+          r.ihead[j] = head, r.inum[j] = num, r.lookups[j] = lookups, r.skips[j] = skips;
+          r.bflags[j] = (uint8_t)((dup ? F_DUP : 0) | (any_guess ? F_GUESS : 0) | (any_unfiled ? F_UNFILED : 0));
+        }
+        alive = false;
+      } else {
+        const Ent e0 = entry_of(r.y0[s0 + ai]);
+        rid0 = e0.rid, pos0 = e0.pos1, rlen0 = r.rlen[rid0], dir0 = r.dir[s0 + ai];
+        got = 0, pbase = (uint32_t)ai + 1, row_open = true;
+      }
+    }
+    if (!__ballot(alive)) {
+      if (lane == 0) r.wcur[wave_id] = make_uint4(rcur, rend, icur, iend);
+      break;
+    }
+    // ---- one batch of partners ----
+    const uint32_t step = dup ? 1u : (uint32_t)GL;
+    const uint32_t pi = pbase + (uint32_t)gl;
+    bool valid = alive && (uint32_t)gl < step && pi < n && !cget(pi);
+    uint32_t rid1 = 0, pos1 = 0;
+    if (valid) {
+      const Ent e1 = entry_of(r.y0[s0 + pi]);
+      rid1 = e1.rid, pos1 = e1.pos1;
+      if (rid1 == rid0) valid = false;
+    }
+    uint32_t slot = 0;
+    if (valid) slot = pair_slot(r, rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0));
+    const uint64_t vm = __ballot(valid);
+    bool present = false, accepted = false, guessed = false;
+    uint32_t ptype = 0, type = 0, mslot = NONE;
+    if (valid) {
+      const uint32_t v = r.pt[slot].own;
+      present = v != 0 && own_bucket(v) < j;
+      ptype = present ? own_type(v) : 0;
+      if (!present && dup)  // inserted earlier in THIS evaluation?
+        for (uint32_t it = head; it != NIL; it = r.items[it - 1].next)
+          if (r.items[it - 1].pslot == slot) {
+            present = true, ptype = (r.items[it - 1].info >> 16) & 3;
+            break;
+          }
+      if (!present) {
+        const uint32_t rlen1 = r.rlen[rid1], dir1 = r.dir[s0 + pi];
+        const uint32_t q_off = pos0 - pos1;
+        if (q_off >= (1u << 30)) r.c->overflow = 1;
+        mslot = memo_find(r, (unsigned long long)rid0 << 32 | rid1, q_off << 2 | dir0 << 1 | dir1);
+        uint32_t req = NONE;
+        if (mslot != NONE) req = r.mt[mslot].req;
+        if (req < r.settled) {
+          accepted = classify(r.rq_res[req], rlen0, rlen1, q_off, &type);
+        } else {
+          accepted = true, guessed = true, type = T_OVERLAP;
+          if (r.predict && (rlen1 <= rlen0 - q_off || q_off < (uint32_t)(END_FUZZ * 2 - 8))) type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
+        }
+      }
+    }
+    // ---- the sequential semantics of the row over this batch, lowest partner first ----
+    const uint64_t Vg = gbits<GL>(vm, gbase);
+    const uint64_t P = gbits<GL>(__ballot(valid && present), gbase);
+    const uint64_t PO = gbits<GL>(__ballot(valid && present && ptype == T_OVERLAP), gbase);
+    const uint64_t A = gbits<GL>(__ballot(valid && !present && accepted), gbase);
+    const uint64_t AO = gbits<GL>(__ballot(valid && !present && accepted && type == T_OVERLAP), gbase);
+    const uint64_t AC = gbits<GL>(__ballot(valid && !present && accepted && type == T_CONTAINED), gbase);
+    uint64_t AP = gbits<GL>(__ballot(valid && !present && accepted && type == T_CONTAINS), gbase);
+    const uint64_t inc = PO | AO;
+    int stop = GL;  // the last partner the sequential loop processes in this batch (GL: all of them, and the row goes on)
+    if (alive && row_open) {
+      const uint32_t need = r.bestn - got;  // >= 1
+      if ((uint32_t)__popcll(inc) >= need) {
+        uint64_t m = inc;
+        for (uint32_t k = 1; k < need; ++k) m &= m - 1;
+        stop = __builtin_ctzll(m);
+      }
+      if (AC) stop = min(stop, (int)__builtin_ctzll(AC));
+    }
+    const uint64_t proc = stop >= 63 ? ~0ULL : ((2ULL << stop) - 1ULL);
+    const uint64_t ins = A & proc;
+    {  // the partners the sequential loop really examined register as readers of their pairs (the lists are only walked by
+       // k_update, after this kernel)
+      bool reg = valid && ((proc >> gl) & 1);
+      uint32_t idx = 0;
+      if (reg) {  // a bucket listed by an earlier evaluation is not listed again (the inline part is checked; it holds most lists)
+        const uint32_t c = min(r.pt[slot].cnt, NIN);
+        for (uint32_t i = 0; i < c; ++i)
+          if (r.pt[slot].in[i] == j + 1) {
+            reg = false;
+            break;
+          }
+        if (reg) {
+          idx = atomicAdd(&r.pt[slot].cnt, 1u);
+          if (idx < NIN) r.pt[slot].in[idx] = j + 1, reg = false;
+        }
+      }
+      const uint64_t rm = __ballot(reg);  // (what is left goes to the linked overflow)
+      if (rm) {
+        const uint32_t total = (uint32_t)__popcll(rm);
+        if (rcur + total > rend) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&r.c->rnode_top, NCH);
+          base = (uint32_t)__shfl((int)base, 0, 64);
+          if ((uint64_t)base + NCH > r.rn_cap) {
+            r.c->overflow = 1;
+            return;
+          }
+          rcur = base, rend = base + NCH;
+        }
+        if (reg) {
+          const uint32_t node = rcur + lane_rank(rm);
+          const uint32_t old = atomicExch(&r.pt[slot].rhead, node + 1);
+          r.rn[node] = RNode{old, j};
+        }
+        rcur += total;
+      }
+    }
+    const bool my_ins = valid && !present && accepted && ((proc >> gl) & 1);
+    const uint64_t im = __ballot(my_ins);
+    if (im) {
+      const uint32_t total = (uint32_t)__popcll(im);
+      if (icur + total > iend) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&r.c->item_top, ICHW);
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if ((uint64_t)base + ICHW > r.item_cap) {
+          r.c->overflow = 1;
+          return;
+        }
+        icur = base, iend = base + ICHW;
+      }
+      if (my_ins) {
+        const uint32_t idx = icur + lane_rank(im);
+        const uint32_t grank = (uint32_t)__popcll(ins & ((1ULL << gl) - 1ULL));
+        uint32_t info = (uint32_t)ai | pi << 8 | type << 16;
+        if (guessed) info |= I_GUESS;
+        if (mslot == NONE) info |= I_UNFILED;
+        r.items[idx] = Item{slot, info, mslot, grank ? idx : head};  // (the previous insertion of the group sits at idx - 1)
+      }
+      if (ins) {
+        const int first = gbase + (int)__builtin_ctzll(ins);
+        const uint32_t frank = (uint32_t)__popcll(im & ((1ULL << first) - 1ULL));
+        head = icur + frank + (uint32_t)__popcll(ins);  // index of the group's last insertion, + 1
+        num += (uint32_t)__popcll(ins);
+      }
+      icur += total;
+    }
+    {
+      const uint64_t g1 = gbits<GL>(__ballot(my_ins && guessed), gbase), g2 = gbits<GL>(__ballot(my_ins && mslot == NONE), gbase);
+      any_guess |= g1 != 0, any_unfiled |= g2 != 0;
+    }
+    if (alive && row_open) {
+      got += (uint32_t)__popcll(inc & proc);
+      skips += (uint32_t)__popcll(P & proc);
+      lookups += (uint32_t)__popcll(Vg & ~P & proc);
+      AP &= proc;
+      if (AP) {  // partners found contained: entry pbase + l
+        if (pbase < 64) {
+          clo |= AP << pbase;
+          if (pbase) chi |= AP >> (64 - pbase);
+        } else {
+          chi |= AP << (pbase - 64);
+        }
+      }
+      if (AC & proc) {
+        if (ai < 64) clo |= 1ULL << ai;
+        else chi |= 1ULL << (ai - 64);
+      }
+      if (stop < GL || pbase + step >= n) row_open = false;
+      else pbase += step;
+    }
+  }
+}
+
+__device__ __forceinline__ void mark_readers(const R &r, uint32_t slot, uint32_t j) {
+  const uint32_t c = min(r.pt[slot].cnt, NIN);
+  for (uint32_t i = 0; i < c; ++i) {
+    const uint32_t x = r.pt[slot].in[i];
+    if (x > j + 1) r.dirty[x - 1] = 1;
+  }
+  if (c < NIN) return;
+  for (uint32_t nd = r.pt[slot].rhead; nd != NIL; nd = r.rn[nd - 1].next) {
+    const uint32_t rb = r.rn[nd - 1].bucket;
+    if (rb > j) r.dirty[rb] = 1;
+  }
+}
+
+// ---- apply the evaluated buckets' lists to the pair table ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_update(R r, uint32_t lo, uint32_t hi) {
+  const uint32_t j = lo + blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= hi || !r.evaluated[j] || r.c->overflow) return;
+  r.evaluated[j] = 0;
+  const uint32_t pnew = r.parity[j], pold = pnew ^ 1;
+  // what this evaluation inserts: take or refresh ownership (lowest bucket wins)
+  for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) {
+    const uint32_t slot = r.items[it - 1].pslot, type = (r.items[it - 1].info >> 16) & 3;
+    const uint32_t mine = own_enc(j, pnew, type);
+    uint32_t v = r.pt[slot].own;
+    for (;;) {
+      if (v != 0 && own_bucket(v) < j) {  // an earlier bucket got in first: this evaluation is stale
+        r.dirty[j] = 1;
+        break;
+      }
+      const uint32_t prev = atomicCAS(&r.pt[slot].own, v, mine);
+      if (prev == v) {
+        if (v == 0 || own_bucket(v) > j) mark_readers(r, slot, j);  // absent -> present, or a later owner displaced (it reads the pair too)
+        else if ((own_type(v) == T_OVERLAP) != (type == T_OVERLAP)) mark_readers(r, slot, j);  // ours before: readers see the type class
+        break;
+      }
+      v = prev;
+    }
+  }
+  // what the previous evaluation inserted and this one did not refresh: withdraw
+  for (uint32_t it = r.ohead[j]; it != NIL; it = r.items[it - 1].next) {
+    const uint32_t slot = r.items[it - 1].pslot;
+    const uint32_t v = r.pt[slot].own;
+    if (v != 0 && own_bucket(v) == j && own_parity(v) == pold) {
+      if (atomicCAS(&r.pt[slot].own, v, 0u) == v) mark_readers(r, slot, j);
+    }
+  }
+  r.ohead[j] = NIL;
+}
+
+__global__ __launch_bounds__(256) void k_count(R r) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool d = j < r.nb && r.dirty[j];
+  const uint64_t m = __ballot(d);
+  if (!m) return;
+  if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) {
+    atomicAdd(&r.c->ndirty, (uint32_t)__popcll(m));
+    atomicMin(&r.c->min_dirty, j);
+    atomicMax(&r.c->max_dirty, (j & ~63u) + 63 - (uint32_t)__builtin_clzll(m));
+  }
+}
+
+// ---- file the alignments the converged lists still need ---------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_file(R r) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = j < r.nb && (r.bflags[j] & F_UNFILED);
+  if (!__ballot(active)) return;
+  uint32_t cnt = 0;
+  if (active)
+    for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) cnt += (r.items[it - 1].info & I_UNFILED) ? 1u : 0u;
+  // request numbers: one atomic per wavefront
+  const int lane = threadIdx.x & 63;
+  uint32_t incl = cnt;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+  uint32_t base = 0;
+  if (lane == 63 && total) base = atomicAdd(&r.c->nreq, total);
+  base = (uint32_t)__shfl((int)base, 63, 64);
+  if (!active || !cnt) {
+    if (active) r.bflags[j] &= (uint8_t)~F_UNFILED;
+    return;
+  }
+  if ((unsigned long long)base + total > r.req_cap) {
+    r.c->overflow = 1;
+    return;
+  }
+  uint32_t my = base + incl - cnt;
+  const uint32_t b = r.bid[j], s0 = r.bstart[b];
+  for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) {
+    Item &im = r.items[it - 1];
+    if (!(im.info & I_UNFILED)) continue;
+    const uint32_t ai = im.info & 0xFF, pi = (im.info >> 8) & 0xFF;
+    const Ent e0 = entry_of(r.y0[s0 + ai]), e1 = entry_of(r.y0[s0 + pi]);
+    const uint32_t dir0 = r.dir[s0 + ai], dir1 = r.dir[s0 + pi], q_off = e0.pos1 - e1.pos1;
+    const unsigned long long a = (unsigned long long)e0.rid << 32 | e1.rid;
+    const uint32_t bk = q_off << 2 | dir0 << 1 | dir1;
+    pgx_align_key key;
+    key.rid0 = e0.rid, key.rid1 = e1.rid, key.q_off = q_off, key.dir0 = (uint8_t)dir0, key.dir1 = (uint8_t)dir1, key.pad[0] = key.pad[1] = 0;
+    // find or insert.  Another lane may be inserting the same key right now: its `b` may still read 0, in which case this
+    // lane files a duplicate in another slot (same alignment, same result -- harmless).
+    uint32_t i = (uint32_t)mix64(a ^ mix64(bk)) & r.mmask, found = NONE;
+    bool fresh = false;
+    for (int probes = 0; probes < 1024; ++probes) {
+      unsigned long long cur = r.mt[i].a;
+      if (cur == 0) {
+        cur = atomicCAS(&r.mt[i].a, 0ULL, a);
+        if (cur == 0) {
+          r.mt[i].b = bk + 1;
+          found = i, fresh = true;
+          break;
+        }
+      }
+      if (cur == a && *(volatile uint32_t *)&r.mt[i].b == bk + 1) {
+        found = i;
+        break;
+      }
+      i = (i + 1) & r.mmask;
+    }
+    if (found == NONE) {
+      r.c->overflow = 1;
+      return;
+    }
+    r.rq_key[my] = key;  // (a request slot whose key was already filed by someone else just repeats that alignment)
+    if (fresh) r.mt[found].req = my;
+    ++my;
+    im.mslot = found;
+    im.info &= ~I_UNFILED;
+  }
+  r.bflags[j] &= (uint8_t)~F_UNFILED;
+}
+
+// ---- check the guesses against the results ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_settle(R r) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= r.nb || !(r.bflags[j] & F_GUESS)) return;
+  const uint32_t b = r.bid[j], s0 = r.bstart[b];
+  bool bad = false, remain = false;
+  for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) {
+    Item &im = r.items[it - 1];
+    if (!(im.info & I_GUESS)) continue;
+    const uint32_t req = im.mslot != NONE ? r.mt[im.mslot].req : NONE;
+    if (req >= r.settled) {
+      remain = true;
+      continue;
+    }
+    const uint32_t ai = im.info & 0xFF, pi = (im.info >> 8) & 0xFF, gtype = (im.info >> 16) & 3;
+    const Ent e0 = entry_of(r.y0[s0 + ai]), e1 = entry_of(r.y0[s0 + pi]);
+    uint32_t type;
+    const bool acc = classify(r.rq_res[req], r.rlen[e0.rid], r.rlen[e1.rid], e0.pos1 - e1.pos1, &type);
+    if (!acc || type != gtype) bad = true;
+    else im.info &= ~I_GUESS;
+  }
+  if (bad) r.dirty[j] = 1;
+  if (!remain) r.bflags[j] &= (uint8_t)~F_GUESS;
+}
+
+// ---- the ovlp_t records, bucket by bucket in visit order, each bucket's in evaluation order ---------------------------
+__global__ __launch_bounds__(256) void k_emit(R r, const uint32_t *__restrict__ off, pgx_ovlp *__restrict__ out) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long lk = 0, sk = 0;
+  if (j < r.nb) {
+    lk = r.lookups[j], sk = r.skips[j];
+    const uint32_t num = r.inum[j];
+    if (num) {
+      const uint32_t b = r.bid[j], s0 = r.bstart[b];
+      uint32_t k = 0;
+      for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next, ++k) {  // the list runs newest first
+        const Item im = r.items[it - 1];
+        const uint32_t ai = im.info & 0xFF, pi = (im.info >> 8) & 0xFF;
+        const uint64_t ya = r.y0[s0 + ai], yb = r.y0[s0 + pi];
+        pgx_ovlp o;
+        o.y0 = ya, o.y1 = yb;
+        o.rl0 = r.rlen[(uint32_t)(ya >> 32)], o.rl1 = r.rlen[(uint32_t)(yb >> 32)];
+        o.strand0 = r.dir[s0 + ai], o.strand1 = r.dir[s0 + pi], o.ovlp_type = (uint8_t)((im.info >> 16) & 3), o.pad0 = 0;
+        o.match = r.rq_res[r.mt[im.mslot].req];
+        o.pad1 = 0;
+        out[(size_t)off[j] + (num - 1 - k)] = o;
+      }
+    }
+  }
+  // totals: one atomic pair per wavefront
+  for (int o = 32; o; o >>= 1) {
+    lk += (unsigned long long)__shfl_xor((int)(lk >> 32), o, 64) << 32 | (uint32_t)__shfl_xor((int)lk, o, 64);
+    sk += (unsigned long long)__shfl_xor((int)(sk >> 32), o, 64) << 32 | (uint32_t)__shfl_xor((int)sk, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0 && (lk | sk)) {
+    atomicAdd(&r.c->lookups, lk);
+    atomicAdd(&r.c->skips, sk);
+  }
+}
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+uint32_t pow2_at_least(size_t x) {
+  size_t c = 1024;
+  while (c < x) c <<= 1;
+  return (uint32_t)c;
+}
+unsigned cdiv256(size_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, size_t nb, size_t n_entries,
+                uint32_t bestn, int band, bool predict, uint32_t ovlp_upper, const std::function<pgx_ovlp *(size_t)> &alloc_out,
+                size_t *n_out, pgx_overlap_stats *st, bool trace) {
+  *n_out = 0;
+  // what the encodings hold (anything else goes to the host replay)
+  if (ovlp_upper > 128 || nb >= (1u << 29) - 2 || n_entries >= (1ULL << 31) || !dp.valid) return false;
+  if (nb == 0) {
+    alloc_out(0);
+    return true;
+  }
+  const double t0 = now_ms();
+  hipStream_t s = ctx().stream;
+  const size_t ne = std::max<size_t>(n_entries, 1024);
+  static const double scale = getenv("PGX_REPLAY_SCALE") ? atof(getenv("PGX_REPLAY_SCALE")) : 1.0;
+  R r;
+  memset(&r, 0, sizeof(r));
+  r.nb = (uint32_t)nb;
+  DevBuf<uint32_t> bid(nb);
+  bid.upload(visit_bids, nb);
+  r.bid = bid.p, r.bstart = dp.bstart.p, r.y0 = dp.y0.p, r.dir = dp.dir.p, r.rlen = db->d_rlen.p;
+  const uint32_t pcap = pow2_at_least(ne), mcap = pow2_at_least(ne);
+  DevBuf<PSlot> pt(pcap);
+  DevBuf<MSlot> mt(mcap);
+  r.pt = pt.p, r.pmask = pcap - 1, r.mt = mt.p, r.mmask = mcap - 1;
+  r.item_cap = (uint32_t)std::min<size_t>((size_t)(ne * 6 * scale) + (1u << 20), 0x7FFFFFF0u);
+  r.rn_cap = (uint32_t)std::min<size_t>((size_t)(ne * 24 * scale) + (1u << 22), 0x7FFFFFF0u);
+  r.req_cap = (uint32_t)std::min<size_t>((size_t)(ne * 1 * scale) + 65536, 0x7FFFFFF0u);
+  DevBuf<Item> items(r.item_cap);
+  DevBuf<RNode> rn(r.rn_cap);
+  DevBuf<pgx_align_key> rq_key(r.req_cap);
+  DevBuf<pgx_match> rq_res(r.req_cap);
+  r.items = items.p, r.rn = rn.p, r.rq_key = rq_key.p, r.rq_res = rq_res.p;
+  DevBuf<uint8_t> bytes(nb * 4);
+  DevBuf<uint32_t> words(nb * 5);
+  r.dirty = bytes.p, r.evaluated = bytes.p + nb, r.parity = bytes.p + 2 * nb, r.bflags = bytes.p + 3 * nb;
+  r.ihead = words.p, r.inum = words.p + nb, r.ohead = words.p + 2 * nb, r.lookups = words.p + 3 * nb, r.skips = words.p + 4 * nb;
+  DevBuf<uint4> wcur(nb / 4 + 2);  // (k_eval<16>: four buckets per wavefront)
+  r.wcur = wcur.p;
+  PGX_HIP(hipMemsetAsync(wcur.p, 0, (nb / 4 + 2) * sizeof(uint4), s));
+  DevBuf<Counters> dc(1);
+  r.c = dc.p;
+  r.bestn = bestn, r.predict = predict ? 1 : 0, r.settled = 0;
+  PGX_HIP(hipMemsetAsync(pt.p, 0, (size_t)pcap * sizeof(PSlot), s));
+  PGX_HIP(hipMemsetAsync(mt.p, 0, (size_t)mcap * sizeof(MSlot), s));
+  PGX_HIP(hipMemsetAsync(bytes.p, 0, nb * 4, s));
+  PGX_HIP(hipMemsetAsync(words.p, 0, nb * 5 * sizeof(uint32_t), s));
+  PGX_HIP(hipMemsetAsync(dc.p, 0, sizeof(Counters), s));
+  hipLaunchKernelGGL(k_setup, dim3(cdiv256(nb)), dim3(256), 0, s, r);
+
+  static Counters *hc = nullptr;  // pinned mirror of the device counters
+  static uint32_t *reset3 = nullptr;  // {ndirty, min_dirty, max_dirty} before a count (pinned, constant)
+  if (!hc) {
+    PGX_HIP(hipHostMalloc((void **)&hc, sizeof(Counters), hipHostMallocDefault));
+    PGX_HIP(hipHostMalloc((void **)&reset3, 3 * sizeof(uint32_t), hipHostMallocDefault));
+    reset3[0] = 0, reset3[1] = 0xFFFFFFFFu, reset3[2] = 0;
+  }
+  auto read_counters = [&](bool count_dirty) {
+    if (count_dirty) {  // reset the three dirty statistics, keep the rest
+      PGX_HIP(hipMemcpyAsync(&dc.p->ndirty, reset3, 3 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+      hipLaunchKernelGGL(k_count, dim3(cdiv256(nb)), dim3(256), 0, s, r);
+    }
+    PGX_HIP(hipMemcpyAsync(hc, dc.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    sync();
+    return hc->overflow == 0;
+  };
+  static const size_t window = getenv("PGX_REPLAY_WIN") ? (size_t)atoll(getenv("PGX_REPLAY_WIN")) : (size_t)262144;
+  static const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 3;
+  static const bool deep = getenv("PGX_TRACE") && atoi(getenv("PGX_TRACE")) >= 2;  // per-kernel wall times (synchronises after every launch)
+  double td = 0, t_eval = 0, t_upd = 0;
+  size_t first_req = 0;
+  unsigned sweeps = 0, passes_total = 0;
+  uint32_t d_lo = 0, d_hi = (uint32_t)nb;  // range holding the dirty buckets
+  size_t n_dirty = nb;
+  double align_ms = 0;
+  for (;;) {
+    ++sweeps;
+    const double p0 = now_ms();
+    unsigned passes = 0;
+    while (n_dirty) {
+      ++passes;
+      // dense: window by window, in order (a window's buckets mostly depend on earlier windows); sparse: the whole range at once
+      const size_t win = n_dirty > window / 4 ? window : (size_t)(d_hi - (d_lo & ~63u));
+      for (size_t lo = d_lo & ~(size_t)63; lo < d_hi; lo += win) {  // (aligned: a bucket always belongs to the same wavefront slot)
+        const uint32_t hi = (uint32_t)std::min<size_t>(d_hi, lo + win);
+        for (int k = 0; k < inner; ++k) {
+          if (deep) sync(), td = now_ms();
+          hipLaunchKernelGGL((k_eval<16>), dim3(cdiv256((size_t)(hi - lo) * 16)), dim3(256), 0, s, r, (uint32_t)lo, hi);
+          if (deep) sync(), t_eval += now_ms() - td, td = now_ms();
+          hipLaunchKernelGGL(k_update, dim3(cdiv256(hi - lo)), dim3(256), 0, s, r, (uint32_t)lo, hi);
+          if (deep) sync(), t_upd += now_ms() - td, fprintf(stderr, "[pgx]     iteration: eval %.3f ms, update %.3f ms\n", t_eval, t_upd), t_eval = t_upd = 0;
+        }
+      }
+      if (!read_counters(true)) goto overflowed;
+      if (trace)
+        fprintf(stderr, "[pgx]   pass %u: %zu dirty in [%u, %u) -> %u dirty, %llu evaluations, t = +%.2f ms\n", passes, n_dirty, d_lo, d_hi,
+                hc->ndirty, (unsigned long long)hc->evals, now_ms() - t0);
+      n_dirty = hc->ndirty;
+      d_lo = n_dirty ? hc->min_dirty : 0, d_hi = n_dirty ? hc->max_dirty + 1 : 0;
+      if (passes > 20000) goto overflowed;  // (cannot happen: the lowest unstable bucket rises every pass)
+    }
+    passes_total += passes;
+    hipLaunchKernelGGL(k_file, dim3(cdiv256(nb)), dim3(256), 0, s, r);
+    if (!read_counters(false)) goto overflowed;
+    const size_t nreq = hc->nreq;
+    if (trace)
+      fprintf(stderr, "[pgx] device sweep %u: %u passes, %llu evaluations so far, %.2f ms, %zu requests\n", sweeps, passes,
+              (unsigned long long)hc->evals, now_ms() - p0, nreq - first_req);
+    if (nreq == first_req) break;
+    const double a0 = now_ms();
+    dev_align(db, r.rq_key + first_req, nreq - first_req, band, r.rq_res + first_req);
+    r.settled = (uint32_t)nreq;
+    first_req = nreq;
+    hipLaunchKernelGGL(k_settle, dim3(cdiv256(nb)), dim3(256), 0, s, r);
+    if (!read_counters(true)) goto overflowed;
+    align_ms += now_ms() - a0;
+    n_dirty = hc->ndirty;
+    d_lo = n_dirty ? hc->min_dirty : 0, d_hi = n_dirty ? hc->max_dirty + 1 : 0;
+    if (trace) fprintf(stderr, "[pgx]   alignments + settle %.2f ms, %zu buckets guessed wrong\n", now_ms() - a0, n_dirty);
+    if (!n_dirty) break;
+  }
+  {
+    const double e0 = now_ms();
+    DevBuf<uint32_t> off(nb + 1);
+    size_t tb = 0;
+    PGX_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, r.inum, off.p, (int)nb, s));
+    DevBuf<uint8_t> tmp(tb + 256);
+    PGX_HIP(hipcub::DeviceScan::ExclusiveSum(tmp.p, tb, r.inum, off.p, (int)nb, s));
+    uint32_t last_off = 0, last_num = 0;
+    PGX_HIP(hipMemcpyAsync(&last_off, off.p + nb - 1, 4, hipMemcpyDeviceToHost, s));
+    PGX_HIP(hipMemcpyAsync(&last_num, r.inum + nb - 1, 4, hipMemcpyDeviceToHost, s));
+    sync();
+    const size_t nrec = (size_t)last_off + last_num;
+    pgx_ovlp *host = alloc_out(nrec);
+    DevBuf<pgx_ovlp> d_out(std::max<size_t>(nrec, 1));
+    hipLaunchKernelGGL(k_emit, dim3(cdiv256(nb)), dim3(256), 0, s, r, off.p, d_out.p);
+    if (nrec) PGX_HIP(hipMemcpyAsync(host, d_out.p, nrec * sizeof(pgx_ovlp), hipMemcpyDeviceToHost, s));
+    if (!read_counters(false)) goto overflowed;
+    *n_out = nrec;
+    if (st) {
+      st->n_align_needed = hc->lookups, st->n_seen_skip = hc->skips, st->n_align_gpu = first_req;
+      st->rounds = sweeps;
+    }
+    if (trace)
+      fprintf(stderr, "[pgx] device replay: %u sweeps, %u passes, %llu evaluations, %zu records; emit %.2f ms; alignments %.2f ms; total %.2f ms\n",
+              sweeps, passes_total, (unsigned long long)hc->evals, nrec, now_ms() - e0, align_ms, now_ms() - t0);
+  }
+  return true;
+overflowed:
+  fprintf(stderr, "[pgx] note: the device replay's tables overflowed (items %u of %u, reader nodes %u of %u, requests %u of %u); the host replay takes over\n",
+          hc->item_top, r.item_cap, hc->rnode_top, r.rn_cap, hc->nreq, r.req_cap);
+  return false;
+}
+
+}  // namespace pgx
