@@ -1342,8 +1342,13 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     }
   } defer_scratch{scratch};
   PairTables &pt = scratch->pt;
-  // PGX_GPU_REPLAY=1: the greedy walk itself runs on the GPU (pgx_replay.hip); the host replay below is the fallback
-  static const bool gpu_replay = getenv("PGX_GPU_REPLAY") && atoi(getenv("PGX_GPU_REPLAY")) != 0;
+  // The greedy walk itself runs on the GPU (pgx_replay.hip) from ~1.5 M pair records on, where it is faster than the
+  // multi-threaded host replay below (20 Mb x 30x: 48 vs 53 ms; 80 Mb: 134 vs 217 ms; 150 Mb: 0.23 vs 0.45 s; below that a
+  // pass is bound by the latency of single bucket evaluations: 1 Mb: 17 vs 10 ms).  PGX_GPU_REPLAY=1 / 0 forces either one;
+  // the host replay is also the fallback for jobs the device tables' encodings do not hold.
+  const int gpu_replay_env = getenv("PGX_GPU_REPLAY") ? atoi(getenv("PGX_GPU_REPLAY")) : -1;
+  static const size_t gpu_replay_min = getenv("PGX_GPU_REPLAY_MIN") ? (size_t)atoll(getenv("PGX_GPU_REPLAY_MIN")) : (size_t)1500000;
+  bool gpu_replay = gpu_replay_env != 0;  // (decided once the join has counted the records)
   const bool trace = getenv("PGX_TRACE") != nullptr;
   const bool predict = !(getenv("PGX_PREDICT") && atoi(getenv("PGX_PREDICT")) == 0);
   DevicePairs dpairs;
@@ -1352,6 +1357,8 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
                   dev ? dev->d_top : nullptr, dev ? dev->mc.p : nullptr, gpu_replay ? &dpairs : nullptr);
   sync();
   s.n_pair_records = pt.n_rec;
+  if (gpu_replay_env < 0) gpu_replay = pt.n_rec >= gpu_replay_min;
+  if (!gpu_replay) dpairs = DevicePairs();
   const double t1 = now_ms();
   gpu_ms += t1 - t0;
   NodePin pin;  // from here on the caller and its helper threads stay on one memory node

@@ -61,6 +61,7 @@ struct RNode {
   uint32_t next, bucket;
 };
 constexpr uint32_t I_GUESS = 1u << 18, I_UNFILED = 1u << 19;
+enum : uint32_t { OV_ITEMS = 1, OV_NODES = 2, OV_REQS = 4, OV_PAIRS = 8, OV_MEMO = 16, OV_QOFF = 32, OV_PASSES = 64 };  // Counters::overflow
 constexpr uint8_t F_DUP = 1, F_GUESS = 2, F_UNFILED = 4;
 
 struct Counters {
@@ -136,8 +137,21 @@ __device__ __forceinline__ uint32_t pair_slot(const R &r, uint64_t pair) {
     }
     i = (i + 1) & r.pmask;
   }
-  r.c->overflow = 1;
+  atomicOr(&r.c->overflow, OV_PAIRS);
   return i;
+}
+
+// read-only lookup of a pair (speculative partners must not fill the table with pairs the walk never examines)
+__device__ __forceinline__ uint32_t pair_find(const R &r, uint64_t pair) {
+  const unsigned long long want = pair + 1;
+  uint32_t i = (uint32_t)mix64(pair) & r.pmask;
+  for (int probes = 0; probes < 1024; ++probes) {
+    const unsigned long long k = r.pt[i].key;
+    if (k == want) return i;
+    if (k == 0) return NONE;
+    i = (i + 1) & r.pmask;
+  }
+  return NONE;
 }
 
 // read-only lookup of an alignment in the memo (nothing inserts while k_eval / k_settle / k_emit run)
@@ -255,16 +269,17 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
       rid1 = e1.rid, pos1 = e1.pos1;
       if (rid1 == rid0) valid = false;
     }
-    uint32_t slot = 0;
-    if (valid) slot = pair_slot(r, rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0));
+    uint32_t slot = NONE;
+    const uint64_t pair = rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0);
+    if (valid) slot = pair_find(r, pair);
     const uint64_t vm = __ballot(valid);
     bool present = false, accepted = false, guessed = false;
     uint32_t ptype = 0, type = 0, mslot = NONE;
     if (valid) {
-      const uint32_t v = r.pt[slot].own;
+      const uint32_t v = slot != NONE ? r.pt[slot].own : 0u;
       present = v != 0 && own_bucket(v) < j;
       ptype = present ? own_type(v) : 0;
-      if (!present && dup)  // inserted earlier in THIS evaluation?
+      if (!present && dup && slot != NONE)  // inserted earlier in THIS evaluation?
         for (uint32_t it = head; it != NIL; it = r.items[it - 1].next)
           if (r.items[it - 1].pslot == slot) {
             present = true, ptype = (r.items[it - 1].info >> 16) & 3;
@@ -273,7 +288,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
       if (!present) {
         const uint32_t rlen1 = r.rlen[rid1], dir1 = r.dir[s0 + pi];
         const uint32_t q_off = pos0 - pos1;
-        if (q_off >= (1u << 30)) r.c->overflow = 1;
+        if (q_off >= (1u << 30)) atomicOr(&r.c->overflow, OV_QOFF);
         mslot = memo_find(r, (unsigned long long)rid0 << 32 | rid1, q_off << 2 | dir0 << 1 | dir1);
         uint32_t req = NONE;
         if (mslot != NONE) req = r.mt[mslot].req;
@@ -310,6 +325,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
        // k_update, after this kernel)
       bool reg = valid && ((proc >> gl) & 1);
       uint32_t idx = 0;
+      if (reg && slot == NONE) slot = pair_slot(r, pair);  // a pair the walk really examines gets its slot now
       if (reg) {  // a bucket listed by an earlier evaluation is not listed again (the inline part is checked; it holds most lists)
         const uint32_t c = min(r.pt[slot].cnt, NIN);
         for (uint32_t i = 0; i < c; ++i)
@@ -330,7 +346,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
           if (lane == 0) base = atomicAdd(&r.c->rnode_top, NCH);
           base = (uint32_t)__shfl((int)base, 0, 64);
           if ((uint64_t)base + NCH > r.rn_cap) {
-            r.c->overflow = 1;
+            atomicOr(&r.c->overflow, OV_NODES);
             return;
           }
           rcur = base, rend = base + NCH;
@@ -352,7 +368,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
         if (lane == 0) base = atomicAdd(&r.c->item_top, ICHW);
         base = (uint32_t)__shfl((int)base, 0, 64);
         if ((uint64_t)base + ICHW > r.item_cap) {
-          r.c->overflow = 1;
+          atomicOr(&r.c->overflow, OV_ITEMS);
           return;
         }
         icur = base, iend = base + ICHW;
@@ -485,7 +501,7 @@ __global__ __launch_bounds__(256) void k_file(R r) {
     return;
   }
   if ((unsigned long long)base + total > r.req_cap) {
-    r.c->overflow = 1;
+    atomicOr(&r.c->overflow, OV_REQS);
     return;
   }
   uint32_t my = base + incl - cnt;
@@ -521,7 +537,7 @@ __global__ __launch_bounds__(256) void k_file(R r) {
       i = (i + 1) & r.mmask;
     }
     if (found == NONE) {
-      r.c->overflow = 1;
+      atomicOr(&r.c->overflow, OV_MEMO);
       return;
     }
     r.rq_key[my] = key;  // (a request slot whose key was already filed by someone else just repeats that alignment)
@@ -605,33 +621,27 @@ unsigned cdiv256(size_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
-bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, size_t nb, size_t n_entries,
-                uint32_t bestn, int band, bool predict, uint32_t ovlp_upper, const std::function<pgx_ovlp *(size_t)> &alloc_out,
-                size_t *n_out, pgx_overlap_stats *st, bool trace) {
-  *n_out = 0;
-  // what the encodings hold (anything else goes to the host replay)
-  if (ovlp_upper > 128 || nb >= (1u << 29) - 2 || n_entries >= (1ULL << 31) || !dp.valid) return false;
-  if (nb == 0) {
-    alloc_out(0);
-    return true;
-  }
+namespace {
+// one attempt with the given table sizes (multiples of the defaults); returns 0, or the OV_* bits of what overflowed
+uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, size_t nb, size_t n_entries,
+                        uint32_t bestn, int band, bool predict, const std::function<pgx_ovlp *(size_t)> &alloc_out,
+                        size_t *n_out, pgx_overlap_stats *st, bool trace, const double *mult) {
   const double t0 = now_ms();
   hipStream_t s = ctx().stream;
   const size_t ne = std::max<size_t>(n_entries, 1024);
-  static const double scale = getenv("PGX_REPLAY_SCALE") ? atof(getenv("PGX_REPLAY_SCALE")) : 1.0;
   R r;
   memset(&r, 0, sizeof(r));
   r.nb = (uint32_t)nb;
   DevBuf<uint32_t> bid(nb);
   bid.upload(visit_bids, nb);
   r.bid = bid.p, r.bstart = dp.bstart.p, r.y0 = dp.y0.p, r.dir = dp.dir.p, r.rlen = db->d_rlen.p;
-  const uint32_t pcap = pow2_at_least(ne), mcap = pow2_at_least(ne);
+  const uint32_t pcap = pow2_at_least((size_t)(ne * mult[3])), mcap = pow2_at_least((size_t)(ne * mult[4]));
   DevBuf<PSlot> pt(pcap);
   DevBuf<MSlot> mt(mcap);
   r.pt = pt.p, r.pmask = pcap - 1, r.mt = mt.p, r.mmask = mcap - 1;
-  r.item_cap = (uint32_t)std::min<size_t>((size_t)(ne * 6 * scale) + (1u << 20), 0x7FFFFFF0u);
-  r.rn_cap = (uint32_t)std::min<size_t>((size_t)(ne * 24 * scale) + (1u << 22), 0x7FFFFFF0u);
-  r.req_cap = (uint32_t)std::min<size_t>((size_t)(ne * 1 * scale) + 65536, 0x7FFFFFF0u);
+  r.item_cap = (uint32_t)std::min<size_t>((size_t)(ne * 6 * mult[0]) + (1u << 20), 0x7FFFFFF0u);
+  r.rn_cap = (uint32_t)std::min<size_t>((size_t)(ne * 8 * mult[1]) + (1u << 20), 0x7FFFFFF0u);
+  r.req_cap = (uint32_t)std::min<size_t>((size_t)(ne * 1 * mult[2]) + 65536, 0x7FFFFFF0u);
   DevBuf<Item> items(r.item_cap);
   DevBuf<RNode> rn(r.rn_cap);
   DevBuf<pgx_align_key> rq_key(r.req_cap);
@@ -670,8 +680,8 @@ bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visi
     sync();
     return hc->overflow == 0;
   };
-  static const size_t window = getenv("PGX_REPLAY_WIN") ? (size_t)atoll(getenv("PGX_REPLAY_WIN")) : (size_t)262144;
-  static const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 3;
+  const size_t window = getenv("PGX_REPLAY_WIN") ? (size_t)atoll(getenv("PGX_REPLAY_WIN")) : (size_t)262144;
+  const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 3;
   static const bool deep = getenv("PGX_TRACE") && atoi(getenv("PGX_TRACE")) >= 2;  // per-kernel wall times (synchronises after every launch)
   double td = 0, t_eval = 0, t_upd = 0;
   size_t first_req = 0;
@@ -703,7 +713,10 @@ bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visi
                 hc->ndirty, (unsigned long long)hc->evals, now_ms() - t0);
       n_dirty = hc->ndirty;
       d_lo = n_dirty ? hc->min_dirty : 0, d_hi = n_dirty ? hc->max_dirty + 1 : 0;
-      if (passes > 20000) goto overflowed;  // (cannot happen: the lowest unstable bucket rises every pass)
+      if (passes > 20000) {  // (cannot happen: the lowest unstable bucket rises every pass)
+        hc->overflow |= OV_PASSES;
+        goto overflowed;
+      }
     }
     passes_total += passes;
     hipLaunchKernelGGL(k_file, dim3(cdiv256(nb)), dim3(256), 0, s, r);
@@ -751,10 +764,34 @@ bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visi
       fprintf(stderr, "[pgx] device replay: %u sweeps, %u passes, %llu evaluations, %zu records; emit %.2f ms; alignments %.2f ms; total %.2f ms\n",
               sweeps, passes_total, (unsigned long long)hc->evals, nrec, now_ms() - e0, align_ms, now_ms() - t0);
   }
-  return true;
+  return 0;
 overflowed:
-  fprintf(stderr, "[pgx] note: the device replay's tables overflowed (items %u of %u, reader nodes %u of %u, requests %u of %u); the host replay takes over\n",
-          hc->item_top, r.item_cap, hc->rnode_top, r.rn_cap, hc->nreq, r.req_cap);
+  if (trace || !(hc->overflow & (OV_ITEMS | OV_NODES | OV_REQS | OV_PAIRS | OV_MEMO)))
+    fprintf(stderr, "[pgx] note: the device replay gave up (code %u: items %u of %u, reader nodes %u of %u, requests %u of %u)\n", hc->overflow,
+            hc->item_top, r.item_cap, hc->rnode_top, r.rn_cap, hc->nreq, r.req_cap);
+  return hc->overflow ? hc->overflow : OV_PASSES;
+}
+}  // namespace
+
+bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, size_t nb, size_t n_entries,
+                uint32_t bestn, int band, bool predict, uint32_t ovlp_upper, const std::function<pgx_ovlp *(size_t)> &alloc_out,
+                size_t *n_out, pgx_overlap_stats *st, bool trace) {
+  *n_out = 0;
+  // what the encodings hold (anything else goes to the host replay)
+  if (ovlp_upper > 128 || nb >= (1u << 29) - 2 || n_entries >= (1ULL << 31) || !dp.valid) return false;
+  if (nb == 0) {
+    alloc_out(0);
+    return true;
+  }
+  double mult[5] = {1, 1, 1, 1, 1};  // items, reader nodes, requests, pair table, memo table
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    const uint32_t ov = replay_attempt(db, dp, visit_bids, nb, n_entries, bestn, band, predict, alloc_out, n_out, st, trace, mult);
+    if (!ov) return true;
+    if (ov & (OV_QOFF | OV_PASSES)) break;  // not a matter of table sizes
+    for (int k = 0; k < 5; ++k)
+      if (ov & (1u << k)) mult[k] *= 4;  // unusual data (repeat-rich sets): the same walk again with larger tables
+  }
+  fprintf(stderr, "[pgx] note: the device replay's tables overflowed; the host replay takes over\n");
   return false;
 }
 

@@ -431,6 +431,42 @@ def test_repeat_rich_set_parallel_replay_vs_oracle():
     rdb.close()
 
 
+def test_device_replay_equals_oracle(small, monkeypatch):
+    """the greedy walk on the GPU (pgx_replay.hip; chosen by size in production, forced on here) reaches the sequential fixed
+    point under every schedule: window sizes from one wavefront's worth of buckets to everything at once, 1-5 inner
+    iterations; parameter corners; two overlap chunks; and the repeat-rich set (buckets holding a read twice, best-n
+    saturation, ovlp_upper beyond the device encodings -> the host replay must take over silently)"""
+    db, rdb = small
+    ix = rdb.index()
+    monkeypatch.setenv("PGX_GPU_REPLAY", "1")
+    rng = np.random.default_rng(11)
+    for kw in (dict(), dict(bestn=2, mc_upper=60), dict(bestn=1, ovlp_upper=40), dict(total_chunk=2, mychunk=2), dict(align_bandwidth=30), dict(bestn=0)):
+        okw = dict(mychunk=kw.get("mychunk", 1), total=kw.get("total_chunk", 1), mc_upper=kw.get("mc_upper", 240), bestn=kw.get("bestn", 4),
+                   ovlp_upper=kw.get("ovlp_upper", 120), band=kw.get("align_bandwidth", 100))
+        want, ost = U.orc_overlap(db, ix.top, ix.top_mc, **okw)
+        for it in range(5):
+            monkeypatch.setenv("PGX_REPLAY_WIN", str(int(rng.choice([64, 1024, 16384, 1 << 22]))))
+            monkeypatch.setenv("PGX_REPLAY_K", str(int(rng.choice([1, 2, 3, 5]))))
+            got, st = rdb.overlap(ix.top, ix.top_mc, **kw)
+            assert formats.ovlp_fields_equal(got, want), (kw, it)
+            assert st["n_align_needed"] == ost["n_align"] and st["n_seen_skip"] == ost["n_seen_skip"], (kw, it)
+    monkeypatch.delenv("PGX_REPLAY_WIN"), monkeypatch.delenv("PGX_REPLAY_K")
+    g = simreads.make_genome(2_000_000, 31, repeat_families=6, repeat_len=5000, repeat_copies=12, divergence=0.02, tandem=8)
+    db2 = simreads.simulate_reads(g, coverage=24.0, seed=5, mean_len=9000, sd_len=2500, err=0.012)
+    rdb2 = ResidentDB(db2, 0)
+    ix2 = rdb2.index()
+    for kw in (dict(), dict(bestn=2, mc_upper=40, ovlp_upper=60), dict(total_chunk=2, mychunk=2, bestn=8, align_bandwidth=60),
+               dict(mc_lower=1, mc_upper=1000, ovlp_upper=400)):
+        got, st = rdb2.overlap(ix2.top, ix2.top_mc, **kw)
+        okw = dict(mychunk=kw.get("mychunk", 1), total=kw.get("total_chunk", 1), mc_lower=kw.get("mc_lower", 2),
+                   mc_upper=kw.get("mc_upper", 240), bestn=kw.get("bestn", 4), ovlp_upper=kw.get("ovlp_upper", 120),
+                   band=kw.get("align_bandwidth", 100))
+        want, ost = U.orc_overlap(db2, ix2.top, ix2.top_mc, **okw)
+        assert len(want) > 5000 and formats.ovlp_fields_equal(got, want), kw
+        assert st["n_align_needed"] == ost["n_align"] and st["n_seen_skip"] == ost["n_seen_skip"], kw
+    rdb2.close()
+
+
 def test_query_and_map_edge_cases(tmp_path):
     """rows f3/f4 at the edges: unrelated contigs (no line), a chunk that owns nothing, reads unknown to the index (error, not a
     crash), an empty shimmer list, repeated / interleaved queries on one map"""
