@@ -36,16 +36,16 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 constexpr int END_FUZZ = 48;  // READ_END_FUZZINESS, shmr_overlap.c:36
 enum { T_OVERLAP = 0, T_CONTAINS = 1, T_CONTAINED = 2 };
 
-constexpr uint32_t NIN = 26;
-struct alignas(128) PSlot {  // one read pair: key = (min rid << 32 | max rid) + 1, own = (bucket << 3 | parity << 2 | type) + 1
+constexpr uint32_t NIN = 58;
+struct alignas(256) PSlot {  // one read pair: key = (min rid << 32 | max rid) + 1, own = (bucket << 3 | parity << 2 | type) + 1
   unsigned long long key;
   uint32_t own;
   uint32_t rhead;     // readers beyond the inline ones: linked nodes
   uint32_t cnt;       // registrations so far; the first NIN sit in in[] (bucket + 1)
   uint32_t pad;
-  uint32_t in[NIN];
+  uint32_t in[NIN];   // (a pair of overlapping 15 kb reads shares ~25-40 buckets: nearly every list fits, and is duplicate-free)
 };
-static_assert(sizeof(PSlot) == 128, "pair slot = two cache lines");
+static_assert(sizeof(PSlot) == 256, "pair slot = four cache lines");
 struct MSlot {  // one alignment: a = rid0 << 32 | rid1 (never 0), b = (q_off << 2 | dir0 << 1 | dir1) + 1, req = request number
   unsigned long long a;
   uint32_t b;
@@ -61,6 +61,7 @@ struct RNode {
   uint32_t next, bucket;
 };
 constexpr uint32_t I_GUESS = 1u << 18, I_UNFILED = 1u << 19;
+constexpr uint32_t LIST_CAP = 16384;
 enum : uint32_t { OV_ITEMS = 1, OV_NODES = 2, OV_REQS = 4, OV_PAIRS = 8, OV_MEMO = 16, OV_QOFF = 32, OV_PASSES = 64 };  // Counters::overflow
 constexpr uint8_t F_DUP = 1, F_GUESS = 2, F_UNFILED = 4;
 
@@ -87,8 +88,10 @@ struct R {
   pgx_align_key *rq_key;
   pgx_match *rq_res;
   uint32_t req_cap, settled;
-  uint8_t *dirty, *evaluated, *parity, *bflags;
+  uint8_t *dirty, *evaluated, *parity, *bflags, *ever;
   uint32_t *ihead, *inum, *ohead, *lookups, *skips;
+  uint32_t *dlist;  // the dirty buckets, listed by k_count while there are at most LIST_CAP of them (the sparse passes run from the list)
+  uint32_t wlist0;  // first wcur slot of the list-mode wavefronts
   uint4 *wcur;  // per wavefront of k_eval: the unused rest of its arena chunks {node cur, node end, item cur, item end}, kept across launches
   Counters *c;
   uint32_t bestn;
@@ -141,28 +144,39 @@ __device__ __forceinline__ uint32_t pair_slot(const R &r, uint64_t pair) {
   return i;
 }
 
-// read-only lookup of a pair (speculative partners must not fill the table with pairs the walk never examines)
-__device__ __forceinline__ uint32_t pair_find(const R &r, uint64_t pair) {
+// read-only lookup of a pair (speculative partners must not fill the table with pairs the walk never examines); the
+// slot's first 16 bytes -- key, owner, overflow head -- arrive in one load
+__device__ __forceinline__ uint32_t pair_find(const R &r, uint64_t pair, uint32_t *own) {
   const unsigned long long want = pair + 1;
   uint32_t i = (uint32_t)mix64(pair) & r.pmask;
   for (int probes = 0; probes < 1024; ++probes) {
-    const unsigned long long k = r.pt[i].key;
-    if (k == want) return i;
-    if (k == 0) return NONE;
+    const uint4 h = *reinterpret_cast<const uint4 *>(&r.pt[i]);
+    const unsigned long long k = (unsigned long long)h.y << 32 | h.x;
+    if (k == want) {
+      *own = h.z;
+      return i;
+    }
+    if (k == 0) break;
     i = (i + 1) & r.pmask;
   }
+  *own = 0;
   return NONE;
 }
 
-// read-only lookup of an alignment in the memo (nothing inserts while k_eval / k_settle / k_emit run)
-__device__ __forceinline__ uint32_t memo_find(const R &r, unsigned long long a, uint32_t b) {
+// read-only lookup of an alignment in the memo (nothing inserts while k_eval / k_settle / k_emit run): slot and request
+__device__ __forceinline__ uint32_t memo_find(const R &r, unsigned long long a, uint32_t b, uint32_t *req) {
   uint32_t i = (uint32_t)mix64(a ^ mix64(b)) & r.mmask;
   for (int probes = 0; probes < 1024; ++probes) {
-    const unsigned long long cur = r.mt[i].a;
-    if (cur == 0) return NONE;
-    if (cur == a && r.mt[i].b == b + 1) return i;
+    const uint4 h = *reinterpret_cast<const uint4 *>(&r.mt[i]);
+    const unsigned long long cur = (unsigned long long)h.y << 32 | h.x;
+    if (cur == 0) break;
+    if (cur == a && h.z == b + 1) {
+      *req = h.w;
+      return i;
+    }
     i = (i + 1) & r.mmask;
   }
+  *req = NONE;
   return NONE;
 }
 
@@ -197,17 +211,52 @@ __global__ __launch_bounds__(256) void k_setup(R r) {
 // spurious re-evaluation), loads.  Buckets that hold a read twice can meet a pair twice within one evaluation: they run one
 // partner at a time.  A single evaluation is a chain of dependent memory round trips, so the group form is what bounds
 // the latency of a pass: rows x ~4 round trips instead of examinations x ~4.
-constexpr uint32_t NCH = 256, ICHW = 64;  // arena chunks of a wavefront: reader nodes, items
-template <int GL>
-__device__ __forceinline__ uint64_t gbits(uint64_t wave_mask, int gbase) {
-  return GL == 64 ? wave_mask : ((wave_mask >> gbase) & ((1ULL << (GL & 63)) - 1ULL));
+constexpr uint32_t NCH = 256;  // reader-node arena chunk of a wavefront
+constexpr int GL = 16;         // lanes per bucket
+constexpr uint32_t GPW = 64 / GL, GPB = 256 / GL;
+__device__ __forceinline__ uint64_t gbits(uint64_t wave_mask, int gbase) { return (wave_mask >> gbase) & ((1ULL << GL) - 1ULL); }
+
+// group g of the launch -> its bucket (a range of buckets, or the dirty list)
+__device__ __forceinline__ uint64_t bucket_of_group(const R &r, uint32_t lo, uint32_t hi, uint32_t nlist, uint32_t g) {
+  if (nlist) return g < nlist ? (uint64_t)r.dlist[g] : (uint64_t)hi;
+  return (uint64_t)lo + g;
 }
-template <int GL>
-__global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
-  constexpr uint32_t GPW = 64 / GL;
-  const int lane = threadIdx.x & 63, gl = lane & (GL - 1), gbase = lane & ~(GL - 1);
+
+// readers of a pair later than bucket j become dirty (k_update only: nothing registers while it runs)
+__device__ __forceinline__ void mark_readers(const R &r, uint32_t slot, uint32_t j) {
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pt[slot]);
+  const uint4 h1 = *reinterpret_cast<const uint4 *>(w + 4);  // cnt, pad, in[0], in[1]
+  const uint32_t c = min(h1.x, NIN);
+  if (c > 0 && h1.z > j + 1) r.dirty[h1.z - 1] = 1;
+  if (c > 1 && h1.w > j + 1) r.dirty[h1.w - 1] = 1;
+  for (uint32_t q = 2; q < c; q += 8) {  // in[q .. q+8): two 16-byte loads in flight
+    const uint4 a = *reinterpret_cast<const uint4 *>(w + 6 + q), b = *reinterpret_cast<const uint4 *>(w + 10 + q);
+    const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (uint32_t k = 0; k < 8; ++k)
+      if (q + k < c && x[k] > j + 1) r.dirty[x[k] - 1] = 1;
+  }
+  if (c < NIN) return;
+  for (uint32_t nd = r.pt[slot].rhead; nd != NIL; nd = r.rn[nd - 1].next) {
+    const uint32_t rb = r.rn[nd - 1].bucket;
+    if (rb > j) r.dirty[rb] = 1;
+  }
+}
+
+// ---- shimmer_to_overlap (shmr_overlap.c:52-180) for every dirty bucket of the launch ------------------------------------
+// A group of 16 lanes per bucket.  The rows (ai, descending) are sequential -- they communicate through the "contained"
+// flags -- but the partners of one row are examined 16 at a time, speculatively: lane l takes partner pbase + l, and the
+// sequential semantics (stop once bestn overlaps are counted, or when the row's own read turns out contained) are then
+// resolved with ballots.  What a lane beyond the stop did is harmless: loads.  Buckets that hold a read twice can meet a
+// pair twice within one evaluation: they run one partner at a time.  A single evaluation is a chain of dependent memory
+// round trips, which is what bounds a sparse pass: the bucket's entries are staged in LDS once, a probe brings key and
+// owner in one 16-byte load, and registrations / item stores are not waited for.
+__global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uint32_t nlist) {
+  __shared__ uint32_t s_rid[GPB][128], s_pos[GPB][128], s_rl[GPB][128];
+  __shared__ uint8_t s_dir[GPB][128];
+  const int lane = threadIdx.x & 63, gl = lane & (GL - 1), gbase = lane & ~(GL - 1), gib = threadIdx.x / GL;
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t jj = (uint64_t)lo + (uint64_t)wave * GPW + (uint32_t)(lane / GL);
+  const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPW + (uint32_t)(lane / GL));
   const uint32_t j = (uint32_t)jj;
   bool alive = jj < hi && r.dirty[j] && !r.c->overflow;
   {
@@ -215,19 +264,26 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
     if (!am) return;
     if (lane == (int)__builtin_ctzll(am)) atomicAdd(&r.c->evals, (unsigned long long)(__popcll(am) / GL));
   }
-  // wave-uniform arena cursors; the wavefront that evaluates these buckets next time continues where this one stops
-  const uint32_t wave_id = (uint32_t)(((uint64_t)lo + (uint64_t)wave * GPW) / GPW);
+  // reader-node arena: wave-uniform cursor; the wavefront that evaluates these buckets next time continues where this one stops
+  const uint32_t wave_id = nlist ? r.wlist0 + wave : (uint32_t)(((uint64_t)lo + (uint64_t)wave * GPW) / GPW);
   const uint4 wc = r.wcur[wave_id];
-  uint32_t rcur = wc.x, rend = wc.y, icur = wc.z, iend = wc.w;
+  uint32_t rcur = wc.x, rend = wc.y;
   uint32_t s0 = 0, n = 0;
-  bool dup = false;
+  bool dup = false, first_eval = true;
   if (alive) {
     const uint32_t b = r.bid[j];
     s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
     dup = (r.bflags[j] & F_DUP) != 0;
+    first_eval = r.ever[j] == 0;
+    for (uint32_t i = (uint32_t)gl; i < n; i += GL) {  // the bucket's entries -> LDS
+      const uint64_t y = r.y0[s0 + i];
+      const uint32_t rid = (uint32_t)(y >> 32);
+      s_rid[gib][i] = rid, s_pos[gib][i] = (((uint32_t)y) >> 1) + 1, s_dir[gib][i] = r.dir[s0 + i], s_rl[gib][i] = r.rlen[rid];
+    }
     if (gl == 0) {
       r.dirty[j] = 0;
       r.evaluated[j] = 1;
+      r.ever[j] = 1;
       r.parity[j] ^= 1;
       r.ohead[j] = r.ihead[j];
     }
@@ -235,6 +291,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
   uint64_t clo = 0, chi = 0;  // "contained" flags of the bucket's entries (n <= 128)
   auto cget = [&](uint32_t i) { return (((i < 64 ? clo : chi) >> (i & 63)) & 1) != 0; };
   uint32_t head = NIL, num = 0, lookups = 0, skips = 0;
+  uint32_t chunk = 0;  // base of the item chunk holding insertion ordinals [num & ~15, ...)
   bool any_guess = false, any_unfiled = false;
   int ai = (int)n - 1;  // (the first row opened is n - 2)
   bool row_open = false;
@@ -250,13 +307,12 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
         }
         alive = false;
       } else {
-        const Ent e0 = entry_of(r.y0[s0 + ai]);
-        rid0 = e0.rid, pos0 = e0.pos1, rlen0 = r.rlen[rid0], dir0 = r.dir[s0 + ai];
+        rid0 = s_rid[gib][ai], pos0 = s_pos[gib][ai], rlen0 = s_rl[gib][ai], dir0 = s_dir[gib][ai];
         got = 0, pbase = (uint32_t)ai + 1, row_open = true;
       }
     }
     if (!__ballot(alive)) {
-      if (lane == 0) r.wcur[wave_id] = make_uint4(rcur, rend, icur, iend);
+      if (lane == 0) r.wcur[wave_id] = make_uint4(rcur, rend, 0, 0);
       break;
     }
     // ---- one batch of partners ----
@@ -265,18 +321,16 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
     bool valid = alive && (uint32_t)gl < step && pi < n && !cget(pi);
     uint32_t rid1 = 0, pos1 = 0;
     if (valid) {
-      const Ent e1 = entry_of(r.y0[s0 + pi]);
-      rid1 = e1.rid, pos1 = e1.pos1;
+      rid1 = s_rid[gib][pi], pos1 = s_pos[gib][pi];
       if (rid1 == rid0) valid = false;
     }
-    uint32_t slot = NONE;
+    uint32_t slot = NONE, v = 0;
     const uint64_t pair = rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0);
-    if (valid) slot = pair_find(r, pair);
+    if (valid) slot = pair_find(r, pair, &v);
     const uint64_t vm = __ballot(valid);
     bool present = false, accepted = false, guessed = false;
     uint32_t ptype = 0, type = 0, mslot = NONE;
     if (valid) {
-      const uint32_t v = slot != NONE ? r.pt[slot].own : 0u;
       present = v != 0 && own_bucket(v) < j;
       ptype = present ? own_type(v) : 0;
       if (!present && dup && slot != NONE)  // inserted earlier in THIS evaluation?
@@ -286,12 +340,11 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
             break;
           }
       if (!present) {
-        const uint32_t rlen1 = r.rlen[rid1], dir1 = r.dir[s0 + pi];
+        const uint32_t rlen1 = s_rl[gib][pi], dir1 = s_dir[gib][pi];
         const uint32_t q_off = pos0 - pos1;
         if (q_off >= (1u << 30)) atomicOr(&r.c->overflow, OV_QOFF);
-        mslot = memo_find(r, (unsigned long long)rid0 << 32 | rid1, q_off << 2 | dir0 << 1 | dir1);
-        uint32_t req = NONE;
-        if (mslot != NONE) req = r.mt[mslot].req;
+        uint32_t req;
+        mslot = memo_find(r, (unsigned long long)rid0 << 32 | rid1, q_off << 2 | dir0 << 1 | dir1, &req);
         if (req < r.settled) {
           accepted = classify(r.rq_res[req], rlen0, rlen1, q_off, &type);
         } else {
@@ -301,13 +354,13 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
       }
     }
     // ---- the sequential semantics of the row over this batch, lowest partner first ----
-    const uint64_t Vg = gbits<GL>(vm, gbase);
-    const uint64_t P = gbits<GL>(__ballot(valid && present), gbase);
-    const uint64_t PO = gbits<GL>(__ballot(valid && present && ptype == T_OVERLAP), gbase);
-    const uint64_t A = gbits<GL>(__ballot(valid && !present && accepted), gbase);
-    const uint64_t AO = gbits<GL>(__ballot(valid && !present && accepted && type == T_OVERLAP), gbase);
-    const uint64_t AC = gbits<GL>(__ballot(valid && !present && accepted && type == T_CONTAINED), gbase);
-    uint64_t AP = gbits<GL>(__ballot(valid && !present && accepted && type == T_CONTAINS), gbase);
+    const uint64_t Vg = gbits(vm, gbase);
+    const uint64_t P = gbits(__ballot(valid && present), gbase);
+    const uint64_t PO = gbits(__ballot(valid && present && ptype == T_OVERLAP), gbase);
+    const uint64_t A = gbits(__ballot(valid && !present && accepted), gbase);
+    const uint64_t AO = gbits(__ballot(valid && !present && accepted && type == T_OVERLAP), gbase);
+    const uint64_t AC = gbits(__ballot(valid && !present && accepted && type == T_CONTAINED), gbase);
+    uint64_t AP = gbits(__ballot(valid && !present && accepted && type == T_CONTAINS), gbase);
     const uint64_t inc = PO | AO;
     int stop = GL;  // the last partner the sequential loop processes in this batch (GL: all of them, and the row goes on)
     if (alive && row_open) {
@@ -319,24 +372,28 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
       }
       if (AC) stop = min(stop, (int)__builtin_ctzll(AC));
     }
-    const uint64_t proc = stop >= 63 ? ~0ULL : ((2ULL << stop) - 1ULL);
+    const uint64_t proc = (2ULL << stop) - 1ULL;
     const uint64_t ins = A & proc;
-    {  // the partners the sequential loop really examined register as readers of their pairs (the lists are only walked by
-       // k_update, after this kernel)
+    {  // the partners the sequential loop really examined register as readers of their pairs (the lists are only read by
+       // k_update, after this kernel); a bucket listed by an earlier evaluation is not listed again
       bool reg = valid && ((proc >> gl) & 1);
-      uint32_t idx = 0;
       if (reg && slot == NONE) slot = pair_slot(r, pair);  // a pair the walk really examines gets its slot now
-      if (reg) {  // a bucket listed by an earlier evaluation is not listed again (the inline part is checked; it holds most lists)
-        const uint32_t c = min(r.pt[slot].cnt, NIN);
-        for (uint32_t i = 0; i < c; ++i)
-          if (r.pt[slot].in[i] == j + 1) {
-            reg = false;
-            break;
-          }
-        if (reg) {
-          idx = atomicAdd(&r.pt[slot].cnt, 1u);
-          if (idx < NIN) r.pt[slot].in[idx] = j + 1, reg = false;
+      if (reg && !first_eval) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pt[slot]);
+        const uint4 h1 = *reinterpret_cast<const uint4 *>(w + 4);  // cnt, pad, in[0], in[1]
+        const uint32_t c = min(h1.x, NIN);
+        if ((c > 0 && h1.z == j + 1) || (c > 1 && h1.w == j + 1)) reg = false;
+        for (uint32_t q = 2; q < c && reg; q += 8) {
+          const uint4 a = *reinterpret_cast<const uint4 *>(w + 6 + q), b = *reinterpret_cast<const uint4 *>(w + 10 + q);
+          const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (uint32_t k = 0; k < 8; ++k)
+            if (q + k < c && x[k] == j + 1) reg = false;
         }
+      }
+      if (reg) {
+        const uint32_t idx = atomicAdd(&r.pt[slot].cnt, 1u);
+        if (idx < NIN) r.pt[slot].in[idx] = j + 1, reg = false;
       }
       const uint64_t rm = __ballot(reg);  // (what is left goes to the linked overflow)
       if (rm) {
@@ -359,38 +416,46 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
         rcur += total;
       }
     }
+    // ---- the batch's insertions: the bucket's items fill 16-aligned chunks of 16 in insertion order (k_update walks a
+    // bucket's list a chunk at a time, one lane per item) ----
     const bool my_ins = valid && !present && accepted && ((proc >> gl) & 1);
-    const uint64_t im = __ballot(my_ins);
-    if (im) {
-      const uint32_t total = (uint32_t)__popcll(im);
-      if (icur + total > iend) {
+    const uint32_t cins = (uint32_t)__popcll(ins);
+    const bool need_chunk = cins != 0 && (num == 0 || ((num + cins - 1) >> 4) != ((num - 1) >> 4));  // group-uniform
+    uint32_t fresh = 0;
+    {
+      const uint64_t cm = __ballot(need_chunk && gl == 0);
+      if (cm) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&r.c->item_top, ICHW);
-        base = (uint32_t)__shfl((int)base, 0, 64);
-        if ((uint64_t)base + ICHW > r.item_cap) {
+        if (lane == (int)__builtin_ctzll(cm)) base = atomicAdd(&r.c->item_top, 16u * (uint32_t)__popcll(cm));
+        base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(cm), 64);
+        if ((uint64_t)base + 16u * (uint32_t)__popcll(cm) > r.item_cap) {
           atomicOr(&r.c->overflow, OV_ITEMS);
           return;
         }
-        icur = base, iend = base + ICHW;
+        fresh = base + 16u * (uint32_t)__popcll(cm & ((1ULL << gbase) - 1ULL));  // (gl == 0 lanes: one bit per group)
       }
+    }
+    if (cins) {
       if (my_ins) {
-        const uint32_t idx = icur + lane_rank(im);
-        const uint32_t grank = (uint32_t)__popcll(ins & ((1ULL << gl) - 1ULL));
+        const uint32_t ord = num + (uint32_t)__popcll(ins & ((1ULL << gl) - 1ULL));  // insertion ordinal within the bucket
+        const bool in_fresh = need_chunk && (num == 0 || (ord >> 4) != ((num - 1) >> 4));
+        const uint32_t idx = (in_fresh ? fresh : chunk) + (ord & 15);
+        uint32_t next;
+        if (ord == 0) next = NIL;
+        else if ((ord & 15) == 0) next = chunk + 16;  // the last item of the previous chunk, + 1
+        else next = idx;                              // the item before this one, + 1
         uint32_t info = (uint32_t)ai | pi << 8 | type << 16;
         if (guessed) info |= I_GUESS;
         if (mslot == NONE) info |= I_UNFILED;
-        r.items[idx] = Item{slot, info, mslot, grank ? idx : head};  // (the previous insertion of the group sits at idx - 1)
+        r.items[idx] = Item{slot, info, mslot, next};
       }
-      if (ins) {
-        const int first = gbase + (int)__builtin_ctzll(ins);
-        const uint32_t frank = (uint32_t)__popcll(im & ((1ULL << first) - 1ULL));
-        head = icur + frank + (uint32_t)__popcll(ins);  // index of the group's last insertion, + 1
-        num += (uint32_t)__popcll(ins);
-      }
-      icur += total;
+      const uint32_t last = num + cins - 1;
+      if (need_chunk && (num == 0 || (last >> 4) != ((num - 1) >> 4))) chunk = fresh;
+      head = chunk + (last & 15) + 1;
+      num += cins;
     }
     {
-      const uint64_t g1 = gbits<GL>(__ballot(my_ins && guessed), gbase), g2 = gbits<GL>(__ballot(my_ins && mslot == NONE), gbase);
+      const uint64_t g1 = gbits(__ballot(my_ins && guessed), gbase), g2 = gbits(__ballot(my_ins && mslot == NONE), gbase);
       any_guess |= g1 != 0, any_unfiled |= g2 != 0;
     }
     if (alive && row_open) {
@@ -416,53 +481,59 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi) {
   }
 }
 
-__device__ __forceinline__ void mark_readers(const R &r, uint32_t slot, uint32_t j) {
-  const uint32_t c = min(r.pt[slot].cnt, NIN);
-  for (uint32_t i = 0; i < c; ++i) {
-    const uint32_t x = r.pt[slot].in[i];
-    if (x > j + 1) r.dirty[x - 1] = 1;
-  }
-  if (c < NIN) return;
-  for (uint32_t nd = r.pt[slot].rhead; nd != NIL; nd = r.rn[nd - 1].next) {
-    const uint32_t rb = r.rn[nd - 1].bucket;
-    if (rb > j) r.dirty[rb] = 1;
+// ---- apply the evaluated buckets' lists to the pair table: a group per bucket, a lane per item ---------------------------
+__device__ __forceinline__ void apply_insertion(const R &r, uint32_t j, uint32_t pnew, const Item &im) {
+  const uint32_t slot = im.pslot, type = (im.info >> 16) & 3;
+  const uint32_t mine = own_enc(j, pnew, type);
+  uint32_t v = r.pt[slot].own;
+  for (;;) {
+    if (v != 0 && own_bucket(v) < j) {  // an earlier bucket got in first: this evaluation is stale
+      r.dirty[j] = 1;
+      return;
+    }
+    const uint32_t prev = atomicCAS(&r.pt[slot].own, v, mine);
+    if (prev == v) {
+      if (v == 0 || own_bucket(v) > j) mark_readers(r, slot, j);  // absent -> present, or a later owner displaced (it reads the pair too)
+      else if ((own_type(v) == T_OVERLAP) != (type == T_OVERLAP)) mark_readers(r, slot, j);  // ours before: readers see the type class
+      return;
+    }
+    v = prev;
   }
 }
-
-// ---- apply the evaluated buckets' lists to the pair table ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_update(R r, uint32_t lo, uint32_t hi) {
-  const uint32_t j = lo + blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= hi || !r.evaluated[j] || r.c->overflow) return;
-  r.evaluated[j] = 0;
-  const uint32_t pnew = r.parity[j], pold = pnew ^ 1;
+__global__ __launch_bounds__(256) void k_update(R r, uint32_t lo, uint32_t hi, uint32_t nlist) {
+  const int lane = threadIdx.x & 63, gl = lane & (GL - 1);
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPW + (uint32_t)(lane / GL));
+  const uint32_t j = (uint32_t)jj;
+  const bool alive = jj < hi && r.evaluated[j] && !r.c->overflow;
+  if (!__ballot(alive)) return;
+  const uint32_t pnew = alive ? r.parity[j] : 0, pold = pnew ^ 1;
   // what this evaluation inserts: take or refresh ownership (lowest bucket wins)
-  for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) {
-    const uint32_t slot = r.items[it - 1].pslot, type = (r.items[it - 1].info >> 16) & 3;
-    const uint32_t mine = own_enc(j, pnew, type);
-    uint32_t v = r.pt[slot].own;
-    for (;;) {
-      if (v != 0 && own_bucket(v) < j) {  // an earlier bucket got in first: this evaluation is stale
-        r.dirty[j] = 1;
-        break;
-      }
-      const uint32_t prev = atomicCAS(&r.pt[slot].own, v, mine);
-      if (prev == v) {
-        if (v == 0 || own_bucket(v) > j) mark_readers(r, slot, j);  // absent -> present, or a later owner displaced (it reads the pair too)
-        else if ((own_type(v) == T_OVERLAP) != (type == T_OVERLAP)) mark_readers(r, slot, j);  // ours before: readers see the type class
-        break;
-      }
-      v = prev;
+  uint32_t cur = alive ? r.ihead[j] : NIL;
+  while (__ballot(cur != NIL)) {
+    if (cur != NIL) {
+      const uint32_t last = cur - 1, base = last & ~15u, cnt = (last & 15) + 1;
+      const Item first = r.items[base];
+      if ((uint32_t)gl < cnt) apply_insertion(r, j, pnew, gl == 0 ? first : r.items[base + gl]);
+      cur = first.next;
     }
   }
   // what the previous evaluation inserted and this one did not refresh: withdraw
-  for (uint32_t it = r.ohead[j]; it != NIL; it = r.items[it - 1].next) {
-    const uint32_t slot = r.items[it - 1].pslot;
-    const uint32_t v = r.pt[slot].own;
-    if (v != 0 && own_bucket(v) == j && own_parity(v) == pold) {
-      if (atomicCAS(&r.pt[slot].own, v, 0u) == v) mark_readers(r, slot, j);
+  cur = alive ? r.ohead[j] : NIL;
+  while (__ballot(cur != NIL)) {
+    if (cur != NIL) {
+      const uint32_t last = cur - 1, base = last & ~15u, cnt = (last & 15) + 1;
+      const uint32_t nxt = r.items[base].next;
+      if ((uint32_t)gl < cnt) {
+        const uint32_t slot = r.items[base + gl].pslot;
+        const uint32_t v = r.pt[slot].own;
+        if (v != 0 && own_bucket(v) == j && own_parity(v) == pold)
+          if (atomicCAS(&r.pt[slot].own, v, 0u) == v) mark_readers(r, slot, j);
+      }
+      cur = nxt;
     }
   }
-  r.ohead[j] = NIL;
+  if (alive && gl == 0) r.evaluated[j] = 0, r.ohead[j] = NIL;
 }
 
 __global__ __launch_bounds__(256) void k_count(R r) {
@@ -470,11 +541,16 @@ __global__ __launch_bounds__(256) void k_count(R r) {
   const bool d = j < r.nb && r.dirty[j];
   const uint64_t m = __ballot(d);
   if (!m) return;
-  if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(m)) {
-    atomicAdd(&r.c->ndirty, (uint32_t)__popcll(m));
+  uint32_t base = 0;
+  const int leader = __builtin_ctzll(m);
+  if ((int)(threadIdx.x & 63) == leader) {
+    base = atomicAdd(&r.c->ndirty, (uint32_t)__popcll(m));
     atomicMin(&r.c->min_dirty, j);
     atomicMax(&r.c->max_dirty, (j & ~63u) + 63 - (uint32_t)__builtin_clzll(m));
   }
+  base = (uint32_t)__shfl((int)base, leader, 64);
+  const uint32_t at = base + lane_rank(m);
+  if (d && at < LIST_CAP) r.dlist[at] = j;
 }
 
 // ---- file the alignments the converged lists still need ---------------------------------------------------------------
@@ -639,7 +715,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   DevBuf<PSlot> pt(pcap);
   DevBuf<MSlot> mt(mcap);
   r.pt = pt.p, r.pmask = pcap - 1, r.mt = mt.p, r.mmask = mcap - 1;
-  r.item_cap = (uint32_t)std::min<size_t>((size_t)(ne * 6 * mult[0]) + (1u << 20), 0x7FFFFFF0u);
+  r.item_cap = (uint32_t)std::min<size_t>((size_t)(ne * 6 * mult[0]) + nb * (size_t)64 + (1u << 20), 0x7FFFFFF0u);
   r.rn_cap = (uint32_t)std::min<size_t>((size_t)(ne * 8 * mult[1]) + (1u << 20), 0x7FFFFFF0u);
   r.req_cap = (uint32_t)std::min<size_t>((size_t)(ne * 1 * mult[2]) + 65536, 0x7FFFFFF0u);
   DevBuf<Item> items(r.item_cap);
@@ -647,19 +723,21 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   DevBuf<pgx_align_key> rq_key(r.req_cap);
   DevBuf<pgx_match> rq_res(r.req_cap);
   r.items = items.p, r.rn = rn.p, r.rq_key = rq_key.p, r.rq_res = rq_res.p;
-  DevBuf<uint8_t> bytes(nb * 4);
+  DevBuf<uint8_t> bytes(nb * 5);
   DevBuf<uint32_t> words(nb * 5);
-  r.dirty = bytes.p, r.evaluated = bytes.p + nb, r.parity = bytes.p + 2 * nb, r.bflags = bytes.p + 3 * nb;
+  r.dirty = bytes.p, r.evaluated = bytes.p + nb, r.parity = bytes.p + 2 * nb, r.bflags = bytes.p + 3 * nb, r.ever = bytes.p + 4 * nb;
   r.ihead = words.p, r.inum = words.p + nb, r.ohead = words.p + 2 * nb, r.lookups = words.p + 3 * nb, r.skips = words.p + 4 * nb;
-  DevBuf<uint4> wcur(nb / 4 + 2);  // (k_eval<16>: four buckets per wavefront)
-  r.wcur = wcur.p;
-  PGX_HIP(hipMemsetAsync(wcur.p, 0, (nb / 4 + 2) * sizeof(uint4), s));
+  DevBuf<uint4> wcur(nb / 4 + 2 + LIST_CAP / 4 + 1);  // (k_eval<16>: four buckets per wavefront)
+  r.wcur = wcur.p, r.wlist0 = (uint32_t)(nb / 4 + 2);
+  PGX_HIP(hipMemsetAsync(wcur.p, 0, wcur.n * sizeof(uint4), s));
+  DevBuf<uint32_t> dlist(LIST_CAP);
+  r.dlist = dlist.p;
   DevBuf<Counters> dc(1);
   r.c = dc.p;
   r.bestn = bestn, r.predict = predict ? 1 : 0, r.settled = 0;
   PGX_HIP(hipMemsetAsync(pt.p, 0, (size_t)pcap * sizeof(PSlot), s));
   PGX_HIP(hipMemsetAsync(mt.p, 0, (size_t)mcap * sizeof(MSlot), s));
-  PGX_HIP(hipMemsetAsync(bytes.p, 0, nb * 4, s));
+  PGX_HIP(hipMemsetAsync(bytes.p, 0, nb * 5, s));
   PGX_HIP(hipMemsetAsync(words.p, 0, nb * 5 * sizeof(uint32_t), s));
   PGX_HIP(hipMemsetAsync(dc.p, 0, sizeof(Counters), s));
   hipLaunchKernelGGL(k_setup, dim3(cdiv256(nb)), dim3(256), 0, s, r);
@@ -688,6 +766,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   unsigned sweeps = 0, passes_total = 0;
   uint32_t d_lo = 0, d_hi = (uint32_t)nb;  // range holding the dirty buckets
   size_t n_dirty = nb;
+  bool listed = false;  // dlist holds the n_dirty dirty buckets (after a count)
   double align_ms = 0;
   for (;;) {
     ++sweeps;
@@ -695,18 +774,26 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     unsigned passes = 0;
     while (n_dirty) {
       ++passes;
-      // dense: window by window, in order (a window's buckets mostly depend on earlier windows); sparse: the whole range at once
-      const size_t win = n_dirty > window / 4 ? window : (size_t)(d_hi - (d_lo & ~63u));
-      for (size_t lo = d_lo & ~(size_t)63; lo < d_hi; lo += win) {  // (aligned: a bucket always belongs to the same wavefront slot)
-        const uint32_t hi = (uint32_t)std::min<size_t>(d_hi, lo + win);
-        for (int k = 0; k < inner; ++k) {
-          if (deep) sync(), td = now_ms();
-          hipLaunchKernelGGL((k_eval<16>), dim3(cdiv256((size_t)(hi - lo) * 16)), dim3(256), 0, s, r, (uint32_t)lo, hi);
-          if (deep) sync(), t_eval += now_ms() - td, td = now_ms();
-          hipLaunchKernelGGL(k_update, dim3(cdiv256(hi - lo)), dim3(256), 0, s, r, (uint32_t)lo, hi);
-          if (deep) sync(), t_upd += now_ms() - td, fprintf(stderr, "[pgx]     iteration: eval %.3f ms, update %.3f ms\n", t_eval, t_upd), t_eval = t_upd = 0;
+      if (listed && n_dirty <= LIST_CAP) {
+        // sparse: straight from the list k_count left (what these evaluations dirty in turn is listed by the next count)
+        hipLaunchKernelGGL(k_eval, dim3(cdiv256(n_dirty * 16)), dim3(256), 0, s, r, 0u, (uint32_t)nb, (uint32_t)n_dirty);
+        hipLaunchKernelGGL(k_update, dim3(cdiv256(n_dirty * 16)), dim3(256), 0, s, r, 0u, (uint32_t)nb, (uint32_t)n_dirty);
+      } else {
+        // dense: window by window, in order (a window's buckets mostly depend on earlier windows)
+        const size_t a_lo = d_lo & ~(size_t)63;  // (aligned: a bucket always belongs to the same wavefront slot)
+        const size_t win = n_dirty > window / 4 ? window : (size_t)(d_hi - a_lo);
+        for (size_t lo = a_lo; lo < d_hi; lo += win) {
+          const uint32_t hi = (uint32_t)std::min<size_t>(d_hi, lo + win);
+          for (int k = 0; k < inner; ++k) {
+            if (deep) sync(), td = now_ms();
+            hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * 16)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
+            if (deep) sync(), t_eval += now_ms() - td, td = now_ms();
+            hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)(hi - lo) * 16)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
+            if (deep) sync(), t_upd += now_ms() - td, fprintf(stderr, "[pgx]     iteration: eval %.3f ms, update %.3f ms\n", t_eval, t_upd), t_eval = t_upd = 0;
+          }
         }
       }
+      listed = true;
       if (!read_counters(true)) goto overflowed;
       if (trace)
         fprintf(stderr, "[pgx]   pass %u: %zu dirty in [%u, %u) -> %u dirty, %llu evaluations, t = +%.2f ms\n", passes, n_dirty, d_lo, d_hi,
