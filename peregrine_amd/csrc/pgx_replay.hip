@@ -554,9 +554,11 @@ __global__ __launch_bounds__(256) void k_count(R r) {
 }
 
 // ---- file the alignments the converged lists still need ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_file(R r) {
+// (limit < nb: an early filing while the sweep is still running -- buckets below limit that are not dirty right now.  Filing
+// is always safe: a request is just an alignment whose result the memo will hold; at worst it is never asked for again.)
+__global__ __launch_bounds__(256) void k_file(R r, uint32_t limit) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = j < r.nb && (r.bflags[j] & F_UNFILED);
+  const bool active = j < limit && (r.bflags[j] & F_UNFILED) && (limit == r.nb || !r.dirty[j]);
   if (!__ballot(active)) return;
   uint32_t cnt = 0;
   if (active)
@@ -704,6 +706,9 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
                         size_t *n_out, pgx_overlap_stats *st, bool trace, const double *mult) {
   const double t0 = now_ms();
   hipStream_t s = ctx().stream;
+  struct SideGuard {  // whatever way this attempt ends, nothing of it is still running on the second stream
+    ~SideGuard() { (void)hipStreamSynchronize(ctx().side); }
+  } side_guard;
   const size_t ne = std::max<size_t>(n_entries, 1024);
   R r;
   memset(&r, 0, sizeof(r));
@@ -762,7 +767,16 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 3;
   static const bool deep = getenv("PGX_TRACE") && atoi(getenv("PGX_TRACE")) >= 2;  // per-kernel wall times (synchronises after every launch)
   double td = 0, t_eval = 0, t_upd = 0;
-  size_t first_req = 0;
+  size_t first_req = 0, submitted = 0;  // requests [first_req, ...) belong to the running sweep; [.., submitted) are with the GPU already
+  // PGX_REPLAY_OVERLAP=1: start the alignments of the windows already done on the second stream, beside the next windows'
+  // evaluations.  Measured at 4.5 Gbases: no gain (250-266 vs 244 ms per step) -- the alignment kernel is bound by VALU issue
+  // and holds most wavefront slots, so the latency-bound evaluation kernels beside it just take as much longer (first
+  // sweep 39 -> 117 ms while 77 ms of alignments run).  Off by default.
+  const bool overlap = getenv("PGX_REPLAY_OVERLAP") && atoi(getenv("PGX_REPLAY_OVERLAP")) != 0;
+  const int side_waves = getenv("PGX_REPLAY_SIDE_WAVES") ? atoi(getenv("PGX_REPLAY_SIDE_WAVES")) : 24;
+  bool side_busy = false;
+  static hipEvent_t side_done = nullptr;
+  if (!side_done) PGX_HIP(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
   unsigned sweeps = 0, passes_total = 0;
   uint32_t d_lo = 0, d_hi = (uint32_t)nb;  // range holding the dirty buckets
   size_t n_dirty = nb;
@@ -791,6 +805,26 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
             hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)(hi - lo) * 16)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
             if (deep) sync(), t_upd += now_ms() - td, fprintf(stderr, "[pgx]     iteration: eval %.3f ms, update %.3f ms\n", t_eval, t_upd), t_eval = t_upd = 0;
           }
+          if (overlap && hi < d_hi) {
+            // the alignments of the windows done so far start now, on the second stream, beside the next windows' evaluations
+            hipLaunchKernelGGL(k_file, dim3(cdiv256(hi)), dim3(256), 0, s, r, hi);
+            if (!read_counters(false)) goto overflowed;
+            if (hc->nreq - submitted >= 65536) {
+              const size_t upto = hc->nreq;
+              hipStream_t main_stream = ctx().stream;
+              ctx().stream = ctx().side;  // (dev_align and its timer work on the context's stream)
+              try {
+                dev_align(db, r.rq_key + submitted, upto - submitted, band, r.rq_res + submitted, side_waves);
+              } catch (...) {
+                ctx().stream = main_stream;
+                throw;
+              }
+              ctx().stream = main_stream;
+              side_busy = true;
+              if (trace) fprintf(stderr, "[pgx]   %zu alignments started beside the sweep at t = +%.2f ms\n", upto - submitted, now_ms() - t0);
+              submitted = upto;
+            }
+          }
         }
       }
       listed = true;
@@ -806,7 +840,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
       }
     }
     passes_total += passes;
-    hipLaunchKernelGGL(k_file, dim3(cdiv256(nb)), dim3(256), 0, s, r);
+    hipLaunchKernelGGL(k_file, dim3(cdiv256(nb)), dim3(256), 0, s, r, (uint32_t)nb);
     if (!read_counters(false)) goto overflowed;
     const size_t nreq = hc->nreq;
     if (trace)
@@ -814,9 +848,14 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
               (unsigned long long)hc->evals, now_ms() - p0, nreq - first_req);
     if (nreq == first_req) break;
     const double a0 = now_ms();
-    dev_align(db, r.rq_key + first_req, nreq - first_req, band, r.rq_res + first_req);
+    if (nreq > submitted) dev_align(db, r.rq_key + submitted, nreq - submitted, band, r.rq_res + submitted);
+    if (side_busy) {  // the batches on the second stream must be in before the results are read
+      PGX_HIP(hipEventRecord(side_done, ctx().side));
+      PGX_HIP(hipStreamWaitEvent(s, side_done, 0));
+      side_busy = false;
+    }
     r.settled = (uint32_t)nreq;
-    first_req = nreq;
+    first_req = submitted = nreq;
     hipLaunchKernelGGL(k_settle, dim3(cdiv256(nb)), dim3(256), 0, s, r);
     if (!read_counters(true)) goto overflowed;
     align_ms += now_ms() - a0;
