@@ -178,7 +178,7 @@ def main():
 
     if rank == 0:
         kern = {}
-        for name in ("sketch", "sketch_literal", "sketch_gather", "reduce", "count", "align", "align1"):
+        for name in ("sketch", "sketch_literal", "sketch_gather", "reduce", "count", "pairs", "replay", "align", "align1"):
             ms, launches, units = _lib.timing(name)
             if launches:
                 kern[name] = {"ms_total": ms, "launches": launches, "units": units, "avg_ms": ms / launches}

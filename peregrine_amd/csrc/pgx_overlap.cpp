@@ -1342,13 +1342,14 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     }
   } defer_scratch{scratch};
   PairTables &pt = scratch->pt;
-  // The greedy walk itself runs on the GPU (pgx_replay.hip) from ~0.4 M pair records on, where it is faster than the
-  // multi-threaded host replay below (overlap stage, 30x sets: 5 Mb 18.7 vs 19.7 ms; 20 Mb 44 vs 53 ms; 80 Mb 134 vs 217 ms;
+  // The greedy walk itself runs on the GPU (pgx_replay.hip) from 0.2 M pair records on, where it is as fast as or faster than
+  // the multi-threaded host replay below and does not lean on the host cores, which the ranks of a multi-GPU job share
+  // (overlap stage, 30x sets: E. coli-size 10.2 vs 10.1 ms per step; 5 Mb 18.7 vs 19.7 ms; 20 Mb 44 vs 53 ms; 80 Mb 134 vs 217 ms;
   // 150 Mb 0.23 vs 0.45 s; below that a sweep is bound by the latency of single bucket evaluations and kernel launches:
   // 1 Mb 11.8 vs 9.8 ms, 0.3 Mb 10.9 vs 6.1 ms).  PGX_GPU_REPLAY=1 / 0 forces either one; the host replay is also the
   // fallback for jobs the device tables' encodings do not hold.
   const int gpu_replay_env = getenv("PGX_GPU_REPLAY") ? atoi(getenv("PGX_GPU_REPLAY")) : -1;
-  static const size_t gpu_replay_min = getenv("PGX_GPU_REPLAY_MIN") ? (size_t)atoll(getenv("PGX_GPU_REPLAY_MIN")) : (size_t)400000;
+  static const size_t gpu_replay_min = getenv("PGX_GPU_REPLAY_MIN") ? (size_t)atoll(getenv("PGX_GPU_REPLAY_MIN")) : (size_t)200000;
   bool gpu_replay = gpu_replay_env != 0;  // (decided once the join has counted the records)
   const bool trace = getenv("PGX_TRACE") != nullptr;
   const bool predict = !(getenv("PGX_PREDICT") && atoi(getenv("PGX_PREDICT")) == 0);

@@ -23,6 +23,7 @@
 // observe, and the owner of a pair is the lowest bucket inserting it: by induction over the bucket order that is the
 // sequential walk.  Changes only ever propagate to LATER buckets, so the lowest unstable bucket rises monotonically.
 #include <chrono>
+#include <optional>
 
 #include <hipcub/hipcub.hpp>
 
@@ -61,7 +62,7 @@ struct RNode {
   uint32_t next, bucket;
 };
 constexpr uint32_t I_GUESS = 1u << 18, I_UNFILED = 1u << 19;
-constexpr uint32_t LIST_CAP = 16384;
+constexpr uint32_t LIST_CAP = 16384, DEV_LIST = 0xFFFFFFFFu;
 enum : uint32_t { OV_ITEMS = 1, OV_NODES = 2, OV_REQS = 4, OV_PAIRS = 8, OV_MEMO = 16, OV_QOFF = 32, OV_PASSES = 64 };  // Counters::overflow
 constexpr uint8_t F_DUP = 1, F_GUESS = 2, F_UNFILED = 4;
 
@@ -218,7 +219,10 @@ __device__ __forceinline__ uint64_t gbits(uint64_t wave_mask, int gbase) { retur
 
 // group g of the launch -> its bucket (a range of buckets, or the dirty list)
 __device__ __forceinline__ uint64_t bucket_of_group(const R &r, uint32_t lo, uint32_t hi, uint32_t nlist, uint32_t g) {
-  if (nlist) return g < nlist ? (uint64_t)r.dlist[g] : (uint64_t)hi;
+  if (nlist) {
+    const uint32_t n = nlist == DEV_LIST ? min(r.c->ndirty, LIST_CAP) : nlist;  // (DEV_LIST: as many as the last count listed)
+    return g < n ? (uint64_t)r.dlist[g] : (uint64_t)hi;
+  }
   return (uint64_t)lo + g;
 }
 
@@ -554,11 +558,12 @@ __global__ __launch_bounds__(256) void k_count(R r) {
 }
 
 // ---- file the alignments the converged lists still need ---------------------------------------------------------------
-// (limit < nb: an early filing while the sweep is still running -- buckets below limit that are not dirty right now.  Filing
-// is always safe: a request is just an alignment whose result the memo will hold; at worst it is never asked for again.)
+// (Only buckets that are not dirty right now are filed -- the others are about to be evaluated again.  Filing while the sweep
+// is still running is always safe: a request is just an alignment whose result the memo will hold; at worst it is never
+// asked for again.)
 __global__ __launch_bounds__(256) void k_file(R r, uint32_t limit) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = j < limit && (r.bflags[j] & F_UNFILED) && (limit == r.nb || !r.dirty[j]);
+  const bool active = j < limit && (r.bflags[j] & F_UNFILED) && !r.dirty[j];
   if (!__ballot(active)) return;
   uint32_t cnt = 0;
   if (active)
@@ -765,104 +770,105 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   };
   const size_t window = getenv("PGX_REPLAY_WIN") ? (size_t)atoll(getenv("PGX_REPLAY_WIN")) : (size_t)262144;
   const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 3;
+  const int chain = getenv("PGX_REPLAY_CHAIN") ? std::max(1, atoi(getenv("PGX_REPLAY_CHAIN"))) : 4;
   static const bool deep = getenv("PGX_TRACE") && atoi(getenv("PGX_TRACE")) >= 2;  // per-kernel wall times (synchronises after every launch)
+  static const bool timed = getenv("PGX_REPLAY_TIMING") && atoi(getenv("PGX_REPLAY_TIMING")) != 0;  // "replay" in pgx_timing_get
   double td = 0, t_eval = 0, t_upd = 0;
-  size_t first_req = 0, submitted = 0;  // requests [first_req, ...) belong to the running sweep; [.., submitted) are with the GPU already
-  // PGX_REPLAY_OVERLAP=1: start the alignments of the windows already done on the second stream, beside the next windows'
-  // evaluations.  Measured at 4.5 Gbases: no gain (250-266 vs 244 ms per step) -- the alignment kernel is bound by VALU issue
-  // and holds most wavefront slots, so the latency-bound evaluation kernels beside it just take as much longer (first
-  // sweep 39 -> 117 ms while 77 ms of alignments run).  Off by default.
-  const bool overlap = getenv("PGX_REPLAY_OVERLAP") && atoi(getenv("PGX_REPLAY_OVERLAP")) != 0;
-  const int side_waves = getenv("PGX_REPLAY_SIDE_WAVES") ? atoi(getenv("PGX_REPLAY_SIDE_WAVES")) : 24;
-  bool side_busy = false;
-  static hipEvent_t side_done = nullptr;
-  if (!side_done) PGX_HIP(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
-  unsigned sweeps = 0, passes_total = 0;
+  size_t first_req = 0;  // requests [first_req, ...) belong to the running sweep
+  unsigned sweeps = 0, rounds_total = 0;
   uint32_t d_lo = 0, d_hi = (uint32_t)nb;  // range holding the dirty buckets
-  size_t n_dirty = nb;
-  bool listed = false;  // dlist holds the n_dirty dirty buckets (after a count)
+  size_t n_dirty = nb;                     // as of the last fetch
+  bool have_list = false;                  // the device holds a dirty list (a count has run since the last evaluations)
+  bool known = true;                       // n_dirty / d_lo / d_hi are current
   double align_ms = 0;
+  auto count_dirty = [&] {  // no host round trip: ndirty, the range and the list stay on the device
+    PGX_HIP(hipMemcpyAsync(&dc.p->ndirty, reset3, 3 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_count, dim3(cdiv256(nb)), dim3(256), 0, s, r);
+    have_list = true;
+  };
   for (;;) {
     ++sweeps;
     const double p0 = now_ms();
-    unsigned passes = 0;
-    while (n_dirty) {
-      ++passes;
-      if (listed && n_dirty <= LIST_CAP) {
-        // sparse: straight from the list k_count left (what these evaluations dirty in turn is listed by the next count)
-        hipLaunchKernelGGL(k_eval, dim3(cdiv256(n_dirty * 16)), dim3(256), 0, s, r, 0u, (uint32_t)nb, (uint32_t)n_dirty);
-        hipLaunchKernelGGL(k_update, dim3(cdiv256(n_dirty * 16)), dim3(256), 0, s, r, 0u, (uint32_t)nb, (uint32_t)n_dirty);
-      } else {
+    unsigned rounds = 0;
+    for (;;) {  // until no bucket is dirty
+      ++rounds;
+      if (known && n_dirty > LIST_CAP / 2) {
         // dense: window by window, in order (a window's buckets mostly depend on earlier windows)
         const size_t a_lo = d_lo & ~(size_t)63;  // (aligned: a bucket always belongs to the same wavefront slot)
         const size_t win = n_dirty > window / 4 ? window : (size_t)(d_hi - a_lo);
         for (size_t lo = a_lo; lo < d_hi; lo += win) {
           const uint32_t hi = (uint32_t)std::min<size_t>(d_hi, lo + win);
           for (int k = 0; k < inner; ++k) {
+            std::optional<KernelTimer> tm;
+            if (timed) tm.emplace("replay", k == 0 ? hi - lo : 0);  // (units: buckets of the window, counted once)
             if (deep) sync(), td = now_ms();
             hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * 16)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
             if (deep) sync(), t_eval += now_ms() - td, td = now_ms();
             hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)(hi - lo) * 16)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
             if (deep) sync(), t_upd += now_ms() - td, fprintf(stderr, "[pgx]     iteration: eval %.3f ms, update %.3f ms\n", t_eval, t_upd), t_eval = t_upd = 0;
           }
-          if (overlap && hi < d_hi) {
-            // the alignments of the windows done so far start now, on the second stream, beside the next windows' evaluations
-            hipLaunchKernelGGL(k_file, dim3(cdiv256(hi)), dim3(256), 0, s, r, hi);
-            if (!read_counters(false)) goto overflowed;
-            if (hc->nreq - submitted >= 65536) {
-              const size_t upto = hc->nreq;
-              hipStream_t main_stream = ctx().stream;
-              ctx().stream = ctx().side;  // (dev_align and its timer work on the context's stream)
-              try {
-                dev_align(db, r.rq_key + submitted, upto - submitted, band, r.rq_res + submitted, side_waves);
-              } catch (...) {
-                ctx().stream = main_stream;
-                throw;
-              }
-              ctx().stream = main_stream;
-              side_busy = true;
-              if (trace) fprintf(stderr, "[pgx]   %zu alignments started beside the sweep at t = +%.2f ms\n", upto - submitted, now_ms() - t0);
-              submitted = upto;
-            }
-          }
+        }
+        count_dirty();
+      }
+      // sparse: `chain` passes straight from the list the last count left on the device -- the kernels read its length there,
+      // so the host is not in the loop (a pass with nothing to do costs two empty launches); what a pass dirties is listed by
+      // the count behind it
+      if (!have_list) count_dirty();
+      {
+        const size_t est = known && n_dirty <= LIST_CAP / 2 ? std::max<size_t>(n_dirty * 4, 1024) : (size_t)LIST_CAP;
+        const unsigned groups = (unsigned)std::min<size_t>(est, LIST_CAP);
+        for (int c = 0; c < chain; ++c) {
+          std::optional<KernelTimer> tm;
+          if (timed) tm.emplace("replay", 0);
+          hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)groups * 16)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
+          hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)groups * 16)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
+          tm.reset();
+          count_dirty();
         }
       }
-      listed = true;
-      if (!read_counters(true)) goto overflowed;
-      if (trace)
-        fprintf(stderr, "[pgx]   pass %u: %zu dirty in [%u, %u) -> %u dirty, %llu evaluations, t = +%.2f ms\n", passes, n_dirty, d_lo, d_hi,
-                hc->ndirty, (unsigned long long)hc->evals, now_ms() - t0);
-      n_dirty = hc->ndirty;
+      // file what the clean buckets need (always safe), then one round trip for everything: dirty count, range, requests
+      hipLaunchKernelGGL(k_file, dim3(cdiv256(nb)), dim3(256), 0, s, r, (uint32_t)nb);
+      PGX_HIP(hipMemcpyAsync(hc, dc.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
+      sync();
+      if (hc->overflow) goto overflowed;
+      n_dirty = hc->ndirty, known = true;
       d_lo = n_dirty ? hc->min_dirty : 0, d_hi = n_dirty ? hc->max_dirty + 1 : 0;
-      if (passes > 20000) {  // (cannot happen: the lowest unstable bucket rises every pass)
+      if (trace)
+        fprintf(stderr, "[pgx]   round %u: %zu dirty left in [%u, %u), %llu evaluations, t = +%.2f ms\n", rounds, n_dirty, d_lo, d_hi,
+                (unsigned long long)hc->evals, now_ms() - t0);
+      if (!n_dirty) break;
+      if (rounds > 20000) {  // (cannot happen: the lowest unstable bucket rises every pass)
         hc->overflow |= OV_PASSES;
         goto overflowed;
       }
     }
-    passes_total += passes;
-    hipLaunchKernelGGL(k_file, dim3(cdiv256(nb)), dim3(256), 0, s, r, (uint32_t)nb);
-    if (!read_counters(false)) goto overflowed;
+    rounds_total += rounds;
     const size_t nreq = hc->nreq;
     if (trace)
-      fprintf(stderr, "[pgx] device sweep %u: %u passes, %llu evaluations so far, %.2f ms, %zu requests\n", sweeps, passes,
+      fprintf(stderr, "[pgx] device sweep %u: %u rounds, %llu evaluations so far, %.2f ms, %zu requests\n", sweeps, rounds,
               (unsigned long long)hc->evals, now_ms() - p0, nreq - first_req);
     if (nreq == first_req) break;
     const double a0 = now_ms();
-    if (nreq > submitted) dev_align(db, r.rq_key + submitted, nreq - submitted, band, r.rq_res + submitted);
-    if (side_busy) {  // the batches on the second stream must be in before the results are read
-      PGX_HIP(hipEventRecord(side_done, ctx().side));
-      PGX_HIP(hipStreamWaitEvent(s, side_done, 0));
-      side_busy = false;
-    }
+    const size_t batch = nreq - first_req;
+    dev_align(db, r.rq_key + first_req, batch, band, r.rq_res + first_req);
     r.settled = (uint32_t)nreq;
-    first_req = submitted = nreq;
+    first_req = nreq;
     hipLaunchKernelGGL(k_settle, dim3(cdiv256(nb)), dim3(256), 0, s, r);
-    if (!read_counters(true)) goto overflowed;
+    count_dirty();
+    if (batch > 100000) {  // a big batch: worth a round trip to know how many guesses were wrong (dense or sparse next)
+      PGX_HIP(hipMemcpyAsync(hc, dc.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
+      sync();
+      if (hc->overflow) goto overflowed;
+      n_dirty = hc->ndirty, known = true;
+      d_lo = n_dirty ? hc->min_dirty : 0, d_hi = n_dirty ? hc->max_dirty + 1 : 0;
+      if (trace) fprintf(stderr, "[pgx]   alignments + settle %.2f ms, %zu buckets guessed wrong\n", now_ms() - a0, n_dirty);
+      if (!n_dirty) break;
+    } else {
+      known = false;  // (a small batch: the wrong guesses are handled by the sparse passes of the next round)
+      n_dirty = std::min<size_t>(batch, LIST_CAP / 8);
+      if (trace) fprintf(stderr, "[pgx]   %zu alignments + settle enqueued in %.2f ms\n", batch, now_ms() - a0);
+    }
     align_ms += now_ms() - a0;
-    n_dirty = hc->ndirty;
-    d_lo = n_dirty ? hc->min_dirty : 0, d_hi = n_dirty ? hc->max_dirty + 1 : 0;
-    if (trace) fprintf(stderr, "[pgx]   alignments + settle %.2f ms, %zu buckets guessed wrong\n", now_ms() - a0, n_dirty);
-    if (!n_dirty) break;
   }
   {
     const double e0 = now_ms();
@@ -887,8 +893,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
       st->rounds = sweeps;
     }
     if (trace)
-      fprintf(stderr, "[pgx] device replay: %u sweeps, %u passes, %llu evaluations, %zu records; emit %.2f ms; alignments %.2f ms; total %.2f ms\n",
-              sweeps, passes_total, (unsigned long long)hc->evals, nrec, now_ms() - e0, align_ms, now_ms() - t0);
+      fprintf(stderr, "[pgx] device replay: %u sweeps, %u rounds, %llu evaluations, %zu records; emit %.2f ms; alignments %.2f ms; total %.2f ms\n",
+              sweeps, rounds_total, (unsigned long long)hc->evals, nrec, now_ms() - e0, align_ms, now_ms() - t0);
   }
   return 0;
 overflowed:
