@@ -121,6 +121,8 @@ typedef struct {
   uint32_t rounds;           /* replay rounds until the fixed point */
   double gpu_ms;             /* device time */
   double host_ms;            /* host orchestration time (order emulation + replay) */
+  uint64_t n_evaluations;    /* bucket evaluations of the replay (>= n_buckets: the fixed point re-evaluates) */
+  uint32_t device_replay;    /* 1: the greedy walk ran on the GPU (pgx_replay.hip); 0: on the host threads */
 } pgx_overlap_stats;
 
 /* mmers: concatenation of all index chunks' final-level lists in chunk order; counts: all MC entries */

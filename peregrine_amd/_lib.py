@@ -54,7 +54,8 @@ MP256_DTYPE = np.dtype([("x0", "<u8"), ("x1", "<u8"), ("y0", "<u8"), ("y1", "<u8
 class OverlapStats(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("n_pair_records", C.c_uint64), ("n_buckets", C.c_uint64),
                 ("n_align_needed", C.c_uint64), ("n_align_gpu", C.c_uint64), ("n_seen_skip", C.c_uint64),
-                ("rounds", C.c_uint32), ("gpu_ms", C.c_double), ("host_ms", C.c_double)]
+                ("rounds", C.c_uint32), ("gpu_ms", C.c_double), ("host_ms", C.c_double),
+                ("n_evaluations", C.c_uint64), ("device_replay", C.c_uint32)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -1379,6 +1379,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
                    p->align_bandwidth, predict, (uint32_t)p->ovlp_upper,
                    [&](size_t n) { out.alloc(n); return out.a; }, &nrec, &rs, trace)) {
       s.n_align_needed = rs.n_align_needed, s.n_seen_skip = rs.n_seen_skip, s.n_align_gpu = rs.n_align_gpu, s.rounds = rs.rounds;
+      s.n_evaluations = rs.n_evaluations, s.device_replay = 1;
       gpu_ms += now_ms() - r0;
       timing_flush();
       if (trace) fprintf(stderr, "[pgx] stage total %.2f ms\n", now_ms() - t0);
@@ -1469,6 +1470,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
         rp.sweep_first = rp.submitted = first_req;
         const size_t upto = rp.sweep(&ev, &rounds);
         ++s.rounds;
+        s.n_evaluations = ev;
         if (trace)
           fprintf(stderr, "[pgx] parallel sweep %u (%u threads): %u rounds, %llu evaluations so far, %.2f ms, %zu requests (%zu already on the GPU)\n",
                   s.rounds, threads, rounds, (unsigned long long)ev, now_ms() - p0, upto - first_req, rp.submitted - first_req);
@@ -1512,6 +1514,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
       if (!rp.settle()) break;  // every guess was right: the replay is exact
     }
     rp.collect(out, s.n_align_needed, s.n_seen_skip);
+    s.n_evaluations = rp.n_eval;
   }
   const double tf0 = now_ms();
   timing_flush();

@@ -89,6 +89,7 @@ struct R {
   pgx_align_key *rq_key;
   pgx_match *rq_res;
   uint32_t req_cap, settled;
+  uint32_t memo_used;  // 0: nothing has been filed yet (the first round of the first sweep skips the memo lookups)
   uint8_t *dirty, *evaluated, *parity, *bflags, *ever;
   uint32_t *ihead, *inum, *ohead, *lookups, *skips;
   uint32_t *dlist;  // the dirty buckets, listed by k_count while there are at most LIST_CAP of them (the sparse passes run from the list)
@@ -300,6 +301,33 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
   int ai = (int)n - 1;  // (the first row opened is n - 2)
   bool row_open = false;
   uint32_t pbase = 0, got = 0, rid0 = 0, pos0 = 0, rlen0 = 0, dir0 = 0;
+  bool p_reg = false;  // this lane has a registration whose list position (p_idx) has not been looked at yet
+  uint32_t p_idx = 0, p_slot = 0;
+  auto resolve_pending = [&]() -> bool {  // false: the reader-node arena is exhausted
+    if (p_reg && p_idx < NIN) r.pt[p_slot].in[p_idx] = j + 1, p_reg = false;
+    const uint64_t rm = __ballot(p_reg);  // (what is left goes to the linked overflow)
+    if (rm) {
+      const uint32_t total = (uint32_t)__popcll(rm);
+      if (rcur + total > rend) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&r.c->rnode_top, NCH);
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if ((uint64_t)base + NCH > r.rn_cap) {
+          atomicOr(&r.c->overflow, OV_NODES);
+          return false;
+        }
+        rcur = base, rend = base + NCH;
+      }
+      if (p_reg) {
+        const uint32_t node = rcur + lane_rank(rm);
+        const uint32_t old = atomicExch(&r.pt[p_slot].rhead, node + 1);
+        r.rn[node] = RNode{old, j};
+      }
+      rcur += total;
+      p_reg = false;
+    }
+    return true;
+  };
   for (;;) {
     if (alive && !row_open) {
       do --ai;
@@ -316,6 +344,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
       }
     }
     if (!__ballot(alive)) {
+      if (!resolve_pending()) return;
       if (lane == 0) r.wcur[wave_id] = make_uint4(rcur, rend, 0, 0);
       break;
     }
@@ -347,8 +376,8 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
         const uint32_t rlen1 = s_rl[gib][pi], dir1 = s_dir[gib][pi];
         const uint32_t q_off = pos0 - pos1;
         if (q_off >= (1u << 30)) atomicOr(&r.c->overflow, OV_QOFF);
-        uint32_t req;
-        mslot = memo_find(r, (unsigned long long)rid0 << 32 | rid1, q_off << 2 | dir0 << 1 | dir1, &req);
+        uint32_t req = NONE;
+        if (r.memo_used) mslot = memo_find(r, (unsigned long long)rid0 << 32 | rid1, q_off << 2 | dir0 << 1 | dir1, &req);
         if (req < r.settled) {
           accepted = classify(r.rq_res[req], rlen0, rlen1, q_off, &type);
         } else {
@@ -357,6 +386,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
         }
       }
     }
+    if (!resolve_pending()) return;  // (the previous batch's registrations: their atomics have returned behind the loads above)
     // ---- the sequential semantics of the row over this batch, lowest partner first ----
     const uint64_t Vg = gbits(vm, gbase);
     const uint64_t P = gbits(__ballot(valid && present), gbase);
@@ -379,7 +409,8 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
     const uint64_t proc = (2ULL << stop) - 1ULL;
     const uint64_t ins = A & proc;
     {  // the partners the sequential loop really examined register as readers of their pairs (the lists are only read by
-       // k_update, after this kernel); a bucket listed by an earlier evaluation is not listed again
+       // k_update, after this kernel); a bucket listed by an earlier evaluation is not listed again.  The list position comes
+       // from an atomic whose result is only looked at after the NEXT batch's loads have been issued (resolve_pending).
       bool reg = valid && ((proc >> gl) & 1);
       if (reg && slot == NONE) slot = pair_slot(r, pair);  // a pair the walk really examines gets its slot now
       if (reg && !first_eval) {
@@ -395,30 +426,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
             if (q + k < c && x[k] == j + 1) reg = false;
         }
       }
-      if (reg) {
-        const uint32_t idx = atomicAdd(&r.pt[slot].cnt, 1u);
-        if (idx < NIN) r.pt[slot].in[idx] = j + 1, reg = false;
-      }
-      const uint64_t rm = __ballot(reg);  // (what is left goes to the linked overflow)
-      if (rm) {
-        const uint32_t total = (uint32_t)__popcll(rm);
-        if (rcur + total > rend) {
-          uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(&r.c->rnode_top, NCH);
-          base = (uint32_t)__shfl((int)base, 0, 64);
-          if ((uint64_t)base + NCH > r.rn_cap) {
-            atomicOr(&r.c->overflow, OV_NODES);
-            return;
-          }
-          rcur = base, rend = base + NCH;
-        }
-        if (reg) {
-          const uint32_t node = rcur + lane_rank(rm);
-          const uint32_t old = atomicExch(&r.pt[slot].rhead, node + 1);
-          r.rn[node] = RNode{old, j};
-        }
-        rcur += total;
-      }
+      if (reg) p_idx = atomicAdd(&r.pt[slot].cnt, 1u), p_slot = slot, p_reg = true;
     }
     // ---- the batch's insertions: the bucket's items fill 16-aligned chunks of 16 in insertion order (k_update walks a
     // bucket's list a chunk at a time, one lane per item) ----
@@ -772,7 +780,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 3;
   const int chain = getenv("PGX_REPLAY_CHAIN") ? std::max(1, atoi(getenv("PGX_REPLAY_CHAIN"))) : 4;
   static const bool deep = getenv("PGX_TRACE") && atoi(getenv("PGX_TRACE")) >= 2;  // per-kernel wall times (synchronises after every launch)
-  static const bool timed = getenv("PGX_REPLAY_TIMING") && atoi(getenv("PGX_REPLAY_TIMING")) != 0;  // "replay" in pgx_timing_get
+  const bool timed = getenv("PGX_REPLAY_TIMING") && atoi(getenv("PGX_REPLAY_TIMING")) != 0;  // "replay" in pgx_timing_get
   double td = 0, t_eval = 0, t_upd = 0;
   size_t first_req = 0;  // requests [first_req, ...) belong to the running sweep
   unsigned sweeps = 0, rounds_total = 0;
@@ -832,6 +840,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
       sync();
       if (hc->overflow) goto overflowed;
       n_dirty = hc->ndirty, known = true;
+      r.memo_used = hc->nreq != 0;
       d_lo = n_dirty ? hc->min_dirty : 0, d_hi = n_dirty ? hc->max_dirty + 1 : 0;
       if (trace)
         fprintf(stderr, "[pgx]   round %u: %zu dirty left in [%u, %u), %llu evaluations, t = +%.2f ms\n", rounds, n_dirty, d_lo, d_hi,
@@ -891,6 +900,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     if (st) {
       st->n_align_needed = hc->lookups, st->n_seen_skip = hc->skips, st->n_align_gpu = first_req;
       st->rounds = sweeps;
+      st->n_evaluations = hc->evals;
     }
     if (trace)
       fprintf(stderr, "[pgx] device replay: %u sweeps, %u rounds, %llu evaluations, %zu records; emit %.2f ms; alignments %.2f ms; total %.2f ms\n",

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_bench
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o p -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  timeout -k 5 180 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o p -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
 python - <<PY
 import csv, collections, json, re
@@ -16,7 +16,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if m:
             acc[m.group(1)].append(float(r["Counter_Value"]))
     for k, v in acc.items():
-        if k in ("k_align4", "k_align1", "k_sketch_wave", "k_reduce_read"):
+        if k in ("k_align4", "k_align1", "k_sketch_wave", "k_reduce_read", "k_eval", "k_update"):
             res.setdefault(k, {})[c + "_KB_per_launch"] = sum(v) / len(v)
             res[k]["launches"] = len(v)
 for k, v in res.items():

@@ -11,6 +11,7 @@ def short(name: str) -> str:
     m = re.search(r"rocprim::detail::(?:trampoline_kernel<rocprim::detail::wrapped_)?(\w+)", name)
     if name.startswith("void rocprim") and m:
         return "rocprim::" + m.group(1)
+    name = name.replace("(anonymous namespace)::", "")
     return name.split("(")[0]
 
 
