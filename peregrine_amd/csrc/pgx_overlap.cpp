@@ -1371,6 +1371,13 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     if (trace)
       fprintf(stderr, "[pgx] GPU join: %zu records, %zu buckets, %zu key0 groups in %.2f ms; visit order (%llu buckets, ids only) in %.2f ms\n",
               pt.n_rec, pt.bkey1.size(), pt.gkey0.size(), t1 - t0, (unsigned long long)s.n_buckets, now_ms() - t1);
+    if (trace && atoi(getenv("PGX_TRACE")) >= 2 && visit.n_buckets) {  // bucket sizes: a pass of the device replay lasts as long as its largest bucket
+      std::vector<uint32_t> sz(visit.n_buckets);
+      for (size_t i = 0; i < visit.n_buckets; ++i) sz[i] = pt.bstart[visit.bids[i] + 1] - pt.bstart[visit.bids[i]];
+      std::sort(sz.begin(), sz.end());
+      fprintf(stderr, "[pgx]   bucket sizes: median %u, 90 %% %u, 99 %% %u, 99.9 %% %u, max %u\n", sz[sz.size() / 2], sz[sz.size() * 9 / 10],
+              sz[sz.size() * 99 / 100], sz[sz.size() * 999 / 1000], sz.back());
+    }
     const double r0 = now_ms();
     size_t nrec = 0;
     pgx_overlap_stats rs;

@@ -214,7 +214,10 @@ __global__ __launch_bounds__(256) void k_setup(R r) {
 // partner at a time.  A single evaluation is a chain of dependent memory round trips, so the group form is what bounds
 // the latency of a pass: rows x ~4 round trips instead of examinations x ~4.
 constexpr uint32_t NCH = 256;  // reader-node arena chunk of a wavefront
-constexpr int GL = 16;         // lanes per bucket
+#ifndef PGX_REPLAY_GL
+#define PGX_REPLAY_GL 16
+#endif
+constexpr int GL = PGX_REPLAY_GL;  // lanes per bucket
 constexpr uint32_t GPW = 64 / GL, GPB = 256 / GL;
 __device__ __forceinline__ uint64_t gbits(uint64_t wave_mask, int gbase) { return (wave_mask >> gbase) & ((1ULL << GL) - 1ULL); }
 
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(256) void k_update(R r, uint32_t lo, uint32_t hi, u
     if (cur != NIL) {
       const uint32_t last = cur - 1, base = last & ~15u, cnt = (last & 15) + 1;
       const Item first = r.items[base];
-      if ((uint32_t)gl < cnt) apply_insertion(r, j, pnew, gl == 0 ? first : r.items[base + gl]);
+      for (uint32_t o = (uint32_t)gl; o < cnt; o += GL) apply_insertion(r, j, pnew, o == 0 ? first : r.items[base + o]);
       cur = first.next;
     }
   }
@@ -536,8 +539,8 @@ __global__ __launch_bounds__(256) void k_update(R r, uint32_t lo, uint32_t hi, u
     if (cur != NIL) {
       const uint32_t last = cur - 1, base = last & ~15u, cnt = (last & 15) + 1;
       const uint32_t nxt = r.items[base].next;
-      if ((uint32_t)gl < cnt) {
-        const uint32_t slot = r.items[base + gl].pslot;
+      for (uint32_t o = (uint32_t)gl; o < cnt; o += GL) {
+        const uint32_t slot = r.items[base + o].pslot;
         const uint32_t v = r.pt[slot].own;
         if (v != 0 && own_bucket(v) == j && own_parity(v) == pold)
           if (atomicCAS(&r.pt[slot].own, v, 0u) == v) mark_readers(r, slot, j);
@@ -745,8 +748,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   DevBuf<uint32_t> words(nb * 5);
   r.dirty = bytes.p, r.evaluated = bytes.p + nb, r.parity = bytes.p + 2 * nb, r.bflags = bytes.p + 3 * nb, r.ever = bytes.p + 4 * nb;
   r.ihead = words.p, r.inum = words.p + nb, r.ohead = words.p + 2 * nb, r.lookups = words.p + 3 * nb, r.skips = words.p + 4 * nb;
-  DevBuf<uint4> wcur(nb / 4 + 2 + LIST_CAP / 4 + 1);  // (k_eval<16>: four buckets per wavefront)
-  r.wcur = wcur.p, r.wlist0 = (uint32_t)(nb / 4 + 2);
+  DevBuf<uint4> wcur(nb / GPW + 2 + LIST_CAP / GPW + 1);  // (one slot per wavefront of k_eval: GPW buckets each)
+  r.wcur = wcur.p, r.wlist0 = (uint32_t)(nb / GPW + 2);
   PGX_HIP(hipMemsetAsync(wcur.p, 0, wcur.n * sizeof(uint4), s));
   DevBuf<uint32_t> dlist(LIST_CAP);
   r.dlist = dlist.p;
@@ -810,9 +813,9 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
             std::optional<KernelTimer> tm;
             if (timed) tm.emplace("replay", k == 0 ? hi - lo : 0);  // (units: buckets of the window, counted once)
             if (deep) sync(), td = now_ms();
-            hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * 16)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
+            hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
             if (deep) sync(), t_eval += now_ms() - td, td = now_ms();
-            hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)(hi - lo) * 16)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
+            hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
             if (deep) sync(), t_upd += now_ms() - td, fprintf(stderr, "[pgx]     iteration: eval %.3f ms, update %.3f ms\n", t_eval, t_upd), t_eval = t_upd = 0;
           }
         }
@@ -828,8 +831,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
         for (int c = 0; c < chain; ++c) {
           std::optional<KernelTimer> tm;
           if (timed) tm.emplace("replay", 0);
-          hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)groups * 16)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
-          hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)groups * 16)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
+          hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)groups * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
+          hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)groups * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
           tm.reset();
           count_dirty();
         }
@@ -926,6 +929,8 @@ bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visi
     return true;
   }
   double mult[5] = {1, 1, 1, 1, 1};  // items, reader nodes, requests, pair table, memo table
+  if (getenv("PGX_REPLAY_PAIRS_X")) mult[3] = atof(getenv("PGX_REPLAY_PAIRS_X"));
+  if (getenv("PGX_REPLAY_MEMO_X")) mult[4] = atof(getenv("PGX_REPLAY_MEMO_X"));
   for (int attempt = 0; attempt < 3; ++attempt) {
     const uint32_t ov = replay_attempt(db, dp, visit_bids, nb, n_entries, bestn, band, predict, alloc_out, n_out, st, trace, mult);
     if (!ov) return true;
