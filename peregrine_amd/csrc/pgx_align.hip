@@ -388,13 +388,13 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
   }
 }
 
-void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out, int waves_per_cu) {
+void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out) {
   if (n == 0) return;
   static const long small_max = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : 13000;  // measured crossover ~14 k (tools/alignlat.py)
   KernelTimer tm((long)n <= small_max ? "align1" : "align", n);
   int ring = 64;
   while (ring < 2 * band + 8) ring <<= 1;
-  uint32_t *counter = ws<uint32_t>(ctx().stream == ctx().side ? "align.counter.side" : "align.counter", 1);
+  uint32_t *counter = ws<uint32_t>("align.counter", 1);
   if ((long)n > small_max) PGX_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), ctx().stream));  // (k_align1 has no work counter)
   static const int gl = getenv("PGX_ALIGN_GL") ? atoi(getenv("PGX_ALIGN_GL")) : 8;  // measured: 8 lanes per candidate (avg 3.6 live diagonals, <= 8 in 98.7 % of the steps) 45.6 vs 42.1 M aln/s
   if ((long)n <= small_max) {
@@ -403,11 +403,11 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
   } else if (gl == 8) {
     const size_t want = (n + 7) / 8;
     if (db->max_rlen <= 65535u) {
-      const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * (waves_per_cu > 0 ? std::min(waves_per_cu, 32) : 32));
+      const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * 32);
       hipLaunchKernelGGL((k_align4<8, uint16_t>), dim3(grid), dim3(64), 8 * ring * sizeof(uint16_t), ctx().stream, db->d_seq.p,
                          db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter);
     } else {
-      const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * (waves_per_cu > 0 ? std::min(waves_per_cu, 20) : 20));
+      const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * 20);
       hipLaunchKernelGGL((k_align4<8, int32_t>), dim3(grid), dim3(64), 8 * ring * sizeof(int32_t), ctx().stream, db->d_seq.p,
                          db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter);
     }

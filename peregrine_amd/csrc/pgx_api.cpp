@@ -366,8 +366,6 @@ int pgx_init(int device) {
   PGX_HIP(hipSetDevice(device));
   if (c.stream) (void)hipStreamDestroy(c.stream);
   PGX_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
-  if (c.side) (void)hipStreamDestroy(c.side);
-  PGX_HIP(hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking));
   hipDeviceProp_t prop;
   PGX_HIP(hipGetDeviceProperties(&prop, device));
   c.num_cu = prop.multiProcessorCount;
@@ -384,8 +382,7 @@ void pgx_shutdown(void) {
   if (c.stream) (void)hipStreamSynchronize(c.stream);
   dev_cache_trim();
   if (c.stream) (void)hipStreamDestroy(c.stream);
-  if (c.side) (void)hipStreamDestroy(c.side);
-  c.stream = nullptr, c.side = nullptr;
+  c.stream = nullptr;
   c.ready = false;
 }
 

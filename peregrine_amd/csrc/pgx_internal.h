@@ -44,7 +44,6 @@ struct Fail {
 struct Context {
   int device = -1;
   hipStream_t stream = nullptr;
-  hipStream_t side = nullptr;  // second stream: alignment batches that run beside the device replay's sweep
   bool ready = false;
   int num_cu = 256;
 };
@@ -154,8 +153,7 @@ void dev_reduce(const pgx_mm128 *d_in, size_t n, int rs, DevBuf<pgx_mm128> &out,
 // multiplicity of x>>8, sorted by mer
 void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_count> &out, size_t &n_out);
 // banded O(ND) confirmation of n candidate alignments (keys on device)
-// waves_per_cu > 0: cap of resident wavefronts per CU for the large-launch kernel (leaves room for a kernel on another stream)
-void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out, int waves_per_cu = 0);
+void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out);
 
 // Large host arrays.  Never value-initialised (they are about to be overwritten); from 16 MiB up they are pooled anonymous
 // mappings advised to use transparent huge pages, which the allocator would not do for us (THP is in "madvise" mode on

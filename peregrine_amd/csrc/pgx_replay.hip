@@ -722,9 +722,6 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
                         size_t *n_out, pgx_overlap_stats *st, bool trace, const double *mult) {
   const double t0 = now_ms();
   hipStream_t s = ctx().stream;
-  struct SideGuard {  // whatever way this attempt ends, nothing of it is still running on the second stream
-    ~SideGuard() { (void)hipStreamSynchronize(ctx().side); }
-  } side_guard;
   const size_t ne = std::max<size_t>(n_entries, 1024);
   R r;
   memset(&r, 0, sizeof(r));
