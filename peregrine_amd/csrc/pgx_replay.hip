@@ -496,6 +496,287 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
   }
 }
 
+// ---- the same evaluation with FOUR ROWS PER STEP, for the sparse passes (a wavefront per bucket: lanes are plentiful there and
+// a pass lasts as long as its longest bucket's chain of rows).  Lane l works row l / PW, partner l % PW; the rows are committed
+// in order while each one is complete within its PW partners and no earlier row of the step set a contained flag (then the
+// rows below are looked at again with the new flags); a row that needs more partners is continued alone, GLT per step.
+template <int GLT, int PW>
+__global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi, uint32_t nlist) {
+  constexpr uint32_t GPWT = 64 / GLT, GPBT = 256 / GLT;
+  constexpr int SH = PW == 16 ? 4 : 2;  // log2(PW)
+  constexpr uint64_t RM = (1ULL << PW) - 1ULL;  // one row's lanes
+  __shared__ uint32_t s_rid[GPBT][128], s_pos[GPBT][128], s_rl[GPBT][128];
+  __shared__ uint8_t s_dir[GPBT][128];
+  const int lane = threadIdx.x & 63, gl = lane & (GLT - 1), gbase = lane & ~(GLT - 1), gib = threadIdx.x / GLT;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPWT + (uint32_t)(lane / GLT));
+  const uint32_t j = (uint32_t)jj;
+  bool alive = jj < hi && r.dirty[j] && !r.c->overflow;
+  {
+    const uint64_t am = __ballot(alive);
+    if (!am) return;
+    if (lane == (int)__builtin_ctzll(am)) atomicAdd(&r.c->evals, (unsigned long long)(__popcll(am) / GLT));
+  }
+  // reader-node arena: wave-uniform cursor; the wavefront that evaluates these buckets next time continues where this one stops
+  const uint32_t wave_id = nlist ? r.wlist0 + wave : (uint32_t)(((uint64_t)lo + (uint64_t)wave * GPWT) / GPWT);
+  const uint4 wc = r.wcur[wave_id];
+  uint32_t rcur = wc.x, rend = wc.y;
+  uint32_t s0 = 0, n = 0;
+  bool dup = false, first_eval = true;
+  if (alive) {
+    const uint32_t b = r.bid[j];
+    s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
+    dup = (r.bflags[j] & F_DUP) != 0;
+    first_eval = r.ever[j] == 0;
+    for (uint32_t i = (uint32_t)gl; i < n; i += GLT) {  // the bucket's entries -> LDS
+      const uint64_t y = r.y0[s0 + i];
+      const uint32_t rid = (uint32_t)(y >> 32);
+      s_rid[gib][i] = rid, s_pos[gib][i] = (((uint32_t)y) >> 1) + 1, s_dir[gib][i] = r.dir[s0 + i], s_rl[gib][i] = r.rlen[rid];
+    }
+    if (gl == 0) {
+      r.dirty[j] = 0;
+      r.evaluated[j] = 1;
+      r.ever[j] = 1;
+      r.parity[j] ^= 1;
+      r.ohead[j] = r.ihead[j];
+    }
+  }
+  auto gbits = [&](uint64_t wave_mask, int) { return GLT == 64 ? wave_mask : ((wave_mask >> gbase) & ((1ULL << (GLT & 63)) - 1ULL)); };
+  uint64_t clo = 0, chi = 0;  // "contained" flags of the bucket's entries (n <= 128)
+  auto cget = [&](uint32_t i) { return (((i < 64 ? clo : chi) >> (i & 63)) & 1) != 0; };
+  auto cset = [&](uint32_t i) {
+    if (i < 64) clo |= 1ULL << i;
+    else chi |= 1ULL << (i - 64);
+  };
+  uint32_t head = NIL, num = 0, lookups = 0, skips = 0;
+  uint32_t chunk = 0;  // base of the item chunk holding insertion ordinals [num & ~15, ...)
+  bool any_guess = false, any_unfiled = false;
+  int done_to = (int)n - 1;  // rows >= done_to are finished (the first row is n - 2)
+  bool row_open = false;     // a single row (cur_row) is in progress, sixteen partners per step from pbase
+  int cur_row = 0, a0 = -1, a1 = -1, a2 = -1, a3 = -1, nrows = 0;
+  uint32_t pbase = 0, got = 0;
+  bool p_reg = false;  // this lane has a registration whose list position (p_idx) has not been looked at yet
+  uint32_t p_idx = 0, p_slot = 0;
+  auto resolve_pending = [&]() -> bool {  // false: the reader-node arena is exhausted
+    if (p_reg && p_idx < NIN) r.pt[p_slot].in[p_idx] = j + 1, p_reg = false;
+    const uint64_t rm = __ballot(p_reg);  // (what is left goes to the linked overflow)
+    if (rm) {
+      const uint32_t total = (uint32_t)__popcll(rm);
+      if (rcur + total > rend) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&r.c->rnode_top, NCH);
+        base = (uint32_t)__shfl((int)base, 0, 64);
+        if ((uint64_t)base + NCH > r.rn_cap) {
+          atomicOr(&r.c->overflow, OV_NODES);
+          return false;
+        }
+        rcur = base, rend = base + NCH;
+      }
+      if (p_reg) {
+        const uint32_t node = rcur + lane_rank(rm);
+        const uint32_t old = atomicExch(&r.pt[p_slot].rhead, node + 1);
+        r.rn[node] = RNode{old, j};
+      }
+      rcur += total;
+      p_reg = false;
+    }
+    return true;
+  };
+  for (;;) {
+    if (alive && !row_open) {  // the next (up to four) rows that are not contained
+      nrows = 0, a0 = a1 = a2 = a3 = -1;
+      int x = done_to;
+      while (nrows < 4) {
+        do --x;
+        while (x >= 0 && cget((uint32_t)x));
+        if (x < 0) break;
+        if (nrows == 0) a0 = x;
+        else if (nrows == 1) a1 = x;
+        else if (nrows == 2) a2 = x;
+        else a3 = x;
+        ++nrows;
+      }
+      if (nrows == 0 || r.bestn == 0) {  // the bucket is done
+        if (gl == 0) {
+          r.ihead[j] = head, r.inum[j] = num, r.lookups[j] = lookups, r.skips[j] = skips;
+          r.bflags[j] = (uint8_t)((dup ? F_DUP : 0) | (any_guess ? F_GUESS : 0) | (any_unfiled ? F_UNFILED : 0));
+        }
+        alive = false;
+      } else if (dup) {
+        cur_row = a0, got = 0, pbase = (uint32_t)a0 + 1, row_open = true;
+      }
+    }
+    if (!__ballot(alive)) {
+      if (!resolve_pending()) return;
+      if (lane == 0) r.wcur[wave_id] = make_uint4(rcur, rend, 0, 0);
+      break;
+    }
+    // ---- this step's (row, partner) of the lane ----
+    const bool single = row_open;  // group-uniform
+    const uint32_t step = dup ? 1u : (uint32_t)GLT;
+    const int q = gl >> SH;
+    const int myrow = single ? cur_row : (q == 0 ? a0 : q == 1 ? a1 : q == 2 ? a2 : a3);
+    const uint32_t pi = single ? pbase + (uint32_t)gl : (uint32_t)(myrow + 1 + (gl & (PW - 1)));
+    bool valid = alive && (single ? (uint32_t)gl < step : q < nrows) && pi < n && !cget(pi);
+    uint32_t rid0 = 0, pos0 = 0, rlen0 = 0, dir0 = 0, rid1 = 0, pos1 = 0;
+    if (valid) {
+      rid0 = s_rid[gib][myrow], pos0 = s_pos[gib][myrow], rlen0 = s_rl[gib][myrow], dir0 = s_dir[gib][myrow];
+      rid1 = s_rid[gib][pi], pos1 = s_pos[gib][pi];
+      if (rid1 == rid0) valid = false;
+    }
+    uint32_t slot = NONE, v = 0;
+    const uint64_t pair = rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0);
+    if (valid) slot = pair_find(r, pair, &v);
+    const uint64_t vm = __ballot(valid);
+    bool present = false, accepted = false, guessed = false;
+    uint32_t ptype = 0, type = 0, mslot = NONE;
+    if (valid) {
+      present = v != 0 && own_bucket(v) < j;
+      ptype = present ? own_type(v) : 0;
+      if (!present && dup && slot != NONE)  // inserted earlier in THIS evaluation?
+        for (uint32_t it = head; it != NIL; it = r.items[it - 1].next)
+          if (r.items[it - 1].pslot == slot) {
+            present = true, ptype = (r.items[it - 1].info >> 16) & 3;
+            break;
+          }
+      if (!present) {
+        const uint32_t rlen1 = s_rl[gib][pi], dir1 = s_dir[gib][pi];
+        const uint32_t q_off = pos0 - pos1;
+        if (q_off >= (1u << 30)) atomicOr(&r.c->overflow, OV_QOFF);
+        uint32_t req = NONE;
+        if (r.memo_used) mslot = memo_find(r, (unsigned long long)rid0 << 32 | rid1, q_off << 2 | dir0 << 1 | dir1, &req);
+        if (req < r.settled) {
+          accepted = classify(r.rq_res[req], rlen0, rlen1, q_off, &type);
+        } else {
+          accepted = true, guessed = true, type = T_OVERLAP;
+          if (r.predict && (rlen1 <= rlen0 - q_off || q_off < (uint32_t)(END_FUZZ * 2 - 8))) type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
+        }
+      }
+    }
+    if (!resolve_pending()) return;  // (the previous step's registrations: their atomics have returned behind the loads above)
+    // ---- the sequential semantics over this step, lowest lane first ----
+    const uint64_t Vg = gbits(vm, gbase);
+    const uint64_t P = gbits(__ballot(valid && present), gbase);
+    const uint64_t PO = gbits(__ballot(valid && present && ptype == T_OVERLAP), gbase);
+    const uint64_t A = gbits(__ballot(valid && !present && accepted), gbase);
+    const uint64_t AO = gbits(__ballot(valid && !present && accepted && type == T_OVERLAP), gbase);
+    const uint64_t AC = gbits(__ballot(valid && !present && accepted && type == T_CONTAINED), gbase);
+    const uint64_t AP = gbits(__ballot(valid && !present && accepted && type == T_CONTAINS), gbase);
+    const uint64_t inc = PO | AO;
+    uint64_t proc = 0;  // the lanes the sequential walk really visits in this step
+    if (alive && single) {
+      int stop = GLT;  // the last partner the row processes in this step (GLT: all of them, and the row goes on)
+      const uint32_t need = r.bestn - got;  // >= 1
+      if ((uint32_t)__popcll(inc) >= need) {
+        uint64_t m = inc;
+        for (uint32_t k = 1; k < need; ++k) m &= m - 1;
+        stop = __builtin_ctzll(m);
+      }
+      if (AC) stop = min(stop, (int)__builtin_ctzll(AC));
+      proc = stop >= 63 ? ~0ULL : ((2ULL << stop) - 1ULL);
+      got += (uint32_t)__popcll(inc & proc);
+      for (uint64_t m = AP & proc; m; m &= m - 1) cset(pbase + (uint32_t)__builtin_ctzll(m));  // partners found contained
+      if (AC & proc) cset((uint32_t)cur_row);
+      if (stop < GLT || pbase + step >= n) row_open = false, done_to = cur_row;
+      else pbase += step;
+    } else if (alive) {
+      int committed = 0;
+      bool flagged = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k >= nrows || flagged || committed != k) continue;
+        const int row = k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : a3;
+        const uint32_t inc_k = (uint32_t)((inc >> (PW * k)) & RM), ac_k = (uint32_t)((AC >> (PW * k)) & RM), ap_k = (uint32_t)((AP >> (PW * k)) & RM);
+        int stop = PW;
+        if ((uint32_t)__popc(inc_k) >= r.bestn) {
+          uint32_t m = inc_k;
+          for (uint32_t t = 1; t < r.bestn; ++t) m &= m - 1;
+          stop = __builtin_ctz(m);
+        }
+        if (ac_k) stop = min(stop, (int)__builtin_ctz(ac_k));
+        if (stop == PW && (uint32_t)row + 1 + PW < n) continue;  // the row needs more partners: it is continued alone (committed stays k)
+        const uint32_t proc_k = stop < PW ? (2u << stop) - 1u : (uint32_t)RM;
+        proc |= (uint64_t)proc_k << (PW * k);
+        ++committed;
+        if ((ap_k | ac_k) & proc_k) flagged = true;  // contained flags change: the rows below are looked at again with them
+      }
+      for (uint64_t m = AP & proc; m; m &= m - 1) {
+        const int l = __builtin_ctzll(m), k = l >> SH;
+        cset((uint32_t)((k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : a3) + 1 + (l & (PW - 1))));
+      }
+      for (uint64_t m = AC & proc; m; m &= m - 1) {
+        const int k = __builtin_ctzll(m) >> SH;
+        cset((uint32_t)(k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : a3));
+      }
+      if (committed == 0) cur_row = a0, got = 0, pbase = (uint32_t)a0 + 1, row_open = true;  // (nothing done in this step)
+      else done_to = committed == 1 ? a0 : committed == 2 ? a1 : committed == 3 ? a2 : a3;
+    }
+    skips += (uint32_t)__popcll(P & proc);
+    lookups += (uint32_t)__popcll(Vg & ~P & proc);
+    const uint64_t ins = A & proc;
+    {  // the partners the walk really examined register as readers of their pairs (the lists are only read by k_update, after
+       // this kernel); a bucket listed by an earlier evaluation is not listed again.  The list position comes from an atomic
+       // whose result is only looked at after the NEXT step's loads have been issued (resolve_pending).
+      bool reg = valid && ((proc >> gl) & 1);
+      if (reg && slot == NONE) slot = pair_slot(r, pair);  // a pair the walk really examines gets its slot now
+      if (reg && !first_eval) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pt[slot]);
+        const uint4 h1 = *reinterpret_cast<const uint4 *>(w + 4);  // cnt, pad, in[0], in[1]
+        const uint32_t c = min(h1.x, NIN);
+        if ((c > 0 && h1.z == j + 1) || (c > 1 && h1.w == j + 1)) reg = false;
+        for (uint32_t qq = 2; qq < c && reg; qq += 8) {
+          const uint4 a = *reinterpret_cast<const uint4 *>(w + 6 + qq), b = *reinterpret_cast<const uint4 *>(w + 10 + qq);
+          const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+          for (uint32_t k = 0; k < 8; ++k)
+            if (qq + k < c && x[k] == j + 1) reg = false;
+        }
+      }
+      if (reg) p_idx = atomicAdd(&r.pt[slot].cnt, 1u), p_slot = slot, p_reg = true;
+    }
+    // ---- the step's insertions: the bucket's items fill 16-aligned chunks of 16 in insertion order (lane order is the
+    // sequential order; k_update walks a bucket's list a chunk at a time, one lane per item) ----
+    const bool my_ins = valid && !present && accepted && ((proc >> gl) & 1);
+    const uint32_t cins = (uint32_t)__popcll(ins);  // up to 64 in one step here: it may open several 16-item chunks
+    static_assert(GLT == 64, "one bucket per wavefront: the chunk allocation below is wave-uniform");
+    if (cins) {
+      const uint32_t cur_no = num ? (num - 1) >> 4 : 0;                 // number of the chunk `chunk` (meaningless while num == 0)
+      const uint32_t first_new = num ? cur_no + 1 : 0;                   // number of the first chunk this step has to open
+      const uint32_t last = num + cins - 1, last_no = last >> 4;
+      const uint32_t nnew = last_no + 1 > first_new ? last_no + 1 - first_new : 0;
+      uint32_t fresh = 0;
+      if (nnew) {
+        if (lane == 0) fresh = atomicAdd(&r.c->item_top, 16u * nnew);
+        fresh = (uint32_t)__shfl((int)fresh, 0, 64);
+        if ((uint64_t)fresh + 16u * nnew > r.item_cap) {
+          atomicOr(&r.c->overflow, OV_ITEMS);
+          return;
+        }
+      }
+      auto base_of = [&](uint32_t no) { return no >= first_new ? fresh + 16u * (no - first_new) : chunk; };
+      if (my_ins) {
+        const uint32_t ord = num + (uint32_t)__popcll(ins & ((1ULL << gl) - 1ULL));  // insertion ordinal within the bucket
+        const uint32_t idx = base_of(ord >> 4) + (ord & 15);
+        uint32_t next;
+        if (ord == 0) next = NIL;
+        else if ((ord & 15) == 0) next = base_of((ord >> 4) - 1) + 16;  // the last item of the previous chunk, + 1
+        else next = idx;                                                // the item before this one, + 1
+        uint32_t info = (uint32_t)myrow | pi << 8 | type << 16;
+        if (guessed) info |= I_GUESS;
+        if (mslot == NONE) info |= I_UNFILED;
+        r.items[idx] = Item{slot, info, mslot, next};
+      }
+      chunk = base_of(last_no);
+      head = chunk + (last & 15) + 1;
+      num += cins;
+    }
+    {
+      const uint64_t g1 = gbits(__ballot(my_ins && guessed), gbase), g2 = gbits(__ballot(my_ins && mslot == NONE), gbase);
+      any_guess |= g1 != 0, any_unfiled |= g2 != 0;
+    }
+  }
+}
+
 // ---- apply the evaluated buckets' lists to the pair table: a group per bucket, a lane per item ---------------------------
 __device__ __forceinline__ void apply_insertion(const R &r, uint32_t j, uint32_t pnew, const Item &im) {
   const uint32_t slot = im.pslot, type = (im.info >> 16) & 3;
@@ -745,8 +1026,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   DevBuf<uint32_t> words(nb * 5);
   r.dirty = bytes.p, r.evaluated = bytes.p + nb, r.parity = bytes.p + 2 * nb, r.bflags = bytes.p + 3 * nb, r.ever = bytes.p + 4 * nb;
   r.ihead = words.p, r.inum = words.p + nb, r.ohead = words.p + 2 * nb, r.lookups = words.p + 3 * nb, r.skips = words.p + 4 * nb;
-  DevBuf<uint4> wcur(nb / GPW + 2 + LIST_CAP / GPW + 1);  // (one slot per wavefront of k_eval: GPW buckets each)
-  r.wcur = wcur.p, r.wlist0 = (uint32_t)(nb / GPW + 2);
+  DevBuf<uint4> wcur(nb + 2 + LIST_CAP + 1);  // (one slot per wavefront of k_eval: GPW buckets each)
+  r.wcur = wcur.p, r.wlist0 = (uint32_t)(nb + 2);
   PGX_HIP(hipMemsetAsync(wcur.p, 0, wcur.n * sizeof(uint4), s));
   DevBuf<uint32_t> dlist(LIST_CAP);
   r.dlist = dlist.p;
@@ -778,6 +1059,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   };
   const size_t window = getenv("PGX_REPLAY_WIN") ? (size_t)atoll(getenv("PGX_REPLAY_WIN")) : (size_t)262144;
   const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 3;
+  const bool wide = !(getenv("PGX_REPLAY_WIDE") && atoi(getenv("PGX_REPLAY_WIDE")) == 0);  // sparse passes: a wavefront per bucket, four rows per step
+  const bool wide_dense = getenv("PGX_REPLAY_WIDE") && atoi(getenv("PGX_REPLAY_WIDE")) >= 2;
   const int chain = getenv("PGX_REPLAY_CHAIN") ? std::max(1, atoi(getenv("PGX_REPLAY_CHAIN"))) : 4;
   static const bool deep = getenv("PGX_TRACE") && atoi(getenv("PGX_TRACE")) >= 2;  // per-kernel wall times (synchronises after every launch)
   const bool timed = getenv("PGX_REPLAY_TIMING") && atoi(getenv("PGX_REPLAY_TIMING")) != 0;  // "replay" in pgx_timing_get
@@ -810,7 +1093,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
             std::optional<KernelTimer> tm;
             if (timed) tm.emplace("replay", k == 0 ? hi - lo : 0);  // (units: buckets of the window, counted once)
             if (deep) sync(), td = now_ms();
-            hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
+            if (wide_dense) hipLaunchKernelGGL((k_eval_rows<64, 16>), dim3(cdiv256((size_t)(hi - lo) * 64)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
+            else hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
             if (deep) sync(), t_eval += now_ms() - td, td = now_ms();
             hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
             if (deep) sync(), t_upd += now_ms() - td, fprintf(stderr, "[pgx]     iteration: eval %.3f ms, update %.3f ms\n", t_eval, t_upd), t_eval = t_upd = 0;
@@ -828,7 +1112,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
         for (int c = 0; c < chain; ++c) {
           std::optional<KernelTimer> tm;
           if (timed) tm.emplace("replay", 0);
-          hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)groups * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
+          if (wide) hipLaunchKernelGGL((k_eval_rows<64, 16>), dim3(cdiv256((size_t)groups * 64)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
+          else hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)groups * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
           hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)groups * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
           tm.reset();
           count_dirty();
