@@ -62,7 +62,7 @@ struct RNode {
   uint32_t next, bucket;
 };
 constexpr uint32_t I_GUESS = 1u << 18, I_UNFILED = 1u << 19;
-constexpr uint32_t LIST_CAP = 16384, DEV_LIST = 0xFFFFFFFFu;
+constexpr uint32_t LIST_CAP = 65536, DEV_LIST = 0xFFFFFFFFu;
 enum : uint32_t { OV_ITEMS = 1, OV_NODES = 2, OV_REQS = 4, OV_PAIRS = 8, OV_MEMO = 16, OV_QOFF = 32, OV_PASSES = 64 };  // Counters::overflow
 constexpr uint8_t F_DUP = 1, F_GUESS = 2, F_UNFILED = 4;
 
@@ -1083,7 +1083,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     unsigned rounds = 0;
     for (;;) {  // until no bucket is dirty
       ++rounds;
-      if (known && n_dirty > LIST_CAP / 2) {
+      if (known && (n_dirty > LIST_CAP || n_dirty * 3 > nb)) {  // many of the buckets: a group of 16 lanes each, in bucket order
         // dense: window by window, in order (a window's buckets mostly depend on earlier windows)
         const size_t a_lo = d_lo & ~(size_t)63;  // (aligned: a bucket always belongs to the same wavefront slot)
         const size_t win = n_dirty > window / 4 ? window : (size_t)(d_hi - a_lo);
@@ -1107,7 +1107,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
       // the count behind it
       if (!have_list) count_dirty();
       {
-        const size_t est = known && n_dirty <= LIST_CAP / 2 ? std::max<size_t>(n_dirty * 4, 1024) : (size_t)LIST_CAP;
+        const size_t est = known && n_dirty <= LIST_CAP / 4 ? std::max<size_t>(n_dirty * 4, 1024) : (size_t)LIST_CAP;
         const unsigned groups = (unsigned)std::min<size_t>(est, LIST_CAP);
         for (int c = 0; c < chain; ++c) {
           std::optional<KernelTimer> tm;
