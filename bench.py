@@ -192,10 +192,17 @@ def main():
             else:
                 _, st_x = rdb.overlap(mm, mc, total_chunk=world, mychunk=rank + 1)
             os.environ.pop("PGX_REPLAY_TIMING")
-            ms, launches, units = _lib.timing("replay")
-            if launches:
+            rk = {}
+            for nm, kname in (("replay_dense", "k_eval"), ("replay_rows", "k_eval_rows"), ("replay_update", "k_update")):
+                ms, launches, units = _lib.timing(nm)
+                if launches:
+                    rk[kname] = {"ms_total": ms, "launches": launches, "avg_ms": ms / launches}
+            if rk:
+                ms = sum(v["ms_total"] for v in rk.values())
+                launches = max(v["launches"] for v in rk.values())
                 kern["replay"] = {"ms_total": ms, "launches": launches, "units": int(st_x["n_evaluations"]), "avg_ms": ms / launches,
-                                  "steps": 1, "note": "one extra untimed step with PGX_REPLAY_TIMING=1"}
+                                  "steps": 1, "by_kernel": rk, "max_kernel_ms": max(v["ms_total"] for v in rk.values()),
+                                  "note": "one extra untimed step with PGX_REPLAY_TIMING=1; launches = evaluate/update rounds"}
         roof = None
         cands = {}
         if "sketch" in kern:
@@ -224,7 +231,7 @@ def main():
             walk = 13 * st["n_pair_records"] + 16 * (st["n_seen_skip"] + st["n_align_needed"]) + 48 * st["n_align_needed"] + 16 * st["n_records"]
             per_eval = walk / max(1, st["n_buckets"])   # algorithmic bytes of one bucket evaluation
             gbs = per_eval * k["units"] / (k["ms_total"] * 1e-3) / 1e9
-            cands["replay"] = {"kernel": "k_eval + k_update (device replay)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            cands["replay"] = {"kernel": "k_eval + k_eval_rows + k_update (device replay, three kernels)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
                                "bytes_per_unit": per_eval, "unit_name": "bucket evaluation",
                                "evaluations_per_s": k["units"] / (k["ms_total"] * 1e-3)}
@@ -232,8 +239,9 @@ def main():
         # (tools/pmc_traffic.sh) and committed under profiles/; bench.py itself cannot run under two profilers
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if "replay" in cands and "k_eval" in tr and "k_update" in tr:   # a timed launch is one k_eval + one k_update
-                tr["replay"] = {"hbm_bytes_per_launch": tr["k_eval"]["hbm_bytes_per_launch"] + tr["k_update"]["hbm_bytes_per_launch"]}
+            if "replay" in cands and "k_update" in tr:   # a round = one evaluation kernel (k_eval or k_eval_rows) + one k_update
+                tot = sum(tr[k]["hbm_bytes_per_launch"] * tr[k]["launches"] for k in ("k_eval", "k_eval_rows", "k_update") if k in tr)
+                tr["replay"] = {"hbm_bytes_per_launch": tot / tr["k_update"]["launches"]}
             for nm, kk in (("sketch", "k_sketch_wave"), ("align", "k_align4"), ("align1", "k_align1"), ("replay", "replay")):
                 if nm in cands and kk in tr:
                     cands[nm]["traffic"] = tr[kk]["hbm_bytes_per_launch"]
@@ -242,7 +250,8 @@ def main():
         except Exception:
             pass
         if cands:
-            dom = max(cands, key=lambda n: kern[n]["ms_total"] / kern[n]["steps"])   # the kernel with the most device time per step
+            # the kernel with the most device time per step (the device replay is three kernels: its heaviest one counts)
+            dom = max(cands, key=lambda n: kern[n].get("max_kernel_ms", kern[n]["ms_total"]) / kern[n]["steps"])
             roof = cands[dom]
         out = {
             "metric": "confirmed overlaps/sec (ovlp_t records, index+overlap stages, seqdb resident in HBM)",

@@ -1060,6 +1060,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   const size_t window = getenv("PGX_REPLAY_WIN") ? (size_t)atoll(getenv("PGX_REPLAY_WIN")) : (size_t)262144;
   const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 3;
   const bool wide = !(getenv("PGX_REPLAY_WIDE") && atoi(getenv("PGX_REPLAY_WIDE")) == 0);  // sparse passes: a wavefront per bucket, four rows per step
+  const size_t dense_den = getenv("PGX_REPLAY_DENSE") ? (size_t)std::max(1, atoi(getenv("PGX_REPLAY_DENSE"))) : 3;  // dense rounds while more than 1/dense_den of the buckets is dirty
   const bool wide_dense = getenv("PGX_REPLAY_WIDE") && atoi(getenv("PGX_REPLAY_WIDE")) >= 2;
   const int chain = getenv("PGX_REPLAY_CHAIN") ? std::max(1, atoi(getenv("PGX_REPLAY_CHAIN"))) : 4;
   static const bool deep = getenv("PGX_TRACE") && atoi(getenv("PGX_TRACE")) >= 2;  // per-kernel wall times (synchronises after every launch)
@@ -1083,20 +1084,23 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     unsigned rounds = 0;
     for (;;) {  // until no bucket is dirty
       ++rounds;
-      if (known && (n_dirty > LIST_CAP || n_dirty * 3 > nb)) {  // many of the buckets: a group of 16 lanes each, in bucket order
+      if (known && (n_dirty > LIST_CAP || n_dirty * dense_den > nb)) {  // many of the buckets: a group of 16 lanes each, in bucket order
         // dense: window by window, in order (a window's buckets mostly depend on earlier windows)
         const size_t a_lo = d_lo & ~(size_t)63;  // (aligned: a bucket always belongs to the same wavefront slot)
         const size_t win = n_dirty > window / 4 ? window : (size_t)(d_hi - a_lo);
         for (size_t lo = a_lo; lo < d_hi; lo += win) {
           const uint32_t hi = (uint32_t)std::min<size_t>(d_hi, lo + win);
           for (int k = 0; k < inner; ++k) {
-            std::optional<KernelTimer> tm;
-            if (timed) tm.emplace("replay", k == 0 ? hi - lo : 0);  // (units: buckets of the window, counted once)
+            std::optional<KernelTimer> tm;  // PGX_REPLAY_TIMING=1: "replay_dense" = k_eval, "replay_rows" = k_eval_rows, "replay_update" = k_update
+            if (timed) tm.emplace(wide_dense ? "replay_rows" : "replay_dense", k == 0 ? hi - lo : 0);  // (units: buckets of the window, once)
             if (deep) sync(), td = now_ms();
             if (wide_dense) hipLaunchKernelGGL((k_eval_rows<64, 16>), dim3(cdiv256((size_t)(hi - lo) * 64)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
             else hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
+            tm.reset();
             if (deep) sync(), t_eval += now_ms() - td, td = now_ms();
+            if (timed) tm.emplace("replay_update", 0);
             hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
+            tm.reset();
             if (deep) sync(), t_upd += now_ms() - td, fprintf(stderr, "[pgx]     iteration: eval %.3f ms, update %.3f ms\n", t_eval, t_upd), t_eval = t_upd = 0;
           }
         }
@@ -1111,9 +1115,11 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
         const unsigned groups = (unsigned)std::min<size_t>(est, LIST_CAP);
         for (int c = 0; c < chain; ++c) {
           std::optional<KernelTimer> tm;
-          if (timed) tm.emplace("replay", 0);
+          if (timed) tm.emplace(wide ? "replay_rows" : "replay_dense", 0);
           if (wide) hipLaunchKernelGGL((k_eval_rows<64, 16>), dim3(cdiv256((size_t)groups * 64)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
           else hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)groups * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
+          tm.reset();
+          if (timed) tm.emplace("replay_update", 0);
           hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)groups * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
           tm.reset();
           count_dirty();

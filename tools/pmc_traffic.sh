@@ -16,7 +16,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if m:
             acc[m.group(1)].append(float(r["Counter_Value"]))
     for k, v in acc.items():
-        if k in ("k_align4", "k_align1", "k_sketch_wave", "k_reduce_read", "k_eval", "k_update"):
+        if k in ("k_align4", "k_align1", "k_sketch_wave", "k_reduce_read", "k_eval", "k_eval_rows", "k_update"):
             res.setdefault(k, {})[c + "_KB_per_launch"] = sum(v) / len(v)
             res[k]["launches"] = len(v)
 for k, v in res.items():
