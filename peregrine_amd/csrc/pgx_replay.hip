@@ -802,6 +802,7 @@ __global__ __launch_bounds__(256) void k_update(R r, uint32_t lo, uint32_t hi, u
   const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPW + (uint32_t)(lane / GL));
   const uint32_t j = (uint32_t)jj;
   const bool alive = jj < hi && r.evaluated[j] && !r.c->overflow;
+  if (blockIdx.x == 0 && threadIdx.x == 0) r.c->ndirty = 0, r.c->min_dirty = 0xFFFFFFFFu, r.c->max_dirty = 0;  // (the count that follows starts afresh)
   if (!__ballot(alive)) return;
   const uint32_t pnew = alive ? r.parity[j] : 0, pold = pnew ^ 1;
   // what this evaluation inserts: take or refresh ownership (lowest bucket wins)
@@ -927,6 +928,7 @@ __global__ __launch_bounds__(256) void k_file(R r, uint32_t limit) {
 // ---- check the guesses against the results ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_settle(R r) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) r.c->ndirty = 0, r.c->min_dirty = 0xFFFFFFFFu, r.c->max_dirty = 0;  // (the count that follows starts afresh)
   if (j >= r.nb || !(r.bflags[j] & F_GUESS)) return;
   const uint32_t b = r.bid[j], s0 = r.bstart[b];
   bool bad = false, remain = false;
@@ -1073,8 +1075,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   bool have_list = false;                  // the device holds a dirty list (a count has run since the last evaluations)
   bool known = true;                       // n_dirty / d_lo / d_hi are current
   double align_ms = 0;
-  auto count_dirty = [&] {  // no host round trip: ndirty, the range and the list stay on the device
-    PGX_HIP(hipMemcpyAsync(&dc.p->ndirty, reset3, 3 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+  auto count_dirty = [&](bool reset = false) {  // no host round trip: ndirty, the range and the list stay on the device
+    if (reset) PGX_HIP(hipMemcpyAsync(&dc.p->ndirty, reset3, 3 * sizeof(uint32_t), hipMemcpyHostToDevice, s));  // (k_update / k_settle reset otherwise)
     hipLaunchKernelGGL(k_count, dim3(cdiv256(nb)), dim3(256), 0, s, r);
     have_list = true;
   };
@@ -1109,7 +1111,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
       // sparse: `chain` passes straight from the list the last count left on the device -- the kernels read its length there,
       // so the host is not in the loop (a pass with nothing to do costs two empty launches); what a pass dirties is listed by
       // the count behind it
-      if (!have_list) count_dirty();
+      if (!have_list) count_dirty(true);
       {
         const size_t est = known && n_dirty <= LIST_CAP / 4 ? std::max<size_t>(n_dirty * 4, 1024) : (size_t)LIST_CAP;
         const unsigned groups = (unsigned)std::min<size_t>(est, LIST_CAP);
