@@ -445,12 +445,47 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
   const double tv2 = now_ms();
   // final places: groups in ascending outer slot order
   std::vector<uint32_t> order;
-  order.reserve(ng);
-  for (uint32_t s0 = 0; s0 < outer.nb; ++s0)
-    if (outer.used[s0] && go[outer.ids[s0]].nb) order.push_back(outer.ids[s0]);
+  std::vector<uint64_t> eat, bat;
+  if (nin == 1 || outer.nb < (1u << 16)) {
+    order.reserve(ng);
+    for (uint32_t s0 = 0; s0 < outer.nb; ++s0)
+      if (outer.used[s0] && go[outer.ids[s0]].nb) order.push_back(outer.ids[s0]);
+    eat.assign(order.size() + 1, 0), bat.assign(order.size() + 1, 0);
+    for (size_t i = 0; i < order.size(); ++i) eat[i + 1] = eat[i] + go[order[i]].ne, bat[i + 1] = bat[i] + go[order[i]].nb;
+  } else {
+    // the slot scan touches one GroupOut per used slot at random: every worker takes a slot range, the pieces are joined in
+    // range order, and the running totals are carried over the pieces
+    struct Piece {
+      std::vector<uint32_t> ids;
+      uint64_t ne = 0, nb = 0;
+    };
+    std::vector<Piece> piece(nin);
+    par_run(nin, [&](unsigned ti) {
+      Piece &pc = piece[ti];
+      const uint32_t lo = (uint32_t)((uint64_t)outer.nb * ti / nin), hi = (uint32_t)((uint64_t)outer.nb * (ti + 1) / nin);
+      for (uint32_t s0 = lo; s0 < hi; ++s0)
+        if (outer.used[s0]) {
+          const GroupOut &o = go[outer.ids[s0]];
+          if (o.nb) pc.ids.push_back(outer.ids[s0]), pc.ne += o.ne, pc.nb += o.nb;
+        }
+    });
+    std::vector<size_t> first(nin + 1, 0);
+    std::vector<uint64_t> e0(nin + 1, 0), b0(nin + 1, 0);
+    for (unsigned t = 0; t < nin; ++t)
+      first[t + 1] = first[t] + piece[t].ids.size(), e0[t + 1] = e0[t] + piece[t].ne, b0[t + 1] = b0[t] + piece[t].nb;
+    order.resize(first[nin]);
+    eat.assign(first[nin] + 1, 0), bat.assign(first[nin] + 1, 0);
+    par_run(nin, [&](unsigned ti) {
+      uint64_t e = e0[ti], b = b0[ti];
+      size_t at = first[ti];
+      for (uint32_t id : piece[ti].ids) {
+        order[at] = id, eat[at] = e, bat[at] = b;
+        e += go[id].ne, b += go[id].nb, ++at;
+      }
+    });
+    eat[first[nin]] = e0[nin], bat[first[nin]] = b0[nin];
+  }
   const size_t no = order.size();
-  std::vector<uint64_t> eat(no + 1, 0), bat(no + 1, 0);
-  for (size_t i = 0; i < no; ++i) eat[i + 1] = eat[i] + go[order[i]].ne, bat[i + 1] = bat[i] + go[order[i]].nb;
   const uint64_t ne = eat[no], nbk = bat[no];
   v.n_buckets = nbk, v.n_entries = ne;
   if (ids_only) v.bids.alloc(nbk);
