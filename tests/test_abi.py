@@ -31,9 +31,20 @@ def test_header_symbols_are_exported(lib):
         assert hasattr(lib, n), n
 
 
-def test_struct_sizes_match_the_formats():
+def test_struct_sizes_match_the_formats(tmp_path):
     assert C.sizeof(_lib.IndexParams) == 28 and C.sizeof(_lib.OverlapParams) == 28
     assert _lib.MATCH_DTYPE.itemsize == 32 and _lib.ALIGN_KEY_DTYPE.itemsize == 16
+    # the ctypes mirrors against what a C compiler makes of include/pgx.h
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "pgx.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu\\n", '
+                   'sizeof(pgx_overlap_stats), offsetof(pgx_overlap_stats, gpu_ms), offsetof(pgx_overlap_stats, n_evaluations), '
+                   'offsetof(pgx_overlap_stats, device_replay), sizeof(pgx_ovlp), sizeof(pgx_align_key)); return 0; }\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    S = _lib.OverlapStats
+    assert got == [C.sizeof(S), S.gpu_ms.offset, S.n_evaluations.offset, S.device_replay.offset, 64, 16], got
 
 
 def test_codec_is_the_reference_format(lib):
