@@ -1218,6 +1218,20 @@ bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visi
     alloc_out(0);
     return true;
   }
+  {  // the device tables must fit beside what is already resident (otherwise the host replay, which only needs host memory)
+    const size_t ne = std::max<size_t>(n_entries, 1024);
+    const size_t need = (size_t)pow2_at_least(ne) * (sizeof(PSlot) + sizeof(MSlot)) + ne * (6 * sizeof(Item) + 8 * sizeof(RNode) + sizeof(pgx_align_key) + sizeof(pgx_match)) +
+                        nb * (size_t)(64 * sizeof(Item) + 64) + (256u << 20);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b) {
+      dev_cache_trim();  // (blocks the cache holds for re-use count as used)
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b) {
+        fprintf(stderr, "[pgx] note: the device replay's tables (%.1f GB) do not fit the free device memory (%.1f GB); the host replay takes over\n",
+                need / 1e9, free_b / 1e9);
+        return false;
+      }
+    }
+  }
   double mult[5] = {1, 1, 1, 1, 1};  // items, reader nodes, requests, pair table, memo table
   if (getenv("PGX_REPLAY_PAIRS_X")) mult[3] = atof(getenv("PGX_REPLAY_PAIRS_X"));
   if (getenv("PGX_REPLAY_MEMO_X")) mult[4] = atof(getenv("PGX_REPLAY_MEMO_X"));
