@@ -451,6 +451,13 @@ def test_device_replay_equals_oracle(small, monkeypatch):
             assert formats.ovlp_fields_equal(got, want), (kw, it)
             assert st["n_align_needed"] == ost["n_align"] and st["n_seen_skip"] == ost["n_seen_skip"], (kw, it)
     monkeypatch.delenv("PGX_REPLAY_WIN"), monkeypatch.delenv("PGX_REPLAY_K")
+    # undersized device tables: the walk is repeated with larger ones (x4 per attempt), then handed to the host replay
+    want, ost = U.orc_overlap(db, ix.top, ix.top_mc)
+    for x in ("0.3", "0.02", "0.0005"):
+        monkeypatch.setenv("PGX_REPLAY_PAIRS_X", x), monkeypatch.setenv("PGX_REPLAY_MEMO_X", x)
+        got, st = rdb.overlap(ix.top, ix.top_mc)
+        assert formats.ovlp_fields_equal(got, want) and st["n_align_needed"] == ost["n_align"], x
+    monkeypatch.delenv("PGX_REPLAY_PAIRS_X"), monkeypatch.delenv("PGX_REPLAY_MEMO_X")
     g = simreads.make_genome(2_000_000, 31, repeat_families=6, repeat_len=5000, repeat_copies=12, divergence=0.02, tandem=8)
     db2 = simreads.simulate_reads(g, coverage=24.0, seed=5, mean_len=9000, sd_len=2500, err=0.012)
     rdb2 = ResidentDB(db2, 0)
