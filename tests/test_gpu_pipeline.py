@@ -89,3 +89,12 @@ def test_pipeline_like_the_reference_test_scripts(tmp_path):
         for k in ("preads.ovl", "read_map.txt", "ref2ref.out"):
             assert out["ref", k] == out[who, k], (who, k)
     assert out["ref", "preads.ovl"].count(b"\n") > 500 and out["ref", "read_map.txt"].count(b"\n") > 500
+    # the same overlap chunks once more with the greedy walk forced onto the GPU (production picks it from 0.2 M pair records;
+    # this set is smaller): the files must not change
+    env = dict(os.environ, PGX_GPU_REPLAY="1")
+    for c in (1, 2):
+        exe = os.path.join(ROOT, "bin", "native", "pgx_cli")
+        o = tmp_path / f"ovlp_dev.{c:02d}"
+        subprocess.run([exe, "shmr_overlap", "-p", str(tmp_path / "native" / "index" / "seq_dataset"), "-l", str(tmp_path / "native" / "index" / "shmr-L2"),
+                        "-t", "2", "-c", f"{c:02d}", "-o", str(o)], check=True, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert o.read_bytes() == (tmp_path / "ref" / "ovlp" / f"ovlp.{c:02d}").read_bytes(), c
