@@ -25,53 +25,208 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SKETCH_BYTES_PER_BASE = 1.04     # 1 B seqdb + 16 B/408 L2 + MC  (-m 0)
 ALIGN_BYTES_PER_PAIR = 21664.0   # 2 x 10.8 kB read + 64 B written
+LEVELS = 2
+WORKLOAD_TEXT = {
+    "c3": "BASELINE configs[2], uniform-random 150 Mb genome x 30x",
+    "ecoli": "BASELINE configs[1], E. coli-size uniform-random genome (4,639,675 bp), 4,984 reads",
+    "c4s": "BASELINE configs[3] scaled to one GPU, 300 Mb genome seeded with 6 kb x 300-copy repeat families, tandem arrays and homopolymers x 30x",
+    "c5s": "BASELINE configs[4] scaled to one GPU, the c4s read set with -l 1 (L1 shimmers) and mc_upper 240",
+}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--two-stage", action="store_true",
                     help="N=1 only: hand the shimmer list from the index to the overlap stage through host arrays (as the "
                          "multi-GPU path must, around its all-gather) instead of leaving it in HBM")
-    ap.add_argument("--workload", default="ecoli",
-                    help="ecoli (BASELINE configs[1], default) | small | tiny | c3 (configs[2]: 150 Mb x 30x, 4.5 Gbases, "
-                         "generated on the GPU; CPU baseline on a 10 Mb x 30x sample of the same recipe)")
+    ap.add_argument("--workload", default="c3",
+                    help="c3 (default; BASELINE configs[2]: 150 Mb x 30x, 4.5 Gbases, the largest single-GPU configuration, "
+                         "generated on the GPU) | ecoli (configs[1]) | c4s | c5s (repeat-seeded, scaled configs[3]/[4]) | small | tiny")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", default="full", choices=("full", "sample"),
+                    help="full (default): the reference binaries on the WHOLE workload -- one process on one core (its ovlp_t "
+                         "stream is compared field by field with the timed GPU output) and, beside it, N processes over N "
+                         "chunks on N = min(nproc, 24) cores; sample: a 10 Mb x 30x set of the same recipe (count check only)")
     return ap.parse_args()
 
 
-def cpu_baseline(db, n_records_expected):
-    """The REAL reference (oracle/_ref, compiled in the build container) on one host core, whole workload, one chunk;
-    falls back to the oracle port (liboracle.so) if the prebuilt binaries are absent.  Checker/baseline only."""
+def _pair_keys(ov):
+    r0 = ov["y0"] >> np.uint64(32)
+    r1 = ov["y1"] >> np.uint64(32)
+    return (np.minimum(r0, r1) << np.uint64(32)) | np.maximum(r0, r1)
+
+
+def _scratch_dir(need_bytes):
+    """a directory with room for the seqdb file + the reference's outputs (page-cache backed either way)"""
+    best, free = None, -1
+    for d in (os.environ.get("PGX_BENCH_TMP"), "/dev/shm", tempfile.gettempdir()):
+        if d and os.path.isdir(d):
+            try:
+                st = os.statvfs(d)
+            except OSError:
+                continue
+            f = st.f_bavail * st.f_frsize
+            if f > free:
+                best, free = d, f
+    return best if free >= need_bytes else None
+
+
+def cpu_baseline(db, ov_gpu, tag, levels=2, mc_upper=240):
+    """The REAL reference (oracle/_ref: /root/reference/src compiled in the build container; falls back to the oracle port
+    when the prebuilt binaries are absent) on the host cores of this box, same input files, whole workload:
+      (1) one process, one core: shmr_index -t 1 -c 1, shmr_overlap -t 1 -c 1 -- the configuration the GPU step ran; its ovlp_t
+          stream is compared FIELD BY FIELD, in order, with the records of the timed GPU steps;
+      (2) N processes over N index chunks, then N processes over N overlap chunks, N = min(nproc, 24) (24 cores is the
+          reference's own practical ceiling, /root/reference/README.md:127-137) -- raw records/s and unique pairs/s.
+    Also times the GPU drop-in executables end to end (file -> H2D -> kernels -> D2H -> file) on the same files.
+    Checker / baseline only: nothing here is on the product path."""
+    import concurrent.futures as cf
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_util as U
+    from peregrine_amd import formats
+    need = int(db.seqdb.size * 1.1) + 64 * len(ov_gpu) * 8 + (1 << 30)
+    base = _scratch_dir(need)
+    if base is None:
+        return {"value": None, "unit": "overlaps/s", "cores": 0, "kind": "none", "sample": f"no scratch directory with {need >> 30} GiB free"}
+    d = tempfile.mkdtemp(prefix="pgx_bench_", dir=base)
+    try:
+        pre = os.path.join(d, "sd")
+        formats.write_seqdb(pre, db)
+        have = U.have_ref()
+        kind = "reference" if have else "port"
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        N = max(1, min(ncpu, 24))
+
+        def run_index(total, c, out):
+            if have:
+                U.ref_run("shmr_index", "-p", pre, "-t", total, "-c", c, "-m", 0, "-l", levels, "-o", out)
+            else:
+                subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import oracle_util as U; "
+                                "U.orc_index_chunk(%r, %r, %d, %d, %d, 6, 0, 80, 16)" % (os.path.join(ROOT, "tests"), pre, out, total, c, levels)], check=True)
+
+        def run_overlap(total, c, lpre, out):
+            if have:
+                U.ref_run("shmr_overlap", "-p", pre, "-l", lpre, "-t", total, "-c", c, "-M", mc_upper, "-o", out)
+            else:
+                subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import oracle_util as U; "
+                                "U.orc_overlap_chunk(%r, %r, %r, %d, %d, 4, 2, %d)" % (os.path.join(ROOT, "tests"), pre, lpre, out, total, c, mc_upper)], check=True)
+
+        def one_core():
+            t0 = time.perf_counter()
+            run_index(1, 1, os.path.join(d, "ix1"))
+            t1 = time.perf_counter()
+            run_overlap(1, 1, os.path.join(d, "ix1-L%d" % levels), os.path.join(d, "ov1"))
+            t2 = time.perf_counter()
+            return t1 - t0, t2 - t1
+
+        def n_cores():
+            os.makedirs(os.path.join(d, "n"), exist_ok=True)
+            t0 = time.perf_counter()
+            with cf.ThreadPoolExecutor(N) as ex:
+                list(ex.map(lambda c: run_index(N, c, os.path.join(d, "n", "ix")), range(1, N + 1)))
+            t1 = time.perf_counter()
+            with cf.ThreadPoolExecutor(N) as ex:
+                list(ex.map(lambda c: run_overlap(N, c, os.path.join(d, "n", "ix-L%d" % levels), os.path.join(d, "n", "ov.%02d" % c)), range(1, N + 1)))
+            t2 = time.perf_counter()
+            return t1 - t0, t2 - t1
+
+        concurrent = ncpu >= N + 2 and N > 1      # both legs at once only when they do not share cores
+        if concurrent:
+            with cf.ThreadPoolExecutor(2) as ex:
+                f1, fn = ex.submit(one_core), ex.submit(n_cores)
+                (i1, o1), (iN, oN) = f1.result(), fn.result()
+        else:
+            i1, o1 = one_core()
+            iN, oN = n_cores() if N > 1 else (i1, o1)
+        ref1 = formats.read_ovlp(os.path.join(d, "ov1"))
+        fields_equal = bool(formats.ovlp_fields_equal(np.asarray(ov_gpu), ref1))
+        uniq1 = int(len(np.unique(_pair_keys(ref1))))
+        if N > 1:
+            raw = uniqN = 0
+            keys = []
+            for c in range(1, N + 1):
+                o = formats.read_ovlp(os.path.join(d, "n", "ov.%02d" % c))
+                raw += len(o)
+                keys.append(_pair_keys(o))
+            uniqN = int(len(np.unique(np.concatenate(keys)))) if keys else 0
+            del keys
+        else:
+            raw, uniqN = len(ref1), uniq1
+        out = {
+            "value": raw / (iN + oN), "unit": "overlaps/s", "cores": N, "kind": kind,
+            "sample": f"whole workload {tag} ({db.n_reads} reads, {db.n_bases} bases): {N} processes over {N} index chunks, then {N} "
+                      f"processes over {N} overlap chunks (raw ovlp_t records of all chunks / wall time of both stages); host has {ncpu} usable cores"
+                      + ("; run beside the 1-core leg" if concurrent else ""),
+            "index_s": iN, "overlap_s": oN, "records": int(raw), "unique_pairs": uniqN,
+            "index_bases_per_s": db.n_bases / iN, "overlap_records_per_s": raw / oN,
+            "unique_pairs_per_s": uniqN / (iN + oN),
+            "one_core": {"value": len(ref1) / (i1 + o1), "unit": "overlaps/s", "cores": 1, "index_s": i1, "overlap_s": o1,
+                         "records": int(len(ref1)), "unique_pairs": uniq1, "index_bases_per_s": db.n_bases / i1,
+                         "overlap_records_per_s": len(ref1) / o1,
+                         "sample": "1 index chunk + 1 overlap chunk, 1 process (the chunking of the timed GPU step)"},
+            "records_match_gpu": fields_equal,
+            "records_match_gpu_means": "every field of every ovlp_t record of the timed GPU steps equals the reference's 1-chunk "
+                                       "stream, in order (formats.ovlp_fields_equal; padding bytes masked)",
+        }
+        # ---- GPU, end to end through the drop-in executables on the same files (SURVEY 8d: file -> H2D -> kernels -> D2H -> file)
+        exe = os.path.join(ROOT, "bin", "native")
+        if os.path.exists(os.path.join(exe, "shmr_index")):
+            try:
+                env = dict(os.environ)
+                best = None
+                for rep in range(2):    # the second run has the executable, the library and the files in the page cache
+                    t0 = time.perf_counter()
+                    subprocess.run([os.path.join(exe, "shmr_index"), "-p", pre, "-t", "1", "-c", "1", "-m", "0", "-l", str(levels), "-o", os.path.join(d, "gx")],
+                                   check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    t1 = time.perf_counter()
+                    subprocess.run([os.path.join(exe, "shmr_overlap"), "-p", pre, "-l", os.path.join(d, "gx-L%d" % levels), "-t", "1", "-c", "1",
+                                    "-M", str(mc_upper), "-o", os.path.join(d, "gov")], check=True, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                    t2 = time.perf_counter()
+                    if best is None or t2 - t0 < best[0] + best[1]:
+                        best = (t1 - t0, t2 - t1)
+                gov = formats.read_ovlp(os.path.join(d, "gov"))
+                same_l2 = open(os.path.join(d, "gx-L%d-01-of-01.dat" % levels), "rb").read() == open(os.path.join(d, "ix1-L%d-01-of-01.dat" % levels), "rb").read()
+                out["gpu_end_to_end"] = {
+                    "what": "bin/native/shmr_index + bin/native/shmr_overlap as separate processes on the same files: process start, "
+                            "HIP context, file read, H2D, kernels, D2H, file write (best of 2 runs)",
+                    "index_s": best[0], "overlap_s": best[1], "overlaps_per_s": len(gov) / (best[0] + best[1]),
+                    "index_bases_per_s": db.n_bases / best[0], "overlap_records_per_s": len(gov) / best[1],
+                    "l2_file_identical_to_reference": bool(same_l2), "ovlp_fields_equal_reference": bool(formats.ovlp_fields_equal(gov, ref1)),
+                }
+            except Exception as e:   # the drop-ins fail loudly without a GPU; the baseline figures above stand on their own
+                out["gpu_end_to_end"] = {"error": repr(e)}
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def cpu_baseline_sample(sample):
+    """bounded form (--cpu-baseline sample): the reference on one core on a small set of the same recipe; count only"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_util as U
     from peregrine_amd import formats
     with tempfile.TemporaryDirectory() as d:
         pre = os.path.join(d, "sd")
-        formats.write_seqdb(pre, db)
+        formats.write_seqdb(pre, sample)
+        kind = "reference" if U.have_ref() else "port"
+        t0 = time.perf_counter()
         if U.have_ref():
-            kind = "reference"
-            t0 = time.perf_counter()
             U.ref_run("shmr_index", "-p", pre, "-t", 1, "-c", 1, "-m", 0, "-o", os.path.join(d, "ix"))
             t1 = time.perf_counter()
             U.ref_run("shmr_overlap", "-p", pre, "-l", os.path.join(d, "ix-L2"), "-t", 1, "-c", 1, "-o", os.path.join(d, "ov"))
-            t2 = time.perf_counter()
         else:
-            kind = "port"
-            t0 = time.perf_counter()
             U.orc_index_chunk(pre, os.path.join(d, "ix"), 1, 1, 2, 6, 0, 80, 16)
             t1 = time.perf_counter()
             U.orc_overlap_chunk(pre, os.path.join(d, "ix-L2"), os.path.join(d, "ov"), 1, 1)
-            t2 = time.perf_counter()
+        t2 = time.perf_counter()
         nrec = os.path.getsize(os.path.join(d, "ov")) // 64
-    return {
-        "value": nrec / (t2 - t0), "unit": "overlaps/s", "cores": 1, "kind": kind,
-        "sample": f"whole workload ({db.n_reads} reads, {db.n_bases} bases), 1 index chunk + 1 overlap chunk, 1 process",
-        "index_bases_per_s": db.n_bases / (t1 - t0), "overlap_records_per_s": nrec / (t2 - t1),
-        "index_s": t1 - t0, "overlap_s": t2 - t1, "records": int(nrec), "records_match_gpu": bool(nrec == n_records_expected),
-    }
+    return {"value": nrec / (t2 - t0), "unit": "overlaps/s", "cores": 1, "kind": kind,
+            "sample": f"10 Mb x 30x set of the same recipe ({sample.n_reads} reads, {sample.n_bases} bases), 1 chunk, 1 process",
+            "index_s": t1 - t0, "overlap_s": t2 - t1, "records": int(nrec), "records_match_gpu": None}
 
 
 def main():
@@ -102,11 +257,15 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     # ---- synthetic input (untimed): rank r simulates genome r; the union is the job's read set -----------------
-    cfg = dict(simreads.WORKLOADS[a.workload])
-    if a.workload == "c3":   # multi-Gbase sets are generated with the torch recipe on the GPU (seconds instead of tens of minutes)
-        mine = simreads.simulate_reads_torch(cfg["genome_len"], cfg["genome_seed"] + 7919 * rank, cfg["coverage"], seed=42 + rank)
+    sp = dict(levels=2, mc_upper=240)
+    sp.update(simreads.STAGE_PARAMS.get(a.workload, {}))
+    global LEVELS
+    LEVELS = sp["levels"]
+    if a.workload in simreads.TORCH_WORKLOADS:
+        mine = simreads.make_workload_torch(a.workload, rank)
         mine.names = None
     else:
+        cfg = dict(simreads.WORKLOADS[a.workload])
         g = simreads.make_genome(cfg.pop("genome_len"), cfg.pop("genome_seed") + 7919 * rank)
         mine = simreads.simulate_reads(g, seed=42 + rank, **cfg)
     if world > 1:
@@ -122,15 +281,15 @@ def main():
 
     def step():
         if world == 1 and not a.two_stage:
-            return rdb.index_overlap()
-        ix = rdb.index(total_chunk=world, mychunk=rank + 1, levels=2, reduction=6, window=80, kmer=16)
+            return rdb.index_overlap(levels=sp['levels'], mc_upper=sp['mc_upper'])
+        ix = rdb.index(total_chunk=world, mychunk=rank + 1, levels=sp['levels'])
         if world > 1:  # the path's one exchange step: every overlap chunk needs every index chunk's L2 + counts
             got = allgather_many([torch.from_numpy(ix.top.view(np.uint8)).to(xdev), torch.from_numpy(ix.top_mc.view(np.uint8)).to(xdev)], world)
             mm = np.concatenate([p.cpu().numpy().view(MM_DTYPE) for p in got[0]])
             mc = np.concatenate([p.cpu().numpy().view(MC_DTYPE) for p in got[1]])
         else:
             mm, mc = ix.top, ix.top_mc
-        ov, st = rdb.overlap(mm, mc, total_chunk=world, mychunk=rank + 1)
+        ov, st = rdb.overlap(mm, mc, total_chunk=world, mychunk=rank + 1, mc_upper=sp['mc_upper'])
         return ix, ov, st
 
     def fence():
@@ -147,12 +306,12 @@ def main():
     for _ in range(a.steps):
         s0 = time.perf_counter()
         if world == 1 and not a.two_stage:   # one chunk: the shimmer list and its counts stay in HBM between the stages
-            ix, ov, st = rdb.index_overlap()
+            ix, ov, st = rdb.index_overlap(levels=sp['levels'], mc_upper=sp['mc_upper'])
             s2 = time.perf_counter()
             t_index += ix.ms * 1e-3
             t_ovlp += (s2 - s0) - ix.ms * 1e-3
             continue
-        ix = rdb.index(total_chunk=world, mychunk=rank + 1)
+        ix = rdb.index(total_chunk=world, mychunk=rank + 1, levels=sp['levels'])
         s1 = time.perf_counter()
         if world > 1:
             got = allgather_many([torch.from_numpy(ix.top.view(np.uint8)).to(xdev), torch.from_numpy(ix.top_mc.view(np.uint8)).to(xdev)], world)
@@ -160,7 +319,7 @@ def main():
             mc = np.concatenate([p.cpu().numpy().view(MC_DTYPE) for p in got[1]])
         else:
             mm, mc = ix.top, ix.top_mc
-        ov, st = rdb.overlap(mm, mc, total_chunk=world, mychunk=rank + 1)
+        ov, st = rdb.overlap(mm, mc, total_chunk=world, mychunk=rank + 1, mc_upper=sp['mc_upper'])
         s2 = time.perf_counter()
         t_index += s1 - s0
         t_ovlp += s2 - s1
@@ -188,9 +347,9 @@ def main():
             os.environ["PGX_REPLAY_TIMING"] = "1"
             _lib.timing_reset()
             if world == 1 and not a.two_stage:
-                _, _, st_x = rdb.index_overlap()
+                _, _, st_x = rdb.index_overlap(levels=sp['levels'], mc_upper=sp['mc_upper'])
             else:
-                _, st_x = rdb.overlap(mm, mc, total_chunk=world, mychunk=rank + 1)
+                _, st_x = rdb.overlap(mm, mc, total_chunk=world, mychunk=rank + 1, mc_upper=sp['mc_upper'])
             os.environ.pop("PGX_REPLAY_TIMING")
             rk = {}
             for nm, kname in (("replay_dense", "k_eval"), ("replay_rows", "k_eval_rows"), ("replay_update", "k_update")):
@@ -235,20 +394,23 @@ def main():
                                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
                                "bytes_per_unit": per_eval, "unit_name": "bucket evaluation",
                                "evaluations_per_s": k["units"] / (k["ms_total"] * 1e-3)}
-        # HBM traffic from the PMC counters: collected in separate rocprofv3 passes of this same command
-        # (tools/pmc_traffic.sh) and committed under profiles/; bench.py itself cannot run under two profilers
+        # HBM traffic from the PMC counters: collected in separate rocprofv3 passes of this same command ON THIS WORKLOAD
+        # (tools/pmc_traffic.sh <workload>) and committed under profiles/; bench.py itself cannot run under two profilers.
+        # A workload without its own collection reports traffic = null.
+        tfile = os.path.join("profiles", f"r02_traffic_{a.workload}.json")
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            tr = json.load(open(os.path.join(ROOT, tfile)))
             if "replay" in cands and "k_update" in tr:   # a round = one evaluation kernel (k_eval or k_eval_rows) + one k_update
                 tot = sum(tr[k]["hbm_bytes_per_launch"] * tr[k]["launches"] for k in ("k_eval", "k_eval_rows", "k_update") if k in tr)
                 tr["replay"] = {"hbm_bytes_per_launch": tot / tr["k_update"]["launches"]}
             for nm, kk in (("sketch", "k_sketch_wave"), ("align", "k_align4"), ("align1", "k_align1"), ("replay", "replay")):
                 if nm in cands and kk in tr:
                     cands[nm]["traffic"] = tr[kk]["hbm_bytes_per_launch"]
-                    cands[nm]["traffic_source"] = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
-                    cands[nm]["algorithmic_bytes_per_launch"] = cands[nm]["bytes_per_unit"] * kern[nm]["units"] / kern[nm]["launches"]
+                    cands[nm]["traffic_source"] = tfile + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch, read side x2 per the gfx950 note)"
         except Exception:
             pass
+        for nm in cands:
+            cands[nm]["algorithmic_bytes_per_launch"] = cands[nm]["bytes_per_unit"] * kern[nm]["units"] / kern[nm]["launches"]
         if cands:
             # the kernel with the most device time per step (the device replay is three kernels: its heaviest one counts)
             dom = max(cands, key=lambda n: kern[n].get("max_kernel_ms", kern[n]["ms_total"]) / kern[n]["steps"])
@@ -258,8 +420,8 @@ def main():
             "value": records * a.steps / elapsed, "unit": "overlaps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32 integer", "data": "synthetic",
-            "config": {"workload": f"{a.workload}: uniform-random genome per rank, 15 kb +-1.5 kb reads, 1 % errors, "
-                                   f"k=16 w=80 r=6 l=2, index_nchunk=ovlp_nchunk={world}, bestn 4, aln_bw 100",
+            "config": {"workload": f"{a.workload}: {WORKLOAD_TEXT.get(a.workload, a.workload)} per rank, 15 kb +-1.5 kb reads, 1 % errors, "
+                                   f"k=16 w=80 r=6 l={LEVELS}, index_nchunk=ovlp_nchunk={world}, bestn 4, mc 2..240, aln_bw 100",
                        "reads": int(db.n_reads), "bases": int(db.n_bases), "parallelism": f"chunks{world}"},
             "bases_per_sec_indexed": bases * a.steps / t_index if t_index else None,
             "overlap_records_per_sec": records * a.steps / t_ovlp if t_ovlp else None,
@@ -268,14 +430,18 @@ def main():
             "kernels": kern, "roofline": roof, "roofline_all": cands,
         }
         if world == 1 and not a.no_cpu_baseline:
-            if a.workload == "c3":  # bounded sample: the same recipe on a 10 Mb genome (~20 s of single-core reference time)
+            if a.cpu_baseline == "sample":
                 sample = simreads.simulate_reads_torch(10_000_000, 1003, 30.0, seed=42)
-                sample.names = [f"r{i:09d}" for i in range(sample.n_reads)]
-                cb = cpu_baseline(sample, -1)
-                cb["sample"] = "10 Mb x 30x sample of the c3 recipe: " + cb["sample"]
-                out["cpu_baseline"] = cb
+                out["cpu_baseline"] = cpu_baseline_sample(sample)
             else:
-                out["cpu_baseline"] = cpu_baseline(db, int(records))
+                out["cpu_baseline"] = cpu_baseline(db, ov, a.workload, sp["levels"], sp["mc_upper"])
+                cb = out["cpu_baseline"]
+                if cb.get("value"):
+                    out["gpu_over_cpu"] = {"vs_n_cores_raw_records": out["value"] / cb["value"],
+                                           "vs_n_cores_unique_pairs": out["value"] / cb["unique_pairs_per_s"],
+                                           "vs_one_core": out["value"] / cb["one_core"]["value"], "cpu_cores": cb["cores"],
+                                           "note": "GPU value = records of ONE overlap chunk (every read pair once); the N-chunk CPU run "
+                                                   "reports most pairs once per chunk, so both of its rates are given"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -99,17 +99,53 @@ def simulate_reads(genome: np.ndarray, n_reads: int | None = None, coverage: flo
     return SeqDB(seqdb, np.arange(n_reads, dtype=np.uint32), rlen, roff, names)
 
 
+def make_genome_torch(length: int, seed: int, device: str = "cuda", repeat_families: int = 0, repeat_len: int = 6000,
+                      repeat_copies: int = 0, divergence: float = 0.01, tandem: int = 0, homopolymers: int = 0):
+    """Genome of 2-bit codes on the device: uniform-random background (the same stream simulate_reads_torch always drew)
+    plus, optionally, the repeat content SURVEY.md 8(d) C4 asks for in place of CHM13: `repeat_families` families of
+    `repeat_copies` copies of a `repeat_len` unit, each copy diverged independently; `tandem` arrays of a 1..39-base unit,
+    200..3000 bases long; `homopolymers` runs of 30..400 bases.  Plants come from a second seeded generator, so a
+    repeat-free genome is bit-identical to what earlier rounds benchmarked."""
+    import torch
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    g = torch.randint(0, 4, (length,), dtype=torch.uint8, device=dev, generator=gen)
+    if not (repeat_families or tandem or homopolymers):
+        return g
+    rng = np.random.Generator(np.random.PCG64(seed ^ 0x5EED))
+    pg = torch.Generator(device=dev)
+    pg.manual_seed(seed + 0x9E3779B9)
+    for _ in range(repeat_families):
+        unit = torch.randint(0, 4, (repeat_len,), dtype=torch.uint8, device=dev, generator=pg)
+        starts = rng.integers(0, length - repeat_len, repeat_copies)
+        for s in starts:
+            hit = torch.rand(repeat_len, device=dev, generator=pg) < divergence
+            sub = torch.randint(0, 4, (repeat_len,), dtype=torch.uint8, device=dev, generator=pg)
+            g[int(s):int(s) + repeat_len] = torch.where(hit, sub, unit)
+    for _ in range(tandem):
+        period = int(rng.integers(1, 40))
+        n = int(rng.integers(200, 3000))
+        unit = torch.from_numpy(rng.integers(0, 4, period, dtype=np.uint8)).to(dev)
+        s = int(rng.integers(0, length - n))
+        g[s:s + n] = unit.repeat(n // period + 1)[:n]
+    for _ in range(homopolymers):
+        n = int(rng.integers(30, 400))
+        s = int(rng.integers(0, length - n))
+        g[s:s + n] = int(rng.integers(0, 4))
+    return g
+
+
 def simulate_reads_torch(genome_len: int, genome_seed: int, coverage: float, seed: int = 42, device: str = "cuda",
                          mean_len: int = 15000, sd_len: int = 1500, err: float = 0.01, wrap: int = 40000,
-                         batch_reads: int = 2048, min_len: int = 200) -> SeqDB:
+                         batch_reads: int = 2048, min_len: int = 200, **genome_kw) -> SeqDB:
     """The same recipe as simulate_reads, vectorised with torch so that multi-Gbase sets (BASELINE configs[2], 150 Mb x
     30x) are generated in seconds on the GPU.  Seeded torch generators: deterministic for a given device type, but NOT
     the same stream as the numpy generator (the E. coli-size bench set stays on the numpy path)."""
     import torch
     dev = torch.device(device)
     gen = torch.Generator(device=dev)
-    gen.manual_seed(genome_seed)
-    genome = torch.randint(0, 4, (genome_len,), dtype=torch.uint8, device=dev, generator=gen)
+    genome = make_genome_torch(genome_len, genome_seed, device, **genome_kw)
     wrap = min(wrap, genome_len)
     ext = torch.cat([genome, genome[:wrap]])
     L = ext.numel()
@@ -174,16 +210,34 @@ def seqdb_to_fasta(db: SeqDB, path: str) -> None:
 
 
 # ---- the named workloads of BASELINE.json / SURVEY.md 8(d) -------------------------------------------------
+_REPEATS = dict(repeat_families=20, repeat_len=6000, repeat_copies=300, divergence=0.01, tandem=3000, homopolymers=3000)
 WORKLOADS = {
-    # name: (genome_len, genome_seed, coverage or n_reads, kwargs)
     "tiny": dict(genome_len=50_000, genome_seed=7, n_reads=160, mean_len=5000, sd_len=500, wrap=0),
     "small": dict(genome_len=1_000_000, genome_seed=1002, coverage=16.0),
-    "ecoli": dict(genome_len=4_639_675, genome_seed=1001, n_reads=4984, n_files=8),          # C1 / C2
-    "c3": dict(genome_len=150_000_000, genome_seed=1003, coverage=30.0),                      # C3
+    "ecoli": dict(genome_len=4_639_675, genome_seed=1001, n_reads=4984, n_files=8),          # C1 / C2 (configs[0]/[1])
+    "c3": dict(genome_len=150_000_000, genome_seed=1003, coverage=30.0),                      # C3 (configs[2])
+    # C4 / C5 (configs[3]/[4]) scaled to one GPU: CHM13 is not obtainable offline, so a 300 Mb genome seeded with 20 families of
+    # 300 copies of a 6 kb unit at 1 % divergence (36 Mb of interspersed repeats), 3,000 tandem arrays and 3,000 homopolymer
+    # runs, 30x.  c5s is the same read set indexed with -l 1 (dense L1 shimmers) under mc_upper 240.
+    "c4s": dict(genome_len=300_000_000, genome_seed=1004, coverage=30.0, **_REPEATS),
+    "c5s": dict(genome_len=300_000_000, genome_seed=1004, coverage=30.0, **_REPEATS),
+    # the same recipes on a slice small enough for the CPU oracle (parity tests)
+    "c4t": dict(genome_len=20_000_000, genome_seed=1004, coverage=30.0, repeat_families=4, repeat_len=6000, repeat_copies=300,
+                divergence=0.01, tandem=200, homopolymers=200),
 }
+# stage parameters that differ from the defaults (k=16 w=80 r=6 l=2, bestn 4, mc 2..240, aln_bw 100, ovlp_upper 120)
+STAGE_PARAMS = {"c5s": dict(levels=1, mc_upper=240), "c4s": dict(levels=2, mc_upper=240)}
+TORCH_WORKLOADS = ("c3", "c4s", "c5s", "c4t")   # generated on the GPU (multi-Gbase sets in seconds instead of tens of minutes)
 
 
 def make_workload(name: str) -> SeqDB:
     cfg = dict(WORKLOADS[name])
     g = make_genome(cfg.pop("genome_len"), cfg.pop("genome_seed"))
     return simulate_reads(g, seed=42, **cfg)
+
+
+def make_workload_torch(name: str, rank: int = 0, device: str = "cuda") -> SeqDB:
+    """rank r of a weak-scaling job simulates its own genome (seed + 7919 r) with its own read stream (42 + r)"""
+    cfg = dict(WORKLOADS[name])
+    return simulate_reads_torch(cfg.pop("genome_len"), cfg.pop("genome_seed") + 7919 * rank, cfg.pop("coverage"), seed=42 + rank,
+                                device=device, **cfg)

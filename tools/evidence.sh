@@ -1,9 +1,13 @@
+#!/bin/bash
+# Round evidence on the GPU box: the graded bench line on the default workload (c3), the same command under
+# rocprofv3 --kernel-trace --stats, and the PMC traffic passes.   usage: tools/evidence.sh <tag, e.g. r02a> [workload=c3]
+T=${1:-r02}; W=${2:-c3}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-mkdir -p gpurun_out/r01e
-timeout -k 5 300 python bench.py --steps 10 --warmup 2 > gpurun_out/r01e/bench_ecoli.json 2> gpurun_out/r01e/bench_ecoli.err
-timeout -k 5 300 python bench.py --workload c3 --steps 3 --warmup 1 > gpurun_out/r01e/bench_c3.json 2> gpurun_out/r01e/bench_c3.err
-timeout -k 5 300 rocprofv3 --kernel-trace --stats -d gpurun_out/r01e/prof -o p -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > gpurun_out/r01e/bench_under_rocprof.json 2> gpurun_out/r01e/rocprof.err
-ls -R gpurun_out/r01e/prof | head -20
-python tools/rocpd_summary.py $(find gpurun_out/r01e/prof -name "*.db" | head -1) > gpurun_out/r01e/kernel_stats_bench_ecoli.txt 2>&1
-head -30 gpurun_out/r01e/kernel_stats_bench_ecoli.txt
-timeout -k 5 400 bash tools/pmc_traffic.sh < /dev/null | tail -40
+mkdir -p gpurun_out/$T
+timeout -k 5 1500 python bench.py --workload $W > gpurun_out/$T/bench_$W.json 2> gpurun_out/$T/bench_$W.err
+tail -c 600 gpurun_out/$T/bench_$W.err
+timeout -k 5 600 rocprofv3 --kernel-trace --stats -d gpurun_out/$T/prof_$W -o p -- python bench.py --workload $W --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/$T/bench_${W}_under_rocprof.json 2> gpurun_out/$T/rocprof_$W.err
+python tools/rocpd_summary.py $(find gpurun_out/$T/prof_$W -name "*.db" | head -1) > gpurun_out/$T/kernel_stats_bench_$W.txt 2>&1
+head -40 gpurun_out/$T/kernel_stats_bench_$W.txt
+rm -rf gpurun_out/$T/prof_$W      # the database is hundreds of MB; the summary is what is kept
+timeout -k 5 1300 bash tools/pmc_traffic.sh $W 2 < /dev/null | tail -60

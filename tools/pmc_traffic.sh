@@ -1,10 +1,12 @@
 #!/bin/bash
-# HBM traffic of the bench's kernels from PMC counters (separate passes, kernel-trace only), per launch.
+# HBM traffic of the bench's kernels from PMC counters (separate passes, kernel-trace only), per launch, ON ONE WORKLOAD.
+#   usage: tools/pmc_traffic.sh [workload=c3] [steps=2]   ->  gpurun_out/r02_traffic_<workload>.json
 # FETCH_SIZE on gfx950 reports exactly 1/2 of a wide coalesced read stream (MI355X_MICROARCH.md, HBM): doubled below.
+W=${1:-c3}; S=${2:-2}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/pmc_bench
+OUT=gpurun_out/pmc_bench_$W
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 180 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o p -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  timeout -k 5 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o p -- python bench.py --workload $W --steps $S --warmup 1 --no-cpu-baseline > $OUT.$c.log 2>&1
 done
 python - <<PY
 import csv, collections, json, re
@@ -16,13 +18,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         if m:
             acc[m.group(1)].append(float(r["Counter_Value"]))
     for k, v in acc.items():
-        if k in ("k_align4", "k_align1", "k_sketch_wave", "k_reduce_read", "k_eval", "k_eval_rows", "k_update"):
-            res.setdefault(k, {})[c + "_KB_per_launch"] = sum(v) / len(v)
-            res[k]["launches"] = len(v)
+        res.setdefault(k, {})[c + "_KB_per_launch"] = sum(v) / len(v)
+        res[k]["launches"] = len(v)
 for k, v in res.items():
-    # read side doubled (gfx950 FETCH_SIZE = 1/2 of wide coalesced reads; calibrated on k_sketch_wave: 599.8 MB reported
-    # for a 1197.4 MB seqdb scan), write side as reported
+    # read side doubled (gfx950 FETCH_SIZE = 1/2 of wide coalesced reads; calibrated on k_sketch_wave: the seqdb scan),
+    # write side as reported
     v["hbm_bytes_per_launch"] = (2 * v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)) * 1024
-json.dump(res, open("gpurun_out/r01_traffic.json", "w"), indent=1)
-print(json.dumps(res, indent=1))
+res["_workload"] = "$W"
+res["_command"] = "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --workload $W --steps $S --warmup 1 --no-cpu-baseline"
+json.dump(res, open("gpurun_out/r02_traffic_$W.json", "w"), indent=1)
+print(json.dumps({k: v for k, v in res.items() if k in ("k_align4", "k_align1", "k_sketch_wave", "k_reduce_read", "k_eval", "k_eval_rows", "k_update")}, indent=1))
 PY
