@@ -238,7 +238,7 @@ def main():
     import torch.distributed as dist
     from peregrine_amd import _lib, simreads
     from peregrine_amd.formats import MC_DTYPE, MM_DTYPE, SeqDB
-    from peregrine_amd.parallel import allgather_many, allgather_records
+    from peregrine_amd.parallel import GpuEngine, allgather_cat, exchange_overlap
     from peregrine_amd.shimmer import ResidentDB
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
@@ -269,28 +269,42 @@ def main():
         g = simreads.make_genome(cfg.pop("genome_len"), cfg.pop("genome_seed") + 7919 * rank)
         mine = simreads.simulate_reads(g, seed=42 + rank, **cfg)
     if world > 1:
-        parts = allgather_records(torch.from_numpy(mine.seqdb).to(xdev), world)
-        lens = allgather_records(torch.from_numpy(mine.rlen.astype(np.int64)).to(xdev), world)
-        seq = np.concatenate([p.cpu().numpy() for p in parts])
-        rlen = np.concatenate([p.cpu().numpy() for p in lens]).astype(np.uint32)
+        # the job's read set = the union of the ranks' sets, replicated in every GPU's HBM: all-gathered on the
+        # device over xGMI (RCCL), handed to the library as a device pointer -- no host hop
+        home = torch.device("cuda", dev_index)
+        seq_all, _ = allgather_cat(torch.from_numpy(mine.seqdb).to(home), world)
+        len_all, _ = allgather_cat(torch.from_numpy(mine.rlen.astype(np.uint32).view(np.uint8)).to(home), world)
+        rlen = len_all.cpu().numpy().view(np.uint32).copy()
         roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
-        db = SeqDB(seq, np.arange(len(rlen), dtype=np.uint32), rlen, roff, None)
+        rid = np.arange(len(rlen), dtype=np.uint32)
+        torch.cuda.synchronize()
+        rdb = ResidentDB.from_device(seq_all.data_ptr(), seq_all.numel(), rid, rlen, roff, dev_index)
+        db = SeqDB(np.zeros(0, np.uint8), rid, rlen, roff, None)   # (sizes only: the bytes live in HBM)
+        del seq_all, len_all
+        torch.cuda.empty_cache()
     else:
         db = mine
-    rdb = ResidentDB(db, dev_index)  # H2D once; the timed region starts with the seqdb resident in HBM
+        rdb = ResidentDB(db, dev_index)  # H2D once; the timed region starts with the seqdb resident in HBM
+    eng = GpuEngine(rdb, torch.device("cuda", dev_index))
+    ov_params = dict(mc_upper=sp["mc_upper"])
 
     def step():
-        if world == 1 and not a.two_stage:
-            return rdb.index_overlap(levels=sp['levels'], mc_upper=sp['mc_upper'])
-        ix = rdb.index(total_chunk=world, mychunk=rank + 1, levels=sp['levels'])
-        if world > 1:  # the path's one exchange step: every overlap chunk needs every index chunk's L2 + counts
-            got = allgather_many([torch.from_numpy(ix.top.view(np.uint8)).to(xdev), torch.from_numpy(ix.top_mc.view(np.uint8)).to(xdev)], world)
-            mm = np.concatenate([p.cpu().numpy().view(MM_DTYPE) for p in got[0]])
-            mc = np.concatenate([p.cpu().numpy().view(MC_DTYPE) for p in got[1]])
-        else:
-            mm, mc = ix.top, ix.top_mc
-        ov, st = rdb.overlap(mm, mc, total_chunk=world, mychunk=rank + 1, mc_upper=sp['mc_upper'])
-        return ix, ov, st
+        """one pass of the hot path: index chunk rank+1 of world, the exchange, overlap chunk rank+1 of world.
+        Returns (IndexOut, ovlp records, stats, seconds of the index stage)."""
+        s0 = time.perf_counter()
+        if world == 1 and not a.two_stage:   # one chunk: the shimmer list and its counts stay in HBM between the stages
+            ix, ov, st = rdb.index_overlap(levels=sp['levels'], mc_upper=sp['mc_upper'])
+            return ix, ov, st, ix.ms * 1e-3
+        if world == 1:
+            ix = rdb.index(levels=sp['levels'])
+            s1 = time.perf_counter()
+            ov, st = rdb.overlap(ix.top, ix.top_mc, mc_upper=sp['mc_upper'])
+            return ix, ov, st, s1 - s0
+        ix, top, mc = eng.index(world, rank + 1, sp['levels'])
+        s1 = time.perf_counter()
+        (ov, st), info = exchange_overlap(eng, rank, world, top, mc, **ov_params)   # counts all-gather + record all-to-all(v), on device
+        st["exchange"] = info
+        return ix, ov, st, s1 - s0
 
     def fence():
         if world > 1:
@@ -305,24 +319,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         s0 = time.perf_counter()
-        if world == 1 and not a.two_stage:   # one chunk: the shimmer list and its counts stay in HBM between the stages
-            ix, ov, st = rdb.index_overlap(levels=sp['levels'], mc_upper=sp['mc_upper'])
-            s2 = time.perf_counter()
-            t_index += ix.ms * 1e-3
-            t_ovlp += (s2 - s0) - ix.ms * 1e-3
-            continue
-        ix = rdb.index(total_chunk=world, mychunk=rank + 1, levels=sp['levels'])
-        s1 = time.perf_counter()
-        if world > 1:
-            got = allgather_many([torch.from_numpy(ix.top.view(np.uint8)).to(xdev), torch.from_numpy(ix.top_mc.view(np.uint8)).to(xdev)], world)
-            mm = np.concatenate([p.cpu().numpy().view(MM_DTYPE) for p in got[0]])
-            mc = np.concatenate([p.cpu().numpy().view(MC_DTYPE) for p in got[1]])
-        else:
-            mm, mc = ix.top, ix.top_mc
-        ov, st = rdb.overlap(mm, mc, total_chunk=world, mychunk=rank + 1, mc_upper=sp['mc_upper'])
-        s2 = time.perf_counter()
-        t_index += s1 - s0
-        t_ovlp += s2 - s1
+        ix, ov, st, ti = step()
+        t_index += ti
+        t_ovlp += time.perf_counter() - s0 - ti
     fence()
     elapsed = time.perf_counter() - t0
 
@@ -341,15 +340,12 @@ def main():
             ms, launches, units = _lib.timing(name)
             if launches:
                 kern[name] = {"ms_total": ms, "launches": launches, "units": units, "avg_ms": ms / launches, "steps": a.steps}
-        if st.get("device_replay"):
+        if st.get("device_replay") and world == 1:
             # the device replay's kernels (k_eval + k_update pairs) are timed in ONE EXTRA step, outside the timed region: a HIP
             # event pair around each of their ~40 launches per step would cost ~2 % of the step
             os.environ["PGX_REPLAY_TIMING"] = "1"
             _lib.timing_reset()
-            if world == 1 and not a.two_stage:
-                _, _, st_x = rdb.index_overlap(levels=sp['levels'], mc_upper=sp['mc_upper'])
-            else:
-                _, st_x = rdb.overlap(mm, mc, total_chunk=world, mychunk=rank + 1, mc_upper=sp['mc_upper'])
+            _, _, st_x, _ = step()
             os.environ.pop("PGX_REPLAY_TIMING")
             rk = {}
             for nm, kname in (("replay_dense", "k_eval"), ("replay_rows", "k_eval_rows"), ("replay_update", "k_update")):

@@ -45,6 +45,10 @@ typedef struct {
  * (the arguments shimmer_to_overlap passes to ovlp_match, src/shmr_overlap.c:117-125) */
 typedef struct { uint32_t rid0, rid1, q_off; uint8_t dir0, dir1, pad[2]; } pgx_align_key;
 
+/* one shimmer-pair record of build_map (src/shmr_utils.c:337-400: mp128_t {y0, y1, direction} filed under [key0][key1]) in the
+ * form the ranks of a multi-GPU job exchange: npos = ~((y0 & 0xFFFFFFFF) >> 1), the descending-position sort key */
+typedef struct { uint64_t key0, key1, y0; uint32_t npos; uint8_t dir, pad[3]; } pgx_pair_rec; /* 32 bytes */
+
 typedef struct pgx_seqdb pgx_seqdb; /* opaque: a read database resident in HBM */
 
 /* ---- context ---- */
@@ -66,6 +70,10 @@ void pgx_timing_reset(void);
 int pgx_seqdb_upload(const uint8_t *seqdb, size_t nbytes, const uint32_t *rid, const uint32_t *rlen,
                      const uint64_t *roff, uint32_t nreads, pgx_seqdb **out);
 int pgx_seqdb_load(const char *seqdb_prefix, pgx_seqdb **out); /* reads <prefix>.idx + <prefix>.seqdb */
+/* the same with the seqdb bytes already in HBM (e.g. all-gathered over xGMI by the ranks of a multi-GPU job): d_seqdb is a
+ * device pointer, copied device-to-device; rid/rlen/roff are host arrays */
+int pgx_seqdb_upload_dev(const uint8_t *d_seqdb, size_t nbytes, const uint32_t *rid, const uint32_t *rlen,
+                         const uint64_t *roff, uint32_t nreads, pgx_seqdb **out);
 void pgx_seqdb_free(pgx_seqdb *db);
 uint64_t pgx_seqdb_bases(const pgx_seqdb *db);
 uint32_t pgx_seqdb_reads(const pgx_seqdb *db);
@@ -136,6 +144,36 @@ int pgx_overlap_resident(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, con
 int pgx_index_overlap_resident(pgx_seqdb *db, const pgx_index_params *ip, const pgx_overlap_params *op,
                                int want_index_arrays, pgx_index_result *index_out, pgx_ovlp **out, size_t *n_out,
                                pgx_overlap_stats *stats);
+/* ---- multi-GPU hand-over, everything device-resident (one process per GPU, chunk c on rank c-1) ----
+ * The reference couples the chunks through files: every overlap chunk reads EVERY index chunk's list and counts
+ * (src/shmr_overlap.c:359-384) and keeps the records whose first key it owns (src/shmr_utils.c:337,362).  Here each rank
+ * builds the pair records of its OWN index chunk's reads and routes them to the owner chunk: the caller moves (1) the count
+ * tables with an all-gather and (2) the records with an all-to-all(v) (RCCL), both on device pointers, between these calls:
+ *   pgx_index_resident_dev   : index stage; the final-level list and its counts stay in HBM (*d_top, *d_mc: library-owned, valid
+ *                              until the next index call of this process)
+ *   pgx_pairs_prepare_dev    : d_counts_all = all chunks' count tables concatenated; flags the kept shimmers of d_top;
+ *                              *first_strict = list index of the first shimmer with lower <= count < upper, -1 if none (the global
+ *                              scan starts there, src/shmr_utils.c:311-320: the caller passes `start` = that index on the first rank
+ *                              that has one, 0 on later ranks, -1 on earlier ranks)
+ *   pgx_pairs_scatter_dev    : *d_send = the records grouped by destination chunk 1..total_chunk, scan order inside a group
+ *                              (library-owned, valid until the next prepare); send_counts[c-1] = records for chunk c
+ *   pgx_overlap_records_dev  : overlap stage of chunk p->mychunk over the records received, concatenated in SOURCE chunk order
+ *                              (then scan order) = the insertion order of build_map over the concatenated lists; results are
+ *                              those of pgx_overlap_resident on the concatenated lists */
+int pgx_index_resident_dev(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *stats, const pgx_mm128 **d_top,
+                           size_t *n_top, const pgx_mm_count **d_mc, size_t *n_mc);
+int pgx_pairs_prepare_dev(pgx_seqdb *db, const pgx_mm128 *d_top, size_t n_top, const pgx_mm_count *d_counts_all,
+                          size_t n_counts_all, int mc_lower, int mc_upper, int64_t *first_strict);
+int pgx_pairs_scatter_dev(pgx_seqdb *db, int total_chunk, int64_t start, const pgx_pair_rec **d_send, uint64_t *send_counts);
+int pgx_overlap_records_dev(pgx_seqdb *db, const pgx_pair_rec *d_records, size_t n_records, const pgx_overlap_params *p,
+                            pgx_ovlp **out, size_t *n_out, pgx_overlap_stats *stats);
+/* overlap stage over DEVICE lists (the concatenation of all index chunks' lists / counts, e.g. after an all-gather) */
+int pgx_overlap_resident_dev(pgx_seqdb *db, const pgx_mm128 *d_mmers, size_t n_mm, const pgx_mm_count *d_counts,
+                             size_t n_counts, const pgx_overlap_params *p, pgx_ovlp **out, size_t *n_out,
+                             pgx_overlap_stats *stats);
+/* plain device-to-device copy on the library's stream, synchronous (for callers that hold device memory of another runtime) */
+int pgx_copy_dev(void *d_dst, const void *d_src, size_t nbytes);
+
 /* file level: globs <shimmer_prefix>-[0-9]*-of-[0-9]*.dat and -MC- twins like shmr_overlap.c:355-384 */
 int pgx_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, const char *out_path,
                       const pgx_overlap_params *p, pgx_overlap_stats *stats);

@@ -377,8 +377,19 @@ typedef struct {
   bucketv_t buckets;
 } pairmap_t;
 
+/* test hook (orc_pair_records): every insertion of build_map in the order it happens */
+typedef struct { size_t n, cap; orc_pair_rec_t *a; } recv_t;
+static recv_t *g_record_sink = NULL;
+
 static void pairmap_add(pairmap_t *pm, uint64_t k0, uint64_t k1, prec_t r) {
   int absent;
+  if (g_record_sink) {
+    orc_pair_rec_t e;
+    memset(&e, 0, sizeof(e));
+    e.key0 = k0, e.key1 = k1, e.y0 = r.y0, e.dir = r.dir;
+    e.npos = ~(uint32_t)((r.y0 & 0xFFFFFFFFu) >> 1);
+    VEC_PUSH(g_record_sink, orc_pair_rec_t, e);
+  }
   uint32_t s = otab_put(&pm->outer, k0, &absent);
   if (absent) {
     otab_t fresh = {0};
@@ -517,6 +528,26 @@ static void sort_bucket(precv_t *b) {
     while (j > 0 && pos_of(b->a[j - 1].y0) < pos_of(v.y0)) b->a[j] = b->a[j - 1], --j;
     b->a[j] = v;
   }
+}
+
+/* the insertion sequence of build_map (src/shmr_utils.c:295-404) for one overlap chunk: what a rank of the multi-GPU job must
+ * have received, in order, after the record exchange.  Returns a malloc'd array (orc_free). */
+orc_pair_rec_t *orc_pair_records(const orc_mm_t *mmers, size_t n_mm, const orc_mc_t *counts, size_t n_counts, const uint32_t *rlen,
+                                 uint32_t mychunk, uint32_t total_chunk, uint32_t mc_lower, uint32_t mc_upper, size_t *n_out) {
+  otab_t mc = {0};
+  pairmap_t pm;
+  recv_t sink = {0};
+  int absent;
+  memset(&pm, 0, sizeof(pm));
+  for (size_t i = 0; i < n_counts; ++i) { /* aggregate_mm_count, shmr_utils.c:162-176 */
+    uint32_t s = otab_put(&mc, counts[i].mer, &absent);
+    mc.vals[s] += counts[i].count;
+  }
+  g_record_sink = &sink;
+  build_pairmap(&pm, mmers, n_mm, &mc, rlen, mychunk, total_chunk, mc_lower, mc_upper);
+  g_record_sink = NULL;
+  *n_out = sink.n;
+  return sink.a ? sink.a : (orc_pair_rec_t *)malloc(1);
 }
 
 int orc_overlap(const uint8_t *seqdb, const uint32_t *rlen, const uint64_t *roff, uint32_t nreads,

@@ -84,6 +84,11 @@ int orc_overlap(const uint8_t *seqdb, const uint32_t *rlen, const uint64_t *roff
                 uint32_t mychunk, uint32_t total_chunk, uint32_t mc_lower, uint32_t mc_upper,
                 uint32_t bestn, uint32_t ovlp_upper, uint32_t band, orc_ovlpv_t *out, orc_stats_t *stats);
 
+/* ---- the insertion sequence of build_map for one overlap chunk (checks the multi-GPU record exchange) ---- */
+typedef struct { uint64_t key0, key1, y0; uint32_t npos; uint8_t dir, pad[3]; } orc_pair_rec_t; /* 32 bytes */
+orc_pair_rec_t *orc_pair_records(const orc_mm_t *mmers, size_t n_mm, const orc_mc_t *counts, size_t n_counts, const uint32_t *rlen,
+                                 uint32_t mychunk, uint32_t total_chunk, uint32_t mc_lower, uint32_t mc_upper, size_t *n_out);
+
 /* ---- file-level stages (the CPU baseline that travels to the GPU box) ----
  * same flags / file names as src/shmr_index.c:37-245 and src/shmr_overlap.c:233-419; return 0 or -1. */
 int orc_index_chunk(const char *seqdb_prefix, const char *out_prefix, int total, int mychunk, int levels,

@@ -71,6 +71,8 @@ EXPORTS = [
     "pgx_sketch_batch", "pgx_reduce_batch", "pgx_count_batch", "pgx_align_batch",
     "decode_biseq", "encode_biseq", "mm_sketch", "mm_reduce", "ovlp_match", "free_ovlp_match", "read_mmlist", "write_mmlist",
     "pgx_map", "pgx_map_chunk", "pgx_khash_slot_order",
+    "pgx_seqdb_upload_dev", "pgx_index_resident_dev", "pgx_pairs_prepare_dev", "pgx_pairs_scatter_dev", "pgx_overlap_records_dev",
+    "pgx_overlap_resident_dev", "pgx_copy_dev",
     "build_shimmer_map4py", "get_shimmers_for_read", "get_mmer_count", "get_shimmer_hits", "pgx_shimmer_map_free",
 ]
 
@@ -112,6 +114,14 @@ def load():
         lib.pgx_overlap_chunk.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p]
         lib.pgx_index_overlap_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.c_void_p]
+        lib.pgx_seqdb_upload_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.pgx_index_resident_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pgx_pairs_prepare_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        lib.pgx_pairs_scatter_dev.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]
+        lib.pgx_overlap_records_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pgx_overlap_resident_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.pgx_copy_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         lib.pgx_mkseqdb.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p]
         lib.pgx_dedup.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pgx_sketch_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -146,14 +156,49 @@ _inited = None
 
 
 def init(device: int | None = None):
-    """Select the GPU (default: LOCAL_RANK or 0).  Raises when no GPU is visible."""
+    """Select the GPU: the argument, else PGX_DEVICE, else LOCAL_RANK, else 0 -- the order the native drop-ins use
+    (csrc/pgx_cli.c).  One context per process: asking for a different device later raises.  Raises when no GPU is visible."""
     global _inited
     if device is None:
-        device = int(os.environ.get("LOCAL_RANK", "0"))
-    if _inited != device:
-        check(load().pgx_init(int(device)), "pgx_init")
+        device = int(os.environ.get("PGX_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    device = int(device)
+    if _inited is None:
+        check(load().pgx_init(device), "pgx_init")
         _inited = device
+    elif _inited != device:
+        raise PgxError(f"libpgx is one context per process and already runs on device {_inited}; device {device} was asked for")
     return device
+
+
+def shutdown():
+    """release the library's device state; the next init() may choose another device"""
+    global _inited
+    load().pgx_shutdown()
+    _inited = None
+
+
+class _DevMem:
+    """device memory owned by libpgx, exposed through the CUDA array interface (zero-copy torch.as_tensor)"""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+def dev_tensor(ptr: int, nbytes: int, device):
+    """a torch uint8 tensor over `nbytes` of library-owned device memory at `ptr`: a zero-copy view where torch accepts the
+    CUDA array interface, else a device-to-device copy.  The view is valid as long as the library keeps the memory."""
+    import torch
+    if nbytes == 0 or not ptr:
+        return torch.empty(0, dtype=torch.uint8, device=device)
+    try:
+        t = torch.as_tensor(_DevMem(ptr, nbytes), device=device)
+        if t.data_ptr() == ptr and t.numel() == nbytes:
+            return t
+    except Exception:
+        pass
+    t = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    check(load().pgx_copy_dev(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), nbytes), "pgx_copy_dev")
+    return t
 
 
 def take(ptr, n: int, dtype: np.dtype) -> np.ndarray:

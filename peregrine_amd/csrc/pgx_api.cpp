@@ -359,6 +359,8 @@ int pgx_init(int device) {
   PGX_GUARD_BEGIN
   Context &c = ctx();
   if (c.ready && c.device == device) return PGX_OK;
+  // one context per process: workspaces, the block cache and every resident seqdb live on the device of the first call
+  PGX_REQUIRE(!c.ready, PGX_ESTATE, "pgx_init(%d): this process already runs on device %d (call pgx_shutdown first)", device, c.device);
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   PGX_REQUIRE(e == hipSuccess && n > 0, PGX_EHIP, "no HIP device visible (%s)", hipGetErrorString(e));
@@ -406,8 +408,8 @@ void pgx_timing_reset(void) {
 }
 
 // ---- resident seqdb --------------------------------------------------------------------------------------
-int pgx_seqdb_upload(const uint8_t *seqdb, size_t nbytes, const uint32_t *rid, const uint32_t *rlen,
-                     const uint64_t *roff, uint32_t nreads, pgx_seqdb **out) {
+static int seqdb_upload_impl(const uint8_t *seqdb, size_t nbytes, const uint32_t *rid, const uint32_t *rlen,
+                             const uint64_t *roff, uint32_t nreads, pgx_seqdb **out, bool from_device) {
   PGX_GUARD_BEGIN
   require_ready();
   PGX_REQUIRE(out && (nreads == 0 || (rid && rlen && roff)), PGX_EARG, "pgx_seqdb_upload: null argument");
@@ -433,7 +435,7 @@ int pgx_seqdb_upload(const uint8_t *seqdb, size_t nbytes, const uint32_t *rid, c
   try {
     db->d_seq.alloc(nbytes + 1024);
     PGX_HIP(hipMemsetAsync(db->d_seq.p + nbytes, 0, 1024, ctx().stream));
-    if (nbytes) PGX_HIP(hipMemcpyAsync(db->d_seq.p, seqdb, nbytes, hipMemcpyHostToDevice, ctx().stream));
+    if (nbytes) PGX_HIP(hipMemcpyAsync(db->d_seq.p, seqdb, nbytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx().stream));
     db->d_roff.alloc(nr ? nr : 1);
     db->d_rlen.alloc(nr ? nr : 1);
     db->d_roff.upload(db->roff_by_rid.data(), nr);
@@ -444,6 +446,23 @@ int pgx_seqdb_upload(const uint8_t *seqdb, size_t nbytes, const uint32_t *rid, c
     throw;
   }
   *out = db;
+  PGX_GUARD_END
+}
+
+int pgx_seqdb_upload(const uint8_t *seqdb, size_t nbytes, const uint32_t *rid, const uint32_t *rlen,
+                     const uint64_t *roff, uint32_t nreads, pgx_seqdb **out) {
+  return seqdb_upload_impl(seqdb, nbytes, rid, rlen, roff, nreads, out, false);
+}
+int pgx_seqdb_upload_dev(const uint8_t *d_seqdb, size_t nbytes, const uint32_t *rid, const uint32_t *rlen,
+                         const uint64_t *roff, uint32_t nreads, pgx_seqdb **out) {
+  return seqdb_upload_impl(d_seqdb, nbytes, rid, rlen, roff, nreads, out, true);
+}
+int pgx_copy_dev(void *d_dst, const void *d_src, size_t nbytes) {
+  PGX_GUARD_BEGIN
+  require_ready();
+  PGX_REQUIRE((d_dst && d_src) || nbytes == 0, PGX_EARG, "pgx_copy_dev: null argument");
+  if (nbytes) PGX_HIP(hipMemcpyAsync(d_dst, d_src, nbytes, hipMemcpyDeviceToDevice, ctx().stream));
+  sync();
   PGX_GUARD_END
 }
 

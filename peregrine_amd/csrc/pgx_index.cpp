@@ -149,6 +149,39 @@ int pgx_index_resident(pgx_seqdb *db, const pgx_index_params *p, pgx_index_resul
   return PGX_OK;
 }
 
+// index stage of a multi-GPU rank: the final-level list and its counts stay in HBM for the exchange that follows
+int pgx_index_resident_dev(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *stats, const pgx_mm128 **d_top,
+                           size_t *n_top, const pgx_mm_count **d_mc, size_t *n_mc) {
+  static DeviceIndex held;               // one context per process: the previous call's buffers are released here
+  static DevBuf<pgx_mm128> held_top;     // (only when the general index path produced host arrays)
+  try {
+    require_ready();
+    PGX_REQUIRE(db && stats && d_top && n_top && d_mc && n_mc, PGX_EARG, "pgx_index_resident_dev: null argument");
+    check_params(p);
+    PGX_REQUIRE(!p->want_l0, PGX_EARG, "pgx_index_resident_dev returns the final level only");
+    held = DeviceIndex();
+    held_top.release();
+    run_index(db, p, stats, &held, false);
+    if (!held.valid) {  // general path (other w / k, ambiguous bases ...): its result is in host arrays
+      held_top.alloc(stats->n_top);
+      held_top.upload(stats->top, stats->n_top);
+      held.mc.alloc(stats->n_top_mc);
+      held.mc.upload(stats->top_mc, stats->n_top_mc);
+      sync();
+      held.d_top = held_top.p, held.n_top = stats->n_top, held.n_mc = stats->n_top_mc, held.valid = true;
+      out_free(stats->top), out_free(stats->top_mc);
+      stats->top = nullptr, stats->top_mc = nullptr;
+    }
+    *d_top = held.d_top, *n_top = held.n_top, *d_mc = held.mc.p, *n_mc = held.n_mc;
+  } catch (const Fail &f) {
+    return f.code;
+  } catch (const std::bad_alloc &) {
+    set_error("out of host memory");
+    return PGX_ENOMEM;
+  }
+  return PGX_OK;
+}
+
 int pgx_index_chunk(const char *seqdb_prefix, const char *out_prefix, const pgx_index_params *p,
                     pgx_index_result *stats) {
   pgx_seqdb *db = nullptr;

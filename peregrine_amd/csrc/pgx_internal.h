@@ -226,6 +226,7 @@ struct PairTables {
 };
 struct PairParams {
   uint32_t total, mychunk, lower, upper;  // bucket ownership (x>>8) % total == mychunk % total; multiplicity bounds
+  uint32_t n_rid = 0;                     // entries of d_rlen (0: unknown, the list is not checked against the read database)
 };
 enum : unsigned {
   PAIRS_Y1 = 1,               // also return the second coordinate of every record (mp128_t.y1)
@@ -245,6 +246,17 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
                      size_t n_counts, const PairParams &pp, PairTables &out, unsigned flags = 0,
                      const pgx_mm128 *d_mmers = nullptr, const pgx_mm_count *d_counts = nullptr,  // d_*: the same lists, already on the device
                      DevicePairs *keep = nullptr);  // keep: the sorted records stay on the device too
+// ---- multi-GPU hand-over: counts all-gathered, pair records routed to their owner chunk -------------------------
+// prepare: aggregate ALL chunks' counts, flag the kept shimmers of THIS index chunk's list (both on the device); returns the index
+// of the first shimmer with lower <= count < upper (-1: none).  scatter: the records of every adjacent kept pair from `start` on
+// (the list position the global scan starts at, shmr_utils.c:311-320), grouped by destination chunk 1..T in scan order; *d_send
+// stays valid until the next prepare.  from_records: the join of one overlap chunk over the records it received, in arrival order
+// (= source chunk order, then scan order: the insertion order of build_map over the concatenated lists).
+int64_t dev_pairs_prepare(const uint32_t *d_rlen, uint32_t n_rid, const pgx_mm128 *d_mm, size_t n_mm, const pgx_mm_count *d_counts,
+                          size_t n_counts, uint32_t lower, uint32_t upper);
+void dev_pairs_scatter(const uint32_t *d_rlen, uint32_t T, int64_t start, const pgx_pair_rec **d_send, uint64_t *counts);
+void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out, DevicePairs *keep_dev);
+
 // The greedy walk over the visit list (visit_bids: the join's bucket ids in visit order) on the GPU; the records go to the
 // array alloc_out(n) returns.  false: the job does not fit the device tables' encodings or they overflowed -- nothing was
 // produced and the caller runs the host replay.

@@ -1357,8 +1357,15 @@ void check_params(const pgx_overlap_params *p) {
   PGX_REQUIRE(p->ovlp_upper >= 0 && p->mc_lower >= 0 && p->mc_upper >= 0, PGX_EARG, "negative bound");
 }
 
+// the lists either as host arrays (mmers / counts), as device arrays (dev), or -- a rank of a multi-GPU job -- as the pair
+// records this chunk received from all index chunks (d_recs: device pointer, arrival order = insertion order)
+struct DeviceLists {
+  const pgx_mm128 *d_top = nullptr;
+  const pgx_mm_count *d_mc = nullptr;
+};
 void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
-                 const pgx_overlap_params *p, OvOut &out, pgx_overlap_stats *st, const DeviceIndex *dev = nullptr) {
+                 const pgx_overlap_params *p, OvOut &out, pgx_overlap_stats *st, const DeviceLists *dev = nullptr,
+                 const pgx_pair_rec *d_recs = nullptr, size_t n_recs = 0) {
   pgx_overlap_stats s;
   memset(&s, 0, sizeof(s));
   const double t0 = now_ms();
@@ -1389,9 +1396,13 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   const bool trace = getenv("PGX_TRACE") != nullptr;
   const bool predict = !(getenv("PGX_PREDICT") && atoi(getenv("PGX_PREDICT")) == 0);
   DevicePairs dpairs;
-  dev_build_pairs(db->d_rlen.p, mmers, n_mm, counts, n_counts,
-                  PairParams{(uint32_t)p->total_chunk, (uint32_t)p->mychunk, (uint32_t)p->mc_lower, (uint32_t)p->mc_upper}, pt, 0,
-                  dev ? dev->d_top : nullptr, dev ? dev->mc.p : nullptr, gpu_replay ? &dpairs : nullptr);
+  if (d_recs)
+    dev_pairs_from_records(d_recs, n_recs, pt, gpu_replay ? &dpairs : nullptr);
+  else
+    dev_build_pairs(db->d_rlen.p, mmers, n_mm, counts, n_counts,
+                    PairParams{(uint32_t)p->total_chunk, (uint32_t)p->mychunk, (uint32_t)p->mc_lower, (uint32_t)p->mc_upper,
+                               (uint32_t)db->rlen_by_rid.size()},
+                    pt, 0, dev ? dev->d_top : nullptr, dev ? dev->d_mc : nullptr, gpu_replay ? &dpairs : nullptr);
   sync();
   s.n_pair_records = pt.n_rec;
   if (gpu_replay_env < 0) gpu_replay = pt.n_rec >= gpu_replay_min;
@@ -1574,13 +1585,18 @@ void read_counted_files(const std::string &pattern, std::vector<T> &out) {
   if (glob(pattern.c_str(), 0, nullptr, &g) == 0) {  // name-sorted like wordexp in shmr_overlap.c:355-384
     for (size_t i = 0; i < g.gl_pathc; ++i) {
       std::vector<uint8_t> buf;
-      if (!read_file(g.gl_pathv[i], buf) || buf.size() < 8) {
+      const std::string path = g.gl_pathv[i];   // (copied: the glob result is released before the message is formatted)
+      if (!read_file(path, buf) || buf.size() < 8) {
         globfree(&g);
-        PGX_REQUIRE(false, PGX_EIO, "file '%s' open error", g.gl_pathv[i]);
+        PGX_REQUIRE(false, PGX_EIO, "file '%s' open error", path.c_str());
       }
       uint64_t n;
       memcpy(&n, buf.data(), 8);
-      if (8 + n * sizeof(T) > buf.size()) n = (buf.size() - 8) / sizeof(T);
+      if (n > (buf.size() - 8) / sizeof(T)) {   // a truncated index chunk must not yield a quietly smaller overlap set
+        globfree(&g);
+        PGX_REQUIRE(false, PGX_EIO, "file '%s' is truncated: header says %llu entries, %zu bytes follow", path.c_str(),
+                    (unsigned long long)n, buf.size() - 8);
+      }
       const size_t o = out.size();
       out.resize(o + n);
       if (n) memcpy(out.data() + o, buf.data() + 8, n * sizeof(T));
@@ -1646,10 +1662,86 @@ int pgx_index_overlap_resident(pgx_seqdb *db, const pgx_index_params *ip, const 
     index_stage(db, ip, index_out, &dev, want_index_arrays != 0);
     OvOut v;
     if (dev.valid) {
-      run_overlap(db, nullptr, dev.n_top, nullptr, dev.n_mc, op, v, stats, &dev);
+      const DeviceLists dl{dev.d_top, dev.mc.p};
+      run_overlap(db, nullptr, dev.n_top, nullptr, dev.n_mc, op, v, stats, &dl);
     } else {  // (want_l0, ambiguous parameters ...: the general index path has already produced host arrays)
       run_overlap(db, index_out->top, index_out->n_top, index_out->top_mc, index_out->n_top_mc, op, v, stats);
     }
+    *n_out = v.n;
+    *out = v.release();
+  } catch (const Fail &f) {
+    return f.code;
+  } catch (const std::bad_alloc &) {
+    set_error("out of host memory");
+    return PGX_ENOMEM;
+  }
+  return PGX_OK;
+}
+
+// ---- multi-GPU hand-over on device pointers (include/pgx.h) -----------------------------------------------------
+int pgx_overlap_resident_dev(pgx_seqdb *db, const pgx_mm128 *d_mmers, size_t n_mm, const pgx_mm_count *d_counts,
+                             size_t n_counts, const pgx_overlap_params *p, pgx_ovlp **out, size_t *n_out,
+                             pgx_overlap_stats *stats) {
+  try {
+    require_ready();
+    PGX_REQUIRE(db && out && n_out && (n_mm == 0 || d_mmers) && (n_counts == 0 || d_counts), PGX_EARG,
+                "pgx_overlap_resident_dev: null argument");
+    check_params(p);
+    OvOut v;
+    const DeviceLists dl{d_mmers, d_counts};
+    run_overlap(db, nullptr, n_mm, nullptr, n_counts, p, v, stats, &dl);
+    *n_out = v.n;
+    *out = v.release();
+  } catch (const Fail &f) {
+    return f.code;
+  } catch (const std::bad_alloc &) {
+    set_error("out of host memory");
+    return PGX_ENOMEM;
+  }
+  return PGX_OK;
+}
+
+int pgx_pairs_prepare_dev(pgx_seqdb *db, const pgx_mm128 *d_top, size_t n_top, const pgx_mm_count *d_counts_all,
+                          size_t n_counts_all, int mc_lower, int mc_upper, int64_t *first_strict) {
+  try {
+    require_ready();
+    PGX_REQUIRE(db && first_strict && (n_top == 0 || d_top) && (n_counts_all == 0 || d_counts_all) && mc_lower >= 0 && mc_upper >= 0,
+                PGX_EARG, "pgx_pairs_prepare_dev: bad argument");
+    *first_strict = dev_pairs_prepare(db->d_rlen.p, (uint32_t)db->rlen_by_rid.size(), d_top, n_top, d_counts_all, n_counts_all,
+                                      (uint32_t)mc_lower, (uint32_t)mc_upper);
+  } catch (const Fail &f) {
+    return f.code;
+  } catch (const std::bad_alloc &) {
+    set_error("out of host memory");
+    return PGX_ENOMEM;
+  }
+  return PGX_OK;
+}
+
+int pgx_pairs_scatter_dev(pgx_seqdb *db, int total_chunk, int64_t start, const pgx_pair_rec **d_send, uint64_t *send_counts) {
+  try {
+    require_ready();
+    PGX_REQUIRE(db && d_send && send_counts && total_chunk > 0, PGX_EARG, "pgx_pairs_scatter_dev: bad argument");
+    dev_pairs_scatter(db->d_rlen.p, (uint32_t)total_chunk, start, d_send, send_counts);
+    timing_flush();
+  } catch (const Fail &f) {
+    return f.code;
+  } catch (const std::bad_alloc &) {
+    set_error("out of host memory");
+    return PGX_ENOMEM;
+  }
+  return PGX_OK;
+}
+
+int pgx_overlap_records_dev(pgx_seqdb *db, const pgx_pair_rec *d_records, size_t n_records, const pgx_overlap_params *p,
+                            pgx_ovlp **out, size_t *n_out, pgx_overlap_stats *stats) {
+  try {
+    require_ready();
+    PGX_REQUIRE(db && out && n_out && (n_records == 0 || d_records), PGX_EARG, "pgx_overlap_records_dev: null argument");
+    check_params(p);
+    OvOut v;
+    static const pgx_pair_rec none{};   // (an empty record set still takes the records path)
+    run_overlap(db, nullptr, 0, nullptr, 0, p, v, stats, nullptr, n_records ? d_records : &none, n_records);
     *n_out = v.n;
     *out = v.release();
   } catch (const Fail &f) {

@@ -54,11 +54,25 @@ __device__ __forceinline__ bool lookup_count(const uint64_t *mer, const uint32_t
 }
 
 // keep[i] = lower <= count <= upper ; first_strict = min i with lower <= count < upper ; missing = hash not in the table
+// misc[0] = first strict index, misc[1] = hashes missing from the table, misc[2] = shimmers that do not fit the seqdb (read
+// id beyond the idx, or position beyond the read: the reference asserts on the read-length lookup, shmr_utils.c:374-376),
+// misc[3] = one such read id
 __global__ void k_keep(const pgx_mm128 *__restrict__ mm, uint32_t n, const uint64_t *__restrict__ mer,
                        const uint32_t *__restrict__ cnt, uint32_t nu, uint32_t lower, uint32_t upper,
-                       uint8_t *__restrict__ keep, uint32_t *__restrict__ first_strict, uint32_t *__restrict__ missing) {
+                       uint8_t *__restrict__ keep, uint32_t *__restrict__ first_strict, uint32_t *__restrict__ missing,
+                       const uint32_t *__restrict__ rlen, uint32_t n_rid) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (n_rid) {
+    const uint64_t y = mm[i].y;
+    const uint32_t rid = (uint32_t)(y >> 32);
+    if (rid >= n_rid || (uint32_t)((y & 0xFFFFFFFFu) >> 1) >= rlen[rid]) {
+      atomicAdd(missing + 1, 1u);
+      missing[2] = rid;
+      keep[i] = 0;
+      return;
+    }
+  }
   uint32_t c = 0;
   if (!lookup_count(mer, cnt, nu, mm[i].x >> 8, &c)) {
     atomicAdd(missing, 1u);
@@ -128,6 +142,58 @@ __global__ void k_records(const pgx_mm128 *__restrict__ mm, uint32_t n, const in
   }
 }
 
+// ---- multi-GPU scatter: the records of ONE index chunk's reads for EVERY overlap chunk ------------------------
+// MODE 0: number of records shimmer i produces (0..2) over all destinations; MODE 1: write them (record + destination chunk)
+template <int MODE>
+__global__ void k_records_all(const pgx_mm128 *__restrict__ mm, uint32_t n, const int32_t *__restrict__ chain, uint32_t T,
+                              const uint32_t *__restrict__ rlen, uint32_t *__restrict__ nrec, const uint32_t *__restrict__ off,
+                              pgx_pair_rec *__restrict__ rec, uint8_t *__restrict__ dest) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  bool pair = false;
+  pgx_mm128 a{0, 0}, b{0, 0};
+  if (i > 0 && chain[i] == (int32_t)i) {
+    const int32_t p = chain[i - 1];
+    if (p >= 0) {
+      a = mm[p], b = mm[i];
+      pair = (a.y >> 32) == (b.y >> 32) && pos28(b.y) - pos28(a.y) >= 100u;
+    }
+  }
+  if (MODE == 0) {
+    nrec[i] = pair ? 2u : 0u;
+  } else if (pair) {
+    const uint32_t o = off[i];
+    pgx_pair_rec f, r;
+    memset(&f, 0, sizeof(f)), memset(&r, 0, sizeof(r));
+    f.key0 = a.x, f.key1 = b.x, f.y0 = a.y, f.dir = 0, f.npos = ~pos_of(a.y);
+    const uint64_t fy = flip_y(b.y, b.x, rlen);
+    r.key0 = b.x, r.key1 = a.x, r.y0 = fy, r.dir = 1, r.npos = ~pos_of(fy);
+    rec[o] = f, dest[o] = (uint8_t)((a.x >> 8) % T);          // owner chunk c with c % T == (key0 >> 8) % T (shmr_utils.c:337,362)
+    rec[o + 1] = r, dest[o + 1] = (uint8_t)((b.x >> 8) % T);
+  }
+}
+__global__ void k_dest_hist(const uint8_t *__restrict__ dest, uint32_t n, uint32_t *__restrict__ hist /* 256 */) {
+  __shared__ uint32_t h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) atomicAdd(&h[dest[i]], 1u);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void k_gather_rec(const pgx_pair_rec *__restrict__ src, const uint32_t *__restrict__ perm, uint32_t n,
+                             pgx_pair_rec *__restrict__ dst) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[perm[i]];
+}
+__global__ void k_unpack_rec(const pgx_pair_rec *__restrict__ rec, uint32_t n, uint64_t *__restrict__ key0,
+                             uint64_t *__restrict__ key1, uint64_t *__restrict__ y0, uint8_t *__restrict__ dir,
+                             uint32_t *__restrict__ npos) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const pgx_pair_rec r = rec[i];
+  key0[i] = r.key0, key1[i] = r.key1, y0[i] = r.y0, dir[i] = r.dir, npos[i] = r.npos;
+}
+
 __global__ void k_iota(uint32_t *__restrict__ v, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = i;
@@ -188,6 +254,74 @@ HostArray<T> to_host(const DevBuf<T> &d, size_t n, size_t extra = 0) {  // (extr
 }
 }  // namespace
 
+// the records of one overlap chunk in insertion order, structure of arrays
+struct PairRecs {
+  DevBuf<uint64_t> key0, key1, y0, y1;
+  DevBuf<uint8_t> dir;
+  DevBuf<uint32_t> npos;
+  uint32_t nr = 0;
+};
+
+// aggregated multiplicities of all MC entries, sorted by mer (aggregate_mm_count, shmr_utils.c:162-176)
+struct CountTable {
+  DevBuf<uint64_t> umer;
+  DevBuf<uint32_t> ucnt;
+  uint32_t nu = 0;
+};
+static void aggregate_counts(const pgx_mm_count *cin, size_t n_counts, CountTable &ct, Tmp &tmp) {
+  hipStream_t st = ctx().stream;
+  ct.umer.alloc(n_counts), ct.ucnt.alloc(n_counts);
+  ct.nu = 0;
+  if (!n_counts) return;
+  DevBuf<uint64_t> mer(n_counts), mer_s(n_counts);
+  DevBuf<uint32_t> cnt(n_counts), cnt_s(n_counts), d_nu(1);
+  size_t bytes = 0;
+  hipLaunchKernelGGL(k_split_counts, dim3(cdiv(n_counts, 256)), dim3(256), 0, st, cin, n_counts, mer.p, cnt.p);
+  PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, mer.p, mer_s.p, cnt.p, cnt_s.p, (int)n_counts, 0, 56, st));
+  PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, mer.p, mer_s.p, cnt.p, cnt_s.p, (int)n_counts, 0, 56, st));
+  bytes = 0;
+  PGX_HIP(hipcub::DeviceReduce::ReduceByKey(nullptr, bytes, mer_s.p, ct.umer.p, cnt_s.p, ct.ucnt.p, d_nu.p, hipcub::Sum(),
+                                           (int)n_counts, st));
+  PGX_HIP(hipcub::DeviceReduce::ReduceByKey(tmp.get(bytes), bytes, mer_s.p, ct.umer.p, cnt_s.p, ct.ucnt.p, d_nu.p, hipcub::Sum(),
+                                           (int)n_counts, st));
+  d_nu.download(&ct.nu, 1);
+  sync();
+}
+
+// keep flags of a list against the table; returns the first strict index (0xFFFFFFFF: none)
+static uint32_t keep_flags(const pgx_mm128 *mm_dev, uint32_t n, const CountTable &ct, const PairParams &pp, const uint32_t *d_rlen,
+                           DevBuf<uint8_t> &keep, DevBuf<uint32_t> &d_misc) {
+  hipStream_t st = ctx().stream;
+  keep.alloc(n);
+  d_misc.alloc(4);
+  const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
+  d_misc.upload(init, 4);
+  hipLaunchKernelGGL(k_keep, dim3(cdiv(n, 256)), dim3(256), 0, st, mm_dev, n, ct.umer.p, ct.ucnt.p, ct.nu, pp.lower, pp.upper, keep.p,
+                     d_misc.p, d_misc.p + 1, d_rlen, pp.n_rid);
+  uint32_t misc[4];
+  d_misc.download(misc, 4);
+  sync();
+  PGX_REQUIRE(misc[2] == 0, PGX_EARG,
+              "%u shimmers of the list do not fit the read database (e.g. read %u: not in the idx, or a position beyond its length) -- "
+              "shimmer files of another seqdb?", misc[2], misc[3]);
+  PGX_REQUIRE(misc[1] == 0, PGX_EARG, "%u shimmer hashes are missing from the MC files", misc[1]);
+  return misc[0];
+}
+
+// chain of kept shimmers from `start` on: chain[i] == i <=> i is kept; chain[i-1] = previous kept shimmer (or -1)
+static void chain_scan(const DevBuf<uint8_t> &keep, uint32_t n, const uint32_t *d_start, DevBuf<int32_t> &chain, Tmp &tmp) {
+  hipStream_t st = ctx().stream;
+  DevBuf<int32_t> chain_in(n);
+  chain.alloc(n);
+  hipLaunchKernelGGL(k_chain_in, dim3(cdiv(n, 256)), dim3(256), 0, st, keep.p, n, d_start, chain_in.p);
+  size_t bytes = 0;
+  PGX_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, bytes, chain_in.p, chain.p, MaxOp(), (int)n, st));
+  PGX_HIP(hipcub::DeviceScan::InclusiveScan(tmp.get(bytes), bytes, chain_in.p, chain.p, MaxOp(), (int)n, st));
+  // (chain_in goes back to the block cache on return: stream-ordered reuse on the library's one stream)
+}
+
+static void bucketize(PairRecs &R, unsigned flags, PairTables &out, DevicePairs *keep_dev, Tmp &tmp);
+
 void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
                      const PairParams &pp, PairTables &out, unsigned flags, const pgx_mm128 *d_mmers, const pgx_mm_count *d_counts,
                      DevicePairs *keep_dev) {
@@ -204,39 +338,18 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
   // ---- aggregated counts ----------------------------------------------------------------------------------
   DevBuf<pgx_mm_count> cin_own(d_counts ? 0 : n_counts);  // (lists that are already on the device are used in place)
   if (!d_counts) cin_own.upload(counts, n_counts);
-  const pgx_mm_count *cin = d_counts ? d_counts : cin_own.p;
-  DevBuf<uint64_t> mer(n_counts), mer_s(n_counts), umer(n_counts);
-  DevBuf<uint32_t> cnt(n_counts), cnt_s(n_counts), ucnt(n_counts), d_nu(1);
-  uint32_t nu = 0;
-  if (n_counts) {
-    hipLaunchKernelGGL(k_split_counts, dim3(cdiv(n_counts, 256)), dim3(256), 0, st, cin, n_counts, mer.p, cnt.p);
-    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, mer.p, mer_s.p, cnt.p, cnt_s.p, (int)n_counts, 0, 56, st));
-    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, mer.p, mer_s.p, cnt.p, cnt_s.p, (int)n_counts, 0, 56, st));
-    bytes = 0;
-    PGX_HIP(hipcub::DeviceReduce::ReduceByKey(nullptr, bytes, mer_s.p, umer.p, cnt_s.p, ucnt.p, d_nu.p, hipcub::Sum(),
-                                             (int)n_counts, st));
-    PGX_HIP(hipcub::DeviceReduce::ReduceByKey(tmp.get(bytes), bytes, mer_s.p, umer.p, cnt_s.p, ucnt.p, d_nu.p, hipcub::Sum(),
-                                             (int)n_counts, st));
-    d_nu.download(&nu, 1);
-    sync();
-  }
+  CountTable ct;
+  aggregate_counts(d_counts ? d_counts : cin_own.p, n_counts, ct, tmp);
 
   // ---- keep flags, chain, records -------------------------------------------------------------------------
   DevBuf<pgx_mm128> mm_own(d_mmers ? 0 : n);
   if (!d_mmers) mm_own.upload(mmers, n);
   const pgx_mm128 *mm_dev = d_mmers ? d_mmers : mm_own.p;
-  DevBuf<uint8_t> keep(n);
-  DevBuf<uint32_t> d_misc(2);  // [0] first strict index, [1] missing hashes
-  const uint32_t init[2] = {0xFFFFFFFFu, 0u};
-  d_misc.upload(init, 2);
-  hipLaunchKernelGGL(k_keep, dim3(cdiv(n, 256)), dim3(256), 0, st, mm_dev, n, umer.p, ucnt.p, nu, pp.lower, pp.upper, keep.p,
-                     d_misc.p, d_misc.p + 1);
-  DevBuf<int32_t> chain_in(n), chain(n);
-  hipLaunchKernelGGL(k_chain_in, dim3(cdiv(n, 256)), dim3(256), 0, st, keep.p, n, d_misc.p, chain_in.p);
-  bytes = 0;
-  PGX_HIP(hipcub::DeviceScan::InclusiveScan(nullptr, bytes, chain_in.p, chain.p, MaxOp(), (int)n, st));
-  PGX_HIP(hipcub::DeviceScan::InclusiveScan(tmp.get(bytes), bytes, chain_in.p, chain.p, MaxOp(), (int)n, st));
-  // chain[i] == i  <=> i is kept ; chain[i-1] = previous kept shimmer (or -1)
+  DevBuf<uint8_t> keep;
+  DevBuf<uint32_t> d_misc;
+  keep_flags(mm_dev, n, ct, pp, d_rlen, keep, d_misc);
+  DevBuf<int32_t> chain;
+  chain_scan(keep, n, d_misc.p, chain, tmp);
   const uint32_t T = pp.total, c = pp.mychunk % T;
   DevBuf<uint32_t> nrec(n), off(n + 1);
   hipLaunchKernelGGL(k_records<0>, dim3(cdiv(n, 256)), dim3(256), 0, st, mm_dev, n, chain.p, T, c, d_rlen, nrec.p,
@@ -246,23 +359,135 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
   bytes = 0;
   PGX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, bytes, nrec.p, off.p + 1, (int)n, st));
   PGX_HIP(hipcub::DeviceScan::InclusiveSum(tmp.get(bytes), bytes, nrec.p, off.p + 1, (int)n, st));
-  uint32_t misc[2], nr = 0;
-  d_misc.download(misc, 2);
+  uint32_t nr = 0;
   PGX_HIP(hipMemcpyAsync(&nr, off.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   sync();
-  PGX_REQUIRE(misc[1] == 0, PGX_EARG, "%u shimmer hashes are missing from the MC files", misc[1]);
   out.n_rec = nr;
   if (flags & PAIRS_COUNTS) {  // the aggregated multiplicity table, sorted by mer
-    out.umer = to_host(umer, nu);
-    out.ucnt = to_host(ucnt, nu);
+    out.umer = to_host(ct.umer, ct.nu);
+    out.ucnt = to_host(ct.ucnt, ct.nu);
     sync();
   }
   if (nr == 0) return;
-  DevBuf<uint64_t> key0(nr), key1(nr), y0(nr), y1((flags & PAIRS_Y1) ? nr : 0);
-  DevBuf<uint8_t> dir(nr);
-  DevBuf<uint32_t> npos(nr);
+  PairRecs R;
+  R.nr = nr;
+  R.key0.alloc(nr), R.key1.alloc(nr), R.y0.alloc(nr), R.y1.alloc((flags & PAIRS_Y1) ? nr : 0), R.dir.alloc(nr), R.npos.alloc(nr);
   hipLaunchKernelGGL(k_records<1>, dim3(cdiv(n, 256)), dim3(256), 0, st, mm_dev, n, chain.p, T, c, d_rlen, (uint32_t *)nullptr,
-                     off.p, key0.p, key1.p, y0.p, dir.p, npos.p, y1.p);
+                     off.p, R.key0.p, R.key1.p, R.y0.p, R.dir.p, R.npos.p, R.y1.p);
+  bucketize(R, flags, out, keep_dev, tmp);
+}
+
+// ---- multi-GPU: prepare / scatter / from-records (one context per process: the state lives here between the calls) ---------
+namespace {
+struct ScatterState {
+  const pgx_mm128 *mm = nullptr;
+  uint32_t n = 0;
+  DevBuf<uint8_t> keep;
+  DevBuf<pgx_pair_rec> send;
+  bool ready = false;
+};
+ScatterState g_scatter;
+}  // namespace
+
+int64_t dev_pairs_prepare(const uint32_t *d_rlen, uint32_t n_rid, const pgx_mm128 *d_mm, size_t n_mm, const pgx_mm_count *d_counts,
+                          size_t n_counts, uint32_t lower, uint32_t upper) {
+  PGX_REQUIRE(n_mm < (1ULL << 31) && n_counts < (1ULL << 31), PGX_EARG, "shimmer list too long for one chunk");
+  g_scatter = ScatterState();
+  g_scatter.mm = d_mm, g_scatter.n = (uint32_t)n_mm;
+  g_scatter.ready = true;
+  if (n_mm == 0) return -1;
+  Tmp tmp;
+  CountTable ct;
+  aggregate_counts(d_counts, n_counts, ct, tmp);
+  DevBuf<uint32_t> d_misc;
+  PairParams pp{1, 1, lower, upper, n_rid};
+  const uint32_t first = keep_flags(d_mm, (uint32_t)n_mm, ct, pp, d_rlen, g_scatter.keep, d_misc);
+  return first == 0xFFFFFFFFu ? -1 : (int64_t)first;
+}
+
+void dev_pairs_scatter(const uint32_t *d_rlen, uint32_t T, int64_t start, const pgx_pair_rec **d_send, uint64_t *counts) {
+  PGX_REQUIRE(g_scatter.ready, PGX_ESTATE, "pgx_pairs_scatter_dev without pgx_pairs_prepare_dev");
+  PGX_REQUIRE(T >= 1 && T <= 256, PGX_EARG, "the record scatter supports 1..256 overlap chunks");
+  for (uint32_t c = 0; c < T; ++c) counts[c] = 0;
+  *d_send = nullptr;
+  const uint32_t n = g_scatter.n;
+  if (n == 0 || start < 0 || start >= (int64_t)n) return;  // (no eligible anchor on this rank: shmr_utils.c:311-320)
+  hipStream_t st = ctx().stream;
+  KernelTimer tm("pairs_scatter", n);
+  Tmp tmp;
+  DevBuf<uint32_t> d_start(1);
+  const uint32_t s32 = (uint32_t)start;
+  d_start.upload(&s32, 1);
+  DevBuf<int32_t> chain;
+  chain_scan(g_scatter.keep, n, d_start.p, chain, tmp);
+  DevBuf<uint32_t> nrec(n), off(n + 1);
+  hipLaunchKernelGGL(k_records_all<0>, dim3(cdiv(n, 256)), dim3(256), 0, st, g_scatter.mm, n, chain.p, T, d_rlen, nrec.p,
+                     (const uint32_t *)nullptr, (pgx_pair_rec *)nullptr, (uint8_t *)nullptr);
+  PGX_HIP(hipMemsetAsync(off.p, 0, sizeof(uint32_t), st));
+  size_t bytes = 0;
+  PGX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, bytes, nrec.p, off.p + 1, (int)n, st));
+  PGX_HIP(hipcub::DeviceScan::InclusiveSum(tmp.get(bytes), bytes, nrec.p, off.p + 1, (int)n, st));
+  uint32_t nr = 0;
+  PGX_HIP(hipMemcpyAsync(&nr, off.p + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  sync();
+  if (nr == 0) return;
+  PGX_REQUIRE(nr < (1u << 31), PGX_EARG, "too many pair records for one index chunk");
+  DevBuf<pgx_pair_rec> rec(nr);
+  DevBuf<uint8_t> dest(nr), dest_s(nr);
+  DevBuf<uint32_t> idx(nr), perm(nr), hist(256);
+  hipLaunchKernelGGL(k_records_all<1>, dim3(cdiv(n, 256)), dim3(256), 0, st, g_scatter.mm, n, chain.p, T, d_rlen, (uint32_t *)nullptr,
+                     off.p, rec.p, dest.p);
+  // stable by destination: the records of a destination stay in scan order (= insertion order of the receiving chunk)
+  hipLaunchKernelGGL(k_iota, dim3(cdiv(nr, 256)), dim3(256), 0, st, idx.p, nr);
+  bytes = 0;
+  PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dest.p, dest_s.p, idx.p, perm.p, (int)nr, 0, 8, st));
+  PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, dest.p, dest_s.p, idx.p, perm.p, (int)nr, 0, 8, st));
+  g_scatter.send.alloc(nr);
+  hipLaunchKernelGGL(k_gather_rec, dim3(cdiv(nr, 256)), dim3(256), 0, st, rec.p, perm.p, nr, g_scatter.send.p);
+  PGX_HIP(hipMemsetAsync(hist.p, 0, 256 * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(k_dest_hist, dim3(std::min<unsigned>(cdiv(nr, 256), 1024u)), dim3(256), 0, st, dest.p, nr, hist.p);
+  uint32_t h[256];
+  hist.download(h, 256);
+  sync();
+  // dest value v = (key0 >> 8) % T belongs to chunk c with c % T == v: chunk T for v == 0, else chunk v.  Send order = chunk
+  // order 1..T = values 1, 2, ..., T-1, 0 -- but the radix sort grouped by VALUE (0 first): rotate the value-0 group to the end
+  // by reporting the counts in chunk order together with a rotated buffer.
+  if (T > 1 && h[0]) {
+    DevBuf<pgx_pair_rec> rot(nr);
+    const size_t n0 = h[0];
+    PGX_HIP(hipMemcpyAsync(rot.p, g_scatter.send.p + n0, (nr - n0) * sizeof(pgx_pair_rec), hipMemcpyDeviceToDevice, st));
+    PGX_HIP(hipMemcpyAsync(rot.p + (nr - n0), g_scatter.send.p, n0 * sizeof(pgx_pair_rec), hipMemcpyDeviceToDevice, st));
+    sync();
+    g_scatter.send = std::move(rot);
+  }
+  for (uint32_t c = 1; c <= T; ++c) counts[c - 1] = h[c % T];
+  *d_send = g_scatter.send.p;
+}
+
+void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out, DevicePairs *keep_dev) {
+  out = PairTables();
+  if (keep_dev) *keep_dev = DevicePairs();
+  if (n == 0) return;
+  PGX_REQUIRE(n < (1ULL << 31), PGX_EARG, "too many pair records for one overlap chunk");
+  KernelTimer tm("pairs", n);
+  Tmp tmp;
+  const uint32_t nr = (uint32_t)n;
+  PairRecs R;
+  R.nr = nr;
+  R.key0.alloc(nr), R.key1.alloc(nr), R.y0.alloc(nr), R.dir.alloc(nr), R.npos.alloc(nr);
+  hipLaunchKernelGGL(k_unpack_rec, dim3(cdiv(nr, 256)), dim3(256), 0, ctx().stream, d_rec, nr, R.key0.p, R.key1.p, R.y0.p, R.dir.p,
+                     R.npos.p);
+  out.n_rec = nr;
+  bucketize(R, 0, out, keep_dev, tmp);
+}
+
+static void bucketize(PairRecs &R, unsigned flags, PairTables &out, DevicePairs *keep_dev, Tmp &tmp) {
+  hipStream_t st = ctx().stream;
+  size_t bytes = 0;
+  const uint32_t nr = R.nr;
+  DevBuf<uint64_t> &key0 = R.key0, &key1 = R.key1, &y0 = R.y0, &y1 = R.y1;
+  DevBuf<uint8_t> &dir = R.dir;
+  DevBuf<uint32_t> &npos = R.npos;
 
   // ---- bucket order: stable LSD sorts (position desc, key1, key0) carrying the record index --------------------
   DevBuf<uint32_t> idx(nr), perm_a(nr), perm_b(nr), k32s(nr);

@@ -33,7 +33,12 @@ void read_counted(const std::string &pattern, std::vector<T> &out) {
       }
       uint64_t n;
       memcpy(&n, buf.data(), 8);
-      if (8 + n * sizeof(T) > buf.size()) n = (buf.size() - 8) / sizeof(T);
+      if (n > (buf.size() - 8) / sizeof(T)) {
+        const std::string bad = g.gl_pathv[i];
+        globfree(&g);
+        PGX_REQUIRE(false, PGX_EIO, "file '%s' is truncated: header says %llu entries, %zu bytes follow", bad.c_str(),
+                    (unsigned long long)n, buf.size() - 8);
+      }
       const size_t o = out.size();
       out.resize(o + n);
       if (n) memcpy(out.data() + o, buf.data() + 8, n * sizeof(T));

@@ -47,6 +47,62 @@ class ResidentDB:
                                               C.byref(self.h)), "pgx_seqdb_upload")
         self.n_reads, self.n_bases = len(rid), int(rlen.sum(dtype=np.uint64))
 
+    @classmethod
+    def from_device(cls, d_seqdb: int, nbytes: int, rid, rlen, roff, device: int | None = None):
+        """the seqdb bytes are already in HBM at device pointer d_seqdb (e.g. all-gathered by the ranks of a multi-GPU job)"""
+        self = cls.__new__(cls)
+        _lib.init(device)
+        self._lib = _lib.load()
+        self.h = C.c_void_p()
+        rid = np.ascontiguousarray(rid, np.uint32)
+        rlen = np.ascontiguousarray(rlen, np.uint32)
+        roff = np.ascontiguousarray(roff, np.uint64)
+        _lib.check(self._lib.pgx_seqdb_upload_dev(C.c_void_p(d_seqdb), nbytes, _ptr(rid), _ptr(rlen), _ptr(roff), len(rid),
+                                                  C.byref(self.h)), "pgx_seqdb_upload_dev")
+        self.n_reads, self.n_bases = len(rid), int(rlen.sum(dtype=np.uint64))
+        return self
+
+    # ---- multi-GPU hand-over on device pointers (include/pgx.h, SURVEY 8e) ------------------------------------------
+    def index_dev(self, total_chunk=1, mychunk=1, levels=2, reduction=6, window=80, kmer=16):
+        """index stage; returns (IndexOut without arrays, d_top, n_top, d_mc, n_mc): list and counts stay in HBM (library-owned)"""
+        p = _lib.IndexParams(total_chunk, mychunk, levels, reduction, window, kmer, 0)
+        r = _lib.IndexResult()
+        d_top, n_top, d_mc, n_mc = C.c_void_p(), C.c_size_t(0), C.c_void_p(), C.c_size_t(0)
+        _lib.check(self._lib.pgx_index_resident_dev(self.h, C.byref(p), C.byref(r), C.byref(d_top), C.byref(n_top), C.byref(d_mc),
+                                                    C.byref(n_mc)), "pgx_index_resident_dev")
+        ix = IndexOut(top=None, top_mc=None, l0=None, l0_mc=None, bases=int(r.bases), reads=int(r.reads),
+                      reads_literal=int(r.reads_literal), ms=float(r.gpu_ms))
+        return ix, int(d_top.value or 0), int(n_top.value), int(d_mc.value or 0), int(n_mc.value)
+
+    def pairs_prepare_dev(self, d_top: int, n_top: int, d_counts_all: int, n_counts_all: int, mc_lower=2, mc_upper=240) -> int:
+        first = C.c_int64(-1)
+        _lib.check(self._lib.pgx_pairs_prepare_dev(self.h, C.c_void_p(d_top), n_top, C.c_void_p(d_counts_all), n_counts_all,
+                                                   mc_lower, mc_upper, C.byref(first)), "pgx_pairs_prepare_dev")
+        return int(first.value)
+
+    def pairs_scatter_dev(self, total_chunk: int, start: int):
+        """returns (device pointer of the send buffer, records per destination chunk 1..total_chunk)"""
+        d_send = C.c_void_p()
+        counts = np.zeros(total_chunk, np.uint64)
+        _lib.check(self._lib.pgx_pairs_scatter_dev(self.h, total_chunk, start, C.byref(d_send), _ptr(counts)), "pgx_pairs_scatter_dev")
+        return int(d_send.value or 0), counts
+
+    def overlap_records_dev(self, d_records: int, n_records: int, total_chunk=1, mychunk=1, bestn=4, mc_lower=2, mc_upper=240,
+                            align_bandwidth=100, ovlp_upper=120):
+        p = _lib.OverlapParams(total_chunk, mychunk, bestn, mc_lower, mc_upper, align_bandwidth, ovlp_upper)
+        out, n, st = C.c_void_p(), C.c_size_t(0), _lib.OverlapStats()
+        _lib.check(self._lib.pgx_overlap_records_dev(self.h, C.c_void_p(d_records), n_records, C.byref(p), C.byref(out), C.byref(n),
+                                                     C.byref(st)), "pgx_overlap_records_dev")
+        return _lib.take(out.value, n.value, OVLP_DTYPE), st.asdict()
+
+    def overlap_dev(self, d_mmers: int, n_mm: int, d_counts: int, n_counts: int, total_chunk=1, mychunk=1, bestn=4, mc_lower=2,
+                    mc_upper=240, align_bandwidth=100, ovlp_upper=120):
+        p = _lib.OverlapParams(total_chunk, mychunk, bestn, mc_lower, mc_upper, align_bandwidth, ovlp_upper)
+        out, n, st = C.c_void_p(), C.c_size_t(0), _lib.OverlapStats()
+        _lib.check(self._lib.pgx_overlap_resident_dev(self.h, C.c_void_p(d_mmers), n_mm, C.c_void_p(d_counts), n_counts, C.byref(p),
+                                                      C.byref(out), C.byref(n), C.byref(st)), "pgx_overlap_resident_dev")
+        return _lib.take(out.value, n.value, OVLP_DTYPE), st.asdict()
+
     def close(self):
         if self.h:
             self._lib.pgx_seqdb_free(self.h)

@@ -289,3 +289,22 @@ def ref_decode(b, strand) -> bytes:
 def ref_run(tool, *args, cwd=None):
     return subprocess.run([os.path.join(REF_DIR, tool), *map(str, args)], cwd=cwd, check=True,
                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+PAIR_REC_DTYPE = np.dtype([("key0", "<u8"), ("key1", "<u8"), ("y0", "<u8"), ("npos", "<u4"), ("dir", "u1"), ("pad", "u1", 3)])
+assert PAIR_REC_DTYPE.itemsize == 32
+
+
+def orc_pair_records(mmers, counts, rlen_by_rid, mychunk=1, total=1, mc_lower=2, mc_upper=240) -> np.ndarray:
+    """the insertion sequence of build_map for overlap chunk `mychunk` of `total` (what the record exchange must deliver)"""
+    mm = np.ascontiguousarray(mmers, MM_DTYPE)
+    mc = np.ascontiguousarray(counts, MC_DTYPE)
+    rl = np.ascontiguousarray(rlen_by_rid, np.uint32)
+    n = C.c_size_t(0)
+    fn = oracle().orc_pair_records
+    fn.restype = C.c_void_p
+    p = fn(mm.ctypes.data_as(C.c_void_p), C.c_size_t(len(mm)), mc.ctypes.data_as(C.c_void_p), C.c_size_t(len(mc)),
+           rl.ctypes.data_as(C.c_void_p), C.c_uint32(mychunk), C.c_uint32(total), C.c_uint32(mc_lower), C.c_uint32(mc_upper), C.byref(n))
+    out = np.frombuffer(C.string_at(p, n.value * 32), PAIR_REC_DTYPE).copy() if n.value else np.zeros(0, PAIR_REC_DTYPE)
+    oracle().orc_free(C.c_void_p(p))
+    return out

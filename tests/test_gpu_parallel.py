@@ -1,0 +1,147 @@
+"""The multi-GPU exchange with the HIP kernels, on one GPU:
+ * one process plays all ranks in turn (index chunk -> prepare -> scatter per chunk, records regrouped per destination as the
+   all-to-all would, overlap stage per chunk) and every chunk's ovlp_t stream must equal the reference's `-t N -c c`;
+ * two processes under gloo (PGX's debug backend: RCCL refuses two ranks on one GPU) run the real protocol code
+   (peregrine_amd.parallel.exchange_overlap with GpuEngine) end to end."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_util as U
+from peregrine_amd import formats, simreads
+from peregrine_amd.parallel import REC_BYTES, GpuEngine, scan_start
+from peregrine_amd.shimmer import ResidentDB
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _reference_chunks(db, tmp, N, levels=2, extra=()):
+    """the reference (or, without the prebuilt binaries, the oracle) on files: N index chunks, N overlap chunks"""
+    pre = os.path.join(tmp, "sd")
+    formats.write_seqdb(pre, db)
+    outs = []
+    for c in range(1, N + 1):
+        if U.have_ref():
+            U.ref_run("shmr_index", "-p", pre, "-t", N, "-c", c, "-m", 0, "-l", levels, "-o", os.path.join(tmp, "ix"))
+        else:
+            U.orc_index_chunk(pre, os.path.join(tmp, "ix"), N, c, levels, 6, 0, 80, 16)
+    for c in range(1, N + 1):
+        o = os.path.join(tmp, "ov.%02d" % c)
+        if U.have_ref():
+            U.ref_run("shmr_overlap", "-p", pre, "-l", os.path.join(tmp, "ix-L%d" % levels), "-t", N, "-c", c, "-o", o, *extra)
+        else:
+            kw = dict(zip(extra[0::2], extra[1::2]))
+            U.orc_overlap_chunk(pre, os.path.join(tmp, "ix-L%d" % levels), o, N, c, 4, int(kw.get("-m", 2)), int(kw.get("-M", 240)))
+        outs.append(formats.read_ovlp(o))
+    return outs
+
+
+@pytest.mark.parametrize("N,lower,upper", [(2, 2, 240), (3, 2, 240), (3, 1, 12)])
+def test_scatter_and_records_path_equal_reference(tmp_path, N, lower, upper):
+    db = simreads.make_workload("small")
+    want = _reference_chunks(db, str(tmp_path), N, extra=("-m", lower, "-M", upper))
+    dev = torch.device("cuda", 0)
+    rdb = ResidentDB(db, 0)
+    eng = GpuEngine(rdb, dev)
+    tops, mcs = [], []
+    for c in range(1, N + 1):
+        _, top, mc = eng.index(N, c)
+        tops.append(top.clone()), mcs.append(mc.clone())
+    counts_all = torch.cat(mcs)
+    firsts = []
+    for r in range(N):
+        firsts.append(eng.pairs_prepare(tops[r], counts_all, lower, upper))
+    sends, counts = [], []
+    for r in range(N):
+        eng.pairs_prepare(tops[r], counts_all, lower, upper)
+        s, cnt = eng.pairs_scatter(N, scan_start(firsts, r))
+        sends.append(s.clone()), counts.append(cnt)
+    for d in range(N):   # what rank d receives: source-major
+        parts = []
+        for r in range(N):
+            o = sum(counts[r][:d]) * REC_BYTES
+            parts.append(sends[r][o:o + counts[r][d] * REC_BYTES])
+        recv = torch.cat(parts)
+        (ov, st), = [eng.overlap_records(recv, N, d + 1, mc_lower=lower, mc_upper=upper)]
+        assert len(want[d]) > 500 and formats.ovlp_fields_equal(ov, want[d]), f"chunk {d + 1} of {N}"
+        # and the same chunk through the all-gather form (device lists): pgx_overlap_resident_dev
+        allmm = torch.cat(tops)
+        torch.cuda.synchronize()
+        ov2, _ = rdb.overlap_dev(allmm.data_ptr(), allmm.numel() // 16, counts_all.data_ptr(), counts_all.numel() // 16, total_chunk=N,
+                                 mychunk=d + 1, mc_lower=lower, mc_upper=upper)
+        assert formats.ovlp_fields_equal(ov2, want[d])
+    rdb.close()
+
+
+def test_seqdb_from_device_pointer():
+    db = simreads.make_workload("tiny")
+    t = torch.from_numpy(db.seqdb).to("cuda:0")
+    torch.cuda.synchronize()
+    a = ResidentDB.from_device(t.data_ptr(), t.numel(), db.rid, db.rlen, db.roff, 0)
+    b = ResidentDB(db, 0)
+    ia, ib = a.index(), b.index()
+    assert np.array_equal(ia.top, ib.top) and len(ia.top) > 100
+    a.close(), b.close()
+
+
+def test_shimmer_list_of_another_seqdb_is_rejected():
+    """rids / positions that do not fit the loaded seqdb must fail with PGX_EARG, not read out of bounds"""
+    from peregrine_amd import _lib
+    big = simreads.make_workload("small")
+    small = simreads.make_workload("tiny")
+    rb, rs = ResidentDB(big, 0), ResidentDB(small, 0)
+    ix = rb.index()
+    with pytest.raises(_lib.PgxError, match="do not fit the read database"):
+        rs.overlap(ix.top, ix.top_mc)
+    ix2 = rs.index()
+    bad = ix2.top.copy()
+    bad["y"][5] = (bad["y"][5] & np.uint64(0xFFFFFFFF00000001)) | np.uint64(0x7FFFFFFE)   # a position far beyond the read
+    with pytest.raises(_lib.PgxError, match="do not fit the read database"):
+        rs.overlap(bad, ix2.top_mc)
+    ov, _ = rs.overlap(ix2.top, ix2.top_mc)   # the context is still usable
+    assert len(ov) > 100
+    rb.close(), rs.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank_main(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from peregrine_amd.parallel import exchange_overlap
+    db = simreads.make_workload("small")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    rdb = ResidentDB(db, 0)
+    eng = GpuEngine(rdb, dev)
+    _, top, mc = eng.index(world, rank + 1)
+    (ov, st), info = exchange_overlap(eng, rank, world, top, mc)
+    np.save(os.path.join(out_dir, f"ov{rank}.npy"), ov)
+    assert st["n_records"] == len(ov) and info["received_records"] > 0
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pipeline_on_one_gpu(tmp_path):
+    import torch.multiprocessing as mp
+    db = simreads.make_workload("small")
+    want = _reference_chunks(db, str(tmp_path), 2)
+    mp.spawn(_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        got = np.load(tmp_path / f"ov{r}.npy")
+        assert formats.ovlp_fields_equal(got, want[r]), f"rank {r} (overlap chunk {r + 1} of 2)"

@@ -1,6 +1,12 @@
-"""Multi-rank exchange on CPU (gloo, world_size 2): the variable-length all-gather that replaces the reference's
-"every overlap chunk globs every index chunk's files" step (src/shmr_overlap.c:355-384) must hand every rank the
-chunks' lists concatenated in chunk (= rank) order -- the insertion order build_map depends on."""
+"""Multi-rank exchange on CPU (gloo, world_size 2 and 3).
+
+The reference's "every overlap chunk globs every index chunk's files" step (src/shmr_overlap.c:359-384) is, in the multi-GPU
+form, the exchange of peregrine_amd/parallel.py: count tables all-gathered, pair records routed to their owner chunk.  Here
+every rank runs its index chunk (the CPU oracle stands in for the GPU stage), the REAL protocol code (exchange_overlap) with a
+numpy engine standing in for libpgx's record builder, and the records each rank receives must be, element for element and in
+order, the insertion sequence of the reference's build_map over the concatenated lists for that chunk (oracle: orc_pair_records;
+the oracle's overlap stage over the same sequence is pinned to the reference binaries by tests/test_oracle_vs_ref.py).
+The GPU twin (tests/test_gpu_parallel.py) runs the same flow with the HIP kernels and compares ovlp_t streams with the reference."""
 import os
 import socket
 import sys
@@ -12,6 +18,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _free_port():
@@ -22,41 +29,114 @@ def _free_port():
     return p
 
 
+def _index_chunk_oracle(db, world, chunk):
+    """the index stage of one chunk on the CPU oracle: reads with rid % N == chunk % N in idx order (shmr_index.c:157)"""
+    import oracle_util as U
+    from peregrine_amd.formats import MM_DTYPE
+    parts = []
+    for r, n, o in zip(db.rid, db.rlen, db.roff):
+        if int(r) % world != chunk % world:
+            continue
+        l0 = U.orc_sketch_seqdb(db.seqdb[int(o):int(o) + int(n)], 80, 16, int(r))
+        parts.append(U.orc_reduce(U.orc_reduce(l0, 6), 6))
+    top = np.concatenate(parts) if parts else np.zeros(0, MM_DTYPE)
+    return top, U.orc_count(top)
+
+
+def _pipeline_worker(rank, world, port, out_dir, lower, upper):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from np_engine import NumpyEngine
+    from peregrine_amd import simreads
+    from peregrine_amd.parallel import exchange_overlap
+    db = simreads.make_workload("tiny")
+    rl, _ = db.by_rid()
+    top, mc = _index_chunk_oracle(db, world, rank + 1)
+    if upper == "first":   # make the very first element of the concatenated list sit exactly AT the upper bound (strict rule)
+        upper = int(np.load(os.path.join(out_dir, "upper.npy")))
+    eng = NumpyEngine(rl)
+    got, info = exchange_overlap(eng, rank, world, torch.from_numpy(top.view(np.uint8).copy()), torch.from_numpy(mc.view(np.uint8).copy()),
+                                 mc_lower=lower, mc_upper=upper)
+    np.save(os.path.join(out_dir, f"recs{rank}.npy"), got)
+    np.save(os.path.join(out_dir, f"top{rank}.npy"), top)
+    np.save(os.path.join(out_dir, f"mc{rank}.npy"), mc)
+    assert info["received_records"] == len(got) and sum(info["received_per_source"]) == len(got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,lower,upper", [(2, 2, 240), (3, 2, 240), (2, 1, 30), (3, 2, "first")])
+def test_two_rank_pipeline(tmp_path, world, lower, upper):
+    sys.path.insert(0, HERE)
+    import oracle_util as U
+    from peregrine_amd import simreads
+    db = simreads.make_workload("tiny")
+    rl, _ = db.by_rid()
+    if upper == "first":
+        tops = [_index_chunk_oracle(db, world, c) for c in range(1, world + 1)]
+        mc_all = np.concatenate([t[1] for t in tops])
+        first = tops[0][0][0]
+        tot = int(mc_all["count"][mc_all["mer"] == (first["x"] >> np.uint64(8))].sum())
+        np.save(tmp_path / "upper.npy", np.int64(tot))
+        upper_v = tot
+    else:
+        upper_v = upper
+    port = _free_port()
+    mp.spawn(_pipeline_worker, args=(world, port, str(tmp_path), lower, upper), nprocs=world, join=True)
+    mm = np.concatenate([np.load(tmp_path / f"top{r}.npy") for r in range(world)])      # chunk order = the reference's glob order
+    mc = np.concatenate([np.load(tmp_path / f"mc{r}.npy") for r in range(world)])
+    total = 0
+    for r in range(world):
+        want = U.orc_pair_records(mm, mc, rl, mychunk=r + 1, total=world, mc_lower=lower, mc_upper=upper_v)
+        got = np.load(tmp_path / f"recs{r}.npy")
+        assert len(got) == len(want), f"rank {r}: {len(got)} records received, build_map inserts {len(want)}"
+        for f in ("key0", "key1", "y0", "npos", "dir"):
+            assert np.array_equal(got[f], want[f]), f"rank {r}: field {f} differs"
+        total += len(want)
+    assert total > (1000 if upper != "first" else 300)
+    if upper == "first":   # the strict rule really was in play: with the inclusive rule the first element would have anchored
+        want_incl = U.orc_pair_records(mm, mc, rl, mychunk=1, total=1, mc_lower=lower, mc_upper=upper_v + 1)
+        want_strict = U.orc_pair_records(mm, mc, rl, mychunk=1, total=1, mc_lower=lower, mc_upper=upper_v)
+        assert len(want_incl) != len(want_strict) or not np.array_equal(want_incl["y0"], want_strict["y0"])
+
+
 def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from peregrine_amd.formats import MM_DTYPE
-    from peregrine_amd.parallel import allgather_many, allgather_records, chunk_of_rank
+    from peregrine_amd.parallel import allgather_cat, allgather_ints, alltoallv_bytes, chunk_of_rank, scan_start
     rng = np.random.default_rng(100 + rank)
-    n = 1000 + 37 * rank                        # ranks contribute different lengths (rank 1 may even be empty below)
+    n = 1000 + 37 * rank                        # ranks contribute different lengths (rank 1 is empty in the 3-rank run)
     mine = np.zeros(n if rank != 1 or world < 3 else 0, MM_DTYPE)
     mine["x"] = rng.integers(0, 2**40, len(mine), dtype=np.uint64)
     mine["y"] = (np.uint64(rank) << np.uint64(32)) | np.arange(len(mine), dtype=np.uint64)
-    parts = allgather_records(torch.from_numpy(mine.view(np.uint8).copy()), world)
-    got = np.concatenate([p.numpy().view(MM_DTYPE) for p in parts])
-    np.save(os.path.join(out_dir, f"got{rank}.npy"), got)
+    cat, sizes = allgather_cat(torch.from_numpy(mine.view(np.uint8).copy()), world)
+    np.save(os.path.join(out_dir, f"got{rank}.npy"), cat.numpy().view(MM_DTYPE))
     np.save(os.path.join(out_dir, f"mine{rank}.npy"), mine)
-    # the two-collective form used between the stages: shimmer list + a second payload of another length per rank
-    extra = rng.integers(0, 256, 16 * (5 - rank), dtype=np.uint8)
-    two = allgather_many([torch.from_numpy(mine.view(np.uint8).copy()), torch.from_numpy(extra.copy())], world)
-    assert np.array_equal(np.concatenate([p.numpy().view(MM_DTYPE) for p in two[0]]), got)
-    np.save(os.path.join(out_dir, f"extra{rank}.npy"), extra)
-    np.save(os.path.join(out_dir, f"gotx{rank}.npy"), np.concatenate([p.numpy() for p in two[1]]))
+    assert sizes[rank] == mine.nbytes
+    ints = allgather_ints([rank * 7, -1 if rank else 5], world)
+    assert ints == [[r * 7, -1 if r else 5] for r in range(world)]
+    # all-to-all(v): rank r sends (r + 1) * (d + 1) bytes of value 10 r + d to rank d
+    send = torch.cat([torch.full(((rank + 1) * (d + 1),), 10 * rank + d, dtype=torch.uint8) for d in range(world)])
+    recv, rb = alltoallv_bytes(send, [(rank + 1) * (d + 1) for d in range(world)], world)
+    want = torch.cat([torch.full(((s + 1) * (rank + 1),), 10 * s + rank, dtype=torch.uint8) for s in range(world)])
+    assert torch.equal(recv, want) and rb == [(s + 1) * (rank + 1) for s in range(world)]
     assert chunk_of_rank(rank, world) == rank + 1
+    assert scan_start([-1, 4, 9][:world] + [0] * (world - 3), rank) == ([-1, 4, 0][rank] if world >= 3 else [-1, 4][rank])
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_allgather_records_orders_by_chunk(tmp_path, world):
+def test_collectives_order_by_chunk(tmp_path, world):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     want = np.concatenate([np.load(tmp_path / f"mine{r}.npy") for r in range(world)])
     for r in range(world):
-        got = np.load(tmp_path / f"got{r}.npy")
-        assert np.array_equal(got, want), f"rank {r}"
-        assert np.array_equal(np.load(tmp_path / f"gotx{r}.npy"), np.concatenate([np.load(tmp_path / f"extra{q}.npy") for q in range(world)]))
+        assert np.array_equal(np.load(tmp_path / f"got{r}.npy"), want), f"rank {r}"
     # chunk ownership of reads follows the reference: rid % N == chunk % N with 1-based chunks (shmr_index.c:157)
     from peregrine_amd.parallel import reads_of_chunk
     rid = np.arange(20, dtype=np.uint32)

@@ -13,7 +13,7 @@ for it in range(3):
     assert formats.ovlp_fields_equal(ov, ov2)
     outs.append(ov.copy())
     rdb.close()
-    _lib.load().pgx_shutdown()
+    _lib.shutdown()
     _lib._inited = None
 assert all(formats.ovlp_fields_equal(outs[0], o) for o in outs)
 print("re-init ok", len(outs[0]))
