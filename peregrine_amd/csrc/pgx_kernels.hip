@@ -269,6 +269,11 @@ bool sketch_wave_eligible(const ReadDesc &rd, int w, int k);  // pgx_sketch_fast
 void launch_sketch_wave(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n_list, int w,
                         int k, pgx_mm128 *d_slab, const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags);
 bool sketch_fused_supported(int w, int rs, int levels);
+bool sketch_blk_supported(int w, int k, int rs, int levels);
+void launch_sketch_blk(const pgx_seqdb *db, const ReadDesc *d_reads, uint32_t n, int rs, int levels, pgx_mm128 *d_slab,
+                       const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags);
+void launch_sketch_fused_list(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n_list, int rs,
+                              int levels, pgx_mm128 *d_slab, const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags);
 void launch_sketch_fused(const pgx_seqdb *db, const ReadDesc *d_reads, uint32_t n, int rs, int levels, pgx_mm128 *d_slab,
                          const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags);
 
@@ -689,10 +694,45 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
   PGX_HIP(hipMemcpyAsync(d_reads, reads.data(), n * sizeof(ReadDesc), hipMemcpyHostToDevice, st));
   PGX_HIP(hipMemcpyAsync(d_slab_off, slab_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
   PGX_HIP(hipMemsetAsync(d_cnt, 0, (3 * (size_t)n + 4) * sizeof(uint32_t), st));
-  // PGX_FUSE=1: one kernel (sketch + streaming reduce), HBM traffic == the algorithmic 1.04 B/base, measured 9 % slower
-  // than sketch + k_reduce_read because of the extra LDS (8 instead of 9 waves per CU); default: two kernels.
-  static const bool want_fuse = getenv("PGX_FUSE") && atoi(getenv("PGX_FUSE")) != 0;
-  if (want_fuse && sketch_fused_supported(w, rs, levels)) {
+  // Default (round 2): k_sketch_blk -- block-per-lane closed form fused with the streaming reduce, L0 never leaves the CU, HBM
+  // traffic == the algorithmic 1.04 B/base -- and k_sketch_wave (fused form) for the reads it flags (two drops close together,
+  // bursts of ties, very short reads).  PGX_SKETCH=wave: k_sketch_wave + k_reduce_read (round 1's default); PGX_SKETCH=fuse (or
+  // PGX_FUSE=1): k_sketch_wave in its fused form for every read.
+  static const char *mode_env = getenv("PGX_SKETCH");
+  static const bool want_fuse = (getenv("PGX_FUSE") && atoi(getenv("PGX_FUSE")) != 0) || (mode_env && !strcmp(mode_env, "fuse"));
+  static const bool want_wave = mode_env && !strcmp(mode_env, "wave");
+  if (!want_fuse && !want_wave && sketch_blk_supported(w, k, rs, levels)) {
+    {
+      KernelTimer tm("sketch", bases);
+      launch_sketch_blk(db, d_reads, n, rs, levels, slab, d_slab_off, d_ctop, d_flags);
+    }
+    // the flagged reads, once more on the general closed-form kernel
+    uint32_t *d_list = ws<uint32_t>("ix.redo", (size_t)n + 1);
+    size_t sbytes = 0;
+    hipcub::CountingInputIterator<uint32_t, ptrdiff_t> iota(0);
+    PGX_HIP(hipcub::DeviceSelect::Flagged(nullptr, sbytes, iota, d_flags, d_list, d_list + n, (int)n, st));
+    void *stmp = ws_raw("ix.sel_tmp", sbytes);
+    PGX_HIP(hipcub::DeviceSelect::Flagged(stmp, sbytes, iota, d_flags, d_list, d_list + n, (int)n, st));
+    uint32_t nredo = 0;
+    PGX_HIP(hipMemcpyAsync(&nredo, d_list + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    sync();
+    if (getenv("PGX_TRACE")) {
+      std::vector<uint32_t> hf(n);
+      PGX_HIP(hipMemcpy(hf.data(), d_flags, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      unsigned why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (uint32_t f : hf)
+        for (int b = 0; b < 8; ++b) why[b] += (f >> b) & 1u;
+      fprintf(stderr, "[pgx] index: %u of %u reads redone by the general closed-form kernel (short %u, ambiguous base %u, two drops in a tile %u, "
+              "drop in the first window %u, close drops %u, tie burst %u / %u, slab %u)\n", nredo, n, why[0], why[1], why[2], why[3], why[4],
+              why[5], why[6], why[7]);
+    }
+    if (nredo) {
+      KernelTimer tm("sketch_redo", 0);
+      PGX_HIP(hipMemsetAsync(d_flags, 0, (size_t)n * sizeof(uint32_t), st));
+      launch_sketch_fused_list(db, d_reads, d_list, nredo, rs, levels, slab, d_slab_off, d_ctop, d_flags);
+    }
+    hipLaunchKernelGGL(k_count_flags, dim3(cdiv(n, 256)), dim3(256), 0, st, d_flags, n, d_nbad);
+  } else if (want_fuse && sketch_fused_supported(w, rs, levels)) {
     KernelTimer tm("sketch", bases);
     launch_sketch_fused(db, d_reads, n, rs, levels, slab, d_slab_off, d_ctop, d_flags);
     hipLaunchKernelGGL(k_count_flags, dim3(cdiv(n, 256)), dim3(256), 0, st, d_flags, n, d_nbad);

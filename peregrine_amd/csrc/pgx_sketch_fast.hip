@@ -515,6 +515,410 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
   }
 }
 
+// =========================================================================================================
+// k_sketch_blk -- the closed form again, in POSITION space, one lane per 16-base block (round 2).
+//
+// k_sketch_wave above gives a lane one BASE per step in phase A (k-mers through LDS, entries compacted into an
+// entry-indexed LDS buffer, a second layout for phase B).  Here lane l of tile t owns the 16 bases of one aligned
+// 16-byte load -- global block G = 64 t + l -- for BOTH phases: its 16 k-mers come from two funnel shifts each of its own
+// and its left neighbour's 2-bit packs (compile-time shift amounts), its 16 hashes stay in registers, and the window
+// minima / maxima of the closed form are the chunked van Herk scheme over those registers:
+//   WM(i)  = min h over the w entries ending at position i  = min3(suffix of block G-A from offset o+1, minima of blocks
+//            G-A+1..G-1, prefix of block G up to o)                                        (w = 16 A, A = 5)
+//   G(p)  <=> max over the windows containing p of WM >= h(p); the windows containing p = (G-A, o) END in block G-A
+//            from o on, in blocks G-A+1..G-1, and in block G before o: lane G decides block G-A, so every cross-lane
+//            dependence points BACKWARDS (to lower lanes or the previous tile) and a tile never waits for the next one.
+// Cross-lane data moves through one 5 KiB LDS exchange buffer (16 hashes, later 16 suffix maxima per block, rows padded to
+// 20 dwords for conflict-free 128-bit accesses) plus per-block minima / maxima; the last A blocks of a tile are carried.
+// Strand-ambiguous k-mers ("drops", fw == rv: 4^-8 per position, one read in five has one) are not entries: a window that
+// spans a drop at position x reaches one position further back, i.e. its suffix / prefix index moves by one -- handled in
+// MODE 2 of the tile body; MODE 1 is the read's first and last tiles (positions outside [k-1, len), windows that do not
+// exist, the first-window correction); MODE 0 the interior.  Anything else -- two drops within ~1.2 k bases, a drop in the
+// first 200 positions, an ambiguous base, reads shorter than a window + 200, a burst of ties overflowing the staging -- sets
+// the read's flag and k_sketch_wave (the validated general form) redoes that read.
+// The emitted L0 minimizers of a tile are compacted (positions only), their hash and strand recomputed from the pack ring by
+// one lane each, and pushed through the streaming two-level mm_reduce (reduce_flush above): L0 never leaves the CU.
+// =========================================================================================================
+namespace {
+constexpr int BST = 20;      // dwords per block row in the exchange buffer
+constexpr int QCAP = 192;    // emitted positions per tile the queue holds (a tile emits ~25)
+constexpr int XNONE = -(1 << 29);   // "no drop"
+
+template <int A>
+struct BlkLds {
+  uint32_t X[64 * BST];       // phase 1: the 16 hashes of every block of the tile; phase 2: suffix maxima of its window minima
+  uint32_t Vc[2][A * BST];    // the last A blocks' hashes of the previous tile (by tile parity)
+  uint32_t Sc[2][A * BST];    // ... and their suffix maxima
+  uint32_t C[A + 64];         // block minima: [0, A) carried from the previous tile, A + lane = this tile
+  uint32_t M[A + 64];         // block maxima of the window minima, same layout
+  uint32_t Fr[128], Rr[128];  // 2-bit packs of the last two tiles' blocks (index = global block & 127): hash / strand of emitted entries
+  uint32_t Q[QCAP];           // positions of the tile's emitted entries, in order
+  uint32_t fw_mv, fw_e;       // first-window correction: minimum of entries 0..W-2, entry W-1
+  int fw_m;                   // position of the rightmost smallest of entries 0..W-2
+};
+
+// per-read state the tile body shares with the kernel
+struct BlkState {
+  int len, lead;
+  int x_drop;                   // position of the most recent strand-ambiguous k-mer (XNONE: none)
+  uint32_t bad;                 // why the read goes to the general kernel (bits: see the end of the kernel)
+};
+
+__device__ __forceinline__ uint32_t min3u(uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); }
+__device__ __forceinline__ uint32_t max3u(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }
+__device__ __forceinline__ uint32_t lshl_or(uint32_t a, int sh, uint32_t b) { return (a << sh) | b; }
+
+// 16 one-hot bytes -> 2-bit pack of the COMPLEMENT codes (earlier bases at higher bits); the caller inverts it.  v_perm_b32 is
+// the nibble -> code table: A(1)->3, C(2)->2, G(4)->1, T(8)-> selector 8 = sign of table byte 1 (0x03: clear) = 0x00; a zero nibble
+// (and 3, 5, 6, 7, 13..15) reads a byte with the flag bit 0x04.  With no flagged nibble the block is clean iff its nibbles hold
+// exactly 16 set bits (the remaining two-bit nibbles 9, 10, 12 raise the count).
+__device__ __forceinline__ uint32_t decode16c(const uint4 raw, uint32_t &flagacc, uint32_t &popc) {
+  const uint32_t dw[4] = {raw.x, raw.y, raw.z, raw.w};
+  uint32_t Fc = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const uint32_t n = dw[d] & 0x0F0F0F0Fu;
+    const uint32_t pm = __builtin_amdgcn_perm(0x04040401u, 0x04020304u, n);
+    flagacc |= pm;
+    popc += (uint32_t)__builtin_popcount(n);
+    const uint32_t c = pm & 0x03030303u;
+    const uint32_t t1 = lshl_or(c, 10, c);
+    const uint32_t t2 = lshl_or(t1, 20, t1);      // top byte = c0<<6 | c1<<4 | c2<<2 | c3
+    Fc = __builtin_amdgcn_alignbit(Fc, t2, 24);   // (Fc << 8) | (t2 >> 24)
+  }
+  return Fc;
+}
+__device__ __forceinline__ uint32_t revcomp_of_comp(uint32_t Fcomp) {   // Fcomp = ~F
+  const uint32_t rr = __builtin_bitreverse32(Fcomp);
+  return ((rr & 0x55555555u) << 1) | ((rr >> 1) & 0x55555555u);  // complement, later bases at higher bits
+}
+
+// One tile: B1 (window minima of the lane's block), B2 (decisions for block G - A); returns the 16-bit emission mask of block
+// G - A.  MODE 0: interior tile, every position an entry.  MODE 1: the tile touches a read end (positions outside [K-1, len),
+// windows that do not exist, the first-window correction) but no drop is near.  MODE 2: a drop in the tile or within a window
+// before it (and anything MODE 1 handles).
+template <int A, int MODE>
+__device__ __forceinline__ uint32_t blk_tile(BlkLds<A> &s, BlkState &st, const int lane, const int t, const uint32_t F,
+                                             const uint32_t Fp, const uint32_t R, const uint32_t Rp, uint32_t (&v)[16]) {
+  constexpr int W = 16 * A;
+  constexpr bool SPECIAL = MODE != 0, DROP = MODE == 2;
+  const int par = t & 1;
+  const int ibase = t * TILE + lane * 16 - st.lead;
+  const int row_own = lane * BST;
+  const bool from_carry = lane < A;
+  const int row_src = from_carry ? lane * BST : (lane - A) * BST;
+  uint32_t vmask = 0xFFFFu;  // which of the block's positions are entries
+  if (MODE == 1) {
+    vmask = 0;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      const int i = ibase + o;
+      if ((uint32_t)(i - (K - 1)) < (uint32_t)(st.len - (K - 1))) vmask |= 1u << o;
+      else v[o] = INF;
+    }
+  }
+  if (DROP) {
+    uint32_t dbits = 0;
+    vmask = 0;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      const uint32_t fw = o == 15 ? F : __builtin_amdgcn_alignbit(Fp, F, 2 * (15 - o));
+      const uint32_t rv = o == 15 ? R : __builtin_amdgcn_alignbit(R, Rp, 2 * (o + 1));
+      const int i = ibase + o;
+      const bool inpos = i >= K - 1 && i < st.len;
+      if (inpos && fw == rv) dbits |= 1u << o;
+      if (inpos && fw != rv) vmask |= 1u << o;
+      else v[o] = INF;
+    }
+    const uint64_t dm = __ballot(dbits != 0);
+    if (dm) {
+      // one drop at a time: the tile body knows a single x.  (A second one close by, or one inside the first window, is the
+      // general kernel's business.)
+      const int dl = __builtin_ctzll(dm);
+      const uint32_t db = (uint32_t)__builtin_amdgcn_readlane((int)dbits, dl);
+      const int xnew = (t * 64 + dl) * 16 + __builtin_ctz(db) - st.lead;
+      if (__builtin_popcountll(dm) > 1 || __builtin_popcount(db) > 1) st.bad |= 4;
+      if (xnew < 200) st.bad |= 8;
+      if (st.x_drop != XNONE && xnew - st.x_drop < TILE + 2 * W) st.bad |= 16;
+      st.x_drop = xnew;
+    }
+  }
+  const int x = st.x_drop;
+
+  // ---- B1: window minima of the block's 16 window ends -----------------------------------------------------------------
+  uint32_t c = min3u(v[0], v[1], v[2]);
+#pragma unroll
+  for (int o = 3; o < 15; o += 2) c = min3u(c, v[o], v[o + 1]);
+  c = min(c, v[15]);
+  lds_write16(&s.X[row_own], v);
+  if (lane >= 64 - A) lds_write16(&s.Vc[par][(lane - (64 - A)) * BST], v);
+  s.C[A + lane] = c;
+  __syncthreads();
+  uint32_t u[16];
+  lds_read16(from_carry ? &s.Vc[par ^ 1][row_src] : &s.X[row_src], u);
+  uint32_t m4 = INF;
+#pragma unroll
+  for (int d = 1; d <= A - 1; ++d) m4 = min(m4, s.C[A + lane - d]);
+  uint32_t wm[16];
+  {
+    uint32_t S[17];
+    S[16] = INF;
+#pragma unroll
+    for (int o = 15; o >= 0; --o) S[o] = min(S[o + 1], u[o]);
+    uint32_t p = INF;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      p = min(p, v[o]);
+      if (!SPECIAL) {
+        wm[o] = min3u(S[o + 1], m4, p);
+      } else {
+        const int i = ibase + o;
+        const bool dsh = DROP && (uint32_t)(i - x - 1) < (uint32_t)(W - 1);   // the window spans the drop: one position further back
+        const uint32_t w = min3u(dsh ? S[o] : S[o + 1], m4, p);
+        const bool exists = ((vmask >> o) & 1u) && i >= W + K - 2;    // a full window of entries ends here
+        wm[o] = exists ? w : 0u;
+      }
+    }
+  }
+  if (SPECIAL && t == 0) {  // first-window correction (mm_sketch.c:116-125): entries 0..W-2 are positions K-1..W+K-3 (no drop there)
+    const int lim = W - 1;
+    const int ba = st.lead + K - 1 + lane, bb = ba + 64;
+    const uint32_t a = lane < lim ? s.X[(ba >> 4) * BST + (ba & 15)] : INF;
+    const uint32_t b = lane + 64 < lim ? s.X[(bb >> 4) * BST + (bb & 15)] : INF;
+    const uint32_t mv = wave_min_u32(min(a, b));
+    const uint64_t mb = __ballot(lane + 64 < lim && b == mv), ma = __ballot(lane < lim && a == mv);
+    const int be = st.lead + K - 1 + W - 1;
+    if (lane == 0) {
+      s.fw_mv = mv;
+      s.fw_m = K - 1 + (mb ? 64 + (63 - __builtin_clzll(mb)) : (63 - __builtin_clzll(ma)));
+      s.fw_e = s.X[(be >> 4) * BST + (be & 15)];
+    }
+  }
+
+  // ---- B2: decide block G - A --------------------------------------------------------------------------------------------
+  {
+    uint32_t sm[16];
+    sm[15] = wm[15];
+#pragma unroll
+    for (int o = 14; o >= 0; --o) sm[o] = max(sm[o + 1], wm[o]);
+    __syncthreads();  // (every lane has read its source row of hashes)
+    lds_write16(&s.X[row_own], sm);
+    if (lane >= 64 - A) lds_write16(&s.Sc[par][(lane - (64 - A)) * BST], sm);
+  }
+#pragma unroll
+  for (int o = 1; o < 16; ++o) wm[o] = max(wm[o - 1], wm[o]);   // prefix maxima of the block's own window minima
+  const uint32_t Mx = wm[15];                                   // = the block's maximum
+  s.M[A + lane] = Mx;
+  __syncthreads();
+  uint32_t emask = 0;
+  {
+    uint32_t sq[16];
+    lds_read16(from_carry ? &s.Sc[par ^ 1][row_src] : &s.X[row_src], sq);
+    uint32_t m4x = 0;
+#pragma unroll
+    for (int d = 1; d <= A - 1; ++d) m4x = max(m4x, s.M[A + lane - d]);
+    uint32_t rmask = 0;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      uint32_t pmx = o ? wm[o - 1] : 0u;
+      if (DROP) {
+        const int ip = ibase - W + o;
+        if ((uint32_t)(x - ip - 1) < (uint32_t)(W - 1)) pmx = wm[o];   // a drop inside: the last window ends one position later
+      }
+      const uint32_t f = max3u(sq[o], m4x, pmx);
+      asm("v_cmp_ge_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(rmask) : "v"(f), "v"(u[o]) : "vcc");
+    }
+    emask = __builtin_bitreverse32(rmask) >> 16;
+    if (SPECIAL && t == 0) {  // ties of the first window's minimum (positions K-1 .. W+K-3)
+      const uint32_t fw_mv = s.fw_mv, fw_e = s.fw_e;
+      const int fw_m = s.fw_m;
+#pragma unroll
+      for (int o = 0; o < 16; ++o) {
+        const int ip = ibase - W + o;
+        if (ip >= K - 1 && ip <= W + K - 3 && u[o] == fw_mv) {
+          if (ip != fw_m || fw_e > fw_mv) emask |= 1u << o;
+          else emask &= ~(1u << o);
+        }
+      }
+    }
+  }
+  // carries for the next tile; the exchange buffer is free again after the barrier
+  __syncthreads();
+  if (lane >= 64 - A) s.C[lane - (64 - A)] = c, s.M[lane - (64 - A)] = Mx;
+  return emask;
+}
+}  // namespace
+
+template <int A>
+__global__ __launch_bounds__(64, 4) void k_sketch_blk(const uint8_t *__restrict__ seq, const ReadDesc *__restrict__ reads,
+                                                      uint32_t n_reads, pgx_mm128 *__restrict__ slab,
+                                                      const uint64_t *__restrict__ slab_off, uint32_t *__restrict__ counts,
+                                                      uint32_t *__restrict__ flags, int rs, int levels, int dbg) {
+  constexpr int W = 16 * A;          // window size in entries
+  __shared__ __attribute__((aligned(16))) BlkLds<A> s;
+  __shared__ RedLds red;
+  RedState rst[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  const int lane = threadIdx.x;
+  const uint32_t slot = blockIdx.x;
+  if (slot >= n_reads) return;
+  const ReadDesc rd = reads[slot];
+  const int len = (int)rd.len;
+  const int lead = (int)(rd.off & 15);
+  const uint8_t *base = seq + (rd.off - (uint64_t)lead);
+  const int span = lead + len;
+  if (len < W + K - 1 + 200) {  // fewer than a window of entries, or too short for the drop rules: the general kernel
+    if (lane == 0) counts[slot] = 0, flags[slot] = 1;   // (flag bits: see the end of the kernel)
+    return;
+  }
+  const int ntiles = (((span - 1) >> 4) + A) / 64 + 1;  // the block of the last base is decided by global lane + A
+  pgx_mm128 *out = slab + slab_off[slot];
+  const uint32_t cap = (uint32_t)(slab_off[slot + 1] - slab_off[slot]);
+  uint32_t nout = 0;
+  BlkState st{len, lead, XNONE, 0u};
+
+  auto fused_flush = [&]() {
+    const uint64_t yhi = (uint64_t)rd.rid << 32;
+    auto to_slab = [&](bool emit, int idx, int tot, uint32_t hh, uint32_t yy) {
+      if (nout + (uint32_t)tot <= cap) {
+        if (emit) out[nout + (uint32_t)idx] = pgx_mm128{((uint64_t)hh << 8) | (uint64_t)K, yhi | yy};
+      } else {
+        st.bad |= 128;
+      }
+      nout += (uint32_t)tot;
+    };
+    if (levels == 1) {
+      reduce_flush(red, rst[0], 0, rs, lane, to_slab);
+    } else {
+      auto to_l1 = [&](bool emit, int idx, int tot, uint32_t hh, uint32_t yy) {
+        const int w = rst[1].ncarry + rst[1].nnew + idx;
+        if (emit) red.h[1][w] = hh, red.y[1][w] = yy;
+        rst[1].nnew += tot;
+      };
+      reduce_flush(red, rst[0], 0, rs, lane, to_l1);
+      reduce_flush(red, rst[1], 1, rs, lane, to_slab);
+    }
+  };
+
+  // carries of "tile -1": no entries
+  for (int i = lane; i < A * BST; i += 64) s.Vc[1][i] = INF, s.Sc[1][i] = 0;
+  if (lane < A) s.C[lane] = INF, s.M[lane] = 0;
+  uint32_t Fc = 0, Rc = 0;        // packs of the block left of the tile (wave uniform)
+
+  uint4 raw_next = make_uint4(0, 0, 0, 0);
+  if (lane * 16 < span) raw_next = *reinterpret_cast<const uint4 *>(base + lane * 16);
+  for (int t = 0; t < ntiles; ++t) {
+    const int G = t * 64 + lane;
+    const int b0 = t * TILE + lane * 16;   // byte offset of the block from `base`
+    const int ibase = b0 - lead;           // read position of its first base
+    const uint4 raw = raw_next;
+    raw_next = make_uint4(0, 0, 0, 0);
+    if (b0 + TILE < span) raw_next = *reinterpret_cast<const uint4 *>(base + b0 + TILE);
+    const bool edge = (t == 0) || ((t + 1) * TILE - lead > len);
+    // ---- decode ----------------------------------------------------------------------------------------------------
+    uint32_t flagacc = 0, popc = 0;
+    const uint32_t Fcomp = decode16c(raw, flagacc, popc);
+    const uint32_t F = ~Fcomp;
+    const uint32_t R = revcomp_of_comp(Fcomp);
+    if (!edge) {
+      if ((flagacc & 0x04040404u) | (popc != 16u ? 1u : 0u)) st.bad |= 2;
+    } else {  // blocks that reach over a read end: only the read's own bytes count
+      const uint32_t dw[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int i = ibase + 4 * d + b;
+          const uint32_t nb = (dw[d] >> (8 * b)) & 0xF;
+          if (i >= 0 && i < len && __builtin_popcount(nb) != 1) st.bad |= 2;
+        }
+    }
+    uint32_t Fp = (uint32_t)__shfl_up((int)F, 1, 64), Rp = (uint32_t)__shfl_up((int)R, 1, 64);
+    if (lane == 0) Fp = Fc, Rp = Rc;
+    Fc = (uint32_t)__builtin_amdgcn_readlane((int)F, 63), Rc = (uint32_t)__builtin_amdgcn_readlane((int)R, 63);
+    s.Fr[G & 127] = F, s.Rr[G & 127] = R;
+
+    // ---- the 16 hashes of the block ----------------------------------------------------------------------------------
+    uint32_t v[16];
+    bool anyinv = false;
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+      const uint32_t fw = o == 15 ? F : __builtin_amdgcn_alignbit(Fp, F, 2 * (15 - o));
+      const uint32_t rv = o == 15 ? R : __builtin_amdgcn_alignbit(R, Rp, 2 * (o + 1));
+      anyinv |= fw == rv;
+      v[o] = mix32(min(fw, rv));
+    }
+    uint32_t emask;
+    if (!(dbg & 4) && (st.x_drop >= t * TILE - lead - (W + 32) || __ballot(anyinv)))
+      emask = blk_tile<A, 2>(s, st, lane, t, F, Fp, R, Rp, v);
+    else if (!(dbg & 4) && edge)
+      emask = blk_tile<A, 1>(s, st, lane, t, F, Fp, R, Rp, v);
+    else
+      emask = blk_tile<A, 0>(s, st, lane, t, F, Fp, R, Rp, v);
+
+    // ---- emission: positions in order -> queue -> one lane per emitted entry -------------------------------------------------
+    if (dbg & 1) emask = 0;   // (timing experiments only: PGX_BLK_DBG)
+    const int ec = __builtin_popcount(emask);
+    const uint64_t b0m = __ballot(ec & 1), b1m = __ballot(ec & 2), b2m = __ballot(ec & 4), b3m = __ballot(ec > 7);
+    if (b0m | b1m | b2m | b3m) {
+      // exclusive prefix of ec over the lanes from its bit planes (a lane emits 0.4 entries on average, eight or more only in
+      // bursts of ties): ballots + mbcnt instead of a six-step shuffle scan
+      int ex, etot;
+      if (!b3m) {
+        ex = (int)(__builtin_amdgcn_mbcnt_hi((uint32_t)(b0m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0m, 0u)) +
+                   2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1m, 0u)) +
+                   4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2m, 0u)));
+        etot = __builtin_popcountll(b0m) + 2 * __builtin_popcountll(b1m) + 4 * __builtin_popcountll(b2m);
+      } else {
+        const int einc = wave_incl_scan(ec, lane);
+        ex = einc - ec;
+        etot = __shfl(einc, 63, 64);
+      }
+      if (etot > QCAP || etot > RSTAGE) {
+        st.bad |= 64;   // a burst of ties (low-complexity read): the general kernel
+      } else {
+        int w = ex;
+        uint32_t em = emask;
+        const int pbase = ibase - W;
+        while (em) {
+          const int o = __builtin_ctz(em);
+          em &= em - 1;
+          s.Q[w++] = (uint32_t)(pbase + o);
+        }
+        __syncthreads();
+        if (rst[0].nnew + etot > RSTAGE) {
+          if (dbg & 2) rst[0].nnew = 0;
+          else fused_flush();
+        }
+        for (int e0 = 0; e0 < etot; e0 += 64) {
+          const int e = e0 + lane;
+          if (e < etot) {
+            const int ip = (int)s.Q[e];
+            const int bb = ip + lead, B = bb >> 4, o = bb & 15;
+            const uint64_t fq = ((uint64_t)s.Fr[(B - 1) & 127] << 32) | s.Fr[B & 127];
+            const uint64_t rq = ((uint64_t)s.Rr[B & 127] << 32) | s.Rr[(B - 1) & 127];
+            const uint32_t fw = (uint32_t)(fq >> (2 * (15 - o))), rv = (uint32_t)(rq >> (2 * (o + 1)));
+            const int wq = rst[0].ncarry + rst[0].nnew + e;
+            red.h[0][wq] = mix32(min(fw, rv));
+            red.y[0][wq] = ((uint32_t)ip << 1) | (fw > rv ? 1u : 0u);
+          }
+        }
+        rst[0].nnew += etot;
+        __syncthreads();
+      }
+    }
+  }
+  fused_flush();
+  // why a read goes to the general kernel (flag bits): 1 shorter than a window + 200, 2 ambiguous base, 4 two drops in one tile,
+  // 8 a drop in the first 200 positions, 16 two drops within a tile + two windows, 64 a burst of ties, 128 slab overflow
+  uint32_t why = st.bad;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) why |= (uint32_t)__shfl_xor((int)why, o, 64);
+  if (lane == 0) {
+    counts[slot] = why ? 0u : nout;
+    if (why) flags[slot] = why;
+  }
+}
+
 // host side ------------------------------------------------------------------------------------------------
 bool sketch_wave_eligible(const ReadDesc &rd, int w, int k) {
   return k == K && (w == 64 || w == 80 || w == 96 || w == 128) && rd.len < (1u << 30);
@@ -549,6 +953,24 @@ void launch_sketch_fused(const pgx_seqdb *db, const ReadDesc *d_reads, uint32_t 
                          const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags) {
   if (!n) return;
   launch_w<true, 5>(db, d_reads, nullptr, n, d_slab, d_slab_off, d_counts, d_flags, rs, levels);
+  PGX_HIP(hipGetLastError());
+}
+
+// round 2: the block-per-lane closed form (fused with the streaming reduce).  Reads it flags are redone by
+// launch_sketch_fused_list (k_sketch_wave on the listed slots).
+bool sketch_blk_supported(int w, int k, int rs, int levels) { return k == K && sketch_fused_supported(w, rs, levels); }
+void launch_sketch_blk(const pgx_seqdb *db, const ReadDesc *d_reads, uint32_t n, int rs, int levels, pgx_mm128 *d_slab,
+                       const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags) {
+  if (!n) return;
+  static const int dbg = getenv("PGX_BLK_DBG") ? atoi(getenv("PGX_BLK_DBG")) : 0;   // timing experiments (wrong results when set)
+  hipLaunchKernelGGL((k_sketch_blk<5>), dim3(n), dim3(64), 0, ctx().stream, db->d_seq.p, d_reads, n, d_slab, d_slab_off, d_counts,
+                     d_flags, rs, levels, dbg);
+  PGX_HIP(hipGetLastError());
+}
+void launch_sketch_fused_list(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n_list, int rs,
+                              int levels, pgx_mm128 *d_slab, const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags) {
+  if (!n_list) return;
+  launch_w<true, 5>(db, d_reads, d_list, n_list, d_slab, d_slab_off, d_counts, d_flags, rs, levels);
   PGX_HIP(hipGetLastError());
 }
 
