@@ -114,7 +114,21 @@ __device__ __forceinline__ void reduce_flush(RedLds &r, RedState &st, int lv, in
     const int gidx = st.cnt + tl;            // offset of the element within the read's list
     const bool valid = tl < st.nnew && gidx >= rs - 1;
     uint32_t bh = 0, by = 0;
-    if (valid) {
+    bool slow = valid;
+    if (rs == 6) {  // the default reduction factor: minimum by min3, the winner's index from an equality mask; a tie inside a
+                    // window (the same k-mer twice among six consecutive minimizers) takes the general loop below
+      uint32_t eq = 0;
+      const int p0 = st.ncarry + tl - 5;
+      if (valid) {
+        const uint32_t h0 = H[p0], h1 = H[p0 + 1], h2 = H[p0 + 2], h3 = H[p0 + 3], h4 = H[p0 + 4], h5 = H[p0 + 5];
+        bh = min(min(min(h0, h1), h2), min(min(h3, h4), h5));
+        eq = (h0 == bh ? 32u : 0u) | (h1 == bh ? 16u : 0u) | (h2 == bh ? 8u : 0u) | (h3 == bh ? 4u : 0u) | (h4 == bh ? 2u : 0u) |
+             (h5 == bh ? 1u : 0u);
+      }
+      slow = valid && (eq & (eq - 1)) != 0;
+      if (valid && !slow) by = Y[p0 + (__builtin_clz(eq) - 26)];   // bit 5 = element 0
+    }
+    if (slow) {
       int p = st.ncarry + tl - (rs - 1);     // buffer position of the window's first element (>= 0 by construction)
       int sl = (gidx + 1) % rs;              // its ring slot: (gidx - rs + 1) % rs
       bh = H[p], by = Y[p];
