@@ -30,7 +30,10 @@ Context &ctx() {
 void require_ready() { PGX_REQUIRE(ctx().ready, PGX_ESTATE, "pgx_init() has not been called (or failed)"); }
 
 // ---- large host arrays -------------------------------------------------------------------------------------
-static constexpr size_t HUGE = (size_t)2 << 20, BIG = (size_t)16 << 20;  // below BIG the allocator's free lists win
+// Arrays of 1 MiB and more are pooled mappings: glibc serves such sizes by mmap / munmap, i.e. every stage call would map, fault in
+// (4 KiB pages) and unmap its tables of a few MiB again -- ~20 k faults and ~80 MB of munmap per overlap call at 4.5 Gbases, 15-20 ms
+// on a busy host, half of them in the background while the next stage runs.
+static constexpr size_t HUGE = (size_t)2 << 20, BIG = (size_t)1 << 20;
 // Mappings are pooled by size class instead of unmapped: munmap takes the address-space lock exclusively and stalls
 // every page fault of the process for its duration -- freeing one call's tables in the background used to slow the NEXT
 // stage's host side 2-3x.  Two pools: blocks with arbitrary content, and blocks known to be all zero (the lock-free

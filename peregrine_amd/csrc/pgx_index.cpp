@@ -34,23 +34,33 @@ void run_index(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out, 
   memset(out, 0, sizeof(*out));
   if (keep) keep->valid = false;
   const double t0 = now_ms();
-  // read selection: rid % total == mychunk % total, in idx-file order (shmr_index.c:155-157)
-  std::vector<ReadDesc> reads;
-  const uint32_t T = (uint32_t)p->total_chunk, c = (uint32_t)p->mychunk % T;
-  for (size_t i = 0; i < db->rid.size(); ++i) {
-    if (db->rid[i] % T != c) continue;
-    PGX_REQUIRE(db->rlen[i] > 0, PGX_EARG, "read %u is empty (mm_sketch asserts len > 0)", db->rid[i]);
-    reads.push_back(ReadDesc{db->roff[i], db->rlen[i], db->rid[i]});
-    out->bases += db->rlen[i];
+  // read selection: rid % total == mychunk % total, in idx-file order (shmr_index.c:155-157); kept with the seqdb for the next call
+  pgx_seqdb::IndexPlan &plan = db->plan;
+  if (plan.total != p->total_chunk || plan.chunk != p->mychunk) {
+    static uint64_t next_serial = 0;
+    plan.reads.clear();
+    plan.bases = 0;
+    const uint32_t T = (uint32_t)p->total_chunk, c = (uint32_t)p->mychunk % T;
+    for (size_t i = 0; i < db->rid.size(); ++i) {
+      if (db->rid[i] % T != c) continue;
+      PGX_REQUIRE(db->rlen[i] > 0, PGX_EARG, "read %u is empty (mm_sketch asserts len > 0)", db->rid[i]);
+      plan.reads.push_back(ReadDesc{db->roff[i], db->rlen[i], db->rid[i]});
+      plan.bases += db->rlen[i];
+    }
+    plan.total = p->total_chunk, plan.chunk = p->mychunk, plan.serial = ++next_serial;
   }
+  const std::vector<ReadDesc> &reads = plan.reads;
+  out->bases = plan.bases;
   out->reads = (uint32_t)reads.size();
   const int kbits = 2 * p->kmer;
+  const bool trace = getenv("PGX_TRACE") != nullptr;
+  if (trace) fprintf(stderr, "[pgx] index: read selection %.2f ms\n", now_ms() - t0);
 
   // fast path: everything of the chunk goes through the wave kernel and the in-LDS reduce (pg_run.py's defaults)
   if (!p->want_l0) {
     const pgx_mm128 *d_top = nullptr;
     size_t ntop = 0;
-    if (dev_index_fused(db, reads, p->window, p->kmer, p->reduction, p->levels, &d_top, &ntop)) {
+    if (dev_index_fused(db, reads, p->window, p->kmer, p->reduction, p->levels, &d_top, &ntop, plan.serial)) {
       PGX_REQUIRE(ntop < (1ULL << 31), PGX_EARG, "chunk too large (use more index chunks)");
       DevBuf<pgx_mm_count> mc;
       size_t nmc = 0;
@@ -62,9 +72,11 @@ void run_index(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out, 
         out->top_mc = download_list(mc, nmc);
       }
       sync();
+      if (trace) fprintf(stderr, "[pgx] index: counts (+ downloads) done at +%.2f ms\n", now_ms() - t0);
       if (keep) keep->d_top = d_top, keep->n_top = ntop, keep->mc = std::move(mc), keep->n_mc = nmc, keep->valid = true;
       timing_flush();
       out->gpu_ms = now_ms() - t0;
+      if (trace) fprintf(stderr, "[pgx] index: stage total %.2f ms\n", out->gpu_ms);
       return;
     }
   }

@@ -134,6 +134,13 @@ struct pgx_seqdb {
   std::vector<uint64_t> roff_by_rid;
   size_t nbytes = 0;
   uint64_t bases = 0;
+  // the read selection of the last index call (rid % total == mychunk % total, idx order): an index stage that is repeated with
+  // the same chunking -- every step of a resident pipeline -- neither rebuilds nor re-uploads it
+  struct IndexPlan {
+    int total = -1, chunk = -1;
+    uint64_t serial = 0, bases = 0;
+    std::vector<pgx::ReadDesc> reads;
+  } plan;
 };
 
 namespace pgx {
@@ -146,8 +153,9 @@ void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, 
                 size_t &n_out, uint32_t *n_literal);
 // fused index path: sketch (wave kernel) -> per-read reduce x levels in LDS -> ordered gather.  Returns false (and
 // leaves the outputs untouched) when a read needs the general path (other w/k, ambiguous bases, > 1024 minimizers ...).
+// plan_serial != 0: identifies `reads` (same serial => same list as the last call: descriptors and slab offsets are still on the device)
 bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, int rs, int levels,
-                     const pgx_mm128 **d_top, size_t *n_top);
+                     const pgx_mm128 **d_top, size_t *n_top, uint64_t plan_serial = 0);
 // one mm_reduce level over a device list
 void dev_reduce(const pgx_mm128 *d_in, size_t n, int rs, DevBuf<pgx_mm128> &out, size_t &n_out);
 // multiplicity of x>>8, sorted by mer
@@ -232,6 +240,7 @@ enum : unsigned {
   PAIRS_Y1 = 1,               // also return the second coordinate of every record (mp128_t.y1)
   PAIRS_INSERTION_ORDER = 2,  // records of a bucket in insertion order instead of position-descending
   PAIRS_COUNTS = 4,           // also return the aggregated multiplicity table
+  PAIRS_LAZY_RECORDS = 8,     // with `keep`: leave the sorted records (y0, dir) on the device only; pairs_fetch_records downloads them
 };
 // what the join leaves in HBM for the device replay (pgx_replay.hip): the bucket-sorted records
 struct DevicePairs {
@@ -255,7 +264,8 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
 int64_t dev_pairs_prepare(const uint32_t *d_rlen, uint32_t n_rid, const pgx_mm128 *d_mm, size_t n_mm, const pgx_mm_count *d_counts,
                           size_t n_counts, uint32_t lower, uint32_t upper);
 void dev_pairs_scatter(const uint32_t *d_rlen, uint32_t T, int64_t start, const pgx_pair_rec **d_send, uint64_t *counts);
-void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out, DevicePairs *keep_dev);
+void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out, DevicePairs *keep_dev, unsigned flags = 0);
+void pairs_fetch_records(const DevicePairs &dp, PairTables &out);  // the lazily kept records, to the host tables
 
 // The greedy walk over the visit list (visit_bids: the join's bucket ids in visit order) on the GPU; the records go to the
 // array alloc_out(n) returns.  false: the job does not fit the device tables' encodings or they overflowed -- nothing was

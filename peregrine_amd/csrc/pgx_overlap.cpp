@@ -1396,17 +1396,21 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   const bool trace = getenv("PGX_TRACE") != nullptr;
   const bool predict = !(getenv("PGX_PREDICT") && atoi(getenv("PGX_PREDICT")) == 0);
   DevicePairs dpairs;
+  const unsigned jflags = gpu_replay ? PAIRS_LAZY_RECORDS : 0u;
   if (d_recs)
-    dev_pairs_from_records(d_recs, n_recs, pt, gpu_replay ? &dpairs : nullptr);
+    dev_pairs_from_records(d_recs, n_recs, pt, gpu_replay ? &dpairs : nullptr, jflags);
   else
     dev_build_pairs(db->d_rlen.p, mmers, n_mm, counts, n_counts,
                     PairParams{(uint32_t)p->total_chunk, (uint32_t)p->mychunk, (uint32_t)p->mc_lower, (uint32_t)p->mc_upper,
                                (uint32_t)db->rlen_by_rid.size()},
-                    pt, 0, dev ? dev->d_top : nullptr, dev ? dev->d_mc : nullptr, gpu_replay ? &dpairs : nullptr);
+                    pt, jflags, dev ? dev->d_top : nullptr, dev ? dev->d_mc : nullptr, gpu_replay ? &dpairs : nullptr);
   sync();
   s.n_pair_records = pt.n_rec;
   if (gpu_replay_env < 0) gpu_replay = pt.n_rec >= gpu_replay_min;
-  if (!gpu_replay) dpairs = DevicePairs();
+  if (!gpu_replay) {
+    pairs_fetch_records(dpairs, pt);   // (kept on the device in case the device replay ran: the host replay reads them)
+    dpairs = DevicePairs();
+  }
   const double t1 = now_ms();
   gpu_ms += t1 - t0;
   NodePin pin;  // from here on the caller and its helper threads stay on one memory node
@@ -1442,6 +1446,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
       if (st) *st = s;
       return;
     }
+    pairs_fetch_records(dpairs, pt);   // the device replay gave up: the host replay needs the records
     dpairs = DevicePairs();
   }
   build_visit(pt, (uint32_t)p->ovlp_upper, visit);

@@ -464,7 +464,14 @@ void dev_pairs_scatter(const uint32_t *d_rlen, uint32_t T, int64_t start, const 
   *d_send = g_scatter.send.p;
 }
 
-void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out, DevicePairs *keep_dev) {
+void pairs_fetch_records(const DevicePairs &dp, PairTables &out) {
+  if (!dp.valid || out.y0.size() == dp.n_rec) return;
+  out.y0 = to_host(dp.y0, dp.n_rec);
+  out.dir = to_host(dp.dir, dp.n_rec);
+  sync();
+}
+
+void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out, DevicePairs *keep_dev, unsigned flags) {
   out = PairTables();
   if (keep_dev) *keep_dev = DevicePairs();
   if (n == 0) return;
@@ -478,7 +485,7 @@ void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out
   hipLaunchKernelGGL(k_unpack_rec, dim3(cdiv(nr, 256)), dim3(256), 0, ctx().stream, d_rec, nr, R.key0.p, R.key1.p, R.y0.p, R.dir.p,
                      R.npos.p);
   out.n_rec = nr;
-  bucketize(R, 0, out, keep_dev, tmp);
+  bucketize(R, flags, out, keep_dev, tmp);
 }
 
 static void bucketize(PairRecs &R, unsigned flags, PairTables &out, DevicePairs *keep_dev, Tmp &tmp) {
@@ -563,8 +570,13 @@ static void bucketize(PairRecs &R, unsigned flags, PairTables &out, DevicePairs 
     sync();
     tj0 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
   }
-  out.y0 = to_host(sy0, nr);
-  out.dir = to_host(sdir, nr);
+  // the sorted records themselves are only read on the host by the host replay: a caller that keeps them on the device for the
+  // device replay fetches them later if it has to fall back (pairs_fetch_records)
+  const bool lazy = (flags & PAIRS_LAZY_RECORDS) && keep_dev;
+  if (!lazy) {
+    out.y0 = to_host(sy0, nr);
+    out.dir = to_host(sdir, nr);
+  }
   DevBuf<uint64_t> sy1((flags & PAIRS_Y1) ? nr : 0);
   if (flags & PAIRS_Y1) {
     hipLaunchKernelGGL(k_gather_u64, dim3(cdiv(nr, 256)), dim3(256), 0, st, y1.p, perm_a.p, nr, sy1.p);
