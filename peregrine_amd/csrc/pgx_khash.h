@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace pgx {
@@ -101,10 +102,33 @@ struct DistinctSlotTable {
   uint64_t *keys = nullptr;
   uint32_t *ids = nullptr, *skip = nullptr;
   uint8_t *used = nullptr;
+  // reserve(): all arrays at their final size from the caller's allocator (pooled huge-page mappings in the overlap stage), the
+  // occupancy / skip arrays twice (a resize builds the new ones beside the old): no realloc, no calloc, no page faults per resize
+  void *(*arena_alloc)(size_t) = nullptr;
+  void (*arena_free)(void *, size_t) = nullptr;
+  uint32_t cap = 0;
+  uint8_t *ub[2] = {nullptr, nullptr};
+  uint32_t *sb[2] = {nullptr, nullptr};
+  int cur = 0;
   DistinctSlotTable() = default;
   DistinctSlotTable(const DistinctSlotTable &) = delete;
   DistinctSlotTable &operator=(const DistinctSlotTable &) = delete;
-  ~DistinctSlotTable() { free(keys), free(ids), free(used), free(skip); }
+  ~DistinctSlotTable() {
+    if (cap) {
+      arena_free(keys, (size_t)cap * 8), arena_free(ids, (size_t)cap * 4);
+      for (int i = 0; i < 2; ++i) arena_free(ub[i], cap), arena_free(sb[i], (size_t)cap * 4);
+    } else {
+      free(keys), free(ids), free(used), free(skip);
+    }
+  }
+  void reserve(size_t n_keys, void *(*al)(size_t), void (*fr)(void *, size_t)) {  // before the first put
+    uint32_t nn = 4;
+    while ((uint32_t)(nn * 0.77 + 0.5) <= n_keys && nn < (1u << 31)) nn <<= 1;   // the table stops growing once upper > size
+    nn = nn < (1u << 31) ? nn * 2 : nn;   // (one spare doubling: a trailing touch() may still resize)
+    arena_alloc = al, arena_free = fr, cap = nn;
+    keys = (uint64_t *)al((size_t)nn * 8), ids = (uint32_t *)al((size_t)nn * 4);
+    for (int i = 0; i < 2; ++i) ub[i] = (uint8_t *)al(nn), sb[i] = (uint32_t *)al((size_t)nn * 4);
+  }
   static inline uint32_t at(uint32_t home, uint32_t step, uint32_t m) {  // position after `step` triangular increments
     return (uint32_t)((uint64_t)home + (uint64_t)step * (step + 1) / 2) & m;
   }
@@ -112,12 +136,34 @@ struct DistinctSlotTable {
     const uint32_t nn = nb ? nb * 2 : 4;
     const uint32_t thr = (uint32_t)(nn * 0.77 + 0.5);
     if (size >= thr) return;
-    uint8_t *fresh = (uint8_t *)calloc(nn, 1);
-    uint32_t *fskip = (uint32_t *)calloc(nn, sizeof(uint32_t));
-    keys = (uint64_t *)realloc(keys, (size_t)nn * 8);
-    ids = (uint32_t *)realloc(ids, (size_t)nn * 4);
+    uint8_t *fresh;
+    uint32_t *fskip;
+    if (cap && nn <= cap) {
+      fresh = ub[cur ^ 1], fskip = sb[cur ^ 1];
+      memset(fresh, 0, nn), memset(fskip, 0, (size_t)nn * 4);
+    } else {
+      if (cap) {  // grew beyond the reservation (cannot happen with a correct n_keys): fall back to the heap, keep the contents
+        uint64_t *k2 = (uint64_t *)malloc((size_t)nn * 8);
+        uint32_t *i2 = (uint32_t *)malloc((size_t)nn * 4);
+        uint8_t *u2 = (uint8_t *)malloc(nb ? nb : 1);
+        memcpy(k2, keys, (size_t)nb * 8), memcpy(i2, ids, (size_t)nb * 4), memcpy(u2, used, nb);
+        arena_free(keys, (size_t)cap * 8), arena_free(ids, (size_t)cap * 4);
+        for (int i = 0; i < 2; ++i) arena_free(ub[i], cap), arena_free(sb[i], (size_t)cap * 4);
+        keys = k2, ids = i2, used = u2, skip = nullptr, cap = 0;
+      } else {
+        keys = (uint64_t *)realloc(keys, (size_t)nn * 8);
+        ids = (uint32_t *)realloc(ids, (size_t)nn * 4);
+      }
+      fresh = (uint8_t *)calloc(nn, 1);
+      fskip = (uint32_t *)calloc(nn, sizeof(uint32_t));
+    }
     const uint32_t m = nn - 1;
     for (uint32_t j = 0; j < nb; ++j) {
+      if (j + 32 < nb && used[j + 32]) __builtin_prefetch(fskip + (SlotTable::h32(keys[j + 32]) & m), 1);
+      if (j + 12 < nb && used[j + 12]) {  // (fskip of that home is in the cache by now)
+        const uint32_t hh = SlotTable::h32(keys[j + 12]) & m, d = at(hh, fskip[hh], m);
+        __builtin_prefetch(fresh + d, 1), __builtin_prefetch(keys + d, 1), __builtin_prefetch(ids + d, 1);
+      }
       if (!used[j]) continue;
       uint64_t key = keys[j];
       uint32_t id = ids[j];
@@ -137,7 +183,8 @@ struct DistinctSlotTable {
         }
       }
     }
-    free(used), free(skip);
+    if (cap) cur ^= 1;
+    else free(used), free(skip);
     used = fresh, skip = fskip, nb = nn, upper = thr;
   }
   void touch() {  // a put of a key that is already present: only the load-factor check has an effect
@@ -150,6 +197,9 @@ struct DistinctSlotTable {
     while (used[i]) i = (i + (++step)) & m;
     skip[h] = step + 1;
     used[i] = 1, keys[i] = key, ids[i] = id, ++size;
+  }
+  void prefetch_home(uint64_t key) const {  // first stage: the skip count of the key's home slot
+    if (nb) __builtin_prefetch(skip + (SlotTable::h32(key) & (nb - 1)), 1);
   }
   void prefetch(uint64_t key) const {  // start the misses a later put_new(key) will take
     if (!nb) return;

@@ -371,7 +371,7 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
     uint32_t ne, nb;    // entries, buckets (0: nothing to visit)
     uint32_t worker;
   };
-  std::vector<GroupOut> go(ng);
+  HostArray<GroupOut> go(ng);   // (every element is assigned by its group's worker)
   struct Frag {  // sized up front from the group range (no growth, no copies)
     HostArray<uint32_t> sizes;  // (ids_only: the bucket ids instead)
     HostArray<Entry> entries;
@@ -379,9 +379,14 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
   };
   std::vector<Frag> frag(nin);
   DistinctSlotTable outer;
+  outer.reserve(ng, big_alloc, big_free);
   auto outer_work = [&] {
     const HostArray<uint32_t> &gord = pt.gord;  // groups by first insertion (sorted on the GPU)
+    // three dependent misses per put on a table that has outgrown the caches -- the key (gkey0 is indexed through the
+    // permutation), the home slot's skip count, the slot the probe sequence resumes at -- each started a stage earlier
     for (size_t i = 0; i < ng; ++i) {
+      if (i + 48 < ng) __builtin_prefetch(&pt.gkey0[gord[i + 48]]);
+      if (i + 24 < ng) outer.prefetch_home(pt.gkey0[gord[i + 24]]);
       if (i + 8 < ng) outer.prefetch(pt.gkey0[gord[i + 8]]);
       outer.put_new(pt.gkey0[gord[i]], gord[i]);
     }
@@ -1415,6 +1420,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   gpu_ms += t1 - t0;
   NodePin pin;  // from here on the caller and its helper threads stay on one memory node
   Visit &visit = scratch->visit;
+  if (trace) fprintf(stderr, "[pgx]   pinned to a memory node at +%.2f ms after the join\n", now_ms() - t1);
   if (gpu_replay && dpairs.valid) {
     build_visit(pt, (uint32_t)p->ovlp_upper, visit, true);
     s.n_buckets = visit.n_buckets;
