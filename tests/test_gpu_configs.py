@@ -1,0 +1,133 @@
+"""BASELINE.json's configs beyond the bench default, on one GPU:
+ * configs[0]/[1] -- the E. coli-size workload itself, record for record against the CPU oracle;
+ * configs[3] scaled to one GPU ("c4s": 300 Mb genome seeded with 6 kb x 300-copy repeat families, tandem arrays and
+   homopolymers, 30x = 9 Gbases) as 8 index chunks + 8 overlap chunks run one after the other, checked
+   through size-independent properties; and a 20 Mb slice of the same recipe ("c4t") with ONE overlap chunk of 8 compared
+   record for record with the oracle;
+ * configs[4] scaled ("c5s"): the same reads with -l 1 (dense L1 shimmers) and mc_upper 240, 8 + 8 chunks, properties; the
+   20 Mb slice record for record."""
+import numpy as np
+import pytest
+
+import oracle_util as U
+from peregrine_amd import formats, simreads
+from peregrine_amd.shimmer import ResidentDB
+
+pytestmark = pytest.mark.gpu
+
+
+def _read(db, r):
+    return db.seqdb[int(db.roff[r]):int(db.roff[r]) + int(db.rlen[r])]
+
+
+def _oracle_index(db, levels):
+    parts = []
+    for r in range(db.n_reads):
+        l = U.orc_sketch_seqdb(_read(db, r), 80, 16, r)
+        for _ in range(levels):
+            l = U.orc_reduce(l, 6)
+        parts.append(l)
+    return np.concatenate(parts)
+
+
+def test_ecoli_workload_equals_oracle():
+    db = simreads.make_workload("ecoli")                     # BASELINE configs[0]/[1]: 4,984 reads, 74.8 Mbases
+    rdb = ResidentDB(db, 0)
+    ix = rdb.index()
+    top = _oracle_index(db, 2)
+    assert np.array_equal(ix.top, top)
+    mc = U.orc_count(top)
+    assert np.array_equal(formats.mc_as_sorted_pairs(ix.top_mc), formats.mc_as_sorted_pairs(mc))
+    want, ost = U.orc_overlap(db, top, mc)
+    ov, st = rdb.overlap(ix.top, ix.top_mc)
+    assert len(want) > 50_000 and formats.ovlp_fields_equal(ov, want)
+    assert st["n_align_needed"] == ost["n_align"] and st["n_seen_skip"] == ost["n_seen_skip"]
+    ix2, ov2, _ = rdb.index_overlap()                        # the resident single-call form the bench times
+    assert formats.ovlp_fields_equal(ov2, want)
+    rdb.close()
+
+
+def _check_records(db, ov, band, rng, n_sample):
+    """properties every chunk's stream must have, whatever the size (shmr_overlap.c:117-173)"""
+    r0 = (ov["y0"] >> np.uint64(32)).astype(np.int64)
+    r1 = (ov["y1"] >> np.uint64(32)).astype(np.int64)
+    pair = np.minimum(r0, r1) << 32 | np.maximum(r0, r1)
+    assert len(np.unique(pair)) == len(pair)                 # the seen-pair table is per chunk: a pair once per chunk
+    assert np.array_equal(ov["rl0"], db.rlen[r0]) and np.array_equal(ov["rl1"], db.rlen[r1])
+    for i in rng.integers(0, len(ov), n_sample):
+        o = ov[i]
+        p0 = ((int(o["y0"]) & 0xFFFFFFFF) >> 1) + 1
+        p1 = ((int(o["y1"]) & 0xFFFFFFFF) >> 1) + 1
+        assert p0 >= p1
+        q = _read(db, r0[i])[p0 - p1:]
+        t = _read(db, r1[i])
+        m = U.orc_ovlp_match(q, int(o["strand0"]), t, int(o["strand1"]), band)
+        assert m == tuple(int(o[f]) for f in formats.MATCH_FIELDS), int(i)
+        q_bgn, q_end, t_bgn, t_end = m[2], m[3], m[4], m[5]
+        assert q_bgn < 48 and t_bgn < 48 and (abs(len(q) - q_end) < 48 or abs(len(t) - t_end) < 48) and q_end > 500 and t_end > 500
+        contain = abs(int(o["rl0"]) - (q_end - q_bgn)) < 96 or abs(int(o["rl1"]) - (t_end - t_bgn)) < 96
+        assert int(o["ovlp_type"]) == ((1 if o["rl0"] >= o["rl1"] else 2) if contain else 0)
+    return pair
+
+
+@pytest.mark.parametrize("name", ["c4s", "c5s"])
+def test_repeat_seeded_scaled_configs_8_chunks(name):
+    sp = dict(levels=2, mc_upper=240)
+    sp.update(simreads.STAGE_PARAMS[name])
+    db = simreads.make_workload_torch(name)                  # 300 Mb x 30x, ~600 k reads, 9 Gbases
+    assert db.n_bases > 8.8e9
+    rdb = ResidentDB(db, 0)
+    rng = np.random.default_rng(17)
+    N = 8
+    parts = [rdb.index(total_chunk=N, mychunk=c, levels=sp["levels"]) for c in range(1, N + 1)]
+    # index: chunks partition the reads (rid % N == c % N), every chunk's list is grouped by rid and position-sorted, sampled
+    # reads equal the oracle's, and the repeat content is really there (multiplicities far above the coverage)
+    for c, p in enumerate(parts, 1):
+        rid = (p.top["y"] >> np.uint64(32)).astype(np.int64)
+        assert np.all(rid % N == c % N) and np.all(np.diff(rid) >= 0)
+        starts = np.searchsorted(rid, np.arange(db.n_reads + 1))
+        mine = np.flatnonzero(np.arange(db.n_reads) % N == c % N)
+        for r in rng.choice(mine, 12, replace=False):
+            want = U.orc_sketch_seqdb(_read(db, r), 80, 16, int(r))
+            for _ in range(sp["levels"]):
+                want = U.orc_reduce(want, 6)
+            assert np.array_equal(p.top[starts[r]:starts[r + 1]], want), (c, int(r))
+    mm = np.concatenate([p.top for p in parts])
+    mc = np.concatenate([p.top_mc for p in parts])
+    agg = {}
+    um, inv = np.unique(mc["mer"], return_inverse=True)
+    cnt = np.zeros(len(um), np.int64)
+    np.add.at(cnt, inv, mc["count"].astype(np.int64))
+    assert int(cnt.sum()) == len(mm) and int(cnt.max()) > 1000   # 300-copy families x 30x
+    total = 0
+    seen_pairs = []
+    for c in range(1, N + 1):
+        ov, st = rdb.overlap(mm, mc, total_chunk=N, mychunk=c, mc_upper=sp["mc_upper"])
+        assert st["n_records"] == len(ov) and len(ov) > 100_000
+        seen_pairs.append(_check_records(db, ov, 100, rng, 40))
+        total += len(ov)
+        if c == 3:   # idempotence of a chunk
+            ov2, _ = rdb.overlap(mm, mc, total_chunk=N, mychunk=c, mc_upper=sp["mc_upper"])
+            assert formats.ovlp_fields_equal(ov, ov2)
+    allp = np.concatenate(seen_pairs)
+    uniq = len(np.unique(allp))
+    assert uniq < total and uniq > 0.15 * total              # most pairs are reported by several chunks (SURVEY 8e caveat)
+    rdb.close()
+
+
+@pytest.mark.parametrize("levels,mc_upper,chunk", [(2, 240, 3), (1, 240, 5)])
+def test_repeat_seeded_slice_one_chunk_equals_oracle(levels, mc_upper, chunk):
+    db = simreads.make_workload_torch("c4t")                 # 20 Mb of the c4s recipe x 30x: ~40 k reads, 600 Mbases
+    rdb = ResidentDB(db, 0)
+    N = 8
+    parts = [rdb.index(total_chunk=N, mychunk=c, levels=levels) for c in range(1, N + 1)]
+    mm = np.concatenate([p.top for p in parts])
+    mc = np.concatenate([p.top_mc for p in parts])
+    top = _oracle_index(db, levels)
+    rid = (mm["y"] >> np.uint64(32)).astype(np.int64)
+    assert np.array_equal(mm[np.argsort(rid, kind="stable")], top)     # the chunk lists are the single list, regrouped
+    want, ost = U.orc_overlap(db, mm, mc, mychunk=chunk, total=N, mc_upper=mc_upper)
+    ov, st = rdb.overlap(mm, mc, total_chunk=N, mychunk=chunk, mc_upper=mc_upper)
+    assert len(want) > 20_000 and formats.ovlp_fields_equal(ov, want)
+    assert st["n_align_needed"] == ost["n_align"]
+    rdb.close()
