@@ -37,7 +37,7 @@ template <int GL>
 __device__ __forceinline__ int group_max_i32(int v) {
   v = dpp_max<0xB1>(v);   // quad_perm [1,0,3,2]
   v = dpp_max<0x4E>(v);   // quad_perm [2,3,0,1]
-  v = dpp_max<0x141>(v);  // row_half_mirror: lanes i <-> 7-i of every 8
+  if (GL >= 8) v = dpp_max<0x141>(v);  // row_half_mirror: lanes i <-> 7-i of every 8
   if (GL == 16) v = dpp_max<0x140>(v);  // row_mirror: lanes i <-> 15-i
   return v;
 }
@@ -388,6 +388,247 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
   }
 }
 
+
+// ---- the same d-loop as a per-group PHASE MACHINE (round 2) ------------------------------------------------------------------
+// k_align4 steps all groups of a wavefront through one d-step per iteration: a step takes as many rounds of GL diagonals, and
+// its snake loop as many iterations, as the NEEDIEST group of the wavefront -- which is why narrower groups did not pay there
+// (with sixteen 4-lane groups some group needs a second round in nearly every step).  Here every group carries its own phase
+//   FETCH -> STEP (loop conditions of DWmatch.c:118-122) -> ROUND (start points + 8-code probe of GL diagonals) -> SNAKE (one
+//   64- or 128-code extension of the group's lowest unfinished diagonal per iteration) -> END (the order-dependent side results
+//   of the round, V, best_m, the first diagonal that reaches an end) -> next ROUND, or BAND (one round of the band scan per
+//   iteration, DWmatch.c:166-183) -> STEP of d + 1
+// and an iteration of the wavefront runs every phase body once, each under its groups' predicate; a group passes through
+// ROUND, SNAKE, END and BAND within ONE iteration when its step has a single round and a single extension (the common case),
+// and only the groups that need more take more iterations.  Lane utilisation is what the kernel is bound by (VALU issue):
+// sixteen 4-lane groups keep 3.6 live diagonals on 4 lanes instead of 8.
+enum { PH_FETCH = 0, PH_STEP = 1, PH_ROUND = 2, PH_SNAKE = 3, PH_END = 4, PH_BAND = 5, PH_DONE = 6 };
+template <int GL, typename VT>
+__global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
+                                                 const uint32_t *__restrict__ rlen, const pgx_align_key *__restrict__ keys,
+                                                 uint32_t n, int band, int ring, pgx_match *__restrict__ out,
+                                                 uint32_t *__restrict__ counter, const uint32_t *__restrict__ redo_n,
+                                                 const uint32_t *__restrict__ redo_list, uint32_t *__restrict__ esc_n,
+                                                 uint32_t *__restrict__ esc_list) {
+  // redo_list != nullptr: the candidates are keys[redo_list[0 .. *redo_n)] (the ones a narrow-ring launch handed on);
+  // esc_list != nullptr: a candidate whose band outgrows this launch's V ring is appended there instead of being finished
+  extern __shared__ int32_t Vall[];
+  const int lane = threadIdx.x, gl = lane & (GL - 1), gbase = lane & ~(GL - 1);
+  VT *V = reinterpret_cast<VT *>(Vall) + (lane / GL) * ring;
+  const int mask = ring - 1, band_size = band * 2;
+  constexpr int SL = GL == 16 ? 8 : 16;  // codes per lane and snake iteration
+  if (redo_list) n = *redo_n;
+
+  // per-candidate state, uniform within a group
+  int phase = PH_FETCH;
+  uint32_t a = 0;
+  const uint8_t *q = seq, *t = seq;
+  int q_len = 0, t_len = 0, qs = 0, ts = 0, max_d = 0, d = 0;
+  int best_m = -1, min_k = 0, max_k = 0, nk = 0, base = 0, bbase = 0, new_min = 0, new_max = 0;
+  uint32_t longest = 0;
+  bool started = false;
+  int q_bgn = 0, t_bgn = 0, q_m_end = 0, t_m_end = 0;
+  // per-lane state of the running round
+  int x = 0, y = 0, x1 = 0, y1 = 0, k = 0;
+  bool active = false, more = false;
+
+  for (;;) {
+    // ---- FETCH: idle groups pull the next candidate --------------------------------------------------------------
+    if (phase == PH_FETCH) {
+      uint32_t na = 0;
+      if (gl == 0) na = atomicAdd(counter, 1u);
+      na = (uint32_t)__shfl((int)na, gbase, 64);
+      if (na >= n) {
+        phase = PH_DONE;
+      } else {
+        a = redo_list ? redo_list[na] : na;
+        const pgx_align_key key = keys[a];
+        q = seq + roff[key.rid0] + key.q_off;
+        t = seq + roff[key.rid1];
+        q_len = (int)(rlen[key.rid0] - key.q_off);
+        t_len = (int)rlen[key.rid1];
+        qs = key.dir0 ? 4 : 0, ts = key.dir1 ? 4 : 0;
+        max_d = (int)(0.3 * (double)(q_len + t_len));  // DWmatch.c:96, one IEEE double multiply
+        d = 0, best_m = -1, min_k = 0, max_k = 0, longest = 0;
+        started = false;
+        q_bgn = t_bgn = q_m_end = t_m_end = 0;
+        if (gl == 0) V[1 & mask] = (VT)0;  // the only slot read before it is written (d = 0 reads V[k+1] = V[1])
+        phase = PH_STEP;
+      }
+    }
+    if (!__ballot(phase != PH_DONE)) break;
+    __syncthreads();
+
+    // ---- STEP: the loop conditions of a new d (DWmatch.c:118-122,196-199) -------------------------------------------
+    if (phase == PH_STEP && esc_list && max_k - min_k + 4 > ring && !(d >= max_d || max_k - min_k > band_size)) {
+      // the live diagonals k-1 .. k+1 no longer fit this launch's ring: the wide-ring launch redoes the candidate
+      if (gl == 0) esc_list[atomicAdd(esc_n, 1u)] = a;
+      phase = PH_FETCH;
+    }
+    if (phase == PH_STEP) {
+      if (d >= max_d || max_k - min_k > band_size) {
+        if (gl == 0) {
+          pgx_match r;
+          r.m_size = 0, r.dist = 0, r.q_bgn = 0, r.q_end = 0, r.t_bgn = 0, r.t_end = 0;
+          r.t_m_end = t_m_end, r.q_m_end = q_m_end;
+          out[a] = r;
+        }
+        phase = PH_FETCH;
+      } else {
+        nk = max_k >= min_k ? ((max_k - min_k) >> 1) + 1 : 0;
+        base = 0;
+        if (nk == 0) {  // degenerate band: an empty k-loop, then the band update over nothing (followed literally)
+          bbase = 0, new_min = max_k, new_max = min_k;
+          phase = PH_BAND;
+        } else {
+          phase = PH_ROUND;
+        }
+      }
+    }
+
+    // ---- ROUND: start points and the 8-code probe of GL diagonals ----------------------------------------------------
+    if (phase == PH_ROUND) {
+      const int j = base + gl;
+      active = j < nk;
+      k = min_k + 2 * j;
+      x = 0, y = 0, x1 = 0, y1 = 0;
+      more = false;
+      if (active) {
+        const int va = (int)V[(k - 1) & mask], vb = (int)V[(k + 1) & mask];
+        x = (k == min_k || (k != max_k && va < vb)) ? vb : va + 1;
+        y = x - k;
+        x1 = x, y1 = y;
+        const int rem = min(q_len - x, t_len - y);
+        if (rem > 0) {
+          int m = match8(load_u64_unaligned(q + x), load_u64_unaligned(t + y), qs, ts);
+          m = min(m, rem);
+          x += m, y += m;
+          more = (m == 8) && (rem > 8);
+        }
+      }
+    }
+    {
+      const uint32_t gm = group_bits<GL>(__ballot(more && phase == PH_ROUND), gbase);
+      if (phase == PH_ROUND) phase = gm ? PH_SNAKE : PH_END;
+    }
+
+    // ---- SNAKE: one extension of the group's lowest unfinished diagonal ----------------------------------------------
+    {
+      const uint64_t mw = __ballot(more && phase == PH_SNAKE);
+      if (mw) {
+        const uint32_t gm = group_bits<GL>(mw, gbase);
+        const bool has = gm != 0 && phase == PH_SNAKE;
+        const int L = has ? __builtin_ctz(gm) : 0;
+        const int xs = __shfl(x, gbase + L, 64), ys = __shfl(y, gbase + L, 64);
+        const int rem = min(q_len - xs, t_len - ys);
+        const int off = gl * SL;
+        int m = SL;
+        if (has) {
+          m = 0;
+          if (off < rem) {
+            m = match8(load_u64_unaligned(q + xs + off), load_u64_unaligned(t + ys + off), qs, ts);
+            if (SL == 16 && m == 8 && off + 8 < rem)
+              m += match8(load_u64_unaligned(q + xs + off + 8), load_u64_unaligned(t + ys + off + 8), qs, ts);
+            m = min(m, rem - off);
+          }
+        }
+        const uint32_t sg = group_bits<GL>(__ballot(has && m < SL), gbase);
+        int ext = GL * SL;
+        if (sg) {
+          const int f = __builtin_ctz(sg);
+          ext = SL * f + __shfl(m, gbase + f, 64);
+        }
+        if (has && gl == L) {
+          x += ext, y += ext;
+          if (sg || ext >= rem) more = false;  // mismatch found or an end reached: this diagonal is done
+        }
+        const uint32_t gm2 = group_bits<GL>(__ballot(more && phase == PH_SNAKE), gbase);
+        if (phase == PH_SNAKE && !gm2) phase = PH_END;
+      }
+    }
+
+    // ---- END of the round: the order-dependent side results, lowest k first (DWmatch.c:142-164) ------------------------
+    {
+      const bool e = phase == PH_END;
+      const int ext = x - x1;
+      const bool hit = e && active && (x >= q_len || y >= t_len);
+      const uint64_t hitw = __ballot(hit);
+      int hl = GL;
+      uint32_t hitm = 0;
+      if (hitw) {
+        hitm = group_bits<GL>(hitw, gbase);
+        if (hitm) hl = __builtin_ctz(hitm);
+      }
+      const bool valid = e && active && gl <= hl;
+      {  // first extension > 16 fixes q_bgn/t_bgn once (DWmatch.c:142-146)
+        const uint64_t sw = __ballot(valid && ext > 16 && !started);
+        if (sw) {
+          const uint32_t m = group_bits<GL>(sw, gbase);
+          const int l = m ? __builtin_ctz(m) : 0;
+          const int bx = __shfl(x1, gbase + l, 64), by = __shfl(y1, gbase + l, 64);
+          if (m) q_bgn = bx, t_bgn = by, started = true;
+        }
+      }
+      if (__ballot(valid && (uint32_t)ext > longest)) {  // strictly longer extension (DWmatch.c:148-152)
+        const int mx = group_max_i32<GL>(valid ? ext : -1);
+        const uint32_t m = group_bits<GL>(__ballot(valid && ext == mx), gbase);
+        const int l = m ? __builtin_ctz(m) : 0;
+        const int ex = __shfl(x, gbase + l, 64), ey = __shfl(y, gbase + l, 64);
+        if (e && mx >= 0 && (uint32_t)mx > longest) longest = (uint32_t)mx, q_m_end = ex, t_m_end = ey;
+      }
+      if (valid) V[k & mask] = (VT)x;
+      {
+        const int s = group_max_i32<GL>(valid ? x + y : -1);
+        if (e) best_m = max(best_m, s);
+      }
+      bool matched = false;
+      if (hitw) {
+        const int ex = __shfl(x, gbase + (hl & (GL - 1)), 64), ey = __shfl(y, gbase + (hl & (GL - 1)), 64);
+        if (e && hitm) {  // DWmatch.c:185-194
+          matched = true;
+          if (gl == 0) {
+            pgx_match r;
+            r.q_bgn = q_bgn, r.t_bgn = t_bgn, r.q_end = ex, r.t_end = ey, r.dist = d;
+            r.m_size = (ex - q_bgn + ey - t_bgn + 2 * d) / 2;
+            r.t_m_end = t_m_end, r.q_m_end = q_m_end;
+            out[a] = r;
+          }
+        }
+      }
+      if (e) {
+        if (matched) {
+          phase = PH_FETCH;
+        } else {
+          base += GL;
+          if (base >= nk) bbase = 0, new_min = max_k, new_max = min_k, phase = PH_BAND;
+          else phase = PH_ROUND;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- BAND: one round of the band update (DWmatch.c:166-183) ------------------------------------------------------
+    {
+      const bool bnd = phase == PH_BAND;
+      if (__ballot(bnd)) {
+        const int thr = best_m - band;
+        const int j = bbase + gl;
+        const int k2 = min_k + 2 * j;
+        int u = 0;
+        if (bnd && j < nk) u = (nk <= GL) ? x + y : 2 * (int)V[k2 & mask] - k2;
+        const uint32_t m = group_bits<GL>(__ballot(bnd && j < nk && u >= thr), gbase);
+        if (bnd) {
+          if (m) {
+            new_min = min(new_min, min_k + 2 * (bbase + __builtin_ctz(m)));
+            new_max = max(new_max, min_k + 2 * (bbase + 31 - __builtin_clz(m)));
+          }
+          bbase += GL;
+          if (bbase >= nk) max_k = new_max + 1, min_k = new_min - 1, ++d, phase = PH_STEP;
+        }
+      }
+    }
+  }
+}
+
 void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out) {
   if (n == 0) return;
   static const long small_max = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : 13000;  // measured crossover ~14 k (tools/alignlat.py)
@@ -397,7 +638,38 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
   uint32_t *counter = ws<uint32_t>("align.counter", 1);
   if ((long)n > small_max) PGX_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), ctx().stream));  // (k_align1 has no work counter)
   static const int gl = getenv("PGX_ALIGN_GL") ? atoi(getenv("PGX_ALIGN_GL")) : 8;  // measured: 8 lanes per candidate (avg 3.6 live diagonals, <= 8 in 98.7 % of the steps) 45.6 vs 42.1 M aln/s
-  if ((long)n <= small_max) {
+  // PGX_ALIGN_MODE: 8 (default) = the phase machine with 8-lane groups: at 4.5 Gbases 66.5 M alignments/s against 61.0 M of
+  // k_align4 (mode 0, round 1: groups in lock-step) -- the same 39 G VALU wavefront-instructions per 2.4 M alignments, 23 % fewer
+  // scalar ones, less waiting.  4 = sixteen 4-lane groups on a NARROW V ring (64 slots, 2 KiB of LDS per wavefront, full
+  // occupancy) followed by a launch of the 8-lane form with the full ring over the candidates whose band outgrew the narrow
+  // one (work list and count stay on the device; with nothing handed on it is an empty launch): measured and NOT chosen -- 17 %
+  // fewer VALU instructions, but 57-60 M alignments/s whatever the occupancy: its probe loads touch sixteen candidates' cache
+  // lines per instruction and the address pipeline, not VALU issue, becomes the limit.
+  static const int mode = getenv("PGX_ALIGN_MODE") ? atoi(getenv("PGX_ALIGN_MODE")) : 8;
+  if ((long)n > small_max && (mode == 4 || mode == 8) && db->max_rlen <= 65535u) {
+    auto grid_for = [&](size_t cands, int groups, int rg) {
+      const size_t lds = (size_t)groups * rg * sizeof(uint16_t);
+      const unsigned per_cu = (unsigned)std::min<size_t>(32, (160u << 10) / lds);
+      return (unsigned)std::min<size_t>((cands + groups - 1) / groups, (size_t)ctx().num_cu * per_cu);
+    };
+    if (mode == 4) {
+      static const int narrow = getenv("PGX_ALIGN_RING") ? atoi(getenv("PGX_ALIGN_RING")) : 64;
+      uint32_t *esc = ws<uint32_t>("align.esc", n + 4);   // [0] handed-on count, [1] the second launch's work counter, [4..) list
+      PGX_HIP(hipMemsetAsync(esc, 0, 4 * sizeof(uint32_t), ctx().stream));
+      const int rg = std::min(narrow, ring);
+      hipLaunchKernelGGL((k_align_ph<4, uint16_t>), dim3(grid_for(n, 16, rg)), dim3(64), 16 * rg * sizeof(uint16_t), ctx().stream,
+                         db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, rg, d_out, counter,
+                         (const uint32_t *)nullptr, (const uint32_t *)nullptr, rg < ring ? esc : nullptr, rg < ring ? esc + 4 : nullptr);
+      if (rg < ring)
+        hipLaunchKernelGGL((k_align_ph<8, uint16_t>), dim3(grid_for(std::max<size_t>(n / 16, 8192), 8, ring)), dim3(64),
+                           8 * ring * sizeof(uint16_t), ctx().stream, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band,
+                           ring, d_out, esc + 1, esc, esc + 4, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    } else {
+      hipLaunchKernelGGL((k_align_ph<8, uint16_t>), dim3(grid_for(n, 8, ring)), dim3(64), 8 * ring * sizeof(uint16_t), ctx().stream,
+                         db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter,
+                         (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    }
+  } else if ((long)n <= small_max) {
     hipLaunchKernelGGL(k_align1, dim3((unsigned)n), dim3(64), ring * sizeof(int32_t), ctx().stream, db->d_seq.p, db->d_roff.p,
                        db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out);
   } else if (gl == 8) {
