@@ -23,6 +23,14 @@ __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t *p) {
   __builtin_memcpy(&v, p, 8);
   return v;
 }
+struct U128 {
+  uint64_t lo, hi;
+};
+__device__ __forceinline__ U128 load_u128_unaligned(const uint8_t *p) {  // one global_load_dwordx4 (the seqdb has 1 KiB of tail padding)
+  U128 v;
+  __builtin_memcpy(&v, p, 16);
+  return v;
+}
 __device__ __forceinline__ int match8(uint64_t qa, uint64_t ta, int qs, int ts) {
   const uint64_t diff = ((qa >> qs) ^ (ta >> ts)) & 0x0F0F0F0F0F0F0F0FULL;
   return diff ? (__builtin_ctzll(diff) >> 3) : 8;
@@ -525,9 +533,13 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
         if (has) {
           m = 0;
           if (off < rem) {
-            m = match8(load_u64_unaligned(q + xs + off), load_u64_unaligned(t + ys + off), qs, ts);
-            if (SL == 16 && m == 8 && off + 8 < rem)
-              m += match8(load_u64_unaligned(q + xs + off + 8), load_u64_unaligned(t + ys + off + 8), qs, ts);
+            if (SL == 16) {  // 16 codes with one 16-byte load per sequence (half the vector-memory instructions of two 8-byte ones)
+              const U128 qa = load_u128_unaligned(q + xs + off), ta = load_u128_unaligned(t + ys + off);
+              m = match8(qa.lo, ta.lo, qs, ts);
+              if (m == 8) m += match8(qa.hi, ta.hi, qs, ts);
+            } else {
+              m = match8(load_u64_unaligned(q + xs + off), load_u64_unaligned(t + ys + off), qs, ts);
+            }
             m = min(m, rem - off);
           }
         }
