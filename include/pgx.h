@@ -211,7 +211,9 @@ int pgx_align_batch(pgx_seqdb *db, const pgx_align_key *keys, size_t n, int band
  * the n keys in ascending slot order.  Runs on the host (it is the routine the overlap stage uses for its outer table). */
 int pgx_khash_slot_order(const uint64_t *keys, size_t n, uint64_t *out);
 
-/* ---- shimmer4py surface (py/peregrine/build_shimmer4py.py:8-84), GPU-backed single-call forms ---- */
+/* ---- shimmer4py surface (py/peregrine/build_shimmer4py.py:8-84), GPU-backed single-call forms ----
+ * NOT exported: shmr_aln / free_shmr_alns (build_shimmer4py.py:64-77; src/shmr_align.c is the consensus stage's aligner, out of
+ * scope per SURVEY.md section 2 #10) -- a caller that needs them keeps the reference's own shimmer4py for those two symbols. */
 typedef struct { size_t n, m; pgx_mm128 *a; } mm128_v; /* kvec layout, src/shimmer.h:27-30; .a is malloc'd, caller frees */
 typedef pgx_match ovlp_match_t;
 void decode_biseq(uint8_t *src, char *seq, size_t len, uint8_t strand);

@@ -54,8 +54,36 @@ def adversarial_strings(rng):
     return out
 
 
+def write_provenance():
+    """The fixtures' record ORDER rests on the libc the reference binaries ran on: the reference sorts a bucket with qsort and a
+    comparator that only returns 0 or 1 (src/shmr_overlap.c:46-50,217), which is a stable descending sort with glibc's merge-sort
+    qsort and something else with an unstable qsort.  Store the libc version and a direct check of that behaviour."""
+    import ctypes
+    import json
+    import platform
+    libc = ctypes.CDLL(None)
+    libc.gnu_get_libc_version.restype = ctypes.c_char_p
+    # qsort with the reference's comparator shape on (position, insertion) pairs: stable-descending iff ties keep insertion order
+    CMP = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32))
+    rng = np.random.Generator(np.random.PCG64(5))
+    ok = True
+    for n in (3, 7, 40, 120, 5000):
+        pos = rng.integers(0, max(2, n // 3), n).astype(np.uint32)
+        arr = np.stack([pos, np.arange(n, dtype=np.uint32)], axis=1).copy()
+        libc.qsort(arr.ctypes.data_as(ctypes.c_void_p), n, 8, CMP(lambda a, b: 1 if a[0] < b[0] else 0))
+        want = arr[np.lexsort((arr[:, 1], -arr[:, 0].astype(np.int64)))]
+        ok = ok and bool(np.array_equal(arr, want))
+    info = {"libc": "glibc " + libc.gnu_get_libc_version().decode(), "machine": platform.machine(),
+            "qsort_with_0_1_comparator_is_stable_descending": ok,
+            "note": "tests/golden/*.npz were produced by oracle/_ref binaries running on this libc"}
+    with open(os.path.join(HERE, "provenance.json"), "w") as f:
+        json.dump(info, f, indent=1)
+    return info
+
+
 def main():
     assert U.have_ref(), "build the reference first: make -C oracle ref"
+    write_provenance()
     rng = np.random.Generator(np.random.PCG64(20260928))
     tmp = tempfile.mkdtemp(prefix="golden_")
 

@@ -114,3 +114,24 @@ def test_map_matches_reference_text():
         text, n = U.orc_map_reads_to_ref(q["ref_l2"], mmers, mc, rlen, c, T, lo, hi)
         want = q[f"map_c{c}t{T}lo{lo}hi{hi}"].tobytes()
         assert text == want and n == want.count(b"\n"), (c, T, lo, hi)
+
+
+def test_golden_provenance_and_qsort_assumption():
+    """The record order of the fixtures (and of the reference itself) rests on qsort being a stable descending sort under the
+    reference's 0/1 comparator (shmr_overlap.c:46-50,217): true for glibc's merge-sort path.  The fixtures carry the libc they
+    were produced on; the same property is checked on the libc running this test, so a failure here explains a record-order
+    mismatch against reference binaries built on this host."""
+    import ctypes
+    import json
+    import os
+    info = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "provenance.json")))
+    assert info["qsort_with_0_1_comparator_is_stable_descending"] is True and info["libc"].startswith("glibc")
+    libc = ctypes.CDLL(None)
+    CMP = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32))
+    rng = np.random.default_rng(3)
+    for n in (5, 120, 3000):
+        pos = rng.integers(0, max(2, n // 4), n).astype(np.uint32)
+        arr = np.stack([pos, np.arange(n, dtype=np.uint32)], axis=1).copy()
+        libc.qsort(arr.ctypes.data_as(ctypes.c_void_p), n, 8, CMP(lambda a, b: 1 if a[0] < b[0] else 0))
+        want = arr[np.lexsort((arr[:, 1], -arr[:, 0].astype(np.int64)))]
+        assert np.array_equal(arr, want), "this libc's qsort is not stable under the reference's comparator"
