@@ -363,14 +363,14 @@ def main():
         if "sketch" in kern:
             k = kern["sketch"]
             gbs = SKETCH_BYTES_PER_BASE * k["units"] / (k["ms_total"] * 1e-3) / 1e9
-            cands["sketch"] = {"kernel": "k_sketch_wave", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            cands["sketch"] = {"kernel": "k_sketch_blk (+ k_sketch_wave for the reads it flags)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
                                "bytes_per_unit": SKETCH_BYTES_PER_BASE, "unit_name": "base",
                                "gbases_per_s": k["units"] / (k["ms_total"] * 1e-3) / 1e9}
         if "align" in kern:
             k = kern["align"]
             gbs = ALIGN_BYTES_PER_PAIR * k["units"] / (k["ms_total"] * 1e-3) / 1e9
-            cands["align"] = {"kernel": "k_align4", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            cands["align"] = {"kernel": "k_align_ph<8> (per-group phase machine; PGX_ALIGN_MODE=0: k_align4)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
                               "bytes_per_unit": ALIGN_BYTES_PER_PAIR, "unit_name": "alignment",
                               "alignments_per_s": k["units"] / (k["ms_total"] * 1e-3)}
@@ -399,9 +399,12 @@ def main():
             if "replay" in cands and "k_update" in tr:   # a round = one evaluation kernel (k_eval or k_eval_rows) + one k_update
                 tot = sum(tr[k]["hbm_bytes_per_launch"] * tr[k]["launches"] for k in ("k_eval", "k_eval_rows", "k_update") if k in tr)
                 tr["replay"] = {"hbm_bytes_per_launch": tot / tr["k_update"]["launches"]}
-            for nm, kk in (("sketch", "k_sketch_wave"), ("align", "k_align4"), ("align1", "k_align1"), ("replay", "replay")):
-                if nm in cands and kk in tr:
+            for nm, kks in (("sketch", ("k_sketch_blk", "k_sketch_wave")), ("align", ("k_align_ph", "k_align4")), ("align1", ("k_align1",)),
+                            ("replay", ("replay",))):
+                kk = next((k for k in kks if k in tr), None)
+                if nm in cands and kk:
                     cands[nm]["traffic"] = tr[kk]["hbm_bytes_per_launch"]
+                    cands[nm]["traffic_read_side_raw"] = tr[kk].get("FETCH_SIZE_KB_per_launch", 0) * 1024 if "FETCH_SIZE_KB_per_launch" in tr[kk] else None
                     cands[nm]["traffic_source"] = tfile + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch, read side x2 per the gfx950 note)"
         except Exception:
             pass
