@@ -65,7 +65,6 @@ constexpr uint32_t I_GUESS = 1u << 18, I_UNFILED = 1u << 19;
 constexpr uint32_t LIST_CAP = 65536, DEV_LIST = 0xFFFFFFFFu;
 enum : uint32_t { OV_ITEMS = 1, OV_NODES = 2, OV_REQS = 4, OV_PAIRS = 8, OV_MEMO = 16, OV_QOFF = 32, OV_PASSES = 64 };  // Counters::overflow
 constexpr uint8_t F_DUP = 1, F_GUESS = 2, F_UNFILED = 4;
-constexpr uint32_t BLK_SH = 10, BLK = 1u << BLK_SH;  // buckets per summary block
 
 struct Counters {
   uint32_t item_top, rnode_top, nreq, overflow;
@@ -92,9 +91,6 @@ struct R {
   uint32_t req_cap, settled;
   uint32_t memo_used;  // 0: nothing has been filed yet (the first round of the first sweep skips the memo lookups)
   uint8_t *dirty, *evaluated, *parity, *bflags, *ever;
-  // summaries over blocks of BLK buckets (set whenever a bucket of the block gets the flag; the scans below only enter flagged
-  // blocks, so a pass over a handful of dirty buckets does not read the state of all of them): dirty, F_UNFILED, F_GUESS
-  uint8_t *dblk, *ublk, *gblk;
   uint32_t *ihead, *inum, *ohead, *lookups, *skips;
   uint32_t *dlist;  // the dirty buckets, listed by k_count while there are at most LIST_CAP of them (the sparse passes run from the list)
   uint32_t wlist0;  // first wcur slot of the list-mode wavefronts
@@ -104,10 +100,6 @@ struct R {
   int predict;
 };
 
-__device__ __forceinline__ void mark_dirty(const R &r, uint32_t j) {
-  r.dirty[j] = 1;
-  r.dblk[j >> BLK_SH] = 1;
-}
 __device__ __forceinline__ uint64_t mix64(uint64_t h) {
   h ^= h >> 33, h *= 0xff51afd7ed558ccdULL, h ^= h >> 33, h *= 0xc4ceb9fe1a85ec53ULL, h ^= h >> 33;
   return h;
@@ -210,7 +202,7 @@ __global__ __launch_bounds__(256) void k_setup(R r) {
       }
   }
   r.bflags[j] = dup ? F_DUP : 0;
-  mark_dirty(r, j);
+  r.dirty[j] = 1;
 }
 
 // ---- shimmer_to_overlap (shmr_overlap.c:52-180) for every dirty bucket in [lo, hi) -------------------------------------
@@ -243,19 +235,19 @@ __device__ __forceinline__ void mark_readers(const R &r, uint32_t slot, uint32_t
   const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pt[slot]);
   const uint4 h1 = *reinterpret_cast<const uint4 *>(w + 4);  // cnt, pad, in[0], in[1]
   const uint32_t c = min(h1.x, NIN);
-  if (c > 0 && h1.z > j + 1) mark_dirty(r, h1.z - 1);
-  if (c > 1 && h1.w > j + 1) mark_dirty(r, h1.w - 1);
+  if (c > 0 && h1.z > j + 1) r.dirty[h1.z - 1] = 1;
+  if (c > 1 && h1.w > j + 1) r.dirty[h1.w - 1] = 1;
   for (uint32_t q = 2; q < c; q += 8) {  // in[q .. q+8): two 16-byte loads in flight
     const uint4 a = *reinterpret_cast<const uint4 *>(w + 6 + q), b = *reinterpret_cast<const uint4 *>(w + 10 + q);
     const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
     for (uint32_t k = 0; k < 8; ++k)
-      if (q + k < c && x[k] > j + 1) mark_dirty(r, x[k] - 1);
+      if (q + k < c && x[k] > j + 1) r.dirty[x[k] - 1] = 1;
   }
   if (c < NIN) return;
   for (uint32_t nd = r.pt[slot].rhead; nd != NIL; nd = r.rn[nd - 1].next) {
     const uint32_t rb = r.rn[nd - 1].bucket;
-    if (rb > j) mark_dirty(r, rb);
+    if (rb > j) r.dirty[rb] = 1;
   }
 }
 
@@ -347,8 +339,6 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
         if (gl == 0) {
           r.ihead[j] = head, r.inum[j] = num, r.lookups[j] = lookups, r.skips[j] = skips;
           r.bflags[j] = (uint8_t)((dup ? F_DUP : 0) | (any_guess ? F_GUESS : 0) | (any_unfiled ? F_UNFILED : 0));
-          if (any_guess) r.gblk[j >> BLK_SH] = 1;
-          if (any_unfiled) r.ublk[j >> BLK_SH] = 1;
         }
         alive = false;
       } else {
@@ -610,8 +600,6 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
         if (gl == 0) {
           r.ihead[j] = head, r.inum[j] = num, r.lookups[j] = lookups, r.skips[j] = skips;
           r.bflags[j] = (uint8_t)((dup ? F_DUP : 0) | (any_guess ? F_GUESS : 0) | (any_unfiled ? F_UNFILED : 0));
-          if (any_guess) r.gblk[j >> BLK_SH] = 1;
-          if (any_unfiled) r.ublk[j >> BLK_SH] = 1;
         }
         alive = false;
       } else if (dup) {
@@ -796,7 +784,7 @@ __device__ __forceinline__ void apply_insertion(const R &r, uint32_t j, uint32_t
   uint32_t v = r.pt[slot].own;
   for (;;) {
     if (v != 0 && own_bucket(v) < j) {  // an earlier bucket got in first: this evaluation is stale
-      mark_dirty(r, j);
+      r.dirty[j] = 1;
       return;
     }
     const uint32_t prev = atomicCAS(&r.pt[slot].own, v, mine);
@@ -845,149 +833,122 @@ __global__ __launch_bounds__(256) void k_update(R r, uint32_t lo, uint32_t hi, u
   if (alive && gl == 0) r.evaluated[j] = 0, r.ohead[j] = NIL;
 }
 
-__global__ __launch_bounds__(256) void k_count(R r) {   // one wavefront per block of BLK buckets
-  const uint32_t blk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if ((uint64_t)blk << BLK_SH >= r.nb || !r.dblk[blk]) return;
-  bool any = false;
-  for (uint32_t j = (blk << BLK_SH) + lane, e = min(r.nb, (blk + 1) << BLK_SH); j - lane < e; j += 64) {
-    const bool d = j < e && r.dirty[j];
-    const uint64_t m = __ballot(d);
-    if (!m) continue;
-    any = true;
-    uint32_t base = 0;
-    const int leader = __builtin_ctzll(m);
-    if ((int)lane == leader) {
-      base = atomicAdd(&r.c->ndirty, (uint32_t)__popcll(m));
-      atomicMin(&r.c->min_dirty, j);
-      atomicMax(&r.c->max_dirty, (j & ~63u) + 63 - (uint32_t)__builtin_clzll(m));
-    }
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    const uint32_t at = base + lane_rank(m);
-    if (d && at < LIST_CAP) r.dlist[at] = j;
+__global__ __launch_bounds__(256) void k_count(R r) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool d = j < r.nb && r.dirty[j];
+  const uint64_t m = __ballot(d);
+  if (!m) return;
+  uint32_t base = 0;
+  const int leader = __builtin_ctzll(m);
+  if ((int)(threadIdx.x & 63) == leader) {
+    base = atomicAdd(&r.c->ndirty, (uint32_t)__popcll(m));
+    atomicMin(&r.c->min_dirty, j);
+    atomicMax(&r.c->max_dirty, (j & ~63u) + 63 - (uint32_t)__builtin_clzll(m));
   }
-  if (!any && lane == 0) r.dblk[blk] = 0;   // (a bucket marked after this scan sets the flag again: marks only come from k_update / k_settle, not concurrently)
+  base = (uint32_t)__shfl((int)base, leader, 64);
+  const uint32_t at = base + lane_rank(m);
+  if (d && at < LIST_CAP) r.dlist[at] = j;
 }
 
 // ---- file the alignments the converged lists still need ---------------------------------------------------------------
 // (Only buckets that are not dirty right now are filed -- the others are about to be evaluated again.  Filing while the sweep
 // is still running is always safe: a request is just an alignment whose result the memo will hold; at worst it is never
 // asked for again.)
-__global__ __launch_bounds__(256) void k_file(R r, uint32_t limit) {   // one wavefront per block of BLK buckets
-  const uint32_t blk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+__global__ __launch_bounds__(256) void k_file(R r, uint32_t limit) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = j < limit && (r.bflags[j] & F_UNFILED) && !r.dirty[j];
+  if (!__ballot(active)) return;
+  uint32_t cnt = 0;
+  if (active)
+    for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) cnt += (r.items[it - 1].info & I_UNFILED) ? 1u : 0u;
+  // request numbers: one atomic per wavefront
   const int lane = threadIdx.x & 63;
-  if ((uint64_t)blk << BLK_SH >= limit || !r.ublk[blk]) return;
-  bool left = false;   // some bucket of the block stays unfiled (it is dirty right now)
-  for (uint32_t jb = blk << BLK_SH, e = min(limit, (blk + 1) << BLK_SH); jb < e; jb += 64) {
-    const uint32_t j = jb + (uint32_t)lane;
-    const bool active = j < e && (r.bflags[j] & F_UNFILED) && !r.dirty[j];
-    if (__ballot(active)) {
-      auto one = [&]() -> bool {
-      uint32_t cnt = 0;
-      if (active)
-        for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) cnt += (r.items[it - 1].info & I_UNFILED) ? 1u : 0u;
-      // request numbers: one atomic per wavefront
-      uint32_t incl = cnt;
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-        if (lane >= o) incl += t;
-      }
-      const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-      uint32_t base = 0;
-      if (lane == 63 && total) base = atomicAdd(&r.c->nreq, total);
-      base = (uint32_t)__shfl((int)base, 63, 64);
-      if (!active || !cnt) {
-        if (active) r.bflags[j] &= (uint8_t)~F_UNFILED;
-        return true;
-      }
-      if ((unsigned long long)base + total > r.req_cap) {
-        atomicOr(&r.c->overflow, OV_REQS);
-        return false;
-      }
-      uint32_t my = base + incl - cnt;
-      const uint32_t b = r.bid[j], s0 = r.bstart[b];
-      for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) {
-        Item &im = r.items[it - 1];
-        if (!(im.info & I_UNFILED)) continue;
-        const uint32_t ai = im.info & 0xFF, pi = (im.info >> 8) & 0xFF;
-        const Ent e0 = entry_of(r.y0[s0 + ai]), e1 = entry_of(r.y0[s0 + pi]);
-        const uint32_t dir0 = r.dir[s0 + ai], dir1 = r.dir[s0 + pi], q_off = e0.pos1 - e1.pos1;
-        const unsigned long long a = (unsigned long long)e0.rid << 32 | e1.rid;
-        const uint32_t bk = q_off << 2 | dir0 << 1 | dir1;
-        pgx_align_key key;
-        key.rid0 = e0.rid, key.rid1 = e1.rid, key.q_off = q_off, key.dir0 = (uint8_t)dir0, key.dir1 = (uint8_t)dir1, key.pad[0] = key.pad[1] = 0;
-        // find or insert.  Another lane may be inserting the same key right now: its `b` may still read 0, in which case this
-        // lane files a duplicate in another slot (same alignment, same result -- harmless).
-        uint32_t i = (uint32_t)mix64(a ^ mix64(bk)) & r.mmask, found = NONE;
-        bool fresh = false;
-        for (int probes = 0; probes < 1024; ++probes) {
-          unsigned long long cur = r.mt[i].a;
-          if (cur == 0) {
-            cur = atomicCAS(&r.mt[i].a, 0ULL, a);
-            if (cur == 0) {
-              r.mt[i].b = bk + 1;
-              found = i, fresh = true;
-              break;
-            }
-          }
-          if (cur == a && *(volatile uint32_t *)&r.mt[i].b == bk + 1) {
-            found = i;
-            break;
-          }
-          i = (i + 1) & r.mmask;
-        }
-        if (found == NONE) {
-          atomicOr(&r.c->overflow, OV_MEMO);
-          return false;
-        }
-        r.rq_key[my] = key;  // (a request slot whose key was already filed by someone else just repeats that alignment)
-        if (fresh) r.mt[found].req = my;
-        ++my;
-        im.mslot = found;
-        im.info &= ~I_UNFILED;
-      }
-      r.bflags[j] &= (uint8_t)~F_UNFILED;
-        return true;
-      };
-      if (!one()) return;
-    }
-    left |= __ballot(j < e && (r.bflags[j] & F_UNFILED)) != 0;
+  uint32_t incl = cnt;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+    if (lane >= o) incl += t;
   }
-  if (!left && lane == 0) r.ublk[blk] = 0;
+  const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+  uint32_t base = 0;
+  if (lane == 63 && total) base = atomicAdd(&r.c->nreq, total);
+  base = (uint32_t)__shfl((int)base, 63, 64);
+  if (!active || !cnt) {
+    if (active) r.bflags[j] &= (uint8_t)~F_UNFILED;
+    return;
+  }
+  if ((unsigned long long)base + total > r.req_cap) {
+    atomicOr(&r.c->overflow, OV_REQS);
+    return;
+  }
+  uint32_t my = base + incl - cnt;
+  const uint32_t b = r.bid[j], s0 = r.bstart[b];
+  for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) {
+    Item &im = r.items[it - 1];
+    if (!(im.info & I_UNFILED)) continue;
+    const uint32_t ai = im.info & 0xFF, pi = (im.info >> 8) & 0xFF;
+    const Ent e0 = entry_of(r.y0[s0 + ai]), e1 = entry_of(r.y0[s0 + pi]);
+    const uint32_t dir0 = r.dir[s0 + ai], dir1 = r.dir[s0 + pi], q_off = e0.pos1 - e1.pos1;
+    const unsigned long long a = (unsigned long long)e0.rid << 32 | e1.rid;
+    const uint32_t bk = q_off << 2 | dir0 << 1 | dir1;
+    pgx_align_key key;
+    key.rid0 = e0.rid, key.rid1 = e1.rid, key.q_off = q_off, key.dir0 = (uint8_t)dir0, key.dir1 = (uint8_t)dir1, key.pad[0] = key.pad[1] = 0;
+    // find or insert.  Another lane may be inserting the same key right now: its `b` may still read 0, in which case this
+    // lane files a duplicate in another slot (same alignment, same result -- harmless).
+    uint32_t i = (uint32_t)mix64(a ^ mix64(bk)) & r.mmask, found = NONE;
+    bool fresh = false;
+    for (int probes = 0; probes < 1024; ++probes) {
+      unsigned long long cur = r.mt[i].a;
+      if (cur == 0) {
+        cur = atomicCAS(&r.mt[i].a, 0ULL, a);
+        if (cur == 0) {
+          r.mt[i].b = bk + 1;
+          found = i, fresh = true;
+          break;
+        }
+      }
+      if (cur == a && *(volatile uint32_t *)&r.mt[i].b == bk + 1) {
+        found = i;
+        break;
+      }
+      i = (i + 1) & r.mmask;
+    }
+    if (found == NONE) {
+      atomicOr(&r.c->overflow, OV_MEMO);
+      return;
+    }
+    r.rq_key[my] = key;  // (a request slot whose key was already filed by someone else just repeats that alignment)
+    if (fresh) r.mt[found].req = my;
+    ++my;
+    im.mslot = found;
+    im.info &= ~I_UNFILED;
+  }
+  r.bflags[j] &= (uint8_t)~F_UNFILED;
 }
 
 // ---- check the guesses against the results ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_settle(R r) {   // one wavefront per block of BLK buckets
-  const uint32_t blk = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  if (blk == 0 && lane == 0) r.c->ndirty = 0, r.c->min_dirty = 0xFFFFFFFFu, r.c->max_dirty = 0;  // (the count that follows starts afresh)
-  if ((uint64_t)blk << BLK_SH >= r.nb || !r.gblk[blk]) return;
-  bool left = false;
-  for (uint32_t jb = blk << BLK_SH, e = min(r.nb, (blk + 1) << BLK_SH); jb < e; jb += 64) {
-    const uint32_t j = jb + (uint32_t)lane;
-    if (j < e && (r.bflags[j] & F_GUESS)) {
-      const uint32_t b = r.bid[j], s0 = r.bstart[b];
-      bool bad = false, remain = false;
-      for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) {
-        Item &im = r.items[it - 1];
-        if (!(im.info & I_GUESS)) continue;
-        const uint32_t req = im.mslot != NONE ? r.mt[im.mslot].req : NONE;
-        if (req >= r.settled) {
-          remain = true;
-          continue;
-        }
-        const uint32_t ai = im.info & 0xFF, pi = (im.info >> 8) & 0xFF, gtype = (im.info >> 16) & 3;
-        const Ent e0 = entry_of(r.y0[s0 + ai]), e1 = entry_of(r.y0[s0 + pi]);
-        uint32_t type;
-        const bool acc = classify(r.rq_res[req], r.rlen[e0.rid], r.rlen[e1.rid], e0.pos1 - e1.pos1, &type);
-        if (!acc || type != gtype) bad = true;
-        else im.info &= ~I_GUESS;
-      }
-      if (bad) mark_dirty(r, j);
-      if (!remain) r.bflags[j] &= (uint8_t)~F_GUESS;
+__global__ __launch_bounds__(256) void k_settle(R r) {
+  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) r.c->ndirty = 0, r.c->min_dirty = 0xFFFFFFFFu, r.c->max_dirty = 0;  // (the count that follows starts afresh)
+  if (j >= r.nb || !(r.bflags[j] & F_GUESS)) return;
+  const uint32_t b = r.bid[j], s0 = r.bstart[b];
+  bool bad = false, remain = false;
+  for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) {
+    Item &im = r.items[it - 1];
+    if (!(im.info & I_GUESS)) continue;
+    const uint32_t req = im.mslot != NONE ? r.mt[im.mslot].req : NONE;
+    if (req >= r.settled) {
+      remain = true;
+      continue;
     }
-    left |= __ballot(j < e && (r.bflags[j] & F_GUESS)) != 0;
+    const uint32_t ai = im.info & 0xFF, pi = (im.info >> 8) & 0xFF, gtype = (im.info >> 16) & 3;
+    const Ent e0 = entry_of(r.y0[s0 + ai]), e1 = entry_of(r.y0[s0 + pi]);
+    uint32_t type;
+    const bool acc = classify(r.rq_res[req], r.rlen[e0.rid], r.rlen[e1.rid], e0.pos1 - e1.pos1, &type);
+    if (!acc || type != gtype) bad = true;
+    else im.info &= ~I_GUESS;
   }
-  if (!left && lane == 0) r.gblk[blk] = 0;
+  if (bad) r.dirty[j] = 1;
+  if (!remain) r.bflags[j] &= (uint8_t)~F_GUESS;
 }
 
 // ---- the ovlp_t records, bucket by bucket in visit order, each bucket's in evaluation order ---------------------------
@@ -1063,11 +1024,9 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   DevBuf<pgx_align_key> rq_key(r.req_cap);
   DevBuf<pgx_match> rq_res(r.req_cap);
   r.items = items.p, r.rn = rn.p, r.rq_key = rq_key.p, r.rq_res = rq_res.p;
-  const size_t nblk = (nb + BLK - 1) / BLK;
-  DevBuf<uint8_t> bytes(nb * 5 + 3 * nblk);
+  DevBuf<uint8_t> bytes(nb * 5);
   DevBuf<uint32_t> words(nb * 5);
   r.dirty = bytes.p, r.evaluated = bytes.p + nb, r.parity = bytes.p + 2 * nb, r.bflags = bytes.p + 3 * nb, r.ever = bytes.p + 4 * nb;
-  r.dblk = bytes.p + 5 * nb, r.ublk = r.dblk + nblk, r.gblk = r.ublk + nblk;
   r.ihead = words.p, r.inum = words.p + nb, r.ohead = words.p + 2 * nb, r.lookups = words.p + 3 * nb, r.skips = words.p + 4 * nb;
   DevBuf<uint4> wcur(nb + 2 + LIST_CAP + 1);  // (one slot per wavefront of k_eval: GPW buckets each)
   r.wcur = wcur.p, r.wlist0 = (uint32_t)(nb + 2);
@@ -1079,7 +1038,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   r.bestn = bestn, r.predict = predict ? 1 : 0, r.settled = 0;
   PGX_HIP(hipMemsetAsync(pt.p, 0, (size_t)pcap * sizeof(PSlot), s));
   PGX_HIP(hipMemsetAsync(mt.p, 0, (size_t)mcap * sizeof(MSlot), s));
-  PGX_HIP(hipMemsetAsync(bytes.p, 0, nb * 5 + 3 * nblk, s));
+  PGX_HIP(hipMemsetAsync(bytes.p, 0, nb * 5, s));
   PGX_HIP(hipMemsetAsync(words.p, 0, nb * 5 * sizeof(uint32_t), s));
   PGX_HIP(hipMemsetAsync(dc.p, 0, sizeof(Counters), s));
   hipLaunchKernelGGL(k_setup, dim3(cdiv256(nb)), dim3(256), 0, s, r);
@@ -1094,7 +1053,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   auto read_counters = [&](bool count_dirty) {
     if (count_dirty) {  // reset the three dirty statistics, keep the rest
       PGX_HIP(hipMemcpyAsync(&dc.p->ndirty, reset3, 3 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(k_count, dim3(cdiv256(nblk * 64)), dim3(256), 0, s, r);
+      hipLaunchKernelGGL(k_count, dim3(cdiv256(nb)), dim3(256), 0, s, r);
     }
     PGX_HIP(hipMemcpyAsync(hc, dc.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
     sync();
@@ -1118,7 +1077,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   double align_ms = 0;
   auto count_dirty = [&](bool reset = false) {  // no host round trip: ndirty, the range and the list stay on the device
     if (reset) PGX_HIP(hipMemcpyAsync(&dc.p->ndirty, reset3, 3 * sizeof(uint32_t), hipMemcpyHostToDevice, s));  // (k_update / k_settle reset otherwise)
-    hipLaunchKernelGGL(k_count, dim3(cdiv256(nblk * 64)), dim3(256), 0, s, r);
+    hipLaunchKernelGGL(k_count, dim3(cdiv256(nb)), dim3(256), 0, s, r);
     have_list = true;
   };
   for (;;) {
@@ -1169,7 +1128,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
         }
       }
       // file what the clean buckets need (always safe), then one round trip for everything: dirty count, range, requests
-      hipLaunchKernelGGL(k_file, dim3(cdiv256(nblk * 64)), dim3(256), 0, s, r, (uint32_t)nb);
+      hipLaunchKernelGGL(k_file, dim3(cdiv256(nb)), dim3(256), 0, s, r, (uint32_t)nb);
       PGX_HIP(hipMemcpyAsync(hc, dc.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
       sync();
       if (hc->overflow) goto overflowed;
@@ -1196,7 +1155,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     dev_align(db, r.rq_key + first_req, batch, band, r.rq_res + first_req);
     r.settled = (uint32_t)nreq;
     first_req = nreq;
-    hipLaunchKernelGGL(k_settle, dim3(cdiv256(nblk * 64)), dim3(256), 0, s, r);
+    hipLaunchKernelGGL(k_settle, dim3(cdiv256(nb)), dim3(256), 0, s, r);
     count_dirty();
     if (batch > 100000) {  // a big batch: worth a round trip to know how many guesses were wrong (dense or sparse next)
       PGX_HIP(hipMemcpyAsync(hc, dc.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
