@@ -228,6 +228,11 @@ struct PairTables {
   HostArray<uint32_t> gbucket;   // ng+1: first bucket of the group
   HostArray<uint32_t> gord;      // groups in order of first insertion
   HostArray<uint32_t> bord;      // buckets ordered by (group, first insertion): group g's slice is [gbucket[g], gbucket[g+1])
+  // PAIRS_ORD_TABLES: what the inner-table replay reads, already IN bord ORDER (sequential on the host instead of three gathers
+  // per bucket): second key and size of bucket bord[i]; per group: is a put repeated after its last first-insertion (khash.h:298-306)
+  HostArray<uint64_t> bkey1_ord;
+  HostArray<uint32_t> bn_ord;
+  HostArray<uint8_t> gtrail;
   HostArray<uint64_t> y1;        // per record, only with PAIRS_Y1
   HostArray<uint64_t> umer;      // aggregated multiplicities, sorted by mer: only with PAIRS_COUNTS
   HostArray<uint32_t> ucnt;
@@ -240,6 +245,7 @@ enum : unsigned {
   PAIRS_Y1 = 1,               // also return the second coordinate of every record (mp128_t.y1)
   PAIRS_INSERTION_ORDER = 2,  // records of a bucket in insertion order instead of position-descending
   PAIRS_COUNTS = 4,           // also return the aggregated multiplicity table
+  PAIRS_ORD_TABLES = 16,      // bkey1_ord / bn_ord / gtrail instead of bkey1 / bfirst (the overlap stage's table replay)
   PAIRS_LAZY_RECORDS = 8,     // with `keep`: leave the sorted records (y0, dir) on the device only; pairs_fetch_records downloads them
 };
 // what the join leaves in HBM for the device replay (pgx_replay.hip): the bucket-sorted records
@@ -250,11 +256,22 @@ struct DevicePairs {
   size_t n_rec = 0, n_buckets = 0;
   bool valid = false;
 };
+// The distinct first keys of the records in the order of their first insertion -- what the host replays klib's OUTER table from
+// (pgx_overlap.cpp) -- computed right after the records exist (a hash aggregation of first occurrences + an ordered select) and
+// handed to `early` while the join's sorts are still to run: the outer-table replay, the longest sequential piece of host work
+// of the stage, then overlaps the rest of the join.  keys[i] == gkey0[gord[i]] of the tables the join returns.
+struct EarlyGroups {
+  HostArray<uint64_t> keys;
+  uint32_t n = 0;
+  uint32_t last_first = 0;   // record index of the last key's first occurrence
+};
+using EarlyFn = std::function<void(EarlyGroups &&)>;
 // d_rlen: read length by rid, on the device
 void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts,
                      size_t n_counts, const PairParams &pp, PairTables &out, unsigned flags = 0,
                      const pgx_mm128 *d_mmers = nullptr, const pgx_mm_count *d_counts = nullptr,  // d_*: the same lists, already on the device
-                     DevicePairs *keep = nullptr);  // keep: the sorted records stay on the device too
+                     DevicePairs *keep = nullptr,   // keep: the sorted records stay on the device too
+                     const EarlyFn &early = nullptr);
 // ---- multi-GPU hand-over: counts all-gathered, pair records routed to their owner chunk -------------------------
 // prepare: aggregate ALL chunks' counts, flag the kept shimmers of THIS index chunk's list (both on the device); returns the index
 // of the first shimmer with lower <= count < upper (-1: none).  scatter: the records of every adjacent kept pair from `start` on
@@ -264,13 +281,16 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
 int64_t dev_pairs_prepare(const uint32_t *d_rlen, uint32_t n_rid, const pgx_mm128 *d_mm, size_t n_mm, const pgx_mm_count *d_counts,
                           size_t n_counts, uint32_t lower, uint32_t upper);
 void dev_pairs_scatter(const uint32_t *d_rlen, uint32_t T, int64_t start, const pgx_pair_rec **d_send, uint64_t *counts);
-void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out, DevicePairs *keep_dev, unsigned flags = 0);
+void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out, DevicePairs *keep_dev, unsigned flags = 0,
+                            const EarlyFn &early = nullptr);
 void pairs_fetch_records(const DevicePairs &dp, PairTables &out);  // the lazily kept records, to the host tables
 
 // The greedy walk over the visit list (visit_bids: the join's bucket ids in visit order) on the GPU; the records go to the
 // array alloc_out(n) returns.  false: the job does not fit the device tables' encodings or they overflowed -- nothing was
 // produced and the caller runs the host replay.
-bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, size_t nb, size_t n_entries,
+void dev_place_bids(const uint32_t *ids_all, size_t n_ids, const uint32_t *psrc, const uint32_t *pcnt, const uint64_t *pdst,
+                    size_t n_groups, size_t nb, DevBuf<uint32_t> &bid);   // the visit list assembled on the device
+bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, const uint32_t *d_bids, size_t nb, size_t n_entries,
                 uint32_t bestn, int band, bool predict, uint32_t ovlp_upper, const std::function<pgx_ovlp *(size_t)> &alloc_out,
                 size_t *n_out, pgx_overlap_stats *st, bool trace);
 

@@ -188,6 +188,12 @@ struct Visit {
   // the ids-only form (device replay): the join's bucket id of every visited bucket, in visit order
   HostArray<uint32_t> bids;
   size_t n_buckets = 0, n_entries = 0;
+  // ids-only form with the placement left to the GPU (dev_place_bids): the groups in visit order, where each one's bucket ids sit in
+  // `ids_all` and where they go
+  bool on_device = false;
+  HostArray<uint32_t> ids_all, psrc, pcnt;
+  HostArray<uint64_t> pdst;
+  size_t n_groups = 0;
 };
 
 // The replay threads hammer one shared table with locked operations: spread over both sockets they run ~1.7x slower than
@@ -351,8 +357,41 @@ void par_run(unsigned nthr, F &&fn) {
 // inserted, plus one detail: a put of an already-present key still runs the load-factor check (khash.h:298-306), so if any
 // put follows the last first-insertion the table may grow once more.  Both levels are replayed on distinct keys only.
 // ids_only: leave the visit list as bucket ids (the device replay reads the records where the join left them)
-void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_only = false) {
+// The outer table replayed AHEAD of the join's end (EarlyFn of dev_build_pairs): ids are positions in first-insertion order,
+// i.e. id i stands for group gord[i] of the tables the join returns later.
+struct PreOuter {
+  DistinctSlotTable table;
+  EarlyGroups eg;
+  std::thread th;
+  bool started = false;
+  double ms = 0;
+  void start(EarlyGroups &&g, size_t n_rec) {
+    eg = std::move(g);
+    if (eg.n < 4096) return;   // (small sets: nothing to hide)
+    started = true;
+    table.reserve(eg.n, big_alloc, big_free);
+    th = std::thread([this, n_rec] {
+      const double t0 = now_ms();
+      const uint64_t *k = eg.keys.data();
+      const size_t n = eg.n;
+      for (size_t i = 0; i < n; ++i) {
+        if (i + 24 < n) table.prefetch_home(k[i + 24]);
+        if (i + 8 < n) table.prefetch(k[i + 8]);
+        table.put_new(k[i], (uint32_t)i);
+      }
+      if ((size_t)eg.last_first + 1 < n_rec) table.touch();  // a put after the last first-insertion (khash.h:298-306)
+      ms = now_ms() - t0;
+    });
+  }
+  void join() {
+    if (th.joinable()) th.join();
+  }
+  ~PreOuter() { join(); }
+};
+
+void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_only = false, PreOuter *pre = nullptr) {
   v.start.assign(1, 0), v.entries.clear(), v.bids.clear();
+  v.on_device = false, v.n_groups = 0;
   v.n_buckets = v.n_entries = 0;
   const size_t ng = pt.gkey0.size();
   if (!ng) return;
@@ -373,14 +412,30 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
   };
   HostArray<GroupOut> go(ng);   // (every element is assigned by its group's worker)
   struct Frag {  // sized up front from the group range (no growth, no copies)
-    HostArray<uint32_t> sizes;  // (ids_only: the bucket ids instead)
+    HostArray<uint32_t> own;    // bucket sizes
+    uint32_t *sizes = nullptr;  // -> own, or (ids_only: the bucket ids) this worker's range of the shared array
+    uint32_t base = 0;          // ids_only: offset of that range
     HostArray<Entry> entries;
     size_t ns = 0, ne = 0;
   };
   std::vector<Frag> frag(nin);
-  DistinctSlotTable outer;
-  outer.reserve(ng, big_alloc, big_free);
+  if (ids_only) v.ids_all.alloc(pt.gbucket[ng]);   // every worker writes the ids of its group range into its own slice
+  // the outer table: already being replayed by the early thread (ids = insertion positions), or replayed here
+  bool pre_ok = pre && pre->started && pre->eg.n == ng;
+  for (size_t i = 0; pre_ok && i < ng; i += 997) pre_ok = pre->eg.keys[i] == pt.gkey0[pt.gord[i]];
+  if (pre && pre->started && !pre_ok) {
+    pre->join();
+    fprintf(stderr, "[pgx] note: the early outer-table keys do not match the join's group tables; replaying the outer table again\n");
+  }
+  DistinctSlotTable local_outer;
+  DistinctSlotTable &outer = pre_ok ? pre->table : local_outer;
+  if (!pre_ok) outer.reserve(ng, big_alloc, big_free);
+  auto gid = [&](uint32_t s0) { return pre_ok ? pt.gord[outer.ids[s0]] : outer.ids[s0]; };
   auto outer_work = [&] {
+    if (pre_ok) {
+      pre->join();
+      return;
+    }
     const HostArray<uint32_t> &gord = pt.gord;  // groups by first insertion (sorted on the GPU)
     // three dependent misses per put on a table that has outgrown the caches -- the key (gkey0 is indexed through the
     // permutation), the home slot's skip count, the slot the probe sequence resumes at -- each started a stage earlier
@@ -404,7 +459,8 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
     Frag &f = frag[ti];
     if (g_lo >= g_hi) return;
     if (!ids_only) f.entries.alloc(pt.gstart[g_hi] - pt.gstart[g_lo]);   // (gstart / gbucket carry an end sentinel)
-    f.sizes.alloc(pt.gbucket[g_hi] - pt.gbucket[g_lo]);
+    if (ids_only) f.sizes = v.ids_all.data() + pt.gbucket[g_lo], f.base = pt.gbucket[g_lo];
+    else f.own.alloc(pt.gbucket[g_hi] - pt.gbucket[g_lo]), f.sizes = f.own.data();
     ScratchTable in;
     bool ab;
     for (size_t g = g_lo; g < g_hi; ++g) {
@@ -413,13 +469,15 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
       if (pt.gstart[g + 1] - pt.gstart[g] <= 2) continue;  // no bucket of this key0 can hold more than 2 records
       const uint32_t b0 = pt.gbucket[g], b1 = pt.gbucket[g + 1];
       const uint32_t *bord = pt.bord.data() + b0;  // this group's buckets by first insertion (sorted on the GPU)
+      const uint64_t *k1 = pt.bkey1_ord.data() + b0;   // their second keys and sizes, in that order (PAIRS_ORD_TABLES)
+      const uint32_t *bsz = pt.bn_ord.data() + b0;
       in.reset();
-      for (uint32_t i = 0; i < b1 - b0; ++i) in.put(pt.bkey1[bord[i]], bord[i], &ab);
-      if (pt.bfirst[bord[b1 - b0 - 1]] < pt.glast[g]) in.put(pt.bkey1[bord[0]], 0, &ab);  // trailing repeat put
+      for (uint32_t i = 0; i < b1 - b0; ++i) in.put(k1[i], i, &ab);   // (id = position in the group's slice)
+      if (pt.gtrail[g]) in.put(k1[0], 0, &ab);  // trailing repeat put
       for (uint32_t s1 = 0; s1 < in.nb; ++s1) {
         if (!in.used[s1]) continue;
-        const uint32_t b = in.ids[s1];
-        const uint32_t bn = pt.bstart[b + 1] - pt.bstart[b];
+        const uint32_t bi = in.ids[s1];
+        const uint32_t bn = bsz[bi], b = bord[bi];
         if (bn <= 2 || bn > ovlp_upper) continue;  // shmr_overlap.c:216
         if (ids_only) {
           f.sizes[f.ns++] = b, f.ne += bn;
@@ -448,13 +506,50 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
     t_inner = now_ms() - tv0;
   }
   const double tv2 = now_ms();
+  if (ids_only && nin > 1 && outer.nb >= (1u << 16)) {
+    // ids-only: one random pass over the groups' results (slot range per worker), then a sequential one that writes the copy
+    // descriptors the GPU assembles the visit list from (dev_place_bids)
+    struct P2 {
+      std::vector<uint32_t> src, cnt;
+      uint64_t ne = 0, nb = 0;
+    };
+    std::vector<P2> piece(nin);
+    par_run(nin, [&](unsigned ti) {
+      P2 &pc = piece[ti];
+      const uint32_t lo = (uint32_t)((uint64_t)outer.nb * ti / nin), hi = (uint32_t)((uint64_t)outer.nb * (ti + 1) / nin);
+      pc.src.reserve((hi - lo) / 2 + 16), pc.cnt.reserve((hi - lo) / 2 + 16);
+      for (uint32_t s0 = lo; s0 < hi; ++s0)
+        if (outer.used[s0]) {
+          const GroupOut &o = go[gid(s0)];
+          if (o.nb) pc.src.push_back(frag[o.worker].base + o.boff), pc.cnt.push_back(o.nb), pc.ne += o.ne, pc.nb += o.nb;
+        }
+    });
+    std::vector<size_t> first(nin + 1, 0);
+    std::vector<uint64_t> b0(nin + 1, 0);
+    uint64_t ne = 0;
+    for (unsigned t = 0; t < nin; ++t)
+      first[t + 1] = first[t] + piece[t].src.size(), b0[t + 1] = b0[t] + piece[t].nb, ne += piece[t].ne;
+    const size_t no = first[nin];
+    v.n_buckets = b0[nin], v.n_entries = ne, v.on_device = true, v.n_groups = no;
+    v.psrc.alloc(no), v.pcnt.alloc(no), v.pdst.alloc(no);
+    par_run(nin, [&](unsigned ti) {
+      uint64_t b = b0[ti];
+      size_t at = first[ti];
+      const P2 &pc = piece[ti];
+      for (size_t k = 0; k < pc.src.size(); ++k, ++at) v.psrc[at] = pc.src[k], v.pcnt[at] = pc.cnt[k], v.pdst[at] = b, b += pc.cnt[k];
+    });
+    if (trace)
+      fprintf(stderr, "[pgx]   visit: outer table %.2f ms%s alongside %u inner-table workers (done at %.2f ms), slot scan %.2f ms\n",
+              pre_ok ? pre->ms : t_outer, pre_ok ? " (started during the join)" : "", nin, t_inner, now_ms() - tv2);
+    return;
+  }
   // final places: groups in ascending outer slot order
   std::vector<uint32_t> order;
   std::vector<uint64_t> eat, bat;
   if (nin == 1 || outer.nb < (1u << 16)) {
     order.reserve(ng);
     for (uint32_t s0 = 0; s0 < outer.nb; ++s0)
-      if (outer.used[s0] && go[outer.ids[s0]].nb) order.push_back(outer.ids[s0]);
+      if (outer.used[s0] && go[gid(s0)].nb) order.push_back(gid(s0));
     eat.assign(order.size() + 1, 0), bat.assign(order.size() + 1, 0);
     for (size_t i = 0; i < order.size(); ++i) eat[i + 1] = eat[i] + go[order[i]].ne, bat[i + 1] = bat[i] + go[order[i]].nb;
   } else {
@@ -470,8 +565,9 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
       const uint32_t lo = (uint32_t)((uint64_t)outer.nb * ti / nin), hi = (uint32_t)((uint64_t)outer.nb * (ti + 1) / nin);
       for (uint32_t s0 = lo; s0 < hi; ++s0)
         if (outer.used[s0]) {
-          const GroupOut &o = go[outer.ids[s0]];
-          if (o.nb) pc.ids.push_back(outer.ids[s0]), pc.ne += o.ne, pc.nb += o.nb;
+          const uint32_t g = gid(s0);
+          const GroupOut &o = go[g];
+          if (o.nb) pc.ids.push_back(g), pc.ne += o.ne, pc.nb += o.nb;
         }
     });
     std::vector<size_t> first(nin + 1, 0);
@@ -493,30 +589,36 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
   const size_t no = order.size();
   const uint64_t ne = eat[no], nbk = bat[no];
   v.n_buckets = nbk, v.n_entries = ne;
-  if (ids_only) v.bids.alloc(nbk);
-  else v.entries.alloc(ne), v.start.resize(nbk + 1);
-  auto place = [&](unsigned ti, unsigned nt) {
-    for (size_t i = no * ti / nt, ie = no * (ti + 1) / nt; i < ie; ++i) {
-      const GroupOut &o = go[order[i]];
-      const Frag &f = frag[o.worker];
-      if (ids_only) {
-        memcpy(v.bids.data() + bat[i], f.sizes.data() + o.boff, (size_t)o.nb * sizeof(uint32_t));
-        continue;
+  if (ids_only) {
+    // the bucket ids are assembled in visit order on the GPU (dev_place_bids): the host only says which slice goes where
+    v.on_device = true, v.n_groups = no;
+    v.psrc.alloc(no), v.pcnt.alloc(no), v.pdst.alloc(no);
+    auto desc = [&](unsigned ti, unsigned nt) {
+      for (size_t i = no * ti / nt, ie = no * (ti + 1) / nt; i < ie; ++i) {
+        const GroupOut &o = go[order[i]];
+        v.psrc[i] = frag[o.worker].base + o.boff, v.pcnt[i] = o.nb, v.pdst[i] = bat[i];
       }
-      memcpy(v.entries.data() + eat[i], f.entries.data() + o.eoff, (size_t)o.ne * sizeof(Entry));
-      uint64_t at = eat[i];
-      for (uint32_t j = 0; j < o.nb; ++j) v.start[bat[i] + j] = at, at += f.sizes[o.boff + j];
-    }
-  };
-  if (nin == 1) {
-    place(0, 1);
+    };
+    if (nin == 1) desc(0, 1);
+    else par_run(nin, [&](unsigned ti) { desc(ti, nin); });
   } else {
-    par_run(nin, [&](unsigned ti) { place(ti, nin); });
+    v.entries.alloc(ne), v.start.resize(nbk + 1);
+    auto place = [&](unsigned ti, unsigned nt) {
+      for (size_t i = no * ti / nt, ie = no * (ti + 1) / nt; i < ie; ++i) {
+        const GroupOut &o = go[order[i]];
+        const Frag &f = frag[o.worker];
+        memcpy(v.entries.data() + eat[i], f.entries.data() + o.eoff, (size_t)o.ne * sizeof(Entry));
+        uint64_t at = eat[i];
+        for (uint32_t j = 0; j < o.nb; ++j) v.start[bat[i] + j] = at, at += f.sizes[o.boff + j];
+      }
+    };
+    if (nin == 1) place(0, 1);
+    else par_run(nin, [&](unsigned ti) { place(ti, nin); });
   }
   if (!ids_only) v.start[nbk] = ne;
   if (trace)
-    fprintf(stderr, "[pgx]   visit: outer table %.2f ms alongside %u inner-table workers (done at %.2f ms), placement %.2f ms\n",
-            t_outer, nin, t_inner, now_ms() - tv2);
+    fprintf(stderr, "[pgx]   visit: outer table %.2f ms%s alongside %u inner-table workers (done at %.2f ms), placement %.2f ms\n",
+            pre_ok ? pre->ms : t_outer, pre_ok ? " (started during the join; waited for" : "", nin, t_inner, now_ms() - tv2);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1379,6 +1481,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   struct Scratch {
     PairTables pt;
     Visit visit;
+    PreOuter pre;   // (its destructor joins the thread)
   };
   Scratch *scratch = new Scratch;
   struct Defer {
@@ -1401,14 +1504,17 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   const bool trace = getenv("PGX_TRACE") != nullptr;
   const bool predict = !(getenv("PGX_PREDICT") && atoi(getenv("PGX_PREDICT")) == 0);
   DevicePairs dpairs;
-  const unsigned jflags = gpu_replay ? PAIRS_LAZY_RECORDS : 0u;
+  const unsigned jflags = PAIRS_ORD_TABLES | (gpu_replay ? PAIRS_LAZY_RECORDS : 0u);
+  static const bool early_outer = !(getenv("PGX_EARLY_OUTER") && atoi(getenv("PGX_EARLY_OUTER")) == 0);
+  EarlyFn early;
+  if (early_outer) early = [&](EarlyGroups &&g) { scratch->pre.start(std::move(g), pt.n_rec); };
   if (d_recs)
-    dev_pairs_from_records(d_recs, n_recs, pt, gpu_replay ? &dpairs : nullptr, jflags);
+    dev_pairs_from_records(d_recs, n_recs, pt, gpu_replay ? &dpairs : nullptr, jflags, early);
   else
     dev_build_pairs(db->d_rlen.p, mmers, n_mm, counts, n_counts,
                     PairParams{(uint32_t)p->total_chunk, (uint32_t)p->mychunk, (uint32_t)p->mc_lower, (uint32_t)p->mc_upper,
                                (uint32_t)db->rlen_by_rid.size()},
-                    pt, jflags, dev ? dev->d_top : nullptr, dev ? dev->d_mc : nullptr, gpu_replay ? &dpairs : nullptr);
+                    pt, jflags, dev ? dev->d_top : nullptr, dev ? dev->d_mc : nullptr, gpu_replay ? &dpairs : nullptr, early);
   sync();
   s.n_pair_records = pt.n_rec;
   if (gpu_replay_env < 0) gpu_replay = pt.n_rec >= gpu_replay_min;
@@ -1422,12 +1528,12 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   Visit &visit = scratch->visit;
   if (trace) fprintf(stderr, "[pgx]   pinned to a memory node at +%.2f ms after the join\n", now_ms() - t1);
   if (gpu_replay && dpairs.valid) {
-    build_visit(pt, (uint32_t)p->ovlp_upper, visit, true);
+    build_visit(pt, (uint32_t)p->ovlp_upper, visit, true, &scratch->pre);
     s.n_buckets = visit.n_buckets;
     if (trace)
       fprintf(stderr, "[pgx] GPU join: %zu records, %zu buckets, %zu key0 groups in %.2f ms; visit order (%llu buckets, ids only) in %.2f ms\n",
-              pt.n_rec, pt.bkey1.size(), pt.gkey0.size(), t1 - t0, (unsigned long long)s.n_buckets, now_ms() - t1);
-    if (trace && atoi(getenv("PGX_TRACE")) >= 2 && visit.n_buckets) {  // bucket sizes: a pass of the device replay lasts as long as its largest bucket
+              pt.n_rec, pt.bkey1_ord.size(), pt.gkey0.size(), t1 - t0, (unsigned long long)s.n_buckets, now_ms() - t1);
+    if (trace && atoi(getenv("PGX_TRACE")) >= 2 && visit.n_buckets && !visit.on_device) {  // bucket sizes: a pass of the device replay lasts as long as its largest bucket
       std::vector<uint32_t> sz(visit.n_buckets);
       for (size_t i = 0; i < visit.n_buckets; ++i) sz[i] = pt.bstart[visit.bids[i] + 1] - pt.bstart[visit.bids[i]];
       std::sort(sz.begin(), sz.end());
@@ -1438,7 +1544,12 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     size_t nrec = 0;
     pgx_overlap_stats rs;
     memset(&rs, 0, sizeof(rs));
-    if (dev_replay(db, dpairs, visit.bids.data(), visit.n_buckets, visit.n_entries, (uint32_t)(uint8_t)p->bestn,
+    DevBuf<uint32_t> d_bids;
+    if (visit.on_device)
+      dev_place_bids(visit.ids_all.data(), visit.ids_all.size(), visit.psrc.data(), visit.pcnt.data(), visit.pdst.data(), visit.n_groups,
+                     visit.n_buckets, d_bids);
+    if (dev_replay(db, dpairs, visit.on_device ? nullptr : visit.bids.data(), visit.on_device ? d_bids.p : nullptr, visit.n_buckets,
+                   visit.n_entries, (uint32_t)(uint8_t)p->bestn,
                    p->align_bandwidth, predict, (uint32_t)p->ovlp_upper,
                    [&](size_t n) { out.alloc(n); return out.a; }, &nrec, &rs, trace)) {
       s.n_align_needed = rs.n_align_needed, s.n_seen_skip = rs.n_seen_skip, s.n_align_gpu = rs.n_align_gpu, s.rounds = rs.rounds;
@@ -1455,11 +1566,11 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     pairs_fetch_records(dpairs, pt);   // the device replay gave up: the host replay needs the records
     dpairs = DevicePairs();
   }
-  build_visit(pt, (uint32_t)p->ovlp_upper, visit);
+  build_visit(pt, (uint32_t)p->ovlp_upper, visit, false, &scratch->pre);
   s.n_buckets = visit.start.size() - 1;
   if (trace)
     fprintf(stderr, "[pgx] GPU join: %zu records, %zu buckets, %zu key0 groups in %.2f ms; visit order (%llu buckets) in %.2f ms\n",
-            pt.n_rec, pt.bkey1.size(), pt.gkey0.size(), t1 - t0, (unsigned long long)s.n_buckets, now_ms() - t1);
+            pt.n_rec, pt.bkey1_ord.size(), pt.gkey0.size(), t1 - t0, (unsigned long long)s.n_buckets, now_ms() - t1);
   auto align_batch = [&](const pgx_align_key *keys, size_t nreq, pgx_match *res) {  // results land in the replay's table
     const double g0 = now_ms();
     pgx_align_key *d_keys = ws<pgx_align_key>("ov.keys", nreq);

@@ -194,6 +194,37 @@ __global__ void k_unpack_rec(const pgx_pair_rec *__restrict__ rec, uint32_t n, u
   key0[i] = r.key0, key1[i] = r.key1, y0[i] = r.y0, dir[i] = r.dir, npos[i] = r.npos;
 }
 
+// ---- first occurrence of every first key (early outer-table keys) ---------------------------------------------------------
+__device__ __forceinline__ uint64_t mixk(uint64_t h) {
+  h ^= h >> 33, h *= 0xff51afd7ed558ccdULL, h ^= h >> 33, h *= 0xc4ceb9fe1a85ec53ULL, h ^= h >> 33;
+  return h;
+}
+__global__ void k_first_insert(const uint64_t *__restrict__ key0, uint32_t nr, unsigned long long *__restrict__ tkeys,
+                               uint32_t *__restrict__ tseq, uint32_t mask) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nr) return;
+  const unsigned long long k = key0[i] + 1;  // (never 0: a key is hash << 8 | span with span > 0)
+  uint32_t h = (uint32_t)mixk(k) & mask;
+  for (;;) {
+    unsigned long long cur = tkeys[h];
+    if (cur == 0) cur = atomicCAS(&tkeys[h], 0ULL, k);
+    if (cur == 0 || cur == k) {
+      atomicMin(&tseq[h], i);
+      return;
+    }
+    h = (h + 1) & mask;
+  }
+}
+__global__ void k_first_flag(const uint64_t *__restrict__ key0, uint32_t nr, const unsigned long long *__restrict__ tkeys,
+                             const uint32_t *__restrict__ tseq, uint32_t mask, uint8_t *__restrict__ flag) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nr) return;
+  const unsigned long long k = key0[i] + 1;
+  uint32_t h = (uint32_t)mixk(k) & mask;
+  while (tkeys[h] != k) h = (h + 1) & mask;
+  flag[i] = tseq[h] == i;
+}
+
 __global__ void k_iota(uint32_t *__restrict__ v, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) v[i] = i;
@@ -244,6 +275,22 @@ __global__ void k_bucket_order_key(const uint32_t *__restrict__ gbucket, uint32_
     else hi = mid;
   }
   key[b] = (uint64_t)lo << 32 | bfirst[b];
+}
+
+// bucket tables in the order the host replays the inner tables in
+__global__ void k_bucket_ord(const uint32_t *__restrict__ bord, const uint32_t *__restrict__ bstart, const uint64_t *__restrict__ sk1,
+                             uint32_t nbk, uint64_t *__restrict__ bkey1_o, uint32_t *__restrict__ bn_o) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nbk) return;
+  const uint32_t b = bord[i], s0 = bstart[b];
+  bkey1_o[i] = sk1[s0], bn_o[i] = bstart[b + 1] - s0;
+}
+__global__ void k_group_trail(const uint32_t *__restrict__ gbucket, const uint32_t *__restrict__ bord, const uint32_t *__restrict__ bfirst,
+                              const uint32_t *__restrict__ glast, uint32_t ng, uint32_t nbk, uint8_t *__restrict__ gtrail) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  const uint32_t b1 = g + 1 < ng ? gbucket[g + 1] : nbk;
+  gtrail[g] = bfirst[bord[b1 - 1]] < glast[g];   // the group's last new bucket is not its last record: one more put follows
 }
 
 template <typename T>
@@ -321,10 +368,11 @@ static void chain_scan(const DevBuf<uint8_t> &keep, uint32_t n, const uint32_t *
 }
 
 static void bucketize(PairRecs &R, unsigned flags, PairTables &out, DevicePairs *keep_dev, Tmp &tmp);
+static void early_groups(const PairRecs &R, Tmp &tmp, const EarlyFn &early);
 
 void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
                      const PairParams &pp, PairTables &out, unsigned flags, const pgx_mm128 *d_mmers, const pgx_mm_count *d_counts,
-                     DevicePairs *keep_dev) {
+                     DevicePairs *keep_dev, const EarlyFn &early) {
   out = PairTables();
   if (keep_dev) *keep_dev = DevicePairs();
   if (n_mm == 0) return;
@@ -374,6 +422,7 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
   R.key0.alloc(nr), R.key1.alloc(nr), R.y0.alloc(nr), R.y1.alloc((flags & PAIRS_Y1) ? nr : 0), R.dir.alloc(nr), R.npos.alloc(nr);
   hipLaunchKernelGGL(k_records<1>, dim3(cdiv(n, 256)), dim3(256), 0, st, mm_dev, n, chain.p, T, c, d_rlen, (uint32_t *)nullptr,
                      off.p, R.key0.p, R.key1.p, R.y0.p, R.dir.p, R.npos.p, R.y1.p);
+  early_groups(R, tmp, early);
   bucketize(R, flags, out, keep_dev, tmp);
 }
 
@@ -471,7 +520,8 @@ void pairs_fetch_records(const DevicePairs &dp, PairTables &out) {
   sync();
 }
 
-void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out, DevicePairs *keep_dev, unsigned flags) {
+void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out, DevicePairs *keep_dev, unsigned flags,
+                            const EarlyFn &early) {
   out = PairTables();
   if (keep_dev) *keep_dev = DevicePairs();
   if (n == 0) return;
@@ -485,7 +535,39 @@ void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out
   hipLaunchKernelGGL(k_unpack_rec, dim3(cdiv(nr, 256)), dim3(256), 0, ctx().stream, d_rec, nr, R.key0.p, R.key1.p, R.y0.p, R.dir.p,
                      R.npos.p);
   out.n_rec = nr;
+  early_groups(R, tmp, early);
   bucketize(R, flags, out, keep_dev, tmp);
+}
+
+static void early_groups(const PairRecs &R, Tmp &tmp, const EarlyFn &early) {
+  if (!early || R.nr == 0) return;
+  hipStream_t st = ctx().stream;
+  const uint32_t nr = R.nr;
+  size_t cap = 1024;
+  while (cap < (size_t)nr * 2) cap <<= 1;
+  DevBuf<unsigned long long> tkeys(cap);
+  DevBuf<uint32_t> tseq(cap), idx(nr), d_n(1);
+  DevBuf<uint8_t> flag(nr);
+  PGX_HIP(hipMemsetAsync(tkeys.p, 0, cap * sizeof(unsigned long long), st));
+  PGX_HIP(hipMemsetAsync(tseq.p, 0xFF, cap * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(k_first_insert, dim3(cdiv(nr, 256)), dim3(256), 0, st, R.key0.p, nr, tkeys.p, tseq.p, (uint32_t)(cap - 1));
+  hipLaunchKernelGGL(k_first_flag, dim3(cdiv(nr, 256)), dim3(256), 0, st, R.key0.p, nr, tkeys.p, tseq.p, (uint32_t)(cap - 1), flag.p);
+  size_t bytes = 0;
+  PGX_HIP(hipcub::DeviceSelect::Flagged(nullptr, bytes, CountIt(0), flag.p, idx.p, d_n.p, (int)nr, st));
+  PGX_HIP(hipcub::DeviceSelect::Flagged(tmp.get(bytes), bytes, CountIt(0), flag.p, idx.p, d_n.p, (int)nr, st));
+  uint32_t nd = 0;
+  d_n.download(&nd, 1);
+  sync();
+  EarlyGroups eg;
+  eg.n = nd;
+  if (nd) {
+    DevBuf<uint64_t> keys(nd);
+    hipLaunchKernelGGL(k_gather_u64, dim3(cdiv(nd, 256)), dim3(256), 0, st, R.key0.p, idx.p, nd, keys.p);
+    eg.keys = to_host(keys, nd);
+    PGX_HIP(hipMemcpyAsync(&eg.last_first, idx.p + nd - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    sync();
+  }
+  early(std::move(eg));
 }
 
 static void bucketize(PairRecs &R, unsigned flags, PairTables &out, DevicePairs *keep_dev, Tmp &tmp) {
@@ -585,12 +667,22 @@ static void bucketize(PairRecs &R, unsigned flags, PairTables &out, DevicePairs 
   out.gord = to_host(gord, ng);
   out.bord = to_host(bord, nbk);
   DevBuf<uint64_t> bkey1(nbk), gkey0(ng);
-  hipLaunchKernelGGL(k_gather_u64, dim3(cdiv(nbk, 256)), dim3(256), 0, st, sk1.p, bstart.p, nbk, bkey1.p);
   hipLaunchKernelGGL(k_gather_u64, dim3(cdiv(ng, 256)), dim3(256), 0, st, kgs.p, gstart.p, ng, gkey0.p);
-  out.bkey1 = to_host(bkey1, nbk);
+  DevBuf<uint32_t> bn_o((flags & PAIRS_ORD_TABLES) ? nbk : 0);
+  DevBuf<uint8_t> gtrail((flags & PAIRS_ORD_TABLES) ? ng : 0);
+  if (flags & PAIRS_ORD_TABLES) {
+    hipLaunchKernelGGL(k_bucket_ord, dim3(cdiv(nbk, 256)), dim3(256), 0, st, bord.p, bstart.p, sk1.p, nbk, bkey1.p, bn_o.p);
+    hipLaunchKernelGGL(k_group_trail, dim3(cdiv(ng, 256)), dim3(256), 0, st, gbucket.p, bord.p, bfirst.p, glast.p, ng, nbk, gtrail.p);
+    out.bkey1_ord = to_host(bkey1, nbk);
+    out.bn_ord = to_host(bn_o, nbk);
+    out.gtrail = to_host(gtrail, ng);
+  } else {
+    hipLaunchKernelGGL(k_gather_u64, dim3(cdiv(nbk, 256)), dim3(256), 0, st, sk1.p, bstart.p, nbk, bkey1.p);
+    out.bkey1 = to_host(bkey1, nbk);
+    out.bfirst = to_host(bfirst, nbk);
+  }
   out.gkey0 = to_host(gkey0, ng);
   out.bstart = to_host(bstart, (size_t)nbk + 1);
-  out.bfirst = to_host(bfirst, nbk);
   out.gstart = to_host(gstart, (size_t)ng + 1);
   out.gfirst = to_host(gfirst, ng);
   out.glast = to_host(glast, ng);

@@ -1000,7 +1000,7 @@ unsigned cdiv256(size_t n) { return (unsigned)((n + 255) / 256); }
 
 namespace {
 // one attempt with the given table sizes (multiples of the defaults); returns 0, or the OV_* bits of what overflowed
-uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, size_t nb, size_t n_entries,
+uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, const uint32_t *d_bids, size_t nb, size_t n_entries,
                         uint32_t bestn, int band, bool predict, const std::function<pgx_ovlp *(size_t)> &alloc_out,
                         size_t *n_out, pgx_overlap_stats *st, bool trace, const double *mult) {
   const double t0 = now_ms();
@@ -1009,9 +1009,9 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   R r;
   memset(&r, 0, sizeof(r));
   r.nb = (uint32_t)nb;
-  DevBuf<uint32_t> bid(nb);
-  bid.upload(visit_bids, nb);
-  r.bid = bid.p, r.bstart = dp.bstart.p, r.y0 = dp.y0.p, r.dir = dp.dir.p, r.rlen = db->d_rlen.p;
+  DevBuf<uint32_t> bid(d_bids ? 0 : nb);   // (d_bids: the visit list was assembled on the device, dev_place_bids)
+  if (!d_bids) bid.upload(visit_bids, nb);
+  r.bid = d_bids ? d_bids : bid.p, r.bstart = dp.bstart.p, r.y0 = dp.y0.p, r.dir = dp.dir.p, r.rlen = db->d_rlen.p;
   const uint32_t pcap = pow2_at_least((size_t)(ne * mult[3])), mcap = pow2_at_least((size_t)(ne * mult[4]));
   DevBuf<PSlot> pt(pcap);
   DevBuf<MSlot> mt(mcap);
@@ -1208,7 +1208,30 @@ overflowed:
 }
 }  // namespace
 
-bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, size_t nb, size_t n_entries,
+// the visit list on the device from the per-group slices the host's table replay left (pgx_overlap.cpp::build_visit, ids-only form)
+namespace {
+__global__ void k_place_bids(const uint32_t *__restrict__ ids_all, const uint32_t *__restrict__ psrc, const uint32_t *__restrict__ pcnt,
+                             const uint64_t *__restrict__ pdst, uint32_t n_groups, uint32_t *__restrict__ bid) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_groups) return;
+  const uint32_t src = psrc[i], n = pcnt[i];
+  const uint64_t dst = pdst[i];
+  for (uint32_t k = 0; k < n; ++k) bid[dst + k] = ids_all[src + k];
+}
+}  // namespace
+void dev_place_bids(const uint32_t *ids_all, size_t n_ids, const uint32_t *psrc, const uint32_t *pcnt, const uint64_t *pdst,
+                    size_t n_groups, size_t nb, DevBuf<uint32_t> &bid) {
+  bid.alloc(std::max<size_t>(nb, 1));
+  if (!n_groups || !nb) return;
+  DevBuf<uint32_t> d_ids(n_ids), d_src(n_groups), d_cnt(n_groups);
+  DevBuf<uint64_t> d_dst(n_groups);
+  d_ids.upload(ids_all, n_ids), d_src.upload(psrc, n_groups), d_cnt.upload(pcnt, n_groups), d_dst.upload(pdst, n_groups);
+  hipLaunchKernelGGL(k_place_bids, dim3((unsigned)((n_groups + 255) / 256)), dim3(256), 0, ctx().stream, d_ids.p, d_src.p, d_cnt.p, d_dst.p,
+                     (uint32_t)n_groups, bid.p);
+  sync();   // (the upload sources are the caller's host arrays; the temporaries go back to the block cache)
+}
+
+bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, const uint32_t *d_bids, size_t nb, size_t n_entries,
                 uint32_t bestn, int band, bool predict, uint32_t ovlp_upper, const std::function<pgx_ovlp *(size_t)> &alloc_out,
                 size_t *n_out, pgx_overlap_stats *st, bool trace) {
   *n_out = 0;
@@ -1236,7 +1259,7 @@ bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visi
   if (getenv("PGX_REPLAY_PAIRS_X")) mult[3] = atof(getenv("PGX_REPLAY_PAIRS_X"));
   if (getenv("PGX_REPLAY_MEMO_X")) mult[4] = atof(getenv("PGX_REPLAY_MEMO_X"));
   for (int attempt = 0; attempt < 3; ++attempt) {
-    const uint32_t ov = replay_attempt(db, dp, visit_bids, nb, n_entries, bestn, band, predict, alloc_out, n_out, st, trace, mult);
+    const uint32_t ov = replay_attempt(db, dp, visit_bids, d_bids, nb, n_entries, bestn, band, predict, alloc_out, n_out, st, trace, mult);
     if (!ov) return true;
     if (ov & (OV_QOFF | OV_PASSES)) break;  // not a matter of table sizes
     for (int k = 0; k < 5; ++k)
