@@ -38,17 +38,39 @@ __global__ void k_split_counts(const pgx_mm_count *__restrict__ in, size_t n, ui
   if (t < n) mer[t] = in[t].mer, cnt[t] = in[t].count;
 }
 
-__device__ __forceinline__ bool lookup_count(const uint64_t *mer, const uint32_t *cnt, uint32_t nu, uint64_t key,
-                                             uint32_t *out) {
-  uint32_t lo = 0, hi = nu;
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if (mer[mid] < key) lo = mid + 1;
-    else hi = mid;
-  }
-  if (lo < nu && mer[lo] == key) {
-    *out = cnt[lo];
-    return true;
+// The multiplicity lookup of build_map (shmr_utils.c:305-320).  The aggregated table is sorted by hash, but a binary search costs
+// ~10 cold sectors per lookup (3.75 GB of reads for 11 M lookups at 4.5 Gbases), and bucketing by the hash's top bits does not
+// work: shimmers are MINIMA, their hashes crowd the bottom of the range.  So the lookups go through an open-addressing table
+// built from the aggregated entries (16-byte slots {hash + 1, count}, load factor <= 1/2): ~1.3 probes of one sector each.
+struct CSlot {
+  unsigned long long key;   // hash + 1 (0 = empty)
+  uint32_t cnt, pad;
+};
+__device__ __forceinline__ uint32_t cmix(uint64_t h) {
+  h ^= h >> 33, h *= 0xff51afd7ed558ccdULL, h ^= h >> 29;
+  return (uint32_t)h;
+}
+__global__ void k_count_insert(const uint64_t *__restrict__ mer, const uint32_t *__restrict__ cnt, uint32_t nu, CSlot *__restrict__ tab,
+                               uint32_t mask) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nu) return;
+  const unsigned long long want = mer[i] + 1;   // (the keys of the aggregated table are distinct)
+  for (uint32_t h = cmix(mer[i]) & mask;; h = (h + 1) & mask)
+    if (atomicCAS(&tab[h].key, 0ULL, want) == 0ULL) {
+      tab[h].cnt = cnt[i];
+      return;
+    }
+}
+__device__ __forceinline__ bool lookup_count(const CSlot *tab, uint32_t mask, uint64_t key, uint32_t *out) {
+  const unsigned long long want = key + 1;
+  for (uint32_t h = cmix(key) & mask, probes = 0; probes <= mask; h = (h + 1) & mask, ++probes) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(&tab[h]);
+    const unsigned long long k = (unsigned long long)v.y << 32 | v.x;
+    if (k == want) {
+      *out = v.z;
+      return true;
+    }
+    if (k == 0) return false;
   }
   return false;
 }
@@ -57,8 +79,8 @@ __device__ __forceinline__ bool lookup_count(const uint64_t *mer, const uint32_t
 // misc[0] = first strict index, misc[1] = hashes missing from the table, misc[2] = shimmers that do not fit the seqdb (read
 // id beyond the idx, or position beyond the read: the reference asserts on the read-length lookup, shmr_utils.c:374-376),
 // misc[3] = one such read id
-__global__ void k_keep(const pgx_mm128 *__restrict__ mm, uint32_t n, const uint64_t *__restrict__ mer,
-                       const uint32_t *__restrict__ cnt, uint32_t nu, uint32_t lower, uint32_t upper,
+__global__ void k_keep(const pgx_mm128 *__restrict__ mm, uint32_t n,
+                       const CSlot *__restrict__ tab, uint32_t tmask, uint32_t lower, uint32_t upper,
                        uint8_t *__restrict__ keep, uint32_t *__restrict__ first_strict, uint32_t *__restrict__ missing,
                        const uint32_t *__restrict__ rlen, uint32_t n_rid) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,13 +96,18 @@ __global__ void k_keep(const pgx_mm128 *__restrict__ mm, uint32_t n, const uint6
     }
   }
   uint32_t c = 0;
-  if (!lookup_count(mer, cnt, nu, mm[i].x >> 8, &c)) {
+  if (!tab || !lookup_count(tab, tmask, mm[i].x >> 8, &c)) {
     atomicAdd(missing, 1u);
     keep[i] = 0;
     return;
   }
   keep[i] = (c >= lower && c <= upper);
-  if (c >= lower && c < upper) atomicMin(first_strict, i);
+  // (nearly every element qualifies: one atomic per wavefront, and only while it can still lower the minimum -- 11 M atomics on
+  // one address were 2 ms of this kernel)
+  if (c >= lower && c < upper && i < *(volatile uint32_t *)first_strict) {
+    const uint64_t m = __ballot(1);
+    if ((int)(threadIdx.x & 63) == __builtin_ctzll(m)) atomicMin(first_strict, i);
+  }
 }
 
 __global__ void k_chain_in(const uint8_t *__restrict__ keep, uint32_t n, const uint32_t *__restrict__ first_strict,
@@ -314,6 +341,8 @@ struct CountTable {
   DevBuf<uint64_t> umer;
   DevBuf<uint32_t> ucnt;
   uint32_t nu = 0;
+  DevBuf<CSlot> tab;            // the same entries as an open-addressing table (lookup_count)
+  uint32_t tmask = 0;
 };
 static void aggregate_counts(const pgx_mm_count *cin, size_t n_counts, CountTable &ct, Tmp &tmp) {
   hipStream_t st = ctx().stream;
@@ -333,6 +362,14 @@ static void aggregate_counts(const pgx_mm_count *cin, size_t n_counts, CountTabl
                                            (int)n_counts, st));
   d_nu.download(&ct.nu, 1);
   sync();
+  ct.tmask = 0;
+  if (!ct.nu) return;
+  uint32_t cap = 1024;
+  while (cap < 2 * (size_t)ct.nu) cap <<= 1;
+  ct.tab.alloc(cap);
+  ct.tmask = cap - 1;
+  PGX_HIP(hipMemsetAsync(ct.tab.p, 0, (size_t)cap * sizeof(CSlot), st));
+  hipLaunchKernelGGL(k_count_insert, dim3(cdiv(ct.nu, 256)), dim3(256), 0, st, ct.umer.p, ct.ucnt.p, ct.nu, ct.tab.p, ct.tmask);
 }
 
 // keep flags of a list against the table; returns the first strict index (0xFFFFFFFF: none)
@@ -343,7 +380,7 @@ static uint32_t keep_flags(const pgx_mm128 *mm_dev, uint32_t n, const CountTable
   d_misc.alloc(4);
   const uint32_t init[4] = {0xFFFFFFFFu, 0u, 0u, 0u};
   d_misc.upload(init, 4);
-  hipLaunchKernelGGL(k_keep, dim3(cdiv(n, 256)), dim3(256), 0, st, mm_dev, n, ct.umer.p, ct.ucnt.p, ct.nu, pp.lower, pp.upper, keep.p,
+  hipLaunchKernelGGL(k_keep, dim3(cdiv(n, 256)), dim3(256), 0, st, mm_dev, n, ct.nu ? ct.tab.p : (const CSlot *)nullptr, ct.tmask, pp.lower, pp.upper, keep.p,
                      d_misc.p, d_misc.p + 1, d_rlen, pp.n_rid);
   uint32_t misc[4];
   d_misc.download(misc, 4);
