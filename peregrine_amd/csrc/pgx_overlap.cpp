@@ -518,11 +518,15 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
       P2 &pc = piece[ti];
       const uint32_t lo = (uint32_t)((uint64_t)outer.nb * ti / nin), hi = (uint32_t)((uint64_t)outer.nb * (ti + 1) / nin);
       pc.src.reserve((hi - lo) / 2 + 16), pc.cnt.reserve((hi - lo) / 2 + 16);
-      for (uint32_t s0 = lo; s0 < hi; ++s0)
+      for (uint32_t s0 = lo; s0 < hi; ++s0) {
+        // (two dependent random reads per used slot -- the group of the slot's key, then its result -- each started ahead)
+        if (pre_ok && s0 + 32 < hi && outer.used[s0 + 32]) __builtin_prefetch(&pt.gord[outer.ids[s0 + 32]]);
+        if (s0 + 12 < hi && outer.used[s0 + 12]) __builtin_prefetch(&go[gid(s0 + 12)]);
         if (outer.used[s0]) {
           const GroupOut &o = go[gid(s0)];
           if (o.nb) pc.src.push_back(frag[o.worker].base + o.boff), pc.cnt.push_back(o.nb), pc.ne += o.ne, pc.nb += o.nb;
         }
+      }
     });
     std::vector<size_t> first(nin + 1, 0);
     std::vector<uint64_t> b0(nin + 1, 0);

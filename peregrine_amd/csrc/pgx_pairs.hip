@@ -290,9 +290,32 @@ __global__ void k_group_first_bucket(const uint32_t *__restrict__ gstart, uint32
   gb[g] = lo;
 }
 
+// first / last insertion per bucket and per key0 group.  The segments are short (a bucket holds ~4 records, a group ~5
+// buckets), which is the worst case of a block-per-segment reduction (hipcub::DeviceSegmentedReduce: 1 ms per call for 3.9 M
+// buckets); a thread per segment reads the same bytes in ~0.05 ms.
+__global__ void k_bucket_minmax(const uint32_t *__restrict__ perm, const uint32_t *__restrict__ bstart, uint32_t nbk,
+                                uint32_t *__restrict__ bfirst, uint32_t *__restrict__ blast) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbk) return;
+  uint32_t mn = 0xFFFFFFFFu, mx = 0;
+  for (uint32_t i = bstart[b], e = bstart[b + 1]; i < e; ++i) {
+    const uint32_t v = perm[i];
+    mn = min(mn, v), mx = max(mx, v);
+  }
+  bfirst[b] = mn, blast[b] = mx;
+}
+__global__ void k_group_minmax(const uint32_t *__restrict__ bfirst, const uint32_t *__restrict__ blast, const uint32_t *__restrict__ gbucket,
+                               uint32_t ng, uint32_t nbk, uint32_t *__restrict__ gfirst, uint32_t *__restrict__ glast) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  uint32_t mn = 0xFFFFFFFFu, mx = 0;
+  for (uint32_t b = gbucket[g], e = g + 1 < ng ? gbucket[g + 1] : nbk; b < e; ++b) mn = min(mn, bfirst[b]), mx = max(mx, blast[b]);
+  gfirst[g] = mn, glast[g] = mx;
+}
+
 // sort key of a bucket for the host's table replay: (its key0 group, its first insertion)
 __global__ void k_bucket_order_key(const uint32_t *__restrict__ gbucket, uint32_t ng, const uint32_t *__restrict__ bfirst,
-                                   uint32_t nbk, uint64_t *__restrict__ key) {
+                                   uint32_t nbk, int fbits, uint64_t *__restrict__ key) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbk) return;
   uint32_t lo = 0, hi = ng;  // last group whose first bucket is <= b
@@ -301,7 +324,7 @@ __global__ void k_bucket_order_key(const uint32_t *__restrict__ gbucket, uint32_
     if (gbucket[mid] <= b) lo = mid;
     else hi = mid;
   }
-  key[b] = (uint64_t)lo << 32 | bfirst[b];
+  key[b] = (uint64_t)lo << fbits | bfirst[b];
 }
 
 // bucket tables in the order the host replays the inner tables in
@@ -607,6 +630,23 @@ static void early_groups(const PairRecs &R, Tmp &tmp, const EarlyFn &early) {
   early(std::move(eg));
 }
 
+// OR of all keys / of all negated positions' complements: the radix sorts only visit the bits that can differ
+__global__ void k_key_bits(const uint64_t *__restrict__ key0, const uint64_t *__restrict__ key1, const uint32_t *__restrict__ npos, uint32_t nr,
+                           unsigned long long *__restrict__ out) {
+  unsigned long long k = 0, p = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nr; i += gridDim.x * blockDim.x) k |= key0[i] | key1[i], p |= (uint32_t)~npos[i];
+  for (int o = 32; o; o >>= 1) k |= __shfl_xor(k, o, 64), p |= __shfl_xor(p, o, 64);
+  if ((threadIdx.x & 63) == 0) {
+    if (k) atomicOr(out, k);
+    if (p) atomicOr(out + 1, p);
+  }
+}
+static int bit_length(unsigned long long v) {
+  int b = 0;
+  while (b < 64 && (v >> b) != 0) ++b;
+  return b < 1 ? 1 : b;
+}
+
 static void bucketize(PairRecs &R, unsigned flags, PairTables &out, DevicePairs *keep_dev, Tmp &tmp) {
   hipStream_t st = ctx().stream;
   size_t bytes = 0;
@@ -618,23 +658,33 @@ static void bucketize(PairRecs &R, unsigned flags, PairTables &out, DevicePairs 
   // ---- bucket order: stable LSD sorts (position desc, key1, key0) carrying the record index --------------------
   DevBuf<uint32_t> idx(nr), perm_a(nr), perm_b(nr), k32s(nr);
   DevBuf<uint64_t> kg(nr), kgs(nr);
+  int kbits = 64, pbits = 32;   // bits the keys / the positions occupy (hash << 8 | span is 40 bits at k = 16; positions < 64 k: 16)
+  if (nr >= (1u << 16)) {       // (a 50 us round trip: not worth it for small joins)
+    DevBuf<unsigned long long> d_or(2);
+    PGX_HIP(hipMemsetAsync(d_or.p, 0, 2 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_key_bits, dim3(2048), dim3(256), 0, st, key0.p, key1.p, npos.p, nr, d_or.p);
+    unsigned long long h_or[2] = {0, 0};
+    d_or.download(h_or, 2);
+    sync();
+    kbits = bit_length(h_or[0]), pbits = std::min(32, bit_length(h_or[1]));
+  }
   {
     if (flags & PAIRS_INSERTION_ORDER) {  // buckets keep their records in insertion order (shmr_map never sorts them)
       hipLaunchKernelGGL(k_iota, dim3(cdiv(nr, 256)), dim3(256), 0, st, perm_a.p, nr);
     } else {
       hipLaunchKernelGGL(k_iota, dim3(cdiv(nr, 256)), dim3(256), 0, st, idx.p, nr);
       bytes = 0;
-      PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, npos.p, k32s.p, idx.p, perm_a.p, (int)nr, 0, 32, st));
-      PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, npos.p, k32s.p, idx.p, perm_a.p, (int)nr, 0, 32, st));
+      PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, npos.p, k32s.p, idx.p, perm_a.p, (int)nr, 0, pbits, st));
+      PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, npos.p, k32s.p, idx.p, perm_a.p, (int)nr, 0, pbits, st));
     }
     hipLaunchKernelGGL(k_gather_u64, dim3(cdiv(nr, 256)), dim3(256), 0, st, key1.p, perm_a.p, nr, kg.p);
     bytes = 0;
-    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kg.p, kgs.p, perm_a.p, perm_b.p, (int)nr, 0, 64, st));
-    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, kg.p, kgs.p, perm_a.p, perm_b.p, (int)nr, 0, 64, st));
+    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kg.p, kgs.p, perm_a.p, perm_b.p, (int)nr, 0, kbits, st));
+    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, kg.p, kgs.p, perm_a.p, perm_b.p, (int)nr, 0, kbits, st));
     hipLaunchKernelGGL(k_gather_u64, dim3(cdiv(nr, 256)), dim3(256), 0, st, key0.p, perm_b.p, nr, kg.p);
     bytes = 0;
-    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kg.p, kgs.p, perm_b.p, perm_a.p, (int)nr, 0, 64, st));
-    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, kg.p, kgs.p, perm_b.p, perm_a.p, (int)nr, 0, 64, st));
+    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kg.p, kgs.p, perm_b.p, perm_a.p, (int)nr, 0, kbits, st));
+    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, kg.p, kgs.p, perm_b.p, perm_a.p, (int)nr, 0, kbits, st));
   }
   // perm_a = final order; kgs = sorted key0
   DevBuf<uint64_t> sk1(nr), sy0(nr);
@@ -657,30 +707,30 @@ static void bucketize(PairRecs &R, unsigned flags, PairTables &out, DevicePairs 
   PGX_HIP(hipMemcpyAsync(gstart.p + ng, &nr, sizeof(uint32_t), hipMemcpyHostToDevice, st));
   // first / last insertion (seq == original record index == perm value) per bucket and per key0 group
   DevBuf<uint32_t> bfirst(nbk), gfirst(ng), glast(ng), gbucket(ng);
-  bytes = 0;
-  PGX_HIP(hipcub::DeviceSegmentedReduce::Min(nullptr, bytes, perm_a.p, bfirst.p, (int)nbk, bstart.p, bstart.p + 1, st));
-  PGX_HIP(hipcub::DeviceSegmentedReduce::Min(tmp.get(bytes), bytes, perm_a.p, bfirst.p, (int)nbk, bstart.p, bstart.p + 1, st));
-  bytes = 0;
-  PGX_HIP(hipcub::DeviceSegmentedReduce::Min(nullptr, bytes, perm_a.p, gfirst.p, (int)ng, gstart.p, gstart.p + 1, st));
-  PGX_HIP(hipcub::DeviceSegmentedReduce::Min(tmp.get(bytes), bytes, perm_a.p, gfirst.p, (int)ng, gstart.p, gstart.p + 1, st));
-  bytes = 0;
-  PGX_HIP(hipcub::DeviceSegmentedReduce::Max(nullptr, bytes, perm_a.p, glast.p, (int)ng, gstart.p, gstart.p + 1, st));
-  PGX_HIP(hipcub::DeviceSegmentedReduce::Max(tmp.get(bytes), bytes, perm_a.p, glast.p, (int)ng, gstart.p, gstart.p + 1, st));
   hipLaunchKernelGGL(k_group_first_bucket, dim3(cdiv(ng, 256)), dim3(256), 0, st, gstart.p, ng, bstart.p, nbk, gbucket.p);
+  {
+    DevBuf<uint32_t> blast(nbk);
+    hipLaunchKernelGGL(k_bucket_minmax, dim3(cdiv(nbk, 256)), dim3(256), 0, st, perm_a.p, bstart.p, nbk, bfirst.p, blast.p);
+    hipLaunchKernelGGL(k_group_minmax, dim3(cdiv(ng, 256)), dim3(256), 0, st, bfirst.p, blast.p, gbucket.p, ng, nbk, gfirst.p, glast.p);
+  }
 
   // insertion orders the host replays the two khash levels in: groups by first insertion, buckets by (group, first insertion)
   DevBuf<uint32_t> gord(ng), bord(nbk), iota_g(ng), iota_b(nbk), gf_sorted(ng);
   DevBuf<uint64_t> bok(nbk), bok_sorted(nbk);
   {
+    // (only the bits the keys can have are sorted: insertion indices < nr, group indices < ng)
+    int fbits = 1, gbits = 1;
+    while (fbits < 32 && ((uint64_t)1 << fbits) < (uint64_t)nr) ++fbits;
+    while (gbits < 32 && ((uint64_t)1 << gbits) < (uint64_t)ng) ++gbits;
     hipLaunchKernelGGL(k_iota, dim3(cdiv(ng, 256)), dim3(256), 0, st, iota_g.p, ng);
     bytes = 0;
-    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, gfirst.p, gf_sorted.p, iota_g.p, gord.p, (int)ng, 0, 32, st));
-    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, gfirst.p, gf_sorted.p, iota_g.p, gord.p, (int)ng, 0, 32, st));
+    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, gfirst.p, gf_sorted.p, iota_g.p, gord.p, (int)ng, 0, fbits, st));
+    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, gfirst.p, gf_sorted.p, iota_g.p, gord.p, (int)ng, 0, fbits, st));
     hipLaunchKernelGGL(k_iota, dim3(cdiv(nbk, 256)), dim3(256), 0, st, iota_b.p, nbk);
-    hipLaunchKernelGGL(k_bucket_order_key, dim3(cdiv(nbk, 256)), dim3(256), 0, st, gbucket.p, ng, bfirst.p, nbk, bok.p);
+    hipLaunchKernelGGL(k_bucket_order_key, dim3(cdiv(nbk, 256)), dim3(256), 0, st, gbucket.p, ng, bfirst.p, nbk, fbits, bok.p);
     bytes = 0;
-    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, bok.p, bok_sorted.p, iota_b.p, bord.p, (int)nbk, 0, 64, st));
-    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, bok.p, bok_sorted.p, iota_b.p, bord.p, (int)nbk, 0, 64, st));
+    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, bok.p, bok_sorted.p, iota_b.p, bord.p, (int)nbk, 0, fbits + gbits, st));
+    PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.get(bytes), bytes, bok.p, bok_sorted.p, iota_b.p, bord.p, (int)nbk, 0, fbits + gbits, st));
   }
 
   const bool trace = getenv("PGX_TRACE") != nullptr;
