@@ -73,10 +73,13 @@ constexpr uint32_t LIST_CAP = 65536, DEV_LIST = 0xFFFFFFFFu;
 enum : uint32_t { OV_ITEMS = 1, OV_NODES = 2, OV_REQS = 4, OV_PAIRS = 8, OV_MEMO = 16, OV_QOFF = 32, OV_PASSES = 64 };  // Counters::overflow
 constexpr uint8_t F_DUP = 1, F_GUESS = 2, F_UNFILED = 4;
 
-struct Counters {
+struct alignas(64) Counters {   // three cache lines: the arenas, the dirty statistics, the totals (an atomic holds its line's L2 channel)
   uint32_t item_top, rnode_top, nreq, overflow;
+  uint32_t pad0[12];
   uint32_t ndirty, min_dirty, max_dirty, pad;
+  uint32_t pad1[12];
   unsigned long long lookups, skips, evals, records;
+  unsigned long long pad2[4];
 };
 
 struct R {
@@ -222,6 +225,7 @@ __global__ __launch_bounds__(256) void k_setup(R r) {
 // partner at a time.  A single evaluation is a chain of dependent memory round trips, so the group form is what bounds
 // the latency of a pass: rows x ~4 round trips instead of examinations x ~4.
 constexpr uint32_t NCH = 256;  // reader-node arena chunk of a wavefront
+constexpr uint32_t ICH = 128;  // item arena piece of a wavefront slot (8 chunks of 16)
 #ifndef PGX_REPLAY_GL
 #define PGX_REPLAY_GL 16
 #endif
@@ -284,6 +288,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
   const uint32_t wave_id = nlist ? r.wlist0 + wave : (uint32_t)(((uint64_t)lo + (uint64_t)wave * GPW) / GPW);
   const uint4 wc = r.wcur[wave_id];
   uint32_t rcur = wc.x, rend = wc.y;
+  uint32_t icur = wc.z, iend = wc.w;   // item arena of this wavefront slot (multiples of 16), same idea
   uint32_t s0 = 0, n = 0;
   bool dup = false, first_eval = true;
   if (alive) {
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
     }
     if (!__ballot(alive)) {
       if (!resolve_pending()) return;
-      if (lane == 0) r.wcur[wave_id] = make_uint4(rcur, rend, 0, 0);
+      if (lane == 0) r.wcur[wave_id] = make_uint4(rcur, rend, icur, iend);
       break;
     }
     // ---- one batch of partners ----
@@ -448,14 +453,20 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
     {
       const uint64_t cm = __ballot(need_chunk && gl == 0);
       if (cm) {
-        uint32_t base = 0;
-        if (lane == (int)__builtin_ctzll(cm)) base = atomicAdd(&r.c->item_top, 16u * (uint32_t)__popcll(cm));
-        base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(cm), 64);
-        if ((uint64_t)base + 16u * (uint32_t)__popcll(cm) > r.item_cap) {
-          atomicOr(&r.c->overflow, OV_ITEMS);
-          return;
+        const uint32_t want = 16u * (uint32_t)__popcll(cm);
+        if (icur + want > iend) {  // refill: one atomic on the shared counter per ICH items instead of one per chunk
+          const uint32_t take = want > ICH ? want : ICH;
+          uint32_t base = 0;
+          if (lane == (int)__builtin_ctzll(cm)) base = atomicAdd(&r.c->item_top, take);
+          base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(cm), 64);
+          if ((uint64_t)base + take > r.item_cap) {
+            atomicOr(&r.c->overflow, OV_ITEMS);
+            return;
+          }
+          icur = base, iend = base + take;   // (what was left of the old piece, < want, is not used)
         }
-        fresh = base + 16u * (uint32_t)__popcll(cm & ((1ULL << gbase) - 1ULL));  // (gl == 0 lanes: one bit per group)
+        fresh = icur + 16u * (uint32_t)__popcll(cm & ((1ULL << gbase) - 1ULL));  // (gl == 0 lanes: one bit per group)
+        icur += want;
       }
     }
     if (cins) {
@@ -529,6 +540,7 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
   const uint32_t wave_id = nlist ? r.wlist0 + wave : (uint32_t)(((uint64_t)lo + (uint64_t)wave * GPWT) / GPWT);
   const uint4 wc = r.wcur[wave_id];
   uint32_t rcur = wc.x, rend = wc.y;
+  uint32_t icur = wc.z, iend = wc.w;   // item arena of this wavefront slot (multiples of 16), same idea
   uint32_t s0 = 0, n = 0;
   bool dup = false, first_eval = true;
   if (alive) {
@@ -616,7 +628,7 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
     }
     if (!__ballot(alive)) {
       if (!resolve_pending()) return;
-      if (lane == 0) r.wcur[wave_id] = make_uint4(rcur, rend, 0, 0);
+      if (lane == 0) r.wcur[wave_id] = make_uint4(rcur, rend, icur, iend);
       break;
     }
     // ---- this step's (row, partner) of the lane ----
@@ -754,12 +766,19 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
       const uint32_t nnew = last_no + 1 > first_new ? last_no + 1 - first_new : 0;
       uint32_t fresh = 0;
       if (nnew) {
-        if (lane == 0) fresh = atomicAdd(&r.c->item_top, 16u * nnew);
-        fresh = (uint32_t)__shfl((int)fresh, 0, 64);
-        if ((uint64_t)fresh + 16u * nnew > r.item_cap) {
-          atomicOr(&r.c->overflow, OV_ITEMS);
-          return;
+        const uint32_t want = 16u * nnew;
+        if (icur + want > iend) {
+          const uint32_t take = want > ICH ? want : ICH;
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&r.c->item_top, take);
+          base = (uint32_t)__shfl((int)base, 0, 64);
+          if ((uint64_t)base + take > r.item_cap) {
+            atomicOr(&r.c->overflow, OV_ITEMS);
+            return;
+          }
+          icur = base, iend = base + take;
         }
+        fresh = icur, icur += want;
       }
       auto base_of = [&](uint32_t no) { return no >= first_new ? fresh + 16u * (no - first_new) : chunk; };
       if (my_ins) {
@@ -842,19 +861,28 @@ __global__ __launch_bounds__(256) void k_update(R r, uint32_t lo, uint32_t hi, u
 }
 
 __global__ __launch_bounds__(256) void k_count(R r) {
+  // One list position per dirty bucket.  Atomics on ONE address are served one wavefront-instruction at a time (~12 ns each):
+  // with every wavefront of a dense round holding a dirty bucket that was 0.7 ms of this kernel.  So: one add per BLOCK (the four
+  // wavefronts' counts meet in LDS; positions stay ascending within the block), and the range atomics only while they can
+  // still move the bound.
+  __shared__ uint32_t s_cnt[4], s_base;
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const bool d = j < r.nb && r.dirty[j];
   const uint64_t m = __ballot(d);
-  if (!m) return;
-  uint32_t base = 0;
-  const int leader = __builtin_ctzll(m);
-  if ((int)(threadIdx.x & 63) == leader) {
-    base = atomicAdd(&r.c->ndirty, (uint32_t)__popcll(m));
-    atomicMin(&r.c->min_dirty, j);
-    atomicMax(&r.c->max_dirty, (j & ~63u) + 63 - (uint32_t)__builtin_clzll(m));
+  if (lane == 0) s_cnt[w] = (uint32_t)__popcll(m);
+  __syncthreads();
+  const uint32_t c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3], total = c0 + c1 + c2 + c3;
+  if (!total) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(&r.c->ndirty, total);
+  if (m && lane == (int)__builtin_ctzll(m)) {
+    if (j < *(volatile uint32_t *)&r.c->min_dirty) atomicMin(&r.c->min_dirty, j);
+    const uint32_t top = (j & ~63u) + 63 - (uint32_t)__builtin_clzll(m);
+    if (top > *(volatile uint32_t *)&r.c->max_dirty) atomicMax(&r.c->max_dirty, top);
   }
-  base = (uint32_t)__shfl((int)base, leader, 64);
-  const uint32_t at = base + lane_rank(m);
+  __syncthreads();
+  const uint32_t before = w == 0 ? 0 : w == 1 ? c0 : w == 2 ? c0 + c1 : c0 + c1 + c2;
+  const uint32_t at = s_base + before + lane_rank(m);
   if (d && at < LIST_CAP) r.dlist[at] = j;
 }
 
