@@ -107,6 +107,7 @@ struct R {
   uint32_t wlist0;  // first wcur slot of the list-mode wavefronts
   uint4 *wcur;  // per wavefront of k_eval: the unused rest of its arena chunks {node cur, node end, item cur, item end}, kept across launches
   Counters *c;
+  unsigned long long *spread;  // the totals (evaluations, look-ups, skips) over SPREAD cache lines: [line * 8 + {0, 1, 2}], summed by the host
   uint32_t bestn;
   int predict;
 };
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(256) void k_setup(R r) {
 // partner at a time.  A single evaluation is a chain of dependent memory round trips, so the group form is what bounds
 // the latency of a pass: rows x ~4 round trips instead of examinations x ~4.
 constexpr uint32_t NCH = 256;  // reader-node arena chunk of a wavefront
+constexpr uint32_t SPREAD = 256;
 constexpr uint32_t ICH = 128;  // item arena piece of a wavefront slot (8 chunks of 16)
 #ifndef PGX_REPLAY_GL
 #define PGX_REPLAY_GL 16
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
   {
     const uint64_t am = __ballot(alive);
     if (!am) return;
-    if (lane == (int)__builtin_ctzll(am)) atomicAdd(&r.c->evals, (unsigned long long)(__popcll(am) / GL));
+    if (lane == (int)__builtin_ctzll(am)) atomicAdd(&r.spread[(wave % SPREAD) * 8], (unsigned long long)(__popcll(am) / GL));
   }
   // reader-node arena: wave-uniform cursor; the wavefront that evaluates these buckets next time continues where this one stops
   const uint32_t wave_id = nlist ? r.wlist0 + wave : (uint32_t)(((uint64_t)lo + (uint64_t)wave * GPW) / GPW);
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
   {
     const uint64_t am = __ballot(alive);
     if (!am) return;
-    if (lane == (int)__builtin_ctzll(am)) atomicAdd(&r.c->evals, (unsigned long long)(__popcll(am) / GLT));
+    if (lane == (int)__builtin_ctzll(am)) atomicAdd(&r.spread[(wave % SPREAD) * 8], (unsigned long long)(__popcll(am) / GLT));
   }
   // reader-node arena: wave-uniform cursor; the wavefront that evaluates these buckets next time continues where this one stops
   const uint32_t wave_id = nlist ? r.wlist0 + wave : (uint32_t)(((uint64_t)lo + (uint64_t)wave * GPWT) / GPWT);
@@ -1017,8 +1019,9 @@ __global__ __launch_bounds__(256) void k_emit(R r, const uint32_t *__restrict__ 
     sk += (unsigned long long)__shfl_xor((int)(sk >> 32), o, 64) << 32 | (uint32_t)__shfl_xor((int)sk, o, 64);
   }
   if ((threadIdx.x & 63) == 0 && (lk | sk)) {
-    atomicAdd(&r.c->lookups, lk);
-    atomicAdd(&r.c->skips, sk);
+    unsigned long long *line = r.spread + ((j >> 6) % SPREAD) * 8;
+    atomicAdd(line + 1, lk);
+    atomicAdd(line + 2, sk);
   }
 }
 
@@ -1072,6 +1075,9 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   r.dlist = dlist.p;
   DevBuf<Counters> dc(1);
   r.c = dc.p;
+  DevBuf<unsigned long long> spread(SPREAD * 8);
+  r.spread = spread.p;
+  PGX_HIP(hipMemsetAsync(spread.p, 0, SPREAD * 8 * sizeof(unsigned long long), s));
   r.bestn = bestn, r.predict = predict ? 1 : 0, r.settled = 0;
   PGX_HIP(hipMemsetAsync(ph.p, 0, (size_t)pcap * sizeof(PHot), s));
   PGX_HIP(hipMemsetAsync(pc.p, 0, (size_t)pcap * sizeof(PCold), s));
@@ -1082,19 +1088,29 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   hipLaunchKernelGGL(k_setup, dim3(cdiv256(nb)), dim3(256), 0, s, r);
 
   static Counters *hc = nullptr;  // pinned mirror of the device counters
+  static unsigned long long *hs = nullptr;  // pinned mirror of the spread totals
   static uint32_t *reset3 = nullptr;  // {ndirty, min_dirty, max_dirty} before a count (pinned, constant)
   if (!hc) {
     PGX_HIP(hipHostMalloc((void **)&hc, sizeof(Counters), hipHostMallocDefault));
+    PGX_HIP(hipHostMalloc((void **)&hs, SPREAD * 8 * sizeof(unsigned long long), hipHostMallocDefault));
     PGX_HIP(hipHostMalloc((void **)&reset3, 3 * sizeof(uint32_t), hipHostMallocDefault));
     reset3[0] = 0, reset3[1] = 0xFFFFFFFFu, reset3[2] = 0;
   }
+  auto fetch = [&](bool totals) {  // counters (and, for the trace / the statistics, the spread totals) to the host; synchronises
+    PGX_HIP(hipMemcpyAsync(hc, dc.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
+    if (totals) PGX_HIP(hipMemcpyAsync(hs, spread.p, SPREAD * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    sync();
+    if (totals) {
+      hc->evals = hc->lookups = hc->skips = 0;
+      for (uint32_t i = 0; i < SPREAD; ++i) hc->evals += hs[i * 8], hc->lookups += hs[i * 8 + 1], hc->skips += hs[i * 8 + 2];
+    }
+  };
   auto read_counters = [&](bool count_dirty) {
     if (count_dirty) {  // reset the three dirty statistics, keep the rest
       PGX_HIP(hipMemcpyAsync(&dc.p->ndirty, reset3, 3 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
       hipLaunchKernelGGL(k_count, dim3(cdiv256(nb)), dim3(256), 0, s, r);
     }
-    PGX_HIP(hipMemcpyAsync(hc, dc.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
-    sync();
+    fetch(true);
     return hc->overflow == 0;
   };
   const size_t window = getenv("PGX_REPLAY_WIN") ? (size_t)atoll(getenv("PGX_REPLAY_WIN")) : (size_t)262144;
@@ -1177,8 +1193,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
       }
       // file what the clean buckets need (always safe), then one round trip for everything: dirty count, range, requests
       hipLaunchKernelGGL(k_file, dim3(cdiv256(nb)), dim3(256), 0, s, r, (uint32_t)nb);
-      PGX_HIP(hipMemcpyAsync(hc, dc.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
-      sync();
+      fetch(trace);
       if (hc->overflow) goto overflowed;
       n_dirty = hc->ndirty, known = true;
       r.memo_used = hc->nreq != 0;
@@ -1206,8 +1221,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     hipLaunchKernelGGL(k_settle, dim3(cdiv256(nb)), dim3(256), 0, s, r);
     count_dirty();
     if (batch > 100000) {  // a big batch: worth a round trip to know how many guesses were wrong (dense or sparse next)
-      PGX_HIP(hipMemcpyAsync(hc, dc.p, sizeof(Counters), hipMemcpyDeviceToHost, s));
-      sync();
+      fetch(false);
       if (hc->overflow) goto overflowed;
       n_dirty = hc->ndirty, known = true;
       d_lo = n_dirty ? hc->min_dirty : 0, d_hi = n_dirty ? hc->max_dirty + 1 : 0;
