@@ -228,6 +228,23 @@ __global__ __launch_bounds__(256) void k_setup(R r) {
 constexpr uint32_t NCH = 256;  // reader-node arena chunk of a wavefront
 constexpr uint32_t SPREAD = 256;
 constexpr uint32_t ICH = 128;  // item arena piece of a wavefront slot (8 chunks of 16)
+
+// every wavefront slot of k_eval starts with its own piece of the item arena (no atomic at all for its first ICH items); the
+// shared counter starts behind the pieces
+// (slots [0, n_dense): the dense rounds' wavefronts, GPW buckets each; [wlist0, nslots): the list-mode wavefronts; the slots
+// between them are only used by the one-bucket-per-wavefront dense variant and start empty)
+__global__ void k_init_slots(uint4 *__restrict__ wcur, uint32_t nslots, uint32_t n_dense, uint32_t wlist0, Counters *c) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w == 0) c->item_top = (n_dense + (nslots - wlist0)) * ICH;
+  if (w >= nslots) return;
+  if (w < n_dense || w >= wlist0) {
+    const uint32_t piece = w < n_dense ? w : n_dense + (w - wlist0);
+    wcur[w] = make_uint4(0u, 0u, piece * ICH, (piece + 1) * ICH);
+  } else {
+    wcur[w] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
 #ifndef PGX_REPLAY_GL
 #define PGX_REPLAY_GL 16
 #endif
@@ -1056,7 +1073,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   DevBuf<PCold> pc(pcap);
   DevBuf<MSlot> mt(mcap);
   r.ph = ph.p, r.pc = pc.p, r.pmask = pcap - 1, r.mt = mt.p, r.mmask = mcap - 1;
-  r.item_cap = (uint32_t)std::min<size_t>((size_t)(ne * 6 * mult[0]) + nb * (size_t)64 + (1u << 20), 0x7FFFFFF0u);
+  r.item_cap = (uint32_t)std::min<size_t>((size_t)(ne * 6 * mult[0]) + nb * (size_t)64 + (size_t)(LIST_CAP + 8) * ICH + (1u << 20), 0x7FFFFFF0u);
   r.rn_cap = (uint32_t)std::min<size_t>((size_t)(ne * 8 * mult[1]) + (1u << 20), 0x7FFFFFF0u);
   r.req_cap = (uint32_t)std::min<size_t>((size_t)(ne * 1 * mult[2]) + 65536, 0x7FFFFFF0u);
   DevBuf<Item> items(r.item_cap);
@@ -1070,7 +1087,6 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   r.ihead = words.p, r.inum = words.p + nb, r.ohead = words.p + 2 * nb, r.lookups = words.p + 3 * nb, r.skips = words.p + 4 * nb;
   DevBuf<uint4> wcur(nb + 2 + LIST_CAP + 1);  // (one slot per wavefront of k_eval: GPW buckets each)
   r.wcur = wcur.p, r.wlist0 = (uint32_t)(nb + 2);
-  PGX_HIP(hipMemsetAsync(wcur.p, 0, wcur.n * sizeof(uint4), s));
   DevBuf<uint32_t> dlist(LIST_CAP);
   r.dlist = dlist.p;
   DevBuf<Counters> dc(1);
@@ -1085,6 +1101,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   PGX_HIP(hipMemsetAsync(bytes.p, 0, nb * 5, s));
   PGX_HIP(hipMemsetAsync(words.p, 0, nb * 5 * sizeof(uint32_t), s));
   PGX_HIP(hipMemsetAsync(dc.p, 0, sizeof(Counters), s));
+  hipLaunchKernelGGL(k_init_slots, dim3(cdiv256(wcur.n)), dim3(256), 0, s, wcur.p, (uint32_t)wcur.n, (uint32_t)(nb / GPW + 2), r.wlist0, dc.p);
   hipLaunchKernelGGL(k_setup, dim3(cdiv256(nb)), dim3(256), 0, s, r);
 
   static Counters *hc = nullptr;  // pinned mirror of the device counters
