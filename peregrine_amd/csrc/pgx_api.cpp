@@ -9,6 +9,10 @@
 #include <mutex>
 #include <thread>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "pgx_internal.h"
 
 namespace pgx {
@@ -411,8 +415,52 @@ void pgx_timing_reset(void) {
 }
 
 // ---- resident seqdb --------------------------------------------------------------------------------------
+// the seqdb file straight into HBM through two pinned staging buffers (the next piece is read while the last one uploads): the
+// host never holds more than 2 x 64 MiB of it
+static void upload_file_pieces(const char *path, uint8_t *d_dst, size_t nbytes) {
+  const int fd = open(path, O_RDONLY);
+  PGX_REQUIRE(fd >= 0, PGX_EIO, "cannot read %s", path);
+  const size_t P = (size_t)64 << 20;
+  uint8_t *pin[2] = {nullptr, nullptr};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  bool used[2] = {false, false};
+  auto cleanup = [&]() {
+    (void)hipStreamSynchronize(ctx().stream);
+    for (int k = 0; k < 2; ++k) {
+      if (pin[k]) (void)hipHostFree(pin[k]);
+      if (ev[k]) (void)hipEventDestroy(ev[k]);
+    }
+    close(fd);
+  };
+  try {
+    for (int k = 0; k < 2; ++k) {
+      PGX_HIP(hipHostMalloc((void **)&pin[k], std::min(P, std::max<size_t>(nbytes, 1)), hipHostMallocDefault));
+      PGX_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    }
+    size_t off = 0;
+    for (int k = 0; off < nbytes; k ^= 1) {
+      const size_t n = std::min(P, nbytes - off);
+      if (used[k]) PGX_HIP(hipEventSynchronize(ev[k]));
+      for (size_t got = 0; got < n;) {
+        const ssize_t r = pread(fd, pin[k] + got, n - got, (off_t)(off + got));
+        PGX_REQUIRE(r > 0, PGX_EIO, "short read from %s (%zu of %zu bytes)", path, off + got, nbytes);
+        got += (size_t)r;
+      }
+      PGX_HIP(hipMemcpyAsync(d_dst + off, pin[k], n, hipMemcpyHostToDevice, ctx().stream));
+      PGX_HIP(hipEventRecord(ev[k], ctx().stream));
+      used[k] = true;
+      off += n;
+    }
+  } catch (...) {
+    cleanup();
+    throw;
+  }
+  cleanup();
+}
+
+// seqdb: host bytes, device bytes (from_device), or -- file != nullptr -- the path of the .seqdb file (nbytes = its size)
 static int seqdb_upload_impl(const uint8_t *seqdb, size_t nbytes, const uint32_t *rid, const uint32_t *rlen,
-                             const uint64_t *roff, uint32_t nreads, pgx_seqdb **out, bool from_device) {
+                             const uint64_t *roff, uint32_t nreads, pgx_seqdb **out, bool from_device, const char *file = nullptr) {
   PGX_GUARD_BEGIN
   require_ready();
   PGX_REQUIRE(out && (nreads == 0 || (rid && rlen && roff)), PGX_EARG, "pgx_seqdb_upload: null argument");
@@ -438,12 +486,13 @@ static int seqdb_upload_impl(const uint8_t *seqdb, size_t nbytes, const uint32_t
   try {
     db->d_seq.alloc(nbytes + 1024);
     PGX_HIP(hipMemsetAsync(db->d_seq.p + nbytes, 0, 1024, ctx().stream));
-    if (nbytes) PGX_HIP(hipMemcpyAsync(db->d_seq.p, seqdb, nbytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx().stream));
+    if (nbytes && file) upload_file_pieces(file, db->d_seq.p, nbytes);
+    else if (nbytes) PGX_HIP(hipMemcpyAsync(db->d_seq.p, seqdb, nbytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx().stream));
     db->d_roff.alloc(nr ? nr : 1);
     db->d_rlen.alloc(nr ? nr : 1);
     db->d_roff.upload(db->roff_by_rid.data(), nr);
     db->d_rlen.upload(db->rlen_by_rid.data(), nr);
-    sync();
+    pgx::sync();
   } catch (...) {
     delete db;
     throw;
@@ -465,7 +514,7 @@ int pgx_copy_dev(void *d_dst, const void *d_src, size_t nbytes) {
   require_ready();
   PGX_REQUIRE((d_dst && d_src) || nbytes == 0, PGX_EARG, "pgx_copy_dev: null argument");
   if (nbytes) PGX_HIP(hipMemcpyAsync(d_dst, d_src, nbytes, hipMemcpyDeviceToDevice, ctx().stream));
-  sync();
+  pgx::sync();
   PGX_GUARD_END
 }
 
@@ -477,9 +526,10 @@ int pgx_seqdb_load(const char *prefix, pgx_seqdb **out) {
   std::vector<uint64_t> roff;
   std::string p(prefix);
   PGX_REQUIRE(load_idx((p + ".idx").c_str(), rid, rlen, roff) == 0, PGX_EIO, "cannot open %s.idx", prefix);
-  std::vector<uint8_t> bytes;
-  PGX_REQUIRE(read_file(p + ".seqdb", bytes), PGX_EIO, "cannot read %s.seqdb", prefix);
-  int rc = pgx_seqdb_upload(bytes.data(), bytes.size(), rid.data(), rlen.data(), roff.data(), (uint32_t)rid.size(), out);
+  const std::string dbpath = p + ".seqdb";
+  struct stat sb;
+  PGX_REQUIRE(stat(dbpath.c_str(), &sb) == 0 && S_ISREG(sb.st_mode), PGX_EIO, "cannot read %s.seqdb", prefix);
+  int rc = seqdb_upload_impl(nullptr, (size_t)sb.st_size, rid.data(), rlen.data(), roff.data(), (uint32_t)rid.size(), out, false, dbpath.c_str());
   if (rc) return rc;
   PGX_GUARD_END
 }
@@ -507,7 +557,7 @@ int pgx_sketch_batch(pgx_seqdb *db, const uint32_t *read_slots, uint32_t n, int 
   dev_sketch(db, reads, w, k, d, m, nullptr);
   std::vector<pgx_mm128> h(m);
   d.download(h.data(), m);
-  sync();
+  pgx::sync();
   *out = host_copy(h);
   *n_out = m;
   PGX_GUARD_END
@@ -525,7 +575,7 @@ int pgx_reduce_batch(const pgx_mm128 *in, size_t n, int rs, pgx_mm128 **out, siz
   dev_reduce(d_in.p, n, rs, d_out, m);
   std::vector<pgx_mm128> h(m);
   d_out.download(h.data(), m);
-  sync();
+  pgx::sync();
   *out = host_copy(h);
   *n_out = m;
   PGX_GUARD_END
@@ -543,7 +593,7 @@ int pgx_count_batch(const pgx_mm128 *in, size_t n, pgx_mm_count **out, size_t *n
   dev_count(d_in.p, n, 56, d_out, m);
   std::vector<pgx_mm_count> h(m);
   d_out.download(h.data(), m);
-  sync();
+  pgx::sync();
   *out = host_copy(h);
   *n_out = m;
   PGX_GUARD_END
@@ -564,7 +614,7 @@ int pgx_align_batch(pgx_seqdb *db, const pgx_align_key *keys, size_t n, int band
   d_keys.upload(keys, n);
   dev_align(db, d_keys.p, n, band, d_out.p);
   d_out.download(out, n);
-  sync();
+  pgx::sync();
   PGX_GUARD_END
 }
 

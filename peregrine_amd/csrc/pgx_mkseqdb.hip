@@ -36,52 +36,60 @@ __global__ __launch_bounds__(256) void k_encode_biseq(const uint8_t *__restrict_
     d[p] = (uint8_t)(onehot_rev(s[len - 1 - p]) << 4 | onehot_fwd(s[p]));
 }
 
-struct Inflated {
-  std::vector<uint8_t> buf;
-  bool ok = false;
-};
-Inflated slurp_gz(const char *path) {  // gzopen reads plain and gzip files alike, as the reference's gzread does
-  Inflated r;
-  gzFile f = gzopen(path, "r");
-  if (!f) return r;
-  std::vector<uint8_t> chunk(1 << 20);
-  for (;;) {
-    const int got = gzread(f, chunk.data(), (unsigned)chunk.size());
-    if (got <= 0) break;
-    r.buf.insert(r.buf.end(), chunk.begin(), chunk.begin() + got);
-  }
-  gzclose(f);
-  r.ok = true;
-  return r;
-}
 inline bool is_space(int c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
 
 struct Records {
   std::vector<std::string> names;
   std::vector<uint64_t> off;  // n+1 offsets into seq
   std::vector<uint8_t> seq;
+  void clear() {
+    names.clear(), seq.clear();
+    off.assign(1, 0);
+  }
+};
+struct ParseState {
+  int last = 0;          // the header marker ('>' / '@') the reader has already consumed, or 0
+  bool stopped = false;  // a malformed FASTQ record ended the file's records (as the reference's loop ends)
 };
 
-// the kseq record grammar (see the header comment); stops at the first malformed FASTQ record like the reference's loop
-void parse_records(const std::vector<uint8_t> &b, Records &out) {
+// The kseq record grammar (see the header comment) over the bytes b[0, n) of a file that is read PIECE BY PIECE: complete
+// records are appended to `out`; the return value is the number of bytes consumed, i.e. where parsing resumes once more
+// data has been appended behind b[n).  A record whose parse reached the end of the piece is not committed unless the piece
+// ends the file (`at_eof`): it is parsed again, from its start, with more data.  At the end of the file the reader's
+// end-of-file behaviour applies (a header marker at the very end, a FASTQ record without its quality string, ... end the
+// records like the reference's reader does).
+size_t parse_some(const uint8_t *b, size_t n, bool at_eof, ParseState &st, Records &out) {
   size_t i = 0;
-  const size_t n = b.size();
-  int last = 0;
+  int last = st.last;
   for (;;) {
+    const size_t rec_i = i;      // where this record's parse starts, and in which reader state
+    const int rec_last = last;
+    const size_t s0 = out.seq.size();
+    auto more_needed = [&]() {   // ran into the end of the piece: come back with more data
+      out.seq.resize(s0);
+      st.last = rec_last;
+      return rec_i;
+    };
     if (last == 0) {
       while (i < n && b[i] != '>' && b[i] != '@') ++i;
-      if (i >= n) return;
+      if (i >= n) {
+        st.last = 0;
+        return n;  // (nothing but skipped bytes)
+      }
       last = b[i++];
     }
     // name: up to the first whitespace; the rest of the header line is the comment
-    if (i >= n) return;  // header marker at the very end: the reference's reader reports EOF
+    if (i >= n) {
+      if (!at_eof) return more_needed();
+      st.last = last;
+      return n;  // header marker at the very end: the reference's reader reports EOF
+    }
     std::string name;
     while (i < n && !is_space(b[i])) name.push_back((char)b[i++]);
     int c = i < n ? b[i++] : -1;
     if (c != '\n' && c != -1)
       while (i < n && b[i++] != '\n') {
       }
-    const size_t s0 = out.seq.size();
     c = -1;
     while (i < n) {
       c = b[i++];
@@ -98,30 +106,39 @@ void parse_records(const std::vector<uint8_t> &b, Records &out) {
     }
     const size_t slen = out.seq.size() - s0;
     last = (c == '>' || c == '@') ? c : 0;
+    bool bad = false;
     if (c == '+') {  // FASTQ: skip the '+' line, then read at least slen quality characters
       while (i < n && b[i] != '\n') ++i;
       if (i >= n) {  // no quality string: error, the record is dropped and reading stops
-        out.seq.resize(s0);
-        return;
+        bad = true;
+      } else {
+        ++i;
+        size_t ql = 0;
+        while (i < n) {
+          const size_t ls = i;
+          while (i < n && b[i] != '\n') ++i;
+          const size_t ll = i - ls;
+          if (i < n) ++i;
+          ql += ll;
+          if (ql > 1 && ll > 0 && b[ls + ll - 1] == '\r') --ql;
+          if (ql >= slen) break;
+        }
+        if (ql != slen) bad = true;
       }
-      ++i;
-      size_t ql = 0;
-      while (i < n) {
-        const size_t ls = i;
-        while (i < n && b[i] != '\n') ++i;
-        const size_t ll = i - ls;
-        if (i < n) ++i;
-        ql += ll;
-        if (ql > 1 && ll > 0 && b[ls + ll - 1] == '\r') --ql;
-        if (ql >= slen) break;
-      }
-      if (ql != slen) {
-        out.seq.resize(s0);
-        return;
-      }
+    }
+    if (i >= n && !at_eof) return more_needed();  // (the record may continue in the next piece)
+    if (bad) {
+      out.seq.resize(s0);
+      st.stopped = true;
+      st.last = 0;
+      return n;
     }
     out.names.push_back(name);
     out.off.push_back(out.seq.size());
+    if (i >= n) {  // (at_eof)
+      st.last = last;
+      return n;
+    }
   }
 }
 
@@ -148,20 +165,19 @@ extern "C" int pgx_mkseqdb(const char *seq_dataset_path, const char *seqdb_prefi
     uint64_t rid = 0, offset = 0;
     char fn[8192];
     int rc = PGX_OK;
-    while (fscanf(lst, "%8191s", fn) == 1) {
-      Inflated in = slurp_gz(fn);
-      if (!in.ok) {
-        set_error("file '%s' open error", fn);
-        rc = PGX_EIO;
-        break;
-      }
-      Records rec;
-      rec.off.push_back(0);
-      parse_records(in.buf, rec);
+    // Bounded host memory (the reference streams record by record): the file is inflated PIECE bytes at a time, complete
+    // records are collected until BATCH bases are pending, encoded by one kernel launch and appended to the output files.
+    const size_t PIECE = getenv("PGX_MKSEQDB_PIECE") ? (size_t)atoll(getenv("PGX_MKSEQDB_PIECE")) : ((size_t)64 << 20);
+    const size_t BATCH = getenv("PGX_MKSEQDB_BATCH") ? (size_t)atoll(getenv("PGX_MKSEQDB_BATCH")) : ((size_t)256 << 20);
+    Records rec;
+    rec.clear();
+    std::vector<uint8_t> enc;
+    auto flush = [&]() -> bool {  // encode and write what is pending
       const uint32_t n = (uint32_t)rec.names.size();
       const size_t nb = rec.seq.size();
-      std::vector<uint8_t> enc(nb);
-      if (n && nb) {
+      if (!n) return true;
+      enc.resize(nb);
+      if (nb) {
         KernelTimer tm("encode", nb);
         uint8_t *d_in = ws<uint8_t>("mk.in", nb), *d_out = ws<uint8_t>("mk.out", nb);
         uint64_t *d_off = ws<uint64_t>("mk.off", (size_t)n + 1);
@@ -176,11 +192,42 @@ extern "C" int pgx_mkseqdb(const char *seq_dataset_path, const char *seqdb_prefi
         fprintf(fidx, "%09d %s %u %lu\n", (int)rid, rec.names[i].c_str(), (unsigned)len, (unsigned long)offset);
         ++rid, offset += len;
       }
-      if (nb && fwrite(enc.data(), 1, nb, fdb) != nb) {
-        set_error("short write to %s.seqdb", seqdb_prefix);
+      rec.clear();
+      return !nb || fwrite(enc.data(), 1, nb, fdb) == nb;
+    };
+    while (rc == PGX_OK && fscanf(lst, "%8191s", fn) == 1) {
+      gzFile gz = gzopen(fn, "r");  // gzopen reads plain and gzip files alike, as the reference's gzread does
+      if (!gz) {
+        set_error("file '%s' open error", fn);
         rc = PGX_EIO;
         break;
       }
+      std::vector<uint8_t> buf(std::max<size_t>(PIECE, 16));
+      size_t have = 0;
+      bool eof = false;
+      ParseState st;
+      while (!st.stopped) {
+        while (!eof && have < buf.size()) {  // fill the piece
+          const int got = gzread(gz, buf.data() + have, (unsigned)std::min<size_t>(buf.size() - have, (size_t)1 << 30));
+          if (got <= 0) eof = true;
+          else have += (size_t)got;
+        }
+        const size_t used = parse_some(buf.data(), have, eof, st, rec);
+        if (rec.seq.size() >= BATCH && !flush()) {
+          set_error("short write to %s.seqdb", seqdb_prefix);
+          rc = PGX_EIO;
+          break;
+        }
+        if (eof) break;
+        if (used == 0 && have == buf.size()) buf.resize(buf.size() * 2);  // a record longer than the piece (a contig): a larger piece
+        memmove(buf.data(), buf.data() + used, have - used);
+        have -= used;
+      }
+      gzclose(gz);
+    }
+    if (rc == PGX_OK && !flush()) {
+      set_error("short write to %s.seqdb", seqdb_prefix);
+      rc = PGX_EIO;
     }
     fclose(lst), fclose(fidx), fclose(fdb);
     timing_flush();

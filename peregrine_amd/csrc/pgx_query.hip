@@ -109,7 +109,7 @@ __global__ void k_ref_flags(const pgx_mm128 *__restrict__ ref, uint32_t n, const
   if (i >= n) return;
   uint32_t at;
   find_u64(gkey0, 0, ng, ref[i].x, &at);
-  if (at < ng && gkey0[at] == ref[i].x) atomicMin(first_key0, i);
+  if (at < ng && gkey0[at] == ref[i].x && i < *(volatile uint32_t *)first_key0) atomicMin(first_key0, i);  // (guarded: one hot address)
   find_u64(umer, 0, nu, ref[i].x >> 8, &at);
   const bool known = at < nu && umer[at] == ref[i].x >> 8;
   const uint32_t c = known ? ucnt[at] : 0;

@@ -200,9 +200,15 @@ def test_edge_cases(lib):
     rdb.close()
 
 
-def test_mkseqdb_matches_reference(tmp_path):
-    """row f1: FASTA / FASTQ / gz / CRLF / multi-line inputs -> seqdb + idx, byte-identical to the reference binary"""
+@pytest.mark.parametrize("piece,batch", [(None, None), ("64", "1000"), ("97", "1"), ("4096", "100000")])
+def test_mkseqdb_matches_reference(tmp_path, monkeypatch, piece, batch):
+    """row f1: FASTA / FASTQ / gz / CRLF / multi-line inputs -> seqdb + idx, byte-identical to the reference binary; the input is
+    read piece by piece and encoded batch by batch (bounded host memory): tiny pieces / batches put record boundaries, header
+    markers and quality strings on every piece border"""
     from peregrine_amd.shimmer import shmr_mkseqdb
+    if piece:
+        monkeypatch.setenv("PGX_MKSEQDB_PIECE", piece)
+        monkeypatch.setenv("PGX_MKSEQDB_BATCH", batch)
     z = G.load("mkseqdb_cases.npz")
     paths = []
     for k in z["order"]:
