@@ -109,7 +109,7 @@ struct R {
   Counters *c;
   unsigned long long *spread;  // the totals (evaluations, look-ups, skips) over SPREAD cache lines: [line * 8 + {0, 1, 2}], summed by the host
   uint32_t bestn;
-  int predict;
+  int predict, predict2;   // margins of predict_contained (0: every pending alignment is guessed a plain overlap)
 };
 
 __device__ __forceinline__ uint64_t mix64(uint64_t h) {
@@ -138,6 +138,17 @@ __device__ __forceinline__ bool classify(const pgx_match &m, uint32_t rlen0, uin
     return true;
   }
   return false;
+}
+
+// The type a pending alignment will most likely have (classify above, with the alignment's geometry predicted): the query is
+// read 0 from q_off on (slen0 = rlen0 - q_off bases), the target read 1 from its start.  If the target runs out first
+// (rlen1 <= slen0) its whole length is covered: contained-type.  If the query runs out first, q_end = slen0 and t_end = slen0 +
+// drift: contained-type iff q_off + q_bgn < 96 (the query side) or rlen1 - slen0 < 96 + drift - t_bgn (the target side: a
+// target that sticks out by less than the fuzz still counts as covered).  q_bgn / t_bgn (the first 17-base run) are a few bases,
+// the drift of 1 % indels over 15 kb is ~ +-10: margins mq / mt, both 88 by default.  (Round 1 tested rlen1 <= slen0 on the
+// target side: every pair with 0 < rlen1 - slen0 < ~90, 0.6 % of all, was guessed wrong -- most of the second sweep's work.)
+__device__ __forceinline__ bool predict_contained(uint32_t rlen0, uint32_t rlen1, uint32_t q_off, int mq, int mt) {
+  return (int)rlen1 - (int)(rlen0 - q_off) < mt || q_off < (uint32_t)mq;
 }
 
 // the slot of a read pair, inserting the key if it is new (keys never change once set, so a stale "empty" only costs a
@@ -417,7 +428,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
           accepted = classify(r.rq_res[req], rlen0, rlen1, q_off, &type);
         } else {
           accepted = true, guessed = true, type = T_OVERLAP;
-          if (r.predict && (rlen1 <= rlen0 - q_off || q_off < (uint32_t)(END_FUZZ * 2 - 8))) type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
+          if (r.predict && predict_contained(rlen0, rlen1, q_off, r.predict, r.predict2)) type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
         }
       }
     }
@@ -688,7 +699,7 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
           accepted = classify(r.rq_res[req], rlen0, rlen1, q_off, &type);
         } else {
           accepted = true, guessed = true, type = T_OVERLAP;
-          if (r.predict && (rlen1 <= rlen0 - q_off || q_off < (uint32_t)(END_FUZZ * 2 - 8))) type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
+          if (r.predict && predict_contained(rlen0, rlen1, q_off, r.predict, r.predict2)) type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
         }
       }
     }
@@ -1094,7 +1105,12 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   DevBuf<unsigned long long> spread(SPREAD * 8);
   r.spread = spread.p;
   PGX_HIP(hipMemsetAsync(spread.p, 0, SPREAD * 8 * sizeof(unsigned long long), s));
-  r.bestn = bestn, r.predict = predict ? 1 : 0, r.settled = 0;
+  {
+    static const int mq = getenv("PGX_PREDICT_MQ") ? atoi(getenv("PGX_PREDICT_MQ")) : END_FUZZ * 2 - 8;
+    static const int mt = getenv("PGX_PREDICT_MT") ? atoi(getenv("PGX_PREDICT_MT")) : END_FUZZ * 2 - 8;
+    r.predict = predict ? std::max(mq, 1) : 0, r.predict2 = mt;
+  }
+  r.bestn = bestn, r.settled = 0;
   PGX_HIP(hipMemsetAsync(ph.p, 0, (size_t)pcap * sizeof(PHot), s));
   PGX_HIP(hipMemsetAsync(pc.p, 0, (size_t)pcap * sizeof(PCold), s));
   PGX_HIP(hipMemsetAsync(mt.p, 0, (size_t)mcap * sizeof(MSlot), s));
