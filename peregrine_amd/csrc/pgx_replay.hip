@@ -1011,6 +1011,15 @@ __global__ __launch_bounds__(256) void k_settle(R r) {
     uint32_t type;
     const bool acc = classify(r.rq_res[req], r.rlen[e0.rid], r.rlen[e1.rid], e0.pos1 - e1.pos1, &type);
     if (!acc || type != gtype) bad = true;
+#ifdef PGX_SETTLE_STATS
+    if (!acc || type != gtype) {
+      const uint32_t rl0 = r.rlen[e0.rid], rl1 = r.rlen[e1.rid], qo = e0.pos1 - e1.pos1;
+      const uint32_t ol = min(rl0 - qo, rl1);
+      const pgx_match mm = r.rq_res[req];
+      int cat = acc ? 3 : (ol <= 520 ? 4 : (mm.q_end == 0 && mm.t_end == 0 ? 5 : 6));
+      atomicAdd(&r.spread[((j >> 6) % SPREAD) * 8 + cat], 1ULL);
+    }
+#endif
     else im.info &= ~I_GUESS;
   }
   if (bad) r.dirty[j] = 1;
@@ -1136,6 +1145,11 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     if (totals) {
       hc->evals = hc->lookups = hc->skips = 0;
       for (uint32_t i = 0; i < SPREAD; ++i) hc->evals += hs[i * 8], hc->lookups += hs[i * 8 + 1], hc->skips += hs[i * 8 + 2];
+#ifdef PGX_SETTLE_STATS
+      unsigned long long c3 = 0, c4 = 0, c5 = 0, c6 = 0;
+      for (uint32_t i = 0; i < SPREAD; ++i) c3 += hs[i * 8 + 3], c4 += hs[i * 8 + 4], c5 += hs[i * 8 + 5], c6 += hs[i * 8 + 6];
+      fprintf(stderr, "[pgx]   wrong guesses so far: type %llu, rejected short overlap %llu, rejected no match %llu, rejected other %llu\n", c3, c4, c5, c6);
+#endif
     }
   };
   auto read_counters = [&](bool count_dirty) {
