@@ -890,30 +890,87 @@ __global__ __launch_bounds__(256) void k_update(R r, uint32_t lo, uint32_t hi, u
   if (alive && gl == 0) r.evaluated[j] = 0, r.ohead[j] = NIL;
 }
 
-__global__ __launch_bounds__(256) void k_count(R r) {
-  // One list position per dirty bucket.  Atomics on ONE address are served one wavefront-instruction at a time (~12 ns each):
-  // with every wavefront of a dense round holding a dirty bucket that was 0.7 ms of this kernel.  So: one add per BLOCK (the four
-  // wavefronts' counts meet in LDS; positions stay ascending within the block), and the range atomics only while they can
-  // still move the bound.
-  __shared__ uint32_t s_cnt[4], s_base;
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const bool d = j < r.nb && r.dirty[j];
-  const uint64_t m = __ballot(d);
-  if (lane == 0) s_cnt[w] = (uint32_t)__popcll(m);
-  __syncthreads();
-  const uint32_t c0 = s_cnt[0], c1 = s_cnt[1], c2 = s_cnt[2], c3 = s_cnt[3], total = c0 + c1 + c2 + c3;
-  if (!total) return;
-  if (threadIdx.x == 0) s_base = atomicAdd(&r.c->ndirty, total);
-  if (m && lane == (int)__builtin_ctzll(m)) {
-    if (j < *(volatile uint32_t *)&r.c->min_dirty) atomicMin(&r.c->min_dirty, j);
-    const uint32_t top = (j & ~63u) + 63 - (uint32_t)__builtin_clzll(m);
-    if (top > *(volatile uint32_t *)&r.c->max_dirty) atomicMax(&r.c->max_dirty, top);
+// ---- the dirty buckets: how many, in which range, and (while they fit) their list, LOWEST FIRST -------------------------
+// Two small launches: blocks of CB buckets count theirs (16 flags per lane, one 16-byte load), then every block adds up the
+// counts of the blocks before it and writes its ids at that offset.  The list is exactly ascending, so when more than LIST_CAP
+// buckets are dirty the list keeps the LOWEST ones (evaluating those first wastes the fewest evaluations -- the round-1 form
+// took list positions by atomics in arrival order, and atomics on one address cost ~12 ns each: with every block holding a
+// dirty bucket a count took 0.46 ms, ten times per step).
+constexpr uint32_t CB = 4096;  // buckets per block of the count kernels (256 lanes x 16)
+__device__ __forceinline__ uint32_t dirty16(const R &r, uint32_t j0) {  // bit i: bucket j0 + i is dirty (j0 a multiple of 16)
+  if (j0 >= r.nb) return 0;
+  uint32_t m = 0;
+  if (j0 + 16 <= r.nb) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(r.dirty + j0);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) m |= ((w[q] >> (8 * b)) & 0xFFu) ? 1u << (4 * q + b) : 0u;
+  } else {
+    for (uint32_t i = 0; j0 + i < r.nb; ++i) m |= r.dirty[j0 + i] ? 1u << i : 0u;
   }
+  return m;
+}
+__global__ __launch_bounds__(256) void k_count_a(R r, uint32_t *__restrict__ blk) {  // blk[3 b + {0, 1, 2}] = count, lowest, highest
+  __shared__ uint32_t s_c[4], s_lo[4], s_hi[4];
+  const uint32_t j0 = blockIdx.x * CB + threadIdx.x * 16;
+  const uint32_t m = dirty16(r, j0);
+  uint32_t c = (uint32_t)__popc(m), lo = m ? j0 + (uint32_t)__builtin_ctz(m) : 0xFFFFFFFFu, hi = m ? j0 + 31u - (uint32_t)__builtin_clz(m) : 0u;
+  for (int o = 32; o; o >>= 1) {
+    c += (uint32_t)__shfl_xor((int)c, o, 64);
+    lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
+    hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) s_c[w] = c, s_lo[w] = lo, s_hi[w] = hi;
   __syncthreads();
-  const uint32_t before = w == 0 ? 0 : w == 1 ? c0 : w == 2 ? c0 + c1 : c0 + c1 + c2;
-  const uint32_t at = s_base + before + lane_rank(m);
-  if (d && at < LIST_CAP) r.dlist[at] = j;
+  if (threadIdx.x == 0) {
+    blk[3 * blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+    blk[3 * blockIdx.x + 1] = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+    blk[3 * blockIdx.x + 2] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
+  }
+}
+__global__ __launch_bounds__(256) void k_count_b(R r, const uint32_t *__restrict__ blk, uint32_t nblk) {
+  __shared__ uint32_t s_part[4], s_lo[4], s_hi[4], s_tot[4], s_w[4];
+  // the counts of the blocks before this one (and, in block 0, the totals of all of them)
+  uint32_t before = 0, total = 0, lo = 0xFFFFFFFFu, hi = 0;
+  const bool totals = blockIdx.x == 0;
+  for (uint32_t b = threadIdx.x; b < nblk; b += 256) {
+    const uint32_t c = blk[3 * b];
+    if (b < blockIdx.x) before += c;
+    if (totals) total += c, lo = min(lo, blk[3 * b + 1]), hi = max(hi, blk[3 * b + 2]);
+  }
+  for (int o = 32; o; o >>= 1) {
+    before += (uint32_t)__shfl_xor((int)before, o, 64);
+    if (totals) {
+      total += (uint32_t)__shfl_xor((int)total, o, 64);
+      lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
+      hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
+    }
+  }
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) s_part[w] = before, s_tot[w] = total, s_lo[w] = lo, s_hi[w] = hi;
+  const uint32_t j0 = blockIdx.x * CB + threadIdx.x * 16;
+  const uint32_t m = dirty16(r, j0);
+  const uint32_t c = (uint32_t)__popc(m);
+  uint32_t incl = c;   // lanes of a wavefront: inclusive scan
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_w[w] = incl;
+  __syncthreads();
+  if (totals && threadIdx.x == 0) {
+    const uint32_t n = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
+    r.c->ndirty = n;
+    r.c->min_dirty = n ? min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3])) : 0xFFFFFFFFu;
+    r.c->max_dirty = n ? max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3])) : 0u;
+  }
+  if (!m) return;
+  uint32_t at = s_part[0] + s_part[1] + s_part[2] + s_part[3] + incl - c;
+  for (int q = 0; q < w; ++q) at += s_w[q];
+  for (uint32_t mm = m; mm && at < LIST_CAP; mm &= mm - 1, ++at) r.dlist[at] = j0 + (uint32_t)__builtin_ctz(mm);
 }
 
 // ---- file the alignments the converged lists still need ---------------------------------------------------------------
@@ -1152,10 +1209,15 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
 #endif
     }
   };
+  const uint32_t nblk = (uint32_t)((nb + CB - 1) / CB);
+  DevBuf<uint32_t> cblk((size_t)nblk * 3);
+  auto launch_count = [&]() {
+    hipLaunchKernelGGL(k_count_a, dim3(nblk), dim3(256), 0, s, r, cblk.p);
+    hipLaunchKernelGGL(k_count_b, dim3(nblk), dim3(256), 0, s, r, cblk.p, nblk);
+  };
   auto read_counters = [&](bool count_dirty) {
     if (count_dirty) {  // reset the three dirty statistics, keep the rest
-      PGX_HIP(hipMemcpyAsync(&dc.p->ndirty, reset3, 3 * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-      hipLaunchKernelGGL(k_count, dim3(cdiv256(nb)), dim3(256), 0, s, r);
+      launch_count();
     }
     fetch(true);
     return hc->overflow == 0;
@@ -1180,8 +1242,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   bool known = true;                       // n_dirty / d_lo / d_hi are current
   double align_ms = 0;
   auto count_dirty = [&](bool reset = false) {  // no host round trip: ndirty, the range and the list stay on the device
-    if (reset) PGX_HIP(hipMemcpyAsync(&dc.p->ndirty, reset3, 3 * sizeof(uint32_t), hipMemcpyHostToDevice, s));  // (k_update / k_settle reset otherwise)
-    hipLaunchKernelGGL(k_count, dim3(cdiv256(nb)), dim3(256), 0, s, r);
+    (void)reset;
+    launch_count();
     have_list = true;
   };
   for (;;) {
