@@ -88,8 +88,6 @@ struct R {
   const uint64_t *y0;
   const uint8_t *dir;
   const uint32_t *rlen;
-  uint2 *hdr;      // per visited bucket j: {first record, number of records | F_DUP << 31} (k_setup): one load instead of bid -> bstart
-  uint32_t *erl;   // per record: the length of its read (k_setup), beside y0 / dir: no dependent gather when a bucket is staged
   PHot *ph;
   PCold *pc;
   uint32_t pmask;
@@ -228,8 +226,6 @@ __global__ __launch_bounds__(256) void k_setup(R r) {
   }
   r.bflags[j] = dup ? F_DUP : 0;
   r.dirty[j] = 1;
-  r.hdr[j] = make_uint2(s0, n | (dup ? 0x80000000u : 0u));
-  for (uint32_t i = 0; i < n; ++i) r.erl[s0 + i] = r.rlen[(uint32_t)(r.y0[s0 + i] >> 32)];
 }
 
 // ---- shimmer_to_overlap (shmr_overlap.c:52-180) for every dirty bucket in [lo, hi) -------------------------------------
@@ -312,7 +308,6 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPW + (uint32_t)(lane / GL));
   const uint32_t j = (uint32_t)jj;
-  const uint2 hd = jj < hi ? r.hdr[j] : make_uint2(0u, 0u);   // (asked for together with the dirty flag, not behind it)
   bool alive = jj < hi && r.dirty[j] && !r.c->overflow;
   {
     const uint64_t am = __ballot(alive);
@@ -327,13 +322,14 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
   uint32_t s0 = 0, n = 0;
   bool dup = false, first_eval = true;
   if (alive) {
-    s0 = hd.x, n = hd.y & 0x7FFFFFFFu;
-    dup = (hd.y >> 31) != 0;
+    const uint32_t b = r.bid[j];
+    s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
+    dup = (r.bflags[j] & F_DUP) != 0;
     first_eval = r.ever[j] == 0;
     for (uint32_t i = (uint32_t)gl; i < n; i += GL) {  // the bucket's entries -> LDS
       const uint64_t y = r.y0[s0 + i];
       const uint32_t rid = (uint32_t)(y >> 32);
-      s_rid[gib][i] = rid, s_pos[gib][i] = (((uint32_t)y) >> 1) + 1, s_dir[gib][i] = r.dir[s0 + i], s_rl[gib][i] = r.erl[s0 + i];
+      s_rid[gib][i] = rid, s_pos[gib][i] = (((uint32_t)y) >> 1) + 1, s_dir[gib][i] = r.dir[s0 + i], s_rl[gib][i] = r.rlen[rid];
     }
     if (gl == 0) {
       r.dirty[j] = 0;
@@ -564,7 +560,6 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPWT + (uint32_t)(lane / GLT));
   const uint32_t j = (uint32_t)jj;
-  const uint2 hd = jj < hi ? r.hdr[j] : make_uint2(0u, 0u);   // (asked for together with the dirty flag, not behind it)
   bool alive = jj < hi && r.dirty[j] && !r.c->overflow;
   {
     const uint64_t am = __ballot(alive);
@@ -579,13 +574,14 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
   uint32_t s0 = 0, n = 0;
   bool dup = false, first_eval = true;
   if (alive) {
-    s0 = hd.x, n = hd.y & 0x7FFFFFFFu;
-    dup = (hd.y >> 31) != 0;
+    const uint32_t b = r.bid[j];
+    s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
+    dup = (r.bflags[j] & F_DUP) != 0;
     first_eval = r.ever[j] == 0;
     for (uint32_t i = (uint32_t)gl; i < n; i += GLT) {  // the bucket's entries -> LDS
       const uint64_t y = r.y0[s0 + i];
       const uint32_t rid = (uint32_t)(y >> 32);
-      s_rid[gib][i] = rid, s_pos[gib][i] = (((uint32_t)y) >> 1) + 1, s_dir[gib][i] = r.dir[s0 + i], s_rl[gib][i] = r.erl[s0 + i];
+      s_rid[gib][i] = rid, s_pos[gib][i] = (((uint32_t)y) >> 1) + 1, s_dir[gib][i] = r.dir[s0 + i], s_rl[gib][i] = r.rlen[rid];
     }
     if (gl == 0) {
       r.dirty[j] = 0;
@@ -1149,9 +1145,6 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   DevBuf<uint32_t> bid(d_bids ? 0 : nb);   // (d_bids: the visit list was assembled on the device, dev_place_bids)
   if (!d_bids) bid.upload(visit_bids, nb);
   r.bid = d_bids ? d_bids : bid.p, r.bstart = dp.bstart.p, r.y0 = dp.y0.p, r.dir = dp.dir.p, r.rlen = db->d_rlen.p;
-  DevBuf<uint2> hdr(nb);
-  DevBuf<uint32_t> erl(std::max<size_t>(dp.y0.n, 1));
-  r.hdr = hdr.p, r.erl = erl.p;
   const uint32_t pcap = pow2_at_least((size_t)(ne * mult[3])), mcap = pow2_at_least((size_t)(ne * mult[4]));
   DevBuf<PHot> ph(pcap);
   DevBuf<PCold> pc(pcap);
