@@ -69,7 +69,9 @@ struct RNode {
   uint32_t next, bucket;
 };
 constexpr uint32_t I_GUESS = 1u << 18, I_UNFILED = 1u << 19;
-constexpr uint32_t LIST_CAP = 65536, DEV_LIST = 0xFFFFFFFFu;
+constexpr uint32_t SPARSE_CAP = 65536;   // buckets a sparse pass takes from the list
+constexpr uint32_t LIST_CAP = 262144;    // capacity of the list (a window of a dense round is listed whole)
+constexpr uint32_t DEV_LIST = 0xFFFFFFFFu, DEV_LIST_WIN = 0xFFFFFFFEu;  // nlist: the device's list, up to SPARSE_CAP / LIST_CAP entries
 enum : uint32_t { OV_ITEMS = 1, OV_NODES = 2, OV_REQS = 4, OV_PAIRS = 8, OV_MEMO = 16, OV_QOFF = 32, OV_PASSES = 64 };  // Counters::overflow
 constexpr uint8_t F_DUP = 1, F_GUESS = 2, F_UNFILED = 4;
 
@@ -266,7 +268,7 @@ __device__ __forceinline__ uint64_t gbits(uint64_t wave_mask, int gbase) { retur
 // group g of the launch -> its bucket (a range of buckets, or the dirty list)
 __device__ __forceinline__ uint64_t bucket_of_group(const R &r, uint32_t lo, uint32_t hi, uint32_t nlist, uint32_t g) {
   if (nlist) {
-    const uint32_t n = nlist == DEV_LIST ? min(r.c->ndirty, LIST_CAP) : nlist;  // (DEV_LIST: as many as the last count listed)
+    const uint32_t n = nlist == DEV_LIST ? min(r.c->ndirty, SPARSE_CAP) : nlist == DEV_LIST_WIN ? min(r.c->ndirty, LIST_CAP) : nlist;  // (DEV_LIST*: as many as the last count listed)
     return g < n ? (uint64_t)r.dlist[g] : (uint64_t)hi;
   }
   return (uint64_t)lo + g;
@@ -859,7 +861,8 @@ __global__ __launch_bounds__(256) void k_update(R r, uint32_t lo, uint32_t hi, u
   const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPW + (uint32_t)(lane / GL));
   const uint32_t j = (uint32_t)jj;
   const bool alive = jj < hi && r.evaluated[j] && !r.c->overflow;
-  if (blockIdx.x == 0 && threadIdx.x == 0) r.c->ndirty = 0, r.c->min_dirty = 0xFFFFFFFFu, r.c->max_dirty = 0;  // (the count that follows starts afresh)
+  // (the dirty statistics are NOT touched here: the list-mode blocks of this very launch read ndirty as their list length, and
+  // the count that follows writes absolute values)
   if (!__ballot(alive)) return;
   const uint32_t pnew = alive ? r.parity[j] : 0, pold = pnew ^ 1;
   // what this evaluation inserts: take or refresh ownership (lowest bucket wins)
@@ -897,10 +900,10 @@ __global__ __launch_bounds__(256) void k_update(R r, uint32_t lo, uint32_t hi, u
 // took list positions by atomics in arrival order, and atomics on one address cost ~12 ns each: with every block holding a
 // dirty bucket a count took 0.46 ms, ten times per step).
 constexpr uint32_t CB = 4096;  // buckets per block of the count kernels (256 lanes x 16)
-__device__ __forceinline__ uint32_t dirty16(const R &r, uint32_t j0) {  // bit i: bucket j0 + i is dirty (j0 a multiple of 16)
-  if (j0 >= r.nb) return 0;
+__device__ __forceinline__ uint32_t dirty16(const R &r, uint32_t j0, uint32_t end) {  // bit i: bucket j0 + i < end is dirty (j0 a multiple of 16)
+  if (j0 >= end) return 0;
   uint32_t m = 0;
-  if (j0 + 16 <= r.nb) {
+  if (j0 + 16 <= end) {
     const uint4 v = *reinterpret_cast<const uint4 *>(r.dirty + j0);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -908,14 +911,14 @@ __device__ __forceinline__ uint32_t dirty16(const R &r, uint32_t j0) {  // bit i
 #pragma unroll
       for (int b = 0; b < 4; ++b) m |= ((w[q] >> (8 * b)) & 0xFFu) ? 1u << (4 * q + b) : 0u;
   } else {
-    for (uint32_t i = 0; j0 + i < r.nb; ++i) m |= r.dirty[j0 + i] ? 1u << i : 0u;
+    for (uint32_t i = 0; j0 + i < end; ++i) m |= r.dirty[j0 + i] ? 1u << i : 0u;
   }
   return m;
 }
-__global__ __launch_bounds__(256) void k_count_a(R r, uint32_t *__restrict__ blk) {  // blk[3 b + {0, 1, 2}] = count, lowest, highest
+__global__ __launch_bounds__(256) void k_count_a(R r, uint32_t rlo, uint32_t rhi, uint32_t *__restrict__ blk) {  // blk[3 b + {0, 1, 2}] = count, lowest, highest
   __shared__ uint32_t s_c[4], s_lo[4], s_hi[4];
-  const uint32_t j0 = blockIdx.x * CB + threadIdx.x * 16;
-  const uint32_t m = dirty16(r, j0);
+  const uint32_t j0 = rlo + blockIdx.x * CB + threadIdx.x * 16;   // (rlo: a multiple of 16)
+  const uint32_t m = dirty16(r, j0, rhi);
   uint32_t c = (uint32_t)__popc(m), lo = m ? j0 + (uint32_t)__builtin_ctz(m) : 0xFFFFFFFFu, hi = m ? j0 + 31u - (uint32_t)__builtin_clz(m) : 0u;
   for (int o = 32; o; o >>= 1) {
     c += (uint32_t)__shfl_xor((int)c, o, 64);
@@ -931,7 +934,7 @@ __global__ __launch_bounds__(256) void k_count_a(R r, uint32_t *__restrict__ blk
     blk[3 * blockIdx.x + 2] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
   }
 }
-__global__ __launch_bounds__(256) void k_count_b(R r, const uint32_t *__restrict__ blk, uint32_t nblk) {
+__global__ __launch_bounds__(256) void k_count_b(R r, uint32_t rlo, uint32_t rhi, const uint32_t *__restrict__ blk, uint32_t nblk) {
   __shared__ uint32_t s_part[4], s_lo[4], s_hi[4], s_tot[4], s_w[4];
   // the counts of the blocks before this one (and, in block 0, the totals of all of them)
   uint32_t before = 0, total = 0, lo = 0xFFFFFFFFu, hi = 0;
@@ -951,8 +954,8 @@ __global__ __launch_bounds__(256) void k_count_b(R r, const uint32_t *__restrict
   }
   const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) s_part[w] = before, s_tot[w] = total, s_lo[w] = lo, s_hi[w] = hi;
-  const uint32_t j0 = blockIdx.x * CB + threadIdx.x * 16;
-  const uint32_t m = dirty16(r, j0);
+  const uint32_t j0 = rlo + blockIdx.x * CB + threadIdx.x * 16;   // (rlo: a multiple of 16)
+  const uint32_t m = dirty16(r, j0, rhi);
   const uint32_t c = (uint32_t)__popc(m);
   uint32_t incl = c;   // lanes of a wavefront: inclusive scan
   for (int o = 1; o < 64; o <<= 1) {
@@ -1051,7 +1054,6 @@ __global__ __launch_bounds__(256) void k_file(R r, uint32_t limit) {
 // ---- check the guesses against the results ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_settle(R r) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j == 0) r.c->ndirty = 0, r.c->min_dirty = 0xFFFFFFFFu, r.c->max_dirty = 0;  // (the count that follows starts afresh)
   if (j >= r.nb || !(r.bflags[j] & F_GUESS)) return;
   const uint32_t b = r.bid[j], s0 = r.bstart[b];
   bool bad = false, remain = false;
@@ -1150,7 +1152,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   DevBuf<PCold> pc(pcap);
   DevBuf<MSlot> mt(mcap);
   r.ph = ph.p, r.pc = pc.p, r.pmask = pcap - 1, r.mt = mt.p, r.mmask = mcap - 1;
-  r.item_cap = (uint32_t)std::min<size_t>((size_t)(ne * 6 * mult[0]) + nb * (size_t)64 + (size_t)(LIST_CAP + 8) * ICH + (1u << 20), 0x7FFFFFF0u);
+  r.item_cap = (uint32_t)std::min<size_t>((size_t)(ne * 6 * mult[0]) + nb * (size_t)64 + (size_t)(SPARSE_CAP + 8) * ICH + (1u << 20), 0x7FFFFFF0u);
   r.rn_cap = (uint32_t)std::min<size_t>((size_t)(ne * 8 * mult[1]) + (1u << 20), 0x7FFFFFF0u);
   r.req_cap = (uint32_t)std::min<size_t>((size_t)(ne * 1 * mult[2]) + 65536, 0x7FFFFFF0u);
   DevBuf<Item> items(r.item_cap);
@@ -1162,7 +1164,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   DevBuf<uint32_t> words(nb * 5);
   r.dirty = bytes.p, r.evaluated = bytes.p + nb, r.parity = bytes.p + 2 * nb, r.bflags = bytes.p + 3 * nb, r.ever = bytes.p + 4 * nb;
   r.ihead = words.p, r.inum = words.p + nb, r.ohead = words.p + 2 * nb, r.lookups = words.p + 3 * nb, r.skips = words.p + 4 * nb;
-  DevBuf<uint4> wcur(nb + 2 + LIST_CAP + 1);  // (one slot per wavefront of k_eval: GPW buckets each)
+  DevBuf<uint4> wcur(nb + 2 + SPARSE_CAP + 1);  // (one slot per wavefront of k_eval: GPW buckets each)
   r.wcur = wcur.p, r.wlist0 = (uint32_t)(nb + 2);
   DevBuf<uint32_t> dlist(LIST_CAP);
   r.dlist = dlist.p;
@@ -1211,9 +1213,11 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   };
   const uint32_t nblk = (uint32_t)((nb + CB - 1) / CB);
   DevBuf<uint32_t> cblk((size_t)nblk * 3);
-  auto launch_count = [&]() {
-    hipLaunchKernelGGL(k_count_a, dim3(nblk), dim3(256), 0, s, r, cblk.p);
-    hipLaunchKernelGGL(k_count_b, dim3(nblk), dim3(256), 0, s, r, cblk.p, nblk);
+  auto launch_count = [&](uint32_t lo = 0, uint32_t hi = 0xFFFFFFFFu) {  // count + list of the dirty buckets of [lo, hi)
+    hi = std::min<uint32_t>(hi, (uint32_t)nb);
+    const uint32_t nbl = std::max<uint32_t>(1, (hi - lo + CB - 1) / CB);
+    hipLaunchKernelGGL(k_count_a, dim3(nbl), dim3(256), 0, s, r, lo, hi, cblk.p);
+    hipLaunchKernelGGL(k_count_b, dim3(nbl), dim3(256), 0, s, r, lo, hi, cblk.p, nbl);
   };
   auto read_counters = [&](bool count_dirty) {
     if (count_dirty) {  // reset the three dirty statistics, keep the rest
@@ -1225,7 +1229,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   const size_t window = getenv("PGX_REPLAY_WIN") ? (size_t)atoll(getenv("PGX_REPLAY_WIN")) : (size_t)262144;
   const size_t win0 = getenv("PGX_REPLAY_WIN0") ? (size_t)std::max(64ll, atoll(getenv("PGX_REPLAY_WIN0")) & ~63ll) : (size_t)16384;
   const size_t win1 = getenv("PGX_REPLAY_WIN1") ? (size_t)std::max(64ll, atoll(getenv("PGX_REPLAY_WIN1")) & ~63ll) : (size_t)131072;  // largest window of the first pass
-  const size_t dense_min = getenv("PGX_REPLAY_DENSE_MIN") ? (size_t)atoll(getenv("PGX_REPLAY_DENSE_MIN")) : (size_t)LIST_CAP;  // dense rounds from this many dirty buckets
+  const size_t dense_min = getenv("PGX_REPLAY_DENSE_MIN") ? (size_t)atoll(getenv("PGX_REPLAY_DENSE_MIN")) : (size_t)SPARSE_CAP;  // dense rounds from this many dirty buckets
+  const bool use_win_list = !(getenv("PGX_REPLAY_WINLIST") && atoi(getenv("PGX_REPLAY_WINLIST")) == 0);
   const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 3;
   const bool wide = !(getenv("PGX_REPLAY_WIDE") && atoi(getenv("PGX_REPLAY_WIDE")) == 0);  // sparse passes: a wavefront per bucket, four rows per step
   const size_t dense_den = getenv("PGX_REPLAY_DENSE") ? (size_t)std::max(1, atoi(getenv("PGX_REPLAY_DENSE"))) : 3;  // dense rounds while more than 1/dense_den of the buckets is dirty
@@ -1269,12 +1274,18 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
             std::optional<KernelTimer> tm;  // PGX_REPLAY_TIMING=1: "replay_dense" = k_eval, "replay_rows" = k_eval_rows, "replay_update" = k_update
             if (timed) tm.emplace(wide_dense ? "replay_rows" : "replay_dense", k == 0 ? hi - lo : 0);  // (units: buckets of the window, once)
             if (deep) sync(), td = now_ms();
+            // all but the very first evaluation of a window find only a part of its buckets dirty: they run from the window's
+            // list (wavefronts full of live buckets) instead of over every bucket of the window
+            const bool from_list = use_win_list && !(first_pass && k == 0) && !wide_dense && hi - lo <= LIST_CAP;
+            if (from_list) launch_count((uint32_t)lo, hi);
             if (wide_dense) hipLaunchKernelGGL((k_eval_rows<64, 16>), dim3(cdiv256((size_t)(hi - lo) * 64)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
+            else if (from_list) hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST_WIN);
             else hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
             tm.reset();
             if (deep) sync(), t_eval += now_ms() - td, td = now_ms();
             if (timed) tm.emplace("replay_update", 0);
-            hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
+            if (from_list) hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST_WIN);
+            else hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
             tm.reset();
             if (deep) sync(), t_upd += now_ms() - td, fprintf(stderr, "[pgx]     iteration: eval %.3f ms, update %.3f ms\n", t_eval, t_upd), t_eval = t_upd = 0;
           }
@@ -1286,8 +1297,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
       // the count behind it
       if (!have_list) count_dirty(true);
       {
-        const size_t est = known && n_dirty <= LIST_CAP / 4 ? std::max<size_t>(n_dirty * 4, 1024) : (size_t)LIST_CAP;
-        const unsigned groups = (unsigned)std::min<size_t>(est, LIST_CAP);
+        const size_t est = known && n_dirty <= SPARSE_CAP / 4 ? std::max<size_t>(n_dirty * 4, 1024) : (size_t)SPARSE_CAP;
+        const unsigned groups = (unsigned)std::min<size_t>(est, SPARSE_CAP);
         for (int c = 0; c < chain; ++c) {
           std::optional<KernelTimer> tm;
           if (timed) tm.emplace(wide ? "replay_rows" : "replay_dense", 0);
@@ -1338,7 +1349,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
       if (!n_dirty) break;
     } else {
       known = false;  // (a small batch: the wrong guesses are handled by the sparse passes of the next round)
-      n_dirty = std::min<size_t>(batch, LIST_CAP / 8);
+      n_dirty = std::min<size_t>(batch, SPARSE_CAP / 8);
       if (trace) fprintf(stderr, "[pgx]   %zu alignments + settle enqueued in %.2f ms\n", batch, now_ms() - a0);
     }
     align_ms += now_ms() - a0;
