@@ -111,6 +111,7 @@ struct R {
   Counters *c;
   unsigned long long *spread;  // the totals (evaluations, look-ups, skips) over SPREAD cache lines: [line * 8 + {0, 1, 2}], summed by the host
   uint32_t bestn;
+  uint32_t tail;           // the sweeps have become small: k_file also files the alignment every OTHER reader of a requested pair would ask for
   int predict, predict2;   // margins of predict_contained (0: every pending alignment is guessed a plain overlap)
 };
 
@@ -976,6 +977,52 @@ __global__ __launch_bounds__(256) void k_count_b(R r, uint32_t rlo, uint32_t rhi
   for (uint32_t mm = m; mm && at < LIST_CAP; mm &= mm - 1, ++at) r.dlist[at] = j0 + (uint32_t)__builtin_ctz(mm);
 }
 
+// Tail sweeps.  A pair whose alignment is rejected is not entered in the seen-pair table, so the next bucket holding both reads
+// aligns it again from its own anchors -- and is rejected again, and so on through the ~30 buckets the two reads share: one
+// sweep (one lone 0.33 ms alignment) per hand-over, which is what the last ~15 sweeps of a 4.5 Gbase set consist of.  Once
+// the sweeps are small, a bucket that files an alignment therefore also files the one every other registered reader of that
+// pair would ask for (its rows for the two reads, its anchors): the results are in the memo when those buckets come to it.
+// A speculative request is just an alignment whose result the memo holds; at worst it is never asked for.
+__device__ __forceinline__ void file_for_reader(const R &r, uint32_t C, uint32_t rid_a, uint32_t rid_b) {
+  const uint32_t b = r.bid[C], s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
+  int ia = -1, ib = -1;
+  bool twice = false;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t rid = (uint32_t)(r.y0[s0 + i] >> 32);
+    if (rid == rid_a) twice |= ia >= 0, ia = (int)i;
+    else if (rid == rid_b) twice |= ib >= 0, ib = (int)i;
+  }
+  if (ia < 0 || ib < 0 || twice) return;
+  const uint32_t row = (uint32_t)min(ia, ib), par = (uint32_t)max(ia, ib);  // the row is the entry with the smaller index
+  const Ent e0 = entry_of(r.y0[s0 + row]), e1 = entry_of(r.y0[s0 + par]);
+  if (e0.pos1 < e1.pos1) return;
+  const uint32_t dir0 = r.dir[s0 + row], dir1 = r.dir[s0 + par], q_off = e0.pos1 - e1.pos1;
+  const unsigned long long a = (unsigned long long)e0.rid << 32 | e1.rid;
+  const uint32_t bk = q_off << 2 | dir0 << 1 | dir1;
+  uint32_t i = (uint32_t)mix64(a ^ mix64(bk)) & r.mmask;
+  for (int probes = 0; probes < 1024; ++probes) {
+    unsigned long long cur = r.mt[i].a;
+    if (cur == 0) {
+      cur = atomicCAS(&r.mt[i].a, 0ULL, a);
+      if (cur == 0) {  // new: a request of its own
+        r.mt[i].b = bk + 1;
+        const uint32_t my = atomicAdd(&r.c->nreq, 1u);
+        if (my >= r.req_cap) {
+          atomicOr(&r.c->overflow, OV_REQS);
+          return;
+        }
+        pgx_align_key key;
+        key.rid0 = e0.rid, key.rid1 = e1.rid, key.q_off = q_off, key.dir0 = (uint8_t)dir0, key.dir1 = (uint8_t)dir1, key.pad[0] = key.pad[1] = 0;
+        r.rq_key[my] = key;
+        r.mt[i].req = my;
+        return;
+      }
+    }
+    if (cur == a && *(volatile uint32_t *)&r.mt[i].b == bk + 1) return;  // known already
+    i = (i + 1) & r.mmask;
+  }
+}
+
 // ---- file the alignments the converged lists still need ---------------------------------------------------------------
 // (Only buckets that are not dirty right now are filed -- the others are about to be evaluated again.  Filing while the sweep
 // is still running is always safe: a request is just an alignment whose result the memo will hold; at worst it is never
@@ -1047,6 +1094,19 @@ __global__ __launch_bounds__(256) void k_file(R r, uint32_t limit) {
     ++my;
     im.mslot = found;
     im.info &= ~I_UNFILED;
+    if (r.tail && fresh) {  // (see file_for_reader)
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[im.pslot]);
+      const uint32_t c = min(w[0], NIN);
+      for (uint32_t q = 0; q < c; ++q) {
+        const uint32_t rb = w[2 + q];
+        if (rb != 0 && rb - 1 != j && rb - 1 < r.nb) file_for_reader(r, rb - 1, e0.rid, e1.rid);
+      }
+      if (c >= NIN)
+        for (uint32_t nd = w[1]; nd != NIL; nd = r.rn[nd - 1].next) {
+          const uint32_t rb = r.rn[nd - 1].bucket;
+          if (rb != j && rb < r.nb) file_for_reader(r, rb, e0.rid, e1.rid);
+        }
+    }
   }
   r.bflags[j] &= (uint8_t)~F_UNFILED;
 }
@@ -1230,6 +1290,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   const size_t win0 = getenv("PGX_REPLAY_WIN0") ? (size_t)std::max(64ll, atoll(getenv("PGX_REPLAY_WIN0")) & ~63ll) : (size_t)16384;
   const size_t win1 = getenv("PGX_REPLAY_WIN1") ? (size_t)std::max(64ll, atoll(getenv("PGX_REPLAY_WIN1")) & ~63ll) : (size_t)131072;  // largest window of the first pass
   const size_t dense_min = getenv("PGX_REPLAY_DENSE_MIN") ? (size_t)atoll(getenv("PGX_REPLAY_DENSE_MIN")) : (size_t)SPARSE_CAP;  // dense rounds from this many dirty buckets
+  const size_t tail_max = getenv("PGX_REPLAY_TAIL") ? (size_t)atoll(getenv("PGX_REPLAY_TAIL")) : (size_t)4000;  // tail mode (file_for_reader) once a sweep asks for at most this many alignments
   const bool use_win_list = !(getenv("PGX_REPLAY_WINLIST") && atoi(getenv("PGX_REPLAY_WINLIST")) == 0);
   const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 3;
   const bool wide = !(getenv("PGX_REPLAY_WIDE") && atoi(getenv("PGX_REPLAY_WIDE")) == 0);  // sparse passes: a wavefront per bucket, four rows per step
@@ -1335,6 +1396,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     if (nreq == first_req) break;
     const double a0 = now_ms();
     const size_t batch = nreq - first_req;
+    r.tail = tail_max && batch <= tail_max ? 1u : 0u;   // (the NEXT sweep's k_file)
     dev_align(db, r.rq_key + first_req, batch, band, r.rq_res + first_req);
     r.settled = (uint32_t)nreq;
     first_req = nreq;
