@@ -111,7 +111,8 @@ struct R {
   Counters *c;
   unsigned long long *spread;  // the totals (evaluations, look-ups, skips) over SPREAD cache lines: [line * 8 + {0, 1, 2}], summed by the host
   uint32_t bestn;
-  uint32_t tail;           // the sweeps have become small: k_file also files the alignment every OTHER reader of a requested pair would ask for
+  uint32_t tail;           // != 0: the sweeps have become small: k_file also files the alignment every OTHER reader of a requested pair would ask
+                           // for and the row's next `tail` partners
   int predict, predict2;   // margins of predict_contained (0: every pending alignment is guessed a plain overlap)
 };
 
@@ -983,20 +984,12 @@ __global__ __launch_bounds__(256) void k_count_b(R r, uint32_t rlo, uint32_t rhi
 // the sweeps are small, a bucket that files an alignment therefore also files the one every other registered reader of that
 // pair would ask for (its rows for the two reads, its anchors): the results are in the memo when those buckets come to it.
 // A speculative request is just an alignment whose result the memo holds; at worst it is never asked for.
-__device__ __forceinline__ void file_for_reader(const R &r, uint32_t C, uint32_t rid_a, uint32_t rid_b) {
-  const uint32_t b = r.bid[C], s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
-  int ia = -1, ib = -1;
-  bool twice = false;
-  for (uint32_t i = 0; i < n; ++i) {
-    const uint32_t rid = (uint32_t)(r.y0[s0 + i] >> 32);
-    if (rid == rid_a) twice |= ia >= 0, ia = (int)i;
-    else if (rid == rid_b) twice |= ib >= 0, ib = (int)i;
-  }
-  if (ia < 0 || ib < 0 || twice) return;
-  const uint32_t row = (uint32_t)min(ia, ib), par = (uint32_t)max(ia, ib);  // the row is the entry with the smaller index
+// file the alignment of entries (row, par) of a bucket whose records start at s0, unless the memo knows it already
+__device__ __forceinline__ void file_entries(const R &r, uint32_t s0, uint32_t row, uint32_t par) {
   const Ent e0 = entry_of(r.y0[s0 + row]), e1 = entry_of(r.y0[s0 + par]);
-  if (e0.pos1 < e1.pos1) return;
+  if (e0.pos1 < e1.pos1 || e0.rid == e1.rid) return;
   const uint32_t dir0 = r.dir[s0 + row], dir1 = r.dir[s0 + par], q_off = e0.pos1 - e1.pos1;
+  if (q_off >= (1u << 30)) return;
   const unsigned long long a = (unsigned long long)e0.rid << 32 | e1.rid;
   const uint32_t bk = q_off << 2 | dir0 << 1 | dir1;
   uint32_t i = (uint32_t)mix64(a ^ mix64(bk)) & r.mmask;
@@ -1021,6 +1014,18 @@ __device__ __forceinline__ void file_for_reader(const R &r, uint32_t C, uint32_t
     if (cur == a && *(volatile uint32_t *)&r.mt[i].b == bk + 1) return;  // known already
     i = (i + 1) & r.mmask;
   }
+}
+__device__ __forceinline__ void file_for_reader(const R &r, uint32_t C, uint32_t rid_a, uint32_t rid_b) {
+  const uint32_t b = r.bid[C], s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
+  int ia = -1, ib = -1;
+  bool twice = false;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t rid = (uint32_t)(r.y0[s0 + i] >> 32);
+    if (rid == rid_a) twice |= ia >= 0, ia = (int)i;
+    else if (rid == rid_b) twice |= ib >= 0, ib = (int)i;
+  }
+  if (ia < 0 || ib < 0 || twice) return;
+  file_entries(r, s0, (uint32_t)min(ia, ib), (uint32_t)max(ia, ib));  // (the row is the entry with the smaller index)
 }
 
 // ---- file the alignments the converged lists still need ---------------------------------------------------------------
@@ -1094,6 +1099,11 @@ __global__ __launch_bounds__(256) void k_file(R r, uint32_t limit) {
     ++my;
     im.mslot = found;
     im.info &= ~I_UNFILED;
+    if (r.tail) {  // ... and the row's next partners: if this one is rejected the row goes on to them (a row of a repeat-rich
+                   // bucket can have dozens of candidates, each rejection otherwise costing a sweep)
+      const uint32_t nn = r.bstart[b + 1] - s0;
+      for (uint32_t p = pi + 1; p < nn && p <= pi + r.tail; ++p) file_entries(r, s0, ai, p);
+    }
     if (r.tail && fresh) {  // (see file_for_reader)
       const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[im.pslot]);
       const uint32_t c = min(w[0], NIN);
@@ -1290,7 +1300,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   const size_t win0 = getenv("PGX_REPLAY_WIN0") ? (size_t)std::max(64ll, atoll(getenv("PGX_REPLAY_WIN0")) & ~63ll) : (size_t)16384;
   const size_t win1 = getenv("PGX_REPLAY_WIN1") ? (size_t)std::max(64ll, atoll(getenv("PGX_REPLAY_WIN1")) & ~63ll) : (size_t)131072;  // largest window of the first pass
   const size_t dense_min = getenv("PGX_REPLAY_DENSE_MIN") ? (size_t)atoll(getenv("PGX_REPLAY_DENSE_MIN")) : (size_t)SPARSE_CAP;  // dense rounds from this many dirty buckets
-  const size_t tail_max = getenv("PGX_REPLAY_TAIL") ? (size_t)atoll(getenv("PGX_REPLAY_TAIL")) : (size_t)4000;  // tail mode (file_for_reader) once a sweep asks for at most this many alignments
+  const size_t tail_max = getenv("PGX_REPLAY_TAIL") ? (size_t)atoll(getenv("PGX_REPLAY_TAIL")) : (size_t)4000;  // tail mode (file_for_reader, look-ahead) once a sweep asks for at most this many alignments, or 1/256 of the first sweep's
+  const uint32_t ahead = getenv("PGX_REPLAY_AHEAD") ? (uint32_t)std::max(1, atoi(getenv("PGX_REPLAY_AHEAD"))) : 8u;   // tail mode: partners of a row filed ahead
   const bool use_win_list = !(getenv("PGX_REPLAY_WINLIST") && atoi(getenv("PGX_REPLAY_WINLIST")) == 0);
   const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 3;
   const bool wide = !(getenv("PGX_REPLAY_WIDE") && atoi(getenv("PGX_REPLAY_WIDE")) == 0);  // sparse passes: a wavefront per bucket, four rows per step
@@ -1307,6 +1318,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   bool have_list = false;                  // the device holds a dirty list (a count has run since the last evaluations)
   bool known = true;                       // n_dirty / d_lo / d_hi are current
   double align_ms = 0;
+  size_t first_batch = 0;   // alignments the first sweep asked for
   auto count_dirty = [&](bool reset = false) {  // no host round trip: ndirty, the range and the list stay on the device
     (void)reset;
     launch_count();
@@ -1396,7 +1408,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     if (nreq == first_req) break;
     const double a0 = now_ms();
     const size_t batch = nreq - first_req;
-    r.tail = tail_max && batch <= tail_max ? 1u : 0u;   // (the NEXT sweep's k_file)
+    if (sweeps == 1) first_batch = batch;
+    r.tail = tail_max && batch <= std::max(tail_max, first_batch / 256) ? ahead : 0u;   // (the NEXT sweep's k_file)
     dev_align(db, r.rq_key + first_req, batch, band, r.rq_res + first_req);
     r.settled = (uint32_t)nreq;
     first_req = nreq;
