@@ -35,9 +35,11 @@ __device__ __forceinline__ int match8(uint64_t qa, uint64_t ta, int qs, int ts) 
   const uint64_t diff = ((qa >> qs) ^ (ta >> ts)) & 0x0F0F0F0F0F0F0F0FULL;
   return diff ? (__builtin_ctzll(diff) >> 3) : 8;
 }
+// (the HIP __ballot takes an int: the compiler materialises 0/1 and compares again; the builtin takes the predicate's lane mask as is)
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 template <int CTRL>
 __device__ __forceinline__ int dpp_max(int v) {
-  return max(v, __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false));
+  return max(v, __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true));   // (bound_ctrl: folds into one v_max_i32_dpp)
 }
 // maximum over the GL (8 or 16) lanes of a group, result in every lane: xor-butterfly with quad_perm / row_half_mirror /
 // row_mirror
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(64) void k_align1(const uint8_t *__restrict__ seq, 
         }
       }
       // long snakes (normally one per step): the whole wavefront extends one diagonal, 512 codes per iteration
-      uint64_t mm = __ballot(more);
+      uint64_t mm = ballot64(more);
       while (mm) {
         const int L = __builtin_ctzll(mm);
         const int xs = __builtin_amdgcn_readlane(x, L), ys = __builtin_amdgcn_readlane(y, L);
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(64) void k_align1(const uint8_t *__restrict__ seq, 
         const int off = lane * 8;
         int m = 0;
         if (off < rem) m = min(match8(load_u64_unaligned(q + xs + off), load_u64_unaligned(t + ys + off), qs, ts), rem - off);
-        const uint64_t stop = __ballot(m < 8);
+        const uint64_t stop = ballot64(m < 8);
         int ext;
         if (stop) {
           const int f = __builtin_ctzll(stop);
@@ -147,20 +149,20 @@ __global__ __launch_bounds__(64) void k_align1(const uint8_t *__restrict__ seq, 
       }
       const int ext = x - x1;
       const bool hit = active && (x >= q_len || y >= t_len);
-      const uint64_t hitmask = __ballot(hit);
+      const uint64_t hitmask = ballot64(hit);
       const int hl = hitmask ? __builtin_ctzll(hitmask) : 64;
       const bool valid = active && lane <= hl;
       if (!started) {
-        const uint64_t m = __ballot(valid && ext > 16);
+        const uint64_t m = ballot64(valid && ext > 16);
         if (m) {
           const int l = __builtin_ctzll(m);
           q_bgn = __builtin_amdgcn_readlane(x1, l), t_bgn = __builtin_amdgcn_readlane(y1, l);
           started = true;
         }
       }
-      if (__ballot(valid && (uint32_t)ext > longest)) {
+      if (ballot64(valid && (uint32_t)ext > longest)) {
         const int mx = wave_max_i32(valid ? ext : -1);
-        const int l = __builtin_ctzll(__ballot(valid && ext == mx));
+        const int l = __builtin_ctzll(ballot64(valid && ext == mx));
         longest = (uint32_t)mx;
         q_m_end = __builtin_amdgcn_readlane(x, l), t_m_end = __builtin_amdgcn_readlane(y, l);
       }
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(64) void k_align1(const uint8_t *__restrict__ seq, 
       int u;
       if (nk <= 64) u = x + y;  // still in registers
       else u = j < nk ? 2 * V[k2 & mask] - k2 : 0;
-      const uint64_t m = __ballot(j < nk && u >= thr);
+      const uint64_t m = ballot64(j < nk && u >= thr);
       if (m) {
         new_min = min(new_min, min_k + 2 * (base + __builtin_ctzll(m)));
         new_max = max(new_max, min_k + 2 * (base + 63 - __builtin_clzll(m)));
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
         alive = true;
       }
     }
-    if (!__ballot(alive)) break;
+    if (!ballot64(alive)) break;
     __syncthreads();
 
     // ---- end of the d-loop without a match (DWmatch.c:118-122,196-199) ---------------------------------------
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
     int x = 0, y = 0;
     for (int base = 0;; base += GL) {
       const bool inround = stepping && !matched && base < nk;
-      if (!__ballot(inround)) break;
+      if (!ballot64(inround)) break;
       const int j = base + gl;
       const bool active = inround && j < nk;
       const int k = min_k + 2 * j;
@@ -296,7 +298,7 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
         }
       }
       // long snakes: the group extends one diagonal at a time, 128 codes per iteration
-      uint64_t mw = __ballot(more);
+      uint64_t mw = ballot64(more);
       while (mw) {
         const uint32_t gm = group_bits<GL>(mw, gbase);
         const bool has = gm != 0;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
             m = min(m, rem - off);
           }
         }
-        const uint32_t sg = group_bits<GL>(__ballot(has && m < SL), gbase);
+        const uint32_t sg = group_bits<GL>(ballot64(has && m < SL), gbase);
         int ext = GL * SL;
         if (sg) {
           const int f = __builtin_ctz(sg);
@@ -326,11 +328,11 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
           x += ext, y += ext;
           if (sg || ext >= rem) more = false;  // mismatch found or an end reached: this diagonal is done
         }
-        mw = __ballot(more);
+        mw = ballot64(more);
       }
       const int ext = x - x1;
       const bool hit = active && (x >= q_len || y >= t_len);
-      const uint64_t hitw = __ballot(hit);  // rare (once per candidate): everything that depends on it sits behind the branch
+      const uint64_t hitw = ballot64(hit);  // rare (once per candidate): everything that depends on it sits behind the branch
       int hl = GL;
       if (hitw) {
         const uint32_t hitm = group_bits<GL>(hitw, gbase);
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
       }
       const bool valid = active && gl <= hl;
       {  // first extension > 16 fixes q_bgn/t_bgn once (DWmatch.c:142-146)
-        const uint64_t sw = __ballot(valid && ext > 16 && !started);
+        const uint64_t sw = ballot64(valid && ext > 16 && !started);
         if (sw) {
           const uint32_t m = group_bits<GL>(sw, gbase);
           const int l = m ? __builtin_ctz(m) : 0;
@@ -346,9 +348,9 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
           if (m) q_bgn = bx, t_bgn = by, started = true;
         }
       }
-      if (__ballot(valid && (uint32_t)ext > longest)) {  // strictly longer extension (DWmatch.c:148-152)
+      if (ballot64(valid && (uint32_t)ext > longest)) {  // strictly longer extension (DWmatch.c:148-152)
         const int mx = group_max_i32<GL>(valid ? ext : -1);
-        const uint32_t m = group_bits<GL>(__ballot(valid && ext == mx), gbase);
+        const uint32_t m = group_bits<GL>(ballot64(valid && ext == mx), gbase);
         const int l = m ? __builtin_ctz(m) : 0;
         const int ex = __shfl(x, gbase + l, 64), ey = __shfl(y, gbase + l, 64);
         if (inround && mx >= 0 && (uint32_t)mx > longest) longest = (uint32_t)mx, q_m_end = ex, t_m_end = ey;
@@ -381,12 +383,12 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
     const int thr = best_m - band;
     for (int base = 0;; base += GL) {
       const bool inround = stepping && base < nk;
-      if (!__ballot(inround)) break;
+      if (!ballot64(inround)) break;
       const int j = base + gl;
       const int k2 = min_k + 2 * j;
       int u = 0;
       if (inround && j < nk) u = (nk <= GL) ? x + y : 2 * (int)V[k2 & mask] - k2;
-      const uint32_t m = group_bits<GL>(__ballot(inround && j < nk && u >= thr), gbase);
+      const uint32_t m = group_bits<GL>(ballot64(inround && j < nk && u >= thr), gbase);
       if (m) {
         new_min = min(new_min, min_k + 2 * (base + __builtin_ctz(m)));
         new_max = max(new_max, min_k + 2 * (base + 31 - __builtin_clz(m)));
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
         phase = PH_STEP;
       }
     }
-    if (!__ballot(phase != PH_DONE)) break;
+    if (!ballot64(phase != PH_DONE)) break;
     __syncthreads();
 
     // ---- STEP: the loop conditions of a new d (DWmatch.c:118-122,196-199) -------------------------------------------
@@ -515,13 +517,13 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
       }
     }
     {
-      const uint32_t gm = group_bits<GL>(__ballot(more && phase == PH_ROUND), gbase);
+      const uint32_t gm = group_bits<GL>(ballot64(more && phase == PH_ROUND), gbase);
       if (phase == PH_ROUND) phase = gm ? PH_SNAKE : PH_END;
     }
 
     // ---- SNAKE: one extension of the group's lowest unfinished diagonal ----------------------------------------------
     {
-      const uint64_t mw = __ballot(more && phase == PH_SNAKE);
+      const uint64_t mw = ballot64(more && phase == PH_SNAKE);
       if (mw) {
         const uint32_t gm = group_bits<GL>(mw, gbase);
         const bool has = gm != 0 && phase == PH_SNAKE;
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
             m = min(m, rem - off);
           }
         }
-        const uint32_t sg = group_bits<GL>(__ballot(has && m < SL), gbase);
+        const uint32_t sg = group_bits<GL>(ballot64(has && m < SL), gbase);
         int ext = GL * SL;
         if (sg) {
           const int f = __builtin_ctz(sg);
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
           x += ext, y += ext;
           if (sg || ext >= rem) more = false;  // mismatch found or an end reached: this diagonal is done
         }
-        const uint32_t gm2 = group_bits<GL>(__ballot(more && phase == PH_SNAKE), gbase);
+        const uint32_t gm2 = group_bits<GL>(ballot64(more && phase == PH_SNAKE), gbase);
         if (phase == PH_SNAKE && !gm2) phase = PH_END;
       }
     }
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
       const bool e = phase == PH_END;
       const int ext = x - x1;
       const bool hit = e && active && (x >= q_len || y >= t_len);
-      const uint64_t hitw = __ballot(hit);
+      const uint64_t hitw = ballot64(hit);
       int hl = GL;
       uint32_t hitm = 0;
       if (hitw) {
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
       }
       const bool valid = e && active && gl <= hl;
       {  // first extension > 16 fixes q_bgn/t_bgn once (DWmatch.c:142-146)
-        const uint64_t sw = __ballot(valid && ext > 16 && !started);
+        const uint64_t sw = ballot64(valid && ext > 16 && !started);
         if (sw) {
           const uint32_t m = group_bits<GL>(sw, gbase);
           const int l = m ? __builtin_ctz(m) : 0;
@@ -580,9 +582,9 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
           if (m) q_bgn = bx, t_bgn = by, started = true;
         }
       }
-      if (__ballot(valid && (uint32_t)ext > longest)) {  // strictly longer extension (DWmatch.c:148-152)
+      if (ballot64(valid && (uint32_t)ext > longest)) {  // strictly longer extension (DWmatch.c:148-152)
         const int mx = group_max_i32<GL>(valid ? ext : -1);
-        const uint32_t m = group_bits<GL>(__ballot(valid && ext == mx), gbase);
+        const uint32_t m = group_bits<GL>(ballot64(valid && ext == mx), gbase);
         const int l = m ? __builtin_ctz(m) : 0;
         const int ex = __shfl(x, gbase + l, 64), ey = __shfl(y, gbase + l, 64);
         if (e && mx >= 0 && (uint32_t)mx > longest) longest = (uint32_t)mx, q_m_end = ex, t_m_end = ey;
@@ -621,13 +623,13 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
     // ---- BAND: one round of the band update (DWmatch.c:166-183) ------------------------------------------------------
     {
       const bool bnd = phase == PH_BAND;
-      if (__ballot(bnd)) {
+      if (ballot64(bnd)) {
         const int thr = best_m - band;
         const int j = bbase + gl;
         const int k2 = min_k + 2 * j;
         int u = 0;
         if (bnd && j < nk) u = (nk <= GL) ? x + y : 2 * (int)V[k2 & mask] - k2;
-        const uint32_t m = group_bits<GL>(__ballot(bnd && j < nk && u >= thr), gbase);
+        const uint32_t m = group_bits<GL>(ballot64(bnd && j < nk && u >= thr), gbase);
         if (bnd) {
           if (m) {
             new_min = min(new_min, min_k + 2 * (bbase + __builtin_ctz(m)));
