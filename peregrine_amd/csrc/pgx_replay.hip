@@ -1301,7 +1301,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   const size_t win1 = getenv("PGX_REPLAY_WIN1") ? (size_t)std::max(64ll, atoll(getenv("PGX_REPLAY_WIN1")) & ~63ll) : (size_t)131072;  // largest window of the first pass
   const size_t dense_min = getenv("PGX_REPLAY_DENSE_MIN") ? (size_t)atoll(getenv("PGX_REPLAY_DENSE_MIN")) : (size_t)SPARSE_CAP;  // dense rounds from this many dirty buckets
   const size_t tail_max = getenv("PGX_REPLAY_TAIL") ? (size_t)atoll(getenv("PGX_REPLAY_TAIL")) : (size_t)4000;  // tail mode (file_for_reader, look-ahead) once a sweep asks for at most this many alignments, or 1/256 of the first sweep's
-  const uint32_t ahead = getenv("PGX_REPLAY_AHEAD") ? (uint32_t)std::max(1, atoi(getenv("PGX_REPLAY_AHEAD"))) : 8u;   // tail mode: partners of a row filed ahead
+  const uint32_t ahead = getenv("PGX_REPLAY_AHEAD") ? (uint32_t)std::max(1, atoi(getenv("PGX_REPLAY_AHEAD"))) : 24u;   // tail mode: partners of a row filed ahead
   const bool use_win_list = !(getenv("PGX_REPLAY_WINLIST") && atoi(getenv("PGX_REPLAY_WINLIST")) == 0);
   const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 3;
   const bool wide = !(getenv("PGX_REPLAY_WIDE") && atoi(getenv("PGX_REPLAY_WIDE")) == 0);  // sparse passes: a wavefront per bucket, four rows per step
