@@ -545,7 +545,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
             m = min(m, rem - off);
           }
         }
-        const uint32_t sg = group_bits<GL>(ballot64(has && m < SL), gbase);
+        const uint32_t sg = group_bits<GL>(ballot64(m < SL), gbase);   // (m == SL wherever !has: one compare, no mask logic)
         int ext = GL * SL;
         if (sg) {
           const int f = __builtin_ctz(sg);
@@ -574,7 +574,8 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
       }
       const bool valid = e && active && gl <= hl;
       {  // first extension > 16 fixes q_bgn/t_bgn once (DWmatch.c:142-146)
-        const uint64_t sw = ballot64(valid && ext > 16 && !started);
+        const uint64_t sw = ballot64((valid && !started ? ext : 0) > 16);   // (a select + ONE compare: the compiler turns a ballot of
+                                                                           // combined predicates into select 0/1 + compare on top of them)
         if (sw) {
           const uint32_t m = group_bits<GL>(sw, gbase);
           const int l = m ? __builtin_ctz(m) : 0;
@@ -582,8 +583,9 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
           if (m) q_bgn = bx, t_bgn = by, started = true;
         }
       }
-      if (ballot64(valid && (uint32_t)ext > longest)) {  // strictly longer extension (DWmatch.c:148-152)
-        const int mx = group_max_i32<GL>(valid ? ext : -1);
+      const int ev = valid ? ext : -1;
+      if (ballot64(ev > (int)longest)) {  // strictly longer extension (DWmatch.c:148-152)
+        const int mx = group_max_i32<GL>(ev);
         const uint32_t m = group_bits<GL>(ballot64(valid && ext == mx), gbase);
         const int l = m ? __builtin_ctz(m) : 0;
         const int ex = __shfl(x, gbase + l, 64), ey = __shfl(y, gbase + l, 64);
@@ -629,7 +631,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
         const int k2 = min_k + 2 * j;
         int u = 0;
         if (bnd && j < nk) u = (nk <= GL) ? x + y : 2 * (int)V[k2 & mask] - k2;
-        const uint32_t m = group_bits<GL>(ballot64(bnd && j < nk && u >= thr), gbase);
+        const uint32_t m = group_bits<GL>(ballot64((bnd && j < nk ? u : INT32_MIN) >= thr), gbase);
         if (bnd) {
           if (m) {
             new_min = min(new_min, min_k + 2 * (bbase + __builtin_ctz(m)));
