@@ -275,16 +275,25 @@ bool sketch_blk_supported(int w, int k, int rs, int levels);
 void launch_sketch_blk(const pgx_seqdb *db, const ReadDesc *d_reads, uint32_t n, int rs, int levels, pgx_mm128 *d_slab,
                        const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags);
 void launch_sketch_fused_list(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n_list, int rs,
-                              int levels, pgx_mm128 *d_slab, const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags);
+                              int levels, pgx_mm128 *d_slab, const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags,
+                              uint32_t *d_need = nullptr, int off_by_list = 0);
 void launch_sketch_fused(const pgx_seqdb *db, const ReadDesc *d_reads, uint32_t n, int rs, int levels, pgx_mm128 *d_slab,
                          const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags);
 
+__global__ void k_need_of_list(const uint32_t *__restrict__ need, const uint32_t *__restrict__ list, uint32_t n, uint64_t *__restrict__ out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = need[list[i]];
+}
+// skip (optional): reads whose elements live elsewhere (the exact-size slabs of the second redo pass); off_by_list: slab_off is
+// indexed by the position in `list`
 __global__ void k_gather_slabs(const pgx_mm128 *__restrict__ slab, const uint64_t *__restrict__ slab_off,
                                const uint32_t *__restrict__ list, uint32_t n_list, const uint32_t *__restrict__ counts,
-                               const uint64_t *__restrict__ out_off, pgx_mm128 *__restrict__ out) {
+                               const uint64_t *__restrict__ out_off, pgx_mm128 *__restrict__ out,
+                               const uint32_t *__restrict__ skip = nullptr, int off_by_list = 0) {
   if (blockIdx.x >= n_list) return;
   const uint32_t slot = list ? list[blockIdx.x] : blockIdx.x;
-  const pgx_mm128 *src = slab + slab_off[slot];
+  if (skip && skip[slot]) return;
+  const pgx_mm128 *src = slab + slab_off[off_by_list ? blockIdx.x : slot];
   pgx_mm128 *dst = out + out_off[slot];
   const uint32_t n = counts[slot];
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
@@ -729,6 +738,10 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
   static const char *mode_env = getenv("PGX_SKETCH");
   static const bool want_fuse = (getenv("PGX_FUSE") && atoi(getenv("PGX_FUSE")) != 0) || (mode_env && !strcmp(mode_env, "fuse"));
   static const bool want_wave = mode_env && !strcmp(mode_env, "wave");
+  uint32_t n_redo2 = 0;               // reads redone into exact-size slabs (slab2, offsets by list position)
+  pgx_mm128 *slab2 = nullptr;
+  uint64_t *d_off2_keep = nullptr;
+  uint32_t *d_list2_keep = nullptr, *d_in2 = nullptr;
   if (!want_fuse && !want_wave && sketch_blk_supported(w, k, rs, levels)) {
     {
       KernelTimer tm("sketch", bases);
@@ -756,8 +769,36 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
     }
     if (nredo) {
       KernelTimer tm("sketch_redo", 0);
+      uint32_t *d_need = ws<uint32_t>("ix.need", n);
       PGX_HIP(hipMemsetAsync(d_flags, 0, (size_t)n * sizeof(uint32_t), st));
-      launch_sketch_fused_list(db, d_reads, d_list, nredo, rs, levels, slab, d_slab_off, d_ctop, d_flags);
+      launch_sketch_fused_list(db, d_reads, d_list, nredo, rs, levels, slab, d_slab_off, d_ctop, d_flags, d_need, 0);
+      // Low-complexity reads (a homopolymer or a short-period tandem array makes every position a tied minimum, on every level)
+      // can outgrow their slab; the kernel reports how many elements each such read has, and a second launch redoes exactly
+      // those reads into slabs of exactly that size.  (Round 1 redid the WHOLE chunk on the slow general path when a single
+      // read was left over: 0.4 s instead of 15 ms at 9 Gbases with 1 % low-complexity sequence.)
+      uint32_t *d_list2 = ws<uint32_t>("ix.redo2", (size_t)n + 1);
+      PGX_HIP(hipcub::DeviceSelect::Flagged(stmp, sbytes, iota, d_flags, d_list2, d_list2 + n, (int)n, st));
+      PGX_HIP(hipMemcpyAsync(&n_redo2, d_list2 + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      sync();
+      if (n_redo2) {
+        uint64_t *d_off2 = ws<uint64_t>("ix.off2", (size_t)n_redo2 + 1);
+        hipLaunchKernelGGL(k_need_of_list, dim3(cdiv(n_redo2, 256)), dim3(256), 0, st, d_need, d_list2, n_redo2, d_off2 + 1);
+        PGX_HIP(hipMemsetAsync(d_off2, 0, sizeof(uint64_t), st));
+        size_t b2 = 0;
+        PGX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, b2, d_off2 + 1, d_off2 + 1, (int)n_redo2, st));
+        void *t2 = ws_raw("ix.scan2_tmp", b2);
+        PGX_HIP(hipcub::DeviceScan::InclusiveSum(t2, b2, d_off2 + 1, d_off2 + 1, (int)n_redo2, st));
+        uint64_t total2 = 0;
+        PGX_HIP(hipMemcpyAsync(&total2, d_off2 + n_redo2, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        sync();
+        slab2 = ws<pgx_mm128>("ix.slab2", std::max<uint64_t>(total2, 1));
+        d_off2_keep = d_off2, d_list2_keep = d_list2;
+        d_in2 = ws<uint32_t>("ix.in2", n);
+        PGX_HIP(hipMemcpyAsync(d_in2, d_flags, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));   // (1 for the reads of list 2)
+        PGX_HIP(hipMemsetAsync(d_flags, 0, (size_t)n * sizeof(uint32_t), st));
+        launch_sketch_fused_list(db, d_reads, d_list2, n_redo2, rs, levels, slab2, d_off2, d_ctop, d_flags, nullptr, 1);
+        if (trace) fprintf(stderr, "[pgx] index: %u reads outgrew their slabs and were redone into exact ones (%llu elements)\n", n_redo2, (unsigned long long)total2);
+      }
     }
     hipLaunchKernelGGL(k_count_flags, dim3(cdiv(n, 256)), dim3(256), 0, st, d_flags, n, d_nbad);
   } else if (want_fuse && sketch_fused_supported(w, rs, levels)) {
@@ -784,12 +825,24 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
   PGX_HIP(hipMemcpyAsync(&nbad, d_nbad, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   sync();
   if (trace) fprintf(stderr, "[pgx] index: sketch + reduce done at +%.2f ms\n", trace_ms() - tr0);
+  if (trace && nbad) {
+    std::vector<uint32_t> hf(n);
+    PGX_HIP(hipMemcpy(hf.data(), d_flags, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    unsigned why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t f : hf)
+      for (int b = 0; b < 8; ++b) why[b] += (f >> b) & 1u;
+    fprintf(stderr, "[pgx] index: %u reads still flagged after the general closed-form kernel (bits 0..7: %u %u %u %u %u %u %u %u)\n", nbad, why[0], why[1], why[2],
+            why[3], why[4], why[5], why[6], why[7]);
+  }
   if (nbad) return false;  // some read needs the general path; the caller redoes the chunk there
   pgx_mm128 *top = ws<pgx_mm128>("ix.top", total);
   if (total) {
     KernelTimer tm("sketch_gather", bases);
     hipLaunchKernelGGL(k_gather_slabs, dim3(n), dim3(64), 0, st, slab, d_slab_off, (const uint32_t *)nullptr, n, d_ctop, d_offs,
-                       top);
+                       top, (const uint32_t *)d_in2, 0);
+    if (n_redo2)
+      hipLaunchKernelGGL(k_gather_slabs, dim3(n_redo2), dim3(64), 0, st, slab2, d_off2_keep, (const uint32_t *)d_list2_keep, n_redo2, d_ctop,
+                         d_offs, top, (const uint32_t *)nullptr, 1);
   }
   *d_top = top;
   *n_top = (size_t)total;

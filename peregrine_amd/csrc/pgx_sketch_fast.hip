@@ -277,7 +277,9 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
                                                     const uint32_t *__restrict__ list, uint32_t n_list,
                                                     pgx_mm128 *__restrict__ slab, const uint64_t *__restrict__ slab_off,
                                                     uint32_t *__restrict__ counts, uint32_t *__restrict__ flags, int rs,
-                                                    int levels) {
+                                                    int levels, uint32_t *__restrict__ need, int off_by_list) {
+  // need (optional): the number of elements the read produces, written even when its slab was too small (a second launch
+  // with exact slabs then redoes exactly those reads); off_by_list: slab_off is indexed by the position in `list`, not by slot
   constexpr int W = 16 * A;  // window size in entries = A chunks of 16
   using Lds = LdsT<nb_for(A)>;
   __shared__ __attribute__((aligned(16))) Lds s;
@@ -292,8 +294,9 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
   const uint8_t *base = seq + (rd.off - (uint64_t)lead);
   const int span = lead + len;
   const int ntiles = (span + TILE - 1) / TILE;
-  pgx_mm128 *out = slab + slab_off[slot];
-  const uint32_t cap = (uint32_t)(slab_off[slot + 1] - slab_off[slot]);
+  const uint32_t oi = off_by_list ? blockIdx.x : slot;
+  pgx_mm128 *out = slab + slab_off[oi];
+  const uint32_t cap = (uint32_t)(slab_off[oi + 1] - slab_off[oi]);
 
   int E = 0;       // entries produced so far
   int qbase = 0;   // absolute chunk number of buffer chunk 0
@@ -496,22 +499,28 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
           }
           nout += (uint32_t)etot;
         } else {
-          if (etot > RSTAGE) {
-            bad |= 1;  // a burst of ties (low-complexity read): the general path redoes this read
-          } else {
-            if (rst[0].nnew + etot > RSTAGE) fused_flush();
-            int w = rst[0].ncarry + rst[0].nnew + (einc - ec);
+          // the step's entries go to the level-0 staging area in position order; a burst of ties (a homopolymer or a short-period
+          // tandem array makes EVERY position a tied window minimum: up to 1,024 entries in a step) is staged and flushed in
+          // pieces of at most RSTAGE
+          for (int done = 0; done < etot;) {  // (wave-uniform)
+            if (rst[0].nnew + min(etot - done, RSTAGE) > RSTAGE) fused_flush();
+            const int take = min(RSTAGE - rst[0].nnew, etot - done);
+            const int w0 = rst[0].ncarry + rst[0].nnew - done;
+            int g = einc - ec;  // ordinal of this lane's first entry among the step's
             uint32_t em = emask;
             while (em) {
               const int o = __builtin_ctz(em);
               em &= em - 1;
-              const uint32_t pz = s.P[bq * CST + o];
-              const int i = imax - ((imax - (int)(pz >> 1)) & 0x7FFF);
-              red.h[0][w] = s.H[bq * CST + o];
-              red.y[0][w] = ((uint32_t)i << 1) | (pz & 1u);
-              ++w;
+              if (g >= done && g < done + take) {
+                const uint32_t pz = s.P[bq * CST + o];
+                const int i = imax - ((imax - (int)(pz >> 1)) & 0x7FFF);
+                red.h[0][w0 + g] = s.H[bq * CST + o];
+                red.y[0][w0 + g] = ((uint32_t)i << 1) | (pz & 1u);
+              }
+              ++g;
             }
-            rst[0].nnew += etot;
+            rst[0].nnew += take;
+            done += take;
             __syncthreads();
             if (rst[0].nnew >= 96) fused_flush();  // a flush costs ~300 wave instructions: amortise it over ~4 tiles
           }
@@ -526,6 +535,7 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
   if (lane == 0) {
     counts[slot] = anybad ? 0u : nout;
     if (anybad) flags[slot] = 1;
+    if (need) need[slot] = nout;
   }
 }
 
@@ -940,9 +950,10 @@ bool sketch_wave_eligible(const ReadDesc &rd, int w, int k) {
 
 template <bool FUSED, int A>
 static void launch_w(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n, pgx_mm128 *d_slab,
-                     const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags, int rs, int levels) {
+                     const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags, int rs, int levels, uint32_t *d_need = nullptr,
+                     int off_by_list = 0) {
   hipLaunchKernelGGL((k_sketch_wave<FUSED, A>), dim3(n), dim3(64), 0, ctx().stream, db->d_seq.p, d_reads, d_list, n, d_slab,
-                     d_slab_off, d_counts, d_flags, rs, levels);
+                     d_slab_off, d_counts, d_flags, rs, levels, d_need, off_by_list);
 }
 
 void launch_sketch_wave(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n_list, int w,
@@ -982,9 +993,10 @@ void launch_sketch_blk(const pgx_seqdb *db, const ReadDesc *d_reads, uint32_t n,
   PGX_HIP(hipGetLastError());
 }
 void launch_sketch_fused_list(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n_list, int rs,
-                              int levels, pgx_mm128 *d_slab, const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags) {
+                              int levels, pgx_mm128 *d_slab, const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags,
+                              uint32_t *d_need, int off_by_list) {
   if (!n_list) return;
-  launch_w<true, 5>(db, d_reads, d_list, n_list, d_slab, d_slab_off, d_counts, d_flags, rs, levels);
+  launch_w<true, 5>(db, d_reads, d_list, n_list, d_slab, d_slab_off, d_counts, d_flags, rs, levels, d_need, off_by_list);
   PGX_HIP(hipGetLastError());
 }
 
