@@ -707,9 +707,12 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
     std::vector<uint64_t> slab_off(n + 1, 0);
     uint64_t bases = 0;
     plan_ok = true;
+    // slab of a read: len / 8 + 64 elements (PGX_SLAB_DIV / PGX_SLAB_MIN: test knobs that make reads outgrow their slabs)
+    const uint64_t slab_div = getenv("PGX_SLAB_DIV") ? std::max(1ll, atoll(getenv("PGX_SLAB_DIV"))) : 8;
+    const uint64_t slab_min = getenv("PGX_SLAB_MIN") ? std::max(1ll, atoll(getenv("PGX_SLAB_MIN"))) : 64;
     for (uint32_t i = 0; i < n; ++i) {
       if (!sketch_wave_eligible(reads[i], w, k)) plan_ok = false;
-      slab_off[i + 1] = slab_off[i] + (uint64_t)reads[i].len / 8 + 64;
+      slab_off[i + 1] = slab_off[i] + (uint64_t)reads[i].len / slab_div + slab_min;
       bases += reads[i].len;
     }
     if (plan_ok) {

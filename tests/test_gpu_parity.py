@@ -315,6 +315,50 @@ def test_adversarial_reads_all_paths():
     rdb.close()
 
 
+@pytest.mark.parametrize("tiny_slabs", [False, True])
+def test_low_complexity_reads_stay_on_the_fused_index_path(monkeypatch, tiny_slabs):
+    """homopolymers and short-period tandem arrays make every position a tied minimizer (bursts of up to 1,024 per tile, thousands
+    of top-level shimmers per read): the fused index path stages the bursts in pieces and redoes reads that outgrow their slab
+    into exact slabs -- no read is handed to the literal kernel, and the lists equal the oracle's"""
+    if tiny_slabs:   # 8 elements per read: nearly every read outgrows its slab and goes through the exact-slab pass
+        monkeypatch.setenv("PGX_SLAB_DIV", "1000000")
+        monkeypatch.setenv("PGX_SLAB_MIN", "8")
+    rng = np.random.default_rng(77)
+    rnd = lambda n: rng.integers(0, 4, n).astype(np.uint8)
+    reads = [
+        np.concatenate([rnd(3000), np.zeros(400, np.uint8), rnd(5000)]),            # poly-A run
+        np.concatenate([rnd(2000), np.resize(rnd(2), 3000), rnd(4000)]),            # period 2
+        np.concatenate([rnd(1000), np.resize(rnd(7), 2500), rnd(6000), np.resize(rnd(39), 3000), rnd(500)]),
+        np.resize(rnd(3), 15000),                                                   # all tandem: ~5,000 shimmers on every level
+        np.resize(rnd(5), 20000), np.full(9000, 2, np.uint8),                       # all tandem / one long homopolymer
+        np.concatenate([np.full(1500, 1, np.uint8), rnd(9000), np.full(1500, 3, np.uint8)]),   # runs at both read ends
+    ]
+    reads += [rnd(int(n)) for n in rng.integers(5000, 20000, 60)]
+    for i in range(0, 40, 4):                                                       # errors inside the arrays, like real reads
+        r = reads[7 + i].copy()
+        r[2000:2600] = np.resize(rnd(4), 600)
+        r[2100] ^= 1
+        r[2300] ^= 2
+        reads[7 + i] = r
+    enc = [_enc(r) for r in reads]
+    rlen = np.array([len(e) for e in enc], np.uint32)
+    roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
+    from peregrine_amd.formats import SeqDB
+    db = SeqDB(np.concatenate(enc), np.arange(len(enc), dtype=np.uint32), rlen, roff, None)
+    rdb = ResidentDB(db, 0)
+    l0 = np.concatenate([U.orc_sketch_seqdb(e, 80, 16, i) for i, e in enumerate(enc)])
+    l1 = U.orc_reduce(l0, 6)
+    l2 = U.orc_reduce(l1, 6)
+    a = rdb.index()
+    assert np.array_equal(a.top, l2)
+    assert a.reads_literal == 0                                                     # nothing fell back to the general path
+    b = rdb.index(levels=1)
+    assert np.array_equal(b.top, l1) and b.reads_literal == 0
+    assert np.array_equal(rdb.index(total_chunk=2, mychunk=2).top,
+                          U.orc_reduce(U.orc_reduce(np.concatenate([U.orc_sketch_seqdb(e, 80, 16, i) for i, e in enumerate(enc) if i % 2 == 0]), 6), 6))
+    rdb.close()
+
+
 def _write_query_files(tmp_path):
     """the tiny set's seqdb / idx / two-chunk level-2 index as files (inputs of query_cases.npz)"""
     q, mmers, mc, rlen = G.query_fixture()
