@@ -199,15 +199,13 @@ struct Visit {
 // The replay threads hammer one shared table with locked operations: spread over both sockets they run ~1.7x slower than
 // on one (measured, 2 x EPYC 9575F).  NodePin keeps the caller and the threads it starts on the memory node the caller
 // is running on, for the lifetime of the object (PGX_PIN=0 disables it).
-struct NodePin {
-  cpu_set_t saved, node;
-  bool active = false;
-  NodePin() {
+// the CPUs of the memory node this process works on (false: pinning is off or not possible)
+static bool choose_node(cpu_set_t &saved, cpu_set_t &node) {
     if (const char *e = getenv("PGX_PIN"))
-      if (atoi(e) == 0) return;
-    if (sched_getaffinity(0, sizeof(saved), &saved) != 0) return;
+      if (atoi(e) == 0) return false;
+    if (sched_getaffinity(0, sizeof(saved), &saved) != 0) return false;
     const int cpu = sched_getcpu();
-    if (cpu < 0) return;
+    if (cpu < 0) return false;
     // the memory nodes and the CPUs of each that this process may use
     std::vector<cpu_set_t> nodes;
     int mine = -1;
@@ -238,14 +236,21 @@ struct NodePin {
       if (CPU_COUNT(&set) >= 2) nodes.push_back(set);
       else if (mine == (int)nodes.size()) mine = -1;
     }
-    if (nodes.empty()) return;
+    if (nodes.empty()) return false;
     // one process per GPU (torchrun exports LOCAL_RANK / LOCAL_WORLD_SIZE): spread the ranks over the nodes evenly instead
     // of wherever their main threads happen to run; a single process stays where it is
     int pick = mine;
     const char *lr = getenv("LOCAL_RANK"), *lw = getenv("LOCAL_WORLD_SIZE");
     if (lr && lw && atoi(lw) > 1) pick = (int)((long)atoi(lr) * (long)nodes.size() / std::max(1, atoi(lw))) % (int)nodes.size();
-    if (pick < 0) return;
+    if (pick < 0) return false;
     node = nodes[(size_t)pick];
+    return true;
+}
+struct NodePin {
+  cpu_set_t saved, node;
+  bool active = false;
+  NodePin() {
+    if (!choose_node(saved, node)) return;
     active = sched_setaffinity(0, sizeof(node), &node) == 0;  // threads created from here on inherit the mask
   }
   ~NodePin() {
@@ -370,7 +375,10 @@ struct PreOuter {
     if (eg.n < 4096) return;   // (small sets: nothing to hide)
     started = true;
     table.reserve(eg.n, big_alloc, big_free);
-    th = std::thread([this, n_rec] {
+    cpu_set_t saved, node;   // (the memory node the stage's other host threads will be pinned to: chosen from the caller's CPU)
+    const bool pin = choose_node(saved, node);
+    th = std::thread([this, n_rec, pin, node] {
+      if (pin) (void)sched_setaffinity(0, sizeof(node), &node);
       const double t0 = now_ms();
       const uint64_t *k = eg.keys.data();
       const size_t n = eg.n;
@@ -403,7 +411,14 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
   // while the others replay the inner tables, group range by group range; then the groups' fragments are moved to their
   // final places in outer-slot order.
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const unsigned nin = (unsigned)std::min<size_t>(std::min(24u, hw), std::max<size_t>(1, ng / 2048));  // inner workers
+  // inner-table workers: 48 for a lone process (2 x 64 cores), fewer per rank when several ranks share the host
+  static const unsigned nin_cap = [] {
+    if (const char *e = getenv("PGX_VISIT_THREADS")) return (unsigned)std::max(1, atoi(e));
+    const char *lw = getenv("LOCAL_WORLD_SIZE");
+    const int world = lw ? std::max(1, atoi(lw)) : 1;
+    return (unsigned)std::max(12, 48 / world);
+  }();
+  const unsigned nin = (unsigned)std::min<size_t>(std::min(nin_cap, hw), std::max<size_t>(1, ng / 2048));  // inner workers
   struct GroupOut {
     uint64_t eoff;      // offset of the group's entries in its worker's fragment
     uint32_t boff;      // offset of its bucket sizes
