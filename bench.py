@@ -79,8 +79,9 @@ def cpu_baseline(db, ov_gpu, tag, levels=2, mc_upper=240):
     when the prebuilt binaries are absent) on the host cores of this box, same input files, whole workload:
       (1) one process, one core: shmr_index -t 1 -c 1, shmr_overlap -t 1 -c 1 -- the configuration the GPU step ran; its ovlp_t
           stream is compared FIELD BY FIELD, in order, with the records of the timed GPU steps;
-      (2) N processes over N index chunks, then N processes over N overlap chunks, N = min(nproc, 24) (24 cores is the
-          reference's own practical ceiling, /root/reference/README.md:127-137) -- raw records/s and unique pairs/s.
+      (2) N processes over N index chunks, then N processes over N overlap chunks, for N = 24 (the reference's own practical
+          ceiling, /root/reference/README.md:127-137), 64 and 128 where the host has the cores, one leg after the other -- raw
+          records/s and unique pairs/s per leg; the headline `value` is the fastest leg.
     Also times the GPU drop-in executables end to end (file -> H2D -> kernels -> D2H -> file) on the same files.
     Checker / baseline only: nothing here is on the product path."""
     import concurrent.futures as cf
@@ -123,55 +124,58 @@ def cpu_baseline(db, ov_gpu, tag, levels=2, mc_upper=240):
             t2 = time.perf_counter()
             return t1 - t0, t2 - t1
 
-        def n_cores():
-            os.makedirs(os.path.join(d, "n"), exist_ok=True)
+        def n_cores(N):
+            nd = os.path.join(d, "n%d" % N)
+            os.makedirs(nd, exist_ok=True)
             t0 = time.perf_counter()
             with cf.ThreadPoolExecutor(N) as ex:
-                list(ex.map(lambda c: run_index(N, c, os.path.join(d, "n", "ix")), range(1, N + 1)))
+                list(ex.map(lambda c: run_index(N, c, os.path.join(nd, "ix")), range(1, N + 1)))
             t1 = time.perf_counter()
             with cf.ThreadPoolExecutor(N) as ex:
-                list(ex.map(lambda c: run_overlap(N, c, os.path.join(d, "n", "ix-L%d" % levels), os.path.join(d, "n", "ov.%02d" % c)), range(1, N + 1)))
+                list(ex.map(lambda c: run_overlap(N, c, os.path.join(nd, "ix-L%d" % levels), os.path.join(nd, "ov.%03d" % c)), range(1, N + 1)))
             t2 = time.perf_counter()
-            return t1 - t0, t2 - t1
+            raw, keys = 0, []
+            for c in range(1, N + 1):
+                o = formats.read_ovlp(os.path.join(nd, "ov.%03d" % c))
+                raw += len(o)
+                keys.append(_pair_keys(o))
+            uniq = int(len(np.unique(np.concatenate(keys)))) if keys else 0
+            shutil.rmtree(nd, ignore_errors=True)
+            return {"cores": N, "index_s": t1 - t0, "overlap_s": t2 - t1, "records": int(raw), "unique_pairs": uniq,
+                    "value": raw / (t2 - t0), "unit": "overlaps/s", "index_bases_per_s": db.n_bases / (t1 - t0),
+                    "overlap_records_per_s": raw / (t2 - t1), "unique_pairs_per_s": uniq / (t2 - t0)}
 
-        concurrent = ncpu >= N + 2 and N > 1      # both legs at once only when they do not share cores
-        if concurrent:
-            with cf.ThreadPoolExecutor(2) as ex:
-                f1, fn = ex.submit(one_core), ex.submit(n_cores)
-                (i1, o1), (iN, oN) = f1.result(), fn.result()
-        else:
-            i1, o1 = one_core()
-            iN, oN = n_cores() if N > 1 else (i1, o1)
+        # The legs run ONE AFTER THE OTHER (side by side they share LLC and DRAM bandwidth and the 1-core time comes
+        # out inflated).  N-process legs: 24 (the reference's own practical ceiling, README.md:127-137) and, to show where THIS
+        # box's plateau is instead of asserting it, 64 and 128 where the host has the cores.
+        i1, o1 = one_core()
         ref1 = formats.read_ovlp(os.path.join(d, "ov1"))
         fields_equal = bool(formats.ovlp_fields_equal(np.asarray(ov_gpu), ref1))
         uniq1 = int(len(np.unique(_pair_keys(ref1))))
-        if N > 1:
-            raw = uniqN = 0
-            keys = []
-            for c in range(1, N + 1):
-                o = formats.read_ovlp(os.path.join(d, "n", "ov.%02d" % c))
-                raw += len(o)
-                keys.append(_pair_keys(o))
-            uniqN = int(len(np.unique(np.concatenate(keys)))) if keys else 0
-            del keys
-        else:
-            raw, uniqN = len(ref1), uniq1
-        out = {
-            "value": raw / (iN + oN), "unit": "overlaps/s", "cores": N, "kind": kind,
-            "sample": f"whole workload {tag} ({db.n_reads} reads, {db.n_bases} bases): {N} processes over {N} index chunks, then {N} "
-                      f"processes over {N} overlap chunks (raw ovlp_t records of all chunks / wall time of both stages); host has {ncpu} usable cores"
-                      + ("; run beside the 1-core leg" if concurrent else ""),
-            "index_s": iN, "overlap_s": oN, "records": int(raw), "unique_pairs": uniqN,
-            "index_bases_per_s": db.n_bases / iN, "overlap_records_per_s": raw / oN,
-            "unique_pairs_per_s": uniqN / (iN + oN),
+        want = [n for n in (24, 64, 128) if n <= ncpu] or [N]
+        if os.environ.get("PGX_BENCH_CPU_LEGS"):
+            want = [int(v) for v in os.environ["PGX_BENCH_CPU_LEGS"].split(",") if int(v) <= ncpu] or [N]
+        legs = [n_cores(n) for n in want] if ncpu > 1 else []
+        if not legs:
+            legs = [{"cores": 1, "index_s": i1, "overlap_s": o1, "records": int(len(ref1)), "unique_pairs": uniq1, "value": len(ref1) / (i1 + o1),
+                     "unit": "overlaps/s", "index_bases_per_s": db.n_bases / i1, "overlap_records_per_s": len(ref1) / o1,
+                     "unique_pairs_per_s": uniq1 / (i1 + o1)}]
+        best = max(legs, key=lambda l: l["value"])
+        out = dict(best)
+        out.update({
+            "kind": kind,
+            "sample": f"whole workload {tag} ({db.n_reads} reads, {db.n_bases} bases): N processes over N index chunks, then N processes over N "
+                      f"overlap chunks (raw ovlp_t records of all chunks / wall time of both stages), N in {[l['cores'] for l in legs]} one after "
+                      f"the other -- the headline is the fastest (N = {best['cores']}); host has {ncpu} usable cores; every leg runs alone",
+            "legs": legs,
             "one_core": {"value": len(ref1) / (i1 + o1), "unit": "overlaps/s", "cores": 1, "index_s": i1, "overlap_s": o1,
                          "records": int(len(ref1)), "unique_pairs": uniq1, "index_bases_per_s": db.n_bases / i1,
                          "overlap_records_per_s": len(ref1) / o1,
-                         "sample": "1 index chunk + 1 overlap chunk, 1 process (the chunking of the timed GPU step)"},
+                         "sample": "1 index chunk + 1 overlap chunk, 1 process (the chunking of the timed GPU step), run alone"},
             "records_match_gpu": fields_equal,
             "records_match_gpu_means": "every field of every ovlp_t record of the timed GPU steps equals the reference's 1-chunk "
                                        "stream, in order (formats.ovlp_fields_equal; padding bytes masked)",
-        }
+        })
         # ---- GPU, end to end through the drop-in executables on the same files (file -> H2D -> kernels -> D2H -> file)
         exe = os.path.join(ROOT, "bin", "native")
         if os.path.exists(os.path.join(exe, "shmr_index")):
@@ -238,7 +242,7 @@ def main():
     import torch.distributed as dist
     from peregrine_amd import _lib, simreads
     from peregrine_amd.formats import MC_DTYPE, MM_DTYPE, SeqDB
-    from peregrine_amd.parallel import GpuEngine, allgather_cat, exchange_overlap
+    from peregrine_amd.parallel import GpuEngine, exchange_overlap, gather_seqdb
     from peregrine_amd.shimmer import ResidentDB
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
@@ -249,7 +253,16 @@ def main():
     dev_index = local if backend == "nccl" else local % ngpu
     torch.cuda.set_device(dev_index)
     xdev = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    # PGX_FORCE_EXCHANGE=1: a one-rank job takes the multi-rank path too -- process group over RCCL, the seqdb gathered into an
+    # adopted device buffer, count all-gather + record all-to-all(v) on device views, event hand-over between the streams --
+    # which is how the RCCL path is executed (and checked against the single-chunk records) on a one-GPU box
+    multi = world > 1 or os.environ.get("PGX_FORCE_EXCHANGE") == "1"
+    if multi:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -268,20 +281,16 @@ def main():
         cfg = dict(simreads.WORKLOADS[a.workload])
         g = simreads.make_genome(cfg.pop("genome_len"), cfg.pop("genome_seed") + 7919 * rank)
         mine = simreads.simulate_reads(g, seed=42 + rank, **cfg)
-    if world > 1:
-        # the job's read set = the union of the ranks' sets, replicated in every GPU's HBM: all-gathered on the
-        # device over xGMI (RCCL), handed to the library as a device pointer -- no host hop
+    if multi:
+        # the job's read set = the union of the ranks' sets, replicated in every GPU's HBM: every rank's bytes are
+        # received over xGMI (RCCL) straight into their place in ONE device buffer, which the library adopts without a copy
         home = torch.device("cuda", dev_index)
-        seq_all, _ = allgather_cat(torch.from_numpy(mine.seqdb).to(home), world)
-        len_all, _ = allgather_cat(torch.from_numpy(mine.rlen.astype(np.uint32).view(np.uint8)).to(home), world)
-        rlen = len_all.cpu().numpy().view(np.uint32).copy()
+        seq_all, total, rlen = gather_seqdb(mine.seqdb, mine.rlen, world, home)
         roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
         rid = np.arange(len(rlen), dtype=np.uint32)
-        torch.cuda.synchronize()
-        rdb = ResidentDB.from_device(seq_all.data_ptr(), seq_all.numel(), rid, rlen, roff, dev_index)
-        db = SeqDB(np.zeros(0, np.uint8), rid, rlen, roff, None)   # (sizes only: the bytes live in HBM)
-        del seq_all, len_all
-        torch.cuda.empty_cache()
+        rdb = ResidentDB.adopt_device(seq_all, total, rid, rlen, roff, dev_index)
+        db = SeqDB(mine.seqdb if world == 1 else np.zeros(0, np.uint8), rid, rlen, roff, None)   # (sizes only when the bytes live in HBM)
+        del seq_all
     else:
         db = mine
         rdb = ResidentDB(db, dev_index)  # H2D once; the timed region starts with the seqdb resident in HBM
@@ -292,10 +301,10 @@ def main():
         """one pass of the hot path: index chunk rank+1 of world, the exchange, overlap chunk rank+1 of world.
         Returns (IndexOut, ovlp records, stats, seconds of the index stage)."""
         s0 = time.perf_counter()
-        if world == 1 and not a.two_stage:   # one chunk: the shimmer list and its counts stay in HBM between the stages
+        if not multi and not a.two_stage:   # one chunk: the shimmer list and its counts stay in HBM between the stages
             ix, ov, st = rdb.index_overlap(levels=sp['levels'], mc_upper=sp['mc_upper'])
             return ix, ov, st, ix.ms * 1e-3
-        if world == 1:
+        if not multi:
             ix = rdb.index(levels=sp['levels'])
             s1 = time.perf_counter()
             ov, st = rdb.overlap(ix.top, ix.top_mc, mc_upper=sp['mc_upper'])
@@ -307,7 +316,7 @@ def main():
         return ix, ov, st, s1 - s0
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -326,7 +335,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     tot = torch.tensor([elapsed, float(len(ov)), float(ix.bases), t_index, t_ovlp], dtype=torch.float64, device=xdev)
-    if world > 1:
+    if multi:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, t_index, t_ovlp = float(mx[0]), float(mx[3]), float(mx[4])
@@ -340,7 +349,7 @@ def main():
             ms, launches, units = _lib.timing(name)
             if launches:
                 kern[name] = {"ms_total": ms, "launches": launches, "units": units, "avg_ms": ms / launches, "steps": a.steps}
-        if st.get("device_replay") and world == 1:
+        if st.get("device_replay") and not multi:
             # the device replay's kernels (k_eval + k_update pairs) are timed in ONE EXTRA step, outside the timed region: a HIP
             # event pair around each of their ~40 launches per step would cost ~2 % of the step
             os.environ["PGX_REPLAY_TIMING"] = "1"
@@ -421,7 +430,7 @@ def main():
             "dtype": "u8/u32 integer", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {WORKLOAD_TEXT.get(a.workload, a.workload)} per rank, 15 kb +-1.5 kb reads, 1 % errors, "
                                    f"k=16 w=80 r=6 l={LEVELS}, index_nchunk=ovlp_nchunk={world}, bestn 4, mc 2..240, aln_bw 100",
-                       "reads": int(db.n_reads), "bases": int(db.n_bases), "parallelism": f"chunks{world}"},
+                       "reads": int(db.n_reads), "bases": int(db.n_bases), "parallelism": f"chunks{world}" + ("+forced-exchange(rccl)" if multi and world == 1 else "")},
             "bases_per_sec_indexed": bases * a.steps / t_index if t_index else None,
             "overlap_records_per_sec": records * a.steps / t_ovlp if t_ovlp else None,
             "records_per_step": records, "index_ms_per_step": t_index / a.steps * 1e3, "overlap_ms_per_step": t_ovlp / a.steps * 1e3,
@@ -442,7 +451,7 @@ def main():
                                            "note": "GPU value = records of ONE overlap chunk (every read pair once); the N-chunk CPU run "
                                                    "reports most pairs once per chunk, so both of its rates are given"}
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -74,6 +74,12 @@ int pgx_seqdb_load(const char *seqdb_prefix, pgx_seqdb **out); /* reads <prefix>
  * device pointer, copied device-to-device; rid/rlen/roff are host arrays */
 int pgx_seqdb_upload_dev(const uint8_t *d_seqdb, size_t nbytes, const uint32_t *rid, const uint32_t *rlen,
                          const uint64_t *roff, uint32_t nreads, pgx_seqdb **out);
+/* the same WITHOUT a copy: the library reads the bytes where they are (d_seqdb stays owned by the caller and must outlive the
+ * pgx_seqdb).  capacity >= nbytes + 1024: the library zeroes [nbytes, nbytes + 1024) once (its kernels' wide loads may run
+ * that far past the last read).  This is what lets the ranks of a multi-GPU job all-gather the job's read set straight into
+ * its final place -- one copy of the seqdb per GPU instead of three (93 GB at 30x human). */
+int pgx_seqdb_adopt_dev(uint8_t *d_seqdb, size_t nbytes, size_t capacity, const uint32_t *rid, const uint32_t *rlen,
+                        const uint64_t *roff, uint32_t nreads, pgx_seqdb **out);
 void pgx_seqdb_free(pgx_seqdb *db);
 uint64_t pgx_seqdb_bases(const pgx_seqdb *db);
 uint32_t pgx_seqdb_reads(const pgx_seqdb *db);
@@ -171,6 +177,12 @@ int pgx_overlap_records_dev(pgx_seqdb *db, const pgx_pair_rec *d_records, size_t
 int pgx_overlap_resident_dev(pgx_seqdb *db, const pgx_mm128 *d_mmers, size_t n_mm, const pgx_mm_count *d_counts,
                              size_t n_counts, const pgx_overlap_params *p, pgx_ovlp **out, size_t *n_out,
                              pgx_overlap_stats *stats);
+/* Ordering against another runtime's stream (e.g. the stream torch / RCCL enqueued a collective on) without stopping the host:
+ *   pgx_stream_wait(s)   : work the library enqueues from now on starts after everything enqueued on s so far
+ *   pgx_stream_signal(s) : work enqueued on s from now on starts after everything the library has enqueued so far
+ * s is a hipStream_t (NULL = the default stream).  The replacement for a full stream synchronisation around each hand-over. */
+int pgx_stream_wait(void *other_stream);
+int pgx_stream_signal(void *other_stream);
 /* plain device-to-device copy on the library's stream, synchronous (for callers that hold device memory of another runtime) */
 int pgx_copy_dev(void *d_dst, const void *d_src, size_t nbytes);
 

@@ -72,7 +72,7 @@ EXPORTS = [
     "decode_biseq", "encode_biseq", "mm_sketch", "mm_reduce", "ovlp_match", "free_ovlp_match", "read_mmlist", "write_mmlist",
     "pgx_map", "pgx_map_chunk", "pgx_khash_slot_order",
     "pgx_seqdb_upload_dev", "pgx_index_resident_dev", "pgx_pairs_prepare_dev", "pgx_pairs_scatter_dev", "pgx_overlap_records_dev",
-    "pgx_overlap_resident_dev", "pgx_copy_dev",
+    "pgx_overlap_resident_dev", "pgx_copy_dev", "pgx_seqdb_adopt_dev", "pgx_stream_wait", "pgx_stream_signal",
     "build_shimmer_map4py", "get_shimmers_for_read", "get_mmer_count", "get_shimmer_hits", "pgx_shimmer_map_free",
 ]
 
@@ -122,6 +122,9 @@ def load():
         lib.pgx_overlap_resident_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p,
                                                  C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pgx_copy_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.pgx_seqdb_adopt_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.pgx_stream_wait.argtypes = [C.c_void_p]
+        lib.pgx_stream_signal.argtypes = [C.c_void_p]
         lib.pgx_mkseqdb.argtypes = [C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p]
         lib.pgx_dedup.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pgx_sketch_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -199,6 +202,21 @@ def dev_tensor(ptr: int, nbytes: int, device):
     t = torch.empty(nbytes, dtype=torch.uint8, device=device)
     check(load().pgx_copy_dev(C.c_void_p(t.data_ptr()), C.c_void_p(ptr), nbytes), "pgx_copy_dev")
     return t
+
+
+def stream_wait(torch_stream=None):
+    """the library's stream waits (on the device, the host does not) for what has been enqueued on `torch_stream` so far --
+    e.g. the collective that produced a buffer the next library call reads.  None: torch's current stream."""
+    import torch
+    s = torch_stream if torch_stream is not None else torch.cuda.current_stream()
+    check(load().pgx_stream_wait(C.c_void_p(s.cuda_stream)), "pgx_stream_wait")
+
+
+def stream_signal(torch_stream=None):
+    """`torch_stream` (None: torch's current stream) waits for what the library has enqueued so far"""
+    import torch
+    s = torch_stream if torch_stream is not None else torch.cuda.current_stream()
+    check(load().pgx_stream_signal(C.c_void_p(s.cuda_stream)), "pgx_stream_signal")
 
 
 def take(ptr, n: int, dtype: np.dtype) -> np.ndarray:

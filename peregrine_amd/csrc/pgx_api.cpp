@@ -264,6 +264,17 @@ void dev_cache_trim() {
   g_dev_free.clear();
 }
 
+// ---- shutdown hooks / generations --------------------------------------------------------------------------
+static std::vector<void (*)()> &shutdown_hooks() {
+  static std::vector<void (*)()> v;
+  return v;
+}
+void on_shutdown(void (*fn)()) { shutdown_hooks().push_back(fn); }
+uint64_t &index_generation() {
+  static uint64_t g = 1;
+  return g;
+}
+
 // ---- persistent workspace --------------------------------------------------------------------------------
 static std::map<std::string, DevBuf<uint8_t>> g_ws;
 void *ws_raw(const char *name, size_t bytes) {
@@ -273,6 +284,12 @@ void *ws_raw(const char *name, size_t bytes) {
     b.alloc(bytes + (bytes >> 3) + 4096);
   }
   return b.p;
+}
+
+bool ws_contains(const void *p) {
+  for (const auto &kv : g_ws)
+    if (kv.second.p && (const uint8_t *)p >= kv.second.p && (const uint8_t *)p < kv.second.p + kv.second.n) return true;
+  return false;
 }
 
 // ---- timing ----------------------------------------------------------------------------------------------
@@ -387,7 +404,9 @@ void pgx_shutdown(void) {
   Context &c = ctx();
   drain_deferred();
   big_pool_trim();
+  for (auto fn : shutdown_hooks()) fn();   // plan caches / held buffers of the stages (nothing may outlive the workspaces)
   g_ws.clear();
+  ++index_generation();
   if (c.stream) (void)hipStreamSynchronize(c.stream);
   dev_cache_trim();
   if (c.stream) (void)hipStreamDestroy(c.stream);
@@ -460,7 +479,8 @@ static void upload_file_pieces(const char *path, uint8_t *d_dst, size_t nbytes) 
 
 // seqdb: host bytes, device bytes (from_device), or -- file != nullptr -- the path of the .seqdb file (nbytes = its size)
 static int seqdb_upload_impl(const uint8_t *seqdb, size_t nbytes, const uint32_t *rid, const uint32_t *rlen,
-                             const uint64_t *roff, uint32_t nreads, pgx_seqdb **out, bool from_device, const char *file = nullptr) {
+                             const uint64_t *roff, uint32_t nreads, pgx_seqdb **out, bool from_device, const char *file = nullptr,
+                             bool adopt = false) {
   PGX_GUARD_BEGIN
   require_ready();
   PGX_REQUIRE(out && (nreads == 0 || (rid && rlen && roff)), PGX_EARG, "pgx_seqdb_upload: null argument");
@@ -484,9 +504,15 @@ static int seqdb_upload_impl(const uint8_t *seqdb, size_t nbytes, const uint32_t
     db->rlen_by_rid[rid[i]] = rlen[i], db->roff_by_rid[rid[i]] = roff[i], db->max_rlen = std::max(db->max_rlen, rlen[i]);
   db->nbytes = nbytes;
   try {
-    db->d_seq.alloc(nbytes + 1024);
+    if (adopt) {
+      db->borrowed = true;
+      db->d_seq.p = const_cast<uint8_t *>(seqdb), db->d_seq.n = nbytes + 1024;
+    } else {
+      db->d_seq.alloc(nbytes + 1024);
+    }
     PGX_HIP(hipMemsetAsync(db->d_seq.p + nbytes, 0, 1024, ctx().stream));
-    if (nbytes && file) upload_file_pieces(file, db->d_seq.p, nbytes);
+    if (adopt) {
+    } else if (nbytes && file) upload_file_pieces(file, db->d_seq.p, nbytes);
     else if (nbytes) PGX_HIP(hipMemcpyAsync(db->d_seq.p, seqdb, nbytes, from_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx().stream));
     db->d_roff.alloc(nr ? nr : 1);
     db->d_rlen.alloc(nr ? nr : 1);
@@ -509,6 +535,28 @@ int pgx_seqdb_upload_dev(const uint8_t *d_seqdb, size_t nbytes, const uint32_t *
                          const uint64_t *roff, uint32_t nreads, pgx_seqdb **out) {
   return seqdb_upload_impl(d_seqdb, nbytes, rid, rlen, roff, nreads, out, true);
 }
+int pgx_seqdb_adopt_dev(uint8_t *d_seqdb, size_t nbytes, size_t capacity, const uint32_t *rid, const uint32_t *rlen,
+                        const uint64_t *roff, uint32_t nreads, pgx_seqdb **out) {
+  if (!d_seqdb || capacity < nbytes + 1024) {
+    pgx::set_error("pgx_seqdb_adopt_dev: need a device pointer with capacity >= nbytes + 1024 (the kernels' wide loads read past the last read)");
+    return PGX_EARG;
+  }
+  return seqdb_upload_impl(d_seqdb, nbytes, rid, rlen, roff, nreads, out, true, nullptr, true);
+}
+// event hand-over between the library's stream and another runtime's
+static int stream_order(hipStream_t first, hipStream_t then) {
+  PGX_GUARD_BEGIN
+  require_ready();
+  hipEvent_t ev;
+  PGX_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, first);
+  if (e == hipSuccess) e = hipStreamWaitEvent(then, ev, 0);
+  (void)hipEventDestroy(ev);   // (deferred by the runtime until the event has completed)
+  PGX_HIP(e);
+  PGX_GUARD_END
+}
+int pgx_stream_wait(void *other_stream) { return stream_order((hipStream_t)other_stream, ctx().stream); }
+int pgx_stream_signal(void *other_stream) { return stream_order(ctx().stream, (hipStream_t)other_stream); }
 int pgx_copy_dev(void *d_dst, const void *d_src, size_t nbytes) {
   PGX_GUARD_BEGIN
   require_ready();

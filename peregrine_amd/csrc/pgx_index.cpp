@@ -31,6 +31,7 @@ T *download_list(const DevBuf<T> &d, size_t n) {
 }
 
 void run_index(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out, DeviceIndex *keep = nullptr, bool host_arrays = true) {
+  ++index_generation();   // every index-stage call rewrites the "ix.*" workspaces: views of them handed out earlier are stale now
   memset(out, 0, sizeof(*out));
   if (keep) keep->valid = false;
   const double t0 = now_ms();
@@ -136,6 +137,21 @@ void index_stage(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out
 }
 }  // namespace pgx
 
+// what pgx_index_resident_dev hands out as library-owned device memory; released by the next call and by pgx_shutdown()
+namespace {
+struct HeldIndex {
+  pgx::DeviceIndex ix;
+  pgx::DevBuf<pgx_mm128> top;
+} g_held;
+pgx::ShutdownHook g_held_reset([] { g_held.ix = pgx::DeviceIndex(); g_held.top.release(); });
+}  // namespace
+namespace pgx {
+bool index_owns(const void *p) {
+  const pgx_mm128 *q = (const pgx_mm128 *)p;
+  return ws_contains(p) || (g_held.top.p && q >= g_held.top.p && q < g_held.top.p + g_held.top.n);
+}
+}  // namespace pgx
+
 extern "C" {
 
 void pgx_index_result_free(pgx_index_result *r) {
@@ -164,8 +180,8 @@ int pgx_index_resident(pgx_seqdb *db, const pgx_index_params *p, pgx_index_resul
 // index stage of a multi-GPU rank: the final-level list and its counts stay in HBM for the exchange that follows
 int pgx_index_resident_dev(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *stats, const pgx_mm128 **d_top,
                            size_t *n_top, const pgx_mm_count **d_mc, size_t *n_mc) {
-  static DeviceIndex held;               // one context per process: the previous call's buffers are released here
-  static DevBuf<pgx_mm128> held_top;     // (only when the general index path produced host arrays)
+  DeviceIndex &held = g_held.ix;             // one context per process: the previous call's buffers are released here
+  DevBuf<pgx_mm128> &held_top = g_held.top;  // (only when the general index path produced host arrays)
   try {
     require_ready();
     PGX_REQUIRE(db && stats && d_top && n_top && d_mc && n_mc, PGX_EARG, "pgx_index_resident_dev: null argument");

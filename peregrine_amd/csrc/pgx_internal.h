@@ -13,6 +13,14 @@
 
 #include "../../include/pgx.h"
 
+// Every kernel of this library is written for 64-lane wavefronts (ballots as 64-bit masks, `threadIdx.x & 63` lane ids, DPP row
+// patterns): refuse to build for a wave32 target instead of computing wrong scan starts there.
+// (neither __AMDGCN_WAVEFRONT_SIZE nor a constexpr warpSize exists on ROCm 7 / gfx950; CDNA targets have no wave32 mode, so the
+// guard is on the target itself)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libpgx kernels assume 64-lane wavefronts and gfx950 instructions: build with --offload-arch=gfx950 only"
+#endif
+
 namespace pgx {
 
 // ---------------------------------------------------------------------------------------------------------
@@ -49,6 +57,18 @@ struct Context {
 };
 Context &ctx();
 void require_ready();
+// Device state that outlives a call (plan caches, buffers handed out as library-owned views) registers a reset function:
+// pgx_shutdown() runs them all BEFORE it returns the cached blocks to the driver, so nothing survives into the next pgx_init()
+// (which may choose another device).  Use: static pgx::ShutdownHook h_([] { ... });
+void on_shutdown(void (*fn)());
+struct ShutdownHook {
+  explicit ShutdownHook(void (*fn)()) { on_shutdown(fn); }
+};
+// bumped by every index-stage call that rewrites the index workspaces ("ix.*"): consumers of zero-copy views of those
+// workspaces (pgx_pairs_prepare_dev -> pgx_pairs_scatter_dev) compare it to detect that their input was overwritten
+uint64_t &index_generation();
+bool ws_contains(const void *p);    // p points into one of the named workspaces
+bool index_owns(const void *p);     // p points into memory an index-stage call handed out as a library-owned view
 
 // device buffer (RAII, grow-only reuse is up to the caller)
 // Device blocks come from a size-class cache: hipMalloc / hipFree are synchronous and cost tens of microseconds each, and
@@ -125,6 +145,10 @@ struct ReadDesc {
 
 struct pgx_seqdb {
   pgx::DevBuf<uint8_t> d_seq;      // seqdb bytes + 1 KiB of zero padding
+  bool borrowed = false;           // d_seq.p belongs to the caller (pgx_seqdb_adopt_dev): never released here
+  ~pgx_seqdb() {
+    if (borrowed) d_seq.p = nullptr, d_seq.n = 0;
+  }
   pgx::DevBuf<uint64_t> d_roff;    // indexed by rid
   pgx::DevBuf<uint32_t> d_rlen;    // indexed by rid
   std::vector<uint32_t> rid, rlen; // idx-file order

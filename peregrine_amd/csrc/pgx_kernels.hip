@@ -688,16 +688,28 @@ static double trace_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// the fused index path's plan cache: which read selection's descriptors and slab offsets the "ix.reads" / "ix.slab_off"
+// workspaces hold.  pgx_shutdown() frees the workspaces, so it must forget the plan too (a pgx_seqdb that outlives a
+// shutdown + init would otherwise run the sketch kernels on uninitialised descriptors).
+namespace {
+struct FusedPlan {
+  uint64_t dev_serial = 0, slab_total = 0, plan_bases = 0;
+  int plan_w = 0, plan_k = 0;
+  bool plan_ok = false;
+} g_plan;
+ShutdownHook g_plan_reset([] { g_plan = FusedPlan(); });
+}  // namespace
+
 bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, int rs, int levels,
                      const pgx_mm128 **d_top, size_t *n_top, uint64_t plan_serial) {
   const uint32_t n = (uint32_t)reads.size();
   if (n == 0 || levels < 1 || levels > 2 || rs < 1) return false;
   const bool trace = getenv("PGX_TRACE") != nullptr;
   const double tr0 = trace ? trace_ms() : 0;
-  // slab offsets and read descriptors: computed and uploaded once per plan
-  static uint64_t dev_serial = 0, slab_total = 0, plan_bases = 0;
-  static int plan_w = 0, plan_k = 0;
-  static bool plan_ok = false;
+  // slab offsets and read descriptors: computed and uploaded once per plan (file-scope state below: reset by pgx_shutdown)
+  uint64_t &dev_serial = g_plan.dev_serial, &slab_total = g_plan.slab_total, &plan_bases = g_plan.plan_bases;
+  int &plan_w = g_plan.plan_w, &plan_k = g_plan.plan_k;
+  bool &plan_ok = g_plan.plan_ok;
   const bool cached = plan_serial != 0 && plan_serial == dev_serial && plan_w == w && plan_k == k;
   hipStream_t st = ctx().stream;
   ReadDesc *d_reads = ws<ReadDesc>("ix.reads", n);

@@ -494,8 +494,10 @@ struct ScatterState {
   DevBuf<uint8_t> keep;
   DevBuf<pgx_pair_rec> send;
   bool ready = false;
+  uint64_t ix_gen = 0;   // index_generation() at prepare, when `mm` is a view of index-stage memory; 0: caller-owned
 };
 ScatterState g_scatter;
+ShutdownHook g_scatter_reset([] { g_scatter = ScatterState(); });
 }  // namespace
 
 int64_t dev_pairs_prepare(const uint32_t *d_rlen, uint32_t n_rid, const pgx_mm128 *d_mm, size_t n_mm, const pgx_mm_count *d_counts,
@@ -503,7 +505,7 @@ int64_t dev_pairs_prepare(const uint32_t *d_rlen, uint32_t n_rid, const pgx_mm12
   PGX_REQUIRE(n_mm < (1ULL << 31) && n_counts < (1ULL << 31), PGX_EARG, "shimmer list too long for one chunk");
   g_scatter = ScatterState();
   g_scatter.mm = d_mm, g_scatter.n = (uint32_t)n_mm;
-  g_scatter.ready = true;
+  g_scatter.ready = true, g_scatter.ix_gen = index_owns(d_mm) ? index_generation() : 0;
   if (n_mm == 0) return -1;
   Tmp tmp;
   CountTable ct;
@@ -516,6 +518,9 @@ int64_t dev_pairs_prepare(const uint32_t *d_rlen, uint32_t n_rid, const pgx_mm12
 
 void dev_pairs_scatter(const uint32_t *d_rlen, uint32_t T, int64_t start, const pgx_pair_rec **d_send, uint64_t *counts) {
   PGX_REQUIRE(g_scatter.ready, PGX_ESTATE, "pgx_pairs_scatter_dev without pgx_pairs_prepare_dev");
+  PGX_REQUIRE(g_scatter.ix_gen == 0 || g_scatter.ix_gen == index_generation(), PGX_ESTATE,
+              "pgx_pairs_scatter_dev: an index-stage call rewrote the shimmer list since pgx_pairs_prepare_dev (the list is a view of "
+              "the index workspace; copy it with pgx_copy_dev to overlap steps)");
   PGX_REQUIRE(T >= 1 && T <= 256, PGX_EARG, "the record scatter supports 1..256 overlap chunks");
   for (uint32_t c = 0; c < T; ++c) counts[c] = 0;
   *d_send = nullptr;
@@ -605,9 +610,20 @@ static void early_groups(const PairRecs &R, Tmp &tmp, const EarlyFn &early) {
   const uint32_t nr = R.nr;
   size_t cap = 1024;
   while (cap < (size_t)nr * 2) cap <<= 1;
-  DevBuf<unsigned long long> tkeys(cap);
-  DevBuf<uint32_t> tseq(cap), idx(nr), d_n(1);
-  DevBuf<uint8_t> flag(nr);
+  // This pass is an optimisation on top of the join's own buffers (12 B per table slot + 5 B per record: ~0.8 GB at 4.5 Gbases,
+  // ~3 GB at 18 Gbases) and runs before bucketize releases anything.  With no headroom left it is skipped -- the callback stays
+  // uncalled and the outer table is replayed after the join, exactly as with PGX_EARLY_OUTER=0 -- instead of failing a chunk
+  // that fits without it.
+  DevBuf<unsigned long long> tkeys;
+  DevBuf<uint32_t> tseq, idx, d_n;
+  DevBuf<uint8_t> flag;
+  try {
+    tkeys.alloc(cap), tseq.alloc(cap), idx.alloc(nr), d_n.alloc(1), flag.alloc(nr);
+  } catch (const Fail &) {
+    (void)hipGetLastError();
+    if (getenv("PGX_TRACE")) fprintf(stderr, "[pgx] join: no device memory for the early outer-key pass (%zu MB); skipped\n", (cap * 12 + (size_t)nr * 5) >> 20);
+    return;
+  }
   PGX_HIP(hipMemsetAsync(tkeys.p, 0, cap * sizeof(unsigned long long), st));
   PGX_HIP(hipMemsetAsync(tseq.p, 0xFF, cap * sizeof(uint32_t), st));
   hipLaunchKernelGGL(k_first_insert, dim3(cdiv(nr, 256)), dim3(256), 0, st, R.key0.p, nr, tkeys.p, tseq.p, (uint32_t)(cap - 1));

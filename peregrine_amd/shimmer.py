@@ -62,6 +62,26 @@ class ResidentDB:
         self.n_reads, self.n_bases = len(rid), int(rlen.sum(dtype=np.uint64))
         return self
 
+    @classmethod
+    def adopt_device(cls, seq_tensor, nbytes: int, rid, rlen, roff, device: int | None = None):
+        """NO copy: the library reads the seqdb where it is -- `seq_tensor` is a torch uint8 device tensor of at least
+        nbytes + 1024 elements (e.g. the buffer the ranks of a multi-GPU job all-gathered their read sets into); the object
+        keeps it alive.  One copy of the job's seqdb per GPU (pgx_seqdb_adopt_dev)."""
+        self = cls.__new__(cls)
+        _lib.init(device)
+        self._lib = _lib.load()
+        self.h = C.c_void_p()
+        rid = np.ascontiguousarray(rid, np.uint32)
+        rlen = np.ascontiguousarray(rlen, np.uint32)
+        roff = np.ascontiguousarray(roff, np.uint64)
+        assert seq_tensor.is_contiguous() and seq_tensor.element_size() == 1
+        _lib.stream_wait()   # whatever filled the buffer on torch's stream comes first
+        _lib.check(self._lib.pgx_seqdb_adopt_dev(C.c_void_p(seq_tensor.data_ptr()), int(nbytes), int(seq_tensor.numel()), _ptr(rid),
+                                                 _ptr(rlen), _ptr(roff), len(rid), C.byref(self.h)), "pgx_seqdb_adopt_dev")
+        self._adopted = seq_tensor
+        self.n_reads, self.n_bases = len(rid), int(rlen.sum(dtype=np.uint64))
+        return self
+
     # ---- multi-GPU hand-over on device pointers (include/pgx.h, SURVEY 8e) ------------------------------------------
     def index_dev(self, total_chunk=1, mychunk=1, levels=2, reduction=6, window=80, kmer=16):
         """index stage; returns (IndexOut without arrays, d_top, n_top, d_mc, n_mc): list and counts stay in HBM (library-owned)"""

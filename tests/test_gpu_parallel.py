@@ -145,3 +145,75 @@ def test_two_rank_pipeline_on_one_gpu(tmp_path):
     for r in range(2):
         got = np.load(tmp_path / f"ov{r}.npy")
         assert formats.ovlp_fields_equal(got, want[r]), f"rank {r} (overlap chunk {r + 1} of 2)"
+
+
+def _rccl_one_rank(rank, port, out_dir):
+    """a ONE-rank job over RCCL with PGX_FORCE_EXCHANGE=1: every collective of the multi-GPU path is really issued, on device
+    views (the nccl code path had never executed)"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", PGX_FORCE_EXCHANGE="1")
+    import torch.distributed as dist
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from peregrine_amd import parallel
+    assert parallel.forced() and dist.get_backend() == "nccl"
+    db = simreads.make_workload("small")
+    seq_all, total, rlen = parallel.gather_seqdb(db.seqdb, db.rlen, 1, dev)        # all-gather into the final buffer, adopted without a copy
+    assert total == db.seqdb.size and np.array_equal(rlen, db.rlen) and seq_all.is_cuda and seq_all.numel() == total + 1024
+    rdb = ResidentDB.adopt_device(seq_all, total, db.rid, db.rlen, db.roff, 0)
+    eng = GpuEngine(rdb, dev)
+    for it in range(2):   # twice: the second step re-uses every workspace the first one left behind
+        os.environ["PGX_FORCE_UNEVEN"] = str(it)   # second pass: the all_gather over views of unequal pieces (grouped broadcasts)
+        _, top, mc = eng.index(1, 1)
+        assert top.is_cuda and mc.is_cuda
+        (ov, st), info = parallel.exchange_overlap(eng, 0, 1, top, mc)
+        assert info["received_records"] == info["sent_records"] > 0 and not info["scan_start_redone"]
+    np.save(os.path.join(out_dir, "ov_rccl.npy"), ov)
+    # a view of the index workspace that an index call rewrote must be refused, not silently read (ADVICE r2)
+    from peregrine_amd import _lib
+    _, top, mc = eng.index(1, 1)
+    eng.pairs_prepare(top, mc, 2, 240)
+    eng.index(1, 1)
+    try:
+        eng.pairs_scatter(1, 0)
+        stale = "accepted"
+    except _lib.PgxError as e:
+        stale = str(e)
+    assert "rewrote the shimmer list" in stale, stale
+    rdb.close()
+    ref = ResidentDB(db, 0)                                                        # the single-chunk path of the same process
+    _, ov1, _ = ref.index_overlap()
+    np.save(os.path.join(out_dir, "ov_direct.npy"), ov1)
+    ref.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_exchange_as_one_rank_job(tmp_path):
+    import torch.multiprocessing as mp
+    db = simreads.make_workload("small")
+    want = _reference_chunks(db, str(tmp_path), 1)[0]
+    mp.spawn(_rccl_one_rank, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    got, direct = np.load(tmp_path / "ov_rccl.npy"), np.load(tmp_path / "ov_direct.npy")
+    assert len(want) > 1000 and formats.ovlp_fields_equal(got, want), "records through the RCCL exchange differ from the reference's"
+    assert formats.ovlp_fields_equal(direct, want)
+
+
+def test_shutdown_forgets_device_state():
+    """pgx_shutdown() must reset the plan caches / held buffers, or a pgx_seqdb that outlives a shutdown + init runs the
+    sketch kernels on freed descriptors.  Runs in its own process (one context per process)."""
+    import subprocess
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from peregrine_amd import _lib, simreads\n"
+        "from peregrine_amd.shimmer import ResidentDB\n"
+        "db = simreads.make_workload('tiny')\n"
+        "a = ResidentDB(db, 0); t1 = a.index().top.copy(); a.index(); a.close()\n"
+        "_lib.shutdown()\n"
+        "b = ResidentDB(db, 0); t2 = b.index().top.copy(); t3 = b.index().top.copy(); b.close()\n"
+        "assert len(t1) > 100 and np.array_equal(t1, t2) and np.array_equal(t1, t3)\n"
+        "print('ok')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -54,6 +54,10 @@ def _pipeline_worker(rank, world, port, out_dir, lower, upper):
     db = simreads.make_workload("tiny")
     rl, _ = db.by_rid()
     top, mc = _index_chunk_oracle(db, world, rank + 1)
+    if upper == "empty0":  # rank 0 holds no shimmers at all and rank 1's first element sits AT the upper bound: the scan starts
+        if rank == 0:      # inside rank 1's list, so rank 1's assumption "rank 0 holds the scan start" is wrong and it rebuilds
+            top, mc = top[:0], mc[:0]
+        upper = int(np.load(os.path.join(out_dir, "upper.npy")))
     if upper == "first":   # make the very first element of the concatenated list sit exactly AT the upper bound (strict rule)
         upper = int(np.load(os.path.join(out_dir, "upper.npy")))
     eng = NumpyEngine(rl)
@@ -63,21 +67,24 @@ def _pipeline_worker(rank, world, port, out_dir, lower, upper):
     np.save(os.path.join(out_dir, f"top{rank}.npy"), top)
     np.save(os.path.join(out_dir, f"mc{rank}.npy"), mc)
     assert info["received_records"] == len(got) and sum(info["received_per_source"]) == len(got)
+    np.save(os.path.join(out_dir, f"redone{rank}.npy"), np.int64(info["scan_start_redone"]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,lower,upper", [(2, 2, 240), (3, 2, 240), (2, 1, 30), (3, 2, "first")])
+@pytest.mark.parametrize("world,lower,upper", [(2, 2, 240), (3, 2, 240), (2, 1, 30), (3, 2, "first"), (3, 2, "empty0")])
 def test_two_rank_pipeline(tmp_path, world, lower, upper):
     sys.path.insert(0, HERE)
     import oracle_util as U
     from peregrine_amd import simreads
     db = simreads.make_workload("tiny")
     rl, _ = db.by_rid()
-    if upper == "first":
+    if upper in ("first", "empty0"):
         tops = [_index_chunk_oracle(db, world, c) for c in range(1, world + 1)]
+        if upper == "empty0":
+            tops[0] = (tops[0][0][:0], tops[0][1][:0])
         mc_all = np.concatenate([t[1] for t in tops])
-        first = tops[0][0][0]
+        first = tops[0 if upper == "first" else 1][0][0]
         tot = int(mc_all["count"][mc_all["mer"] == (first["x"] >> np.uint64(8))].sum())
         np.save(tmp_path / "upper.npy", np.int64(tot))
         upper_v = tot
@@ -95,7 +102,9 @@ def test_two_rank_pipeline(tmp_path, world, lower, upper):
         for f in ("key0", "key1", "y0", "npos", "dir"):
             assert np.array_equal(got[f], want[f]), f"rank {r}: field {f} differs"
         total += len(want)
-    assert total > (1000 if upper != "first" else 300)
+    assert total > (1000 if upper not in ("first", "empty0") else 300)
+    redone = [int(np.load(tmp_path / f"redone{r}.npy")) for r in range(world)]
+    assert redone == [1 if upper == "empty0" else 0] * world, "the speculative scan start must hold except when rank 0 holds no anchor"
     if upper == "first":   # the strict rule really was in play: with the inclusive rule the first element would have anchored
         want_incl = U.orc_pair_records(mm, mc, rl, mychunk=1, total=1, mc_lower=lower, mc_upper=upper_v + 1)
         want_strict = U.orc_pair_records(mm, mc, rl, mychunk=1, total=1, mc_lower=lower, mc_upper=upper_v)
@@ -107,7 +116,7 @@ def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from peregrine_amd.formats import MM_DTYPE
-    from peregrine_amd.parallel import allgather_cat, allgather_ints, alltoallv_bytes, chunk_of_rank, scan_start
+    from peregrine_amd.parallel import allgather_cat, allgather_exact, allgather_ints, alltoallv_bytes, scan_start
     rng = np.random.default_rng(100 + rank)
     n = 1000 + 37 * rank                        # ranks contribute different lengths (rank 1 is empty in the 3-rank run)
     mine = np.zeros(n if rank != 1 or world < 3 else 0, MM_DTYPE)
@@ -124,7 +133,14 @@ def _worker(rank, world, port, out_dir):
     recv, rb = alltoallv_bytes(send, [(rank + 1) * (d + 1) for d in range(world)], world)
     want = torch.cat([torch.full(((s + 1) * (rank + 1),), 10 * s + rank, dtype=torch.uint8) for s in range(world)])
     assert torch.equal(recv, want) and rb == [(s + 1) * (rank + 1) for s in range(world)]
-    assert chunk_of_rank(rank, world) == rank + 1
+    # exact-size gather into a caller's buffer (what the seqdb replication uses): pieces land at their final offsets
+    piece = torch.full((5 + 3 * rank,), rank + 1, dtype=torch.uint8)
+    sizes2 = [5 + 3 * r for r in range(world)]
+    buf = torch.zeros(sum(sizes2) + 7, dtype=torch.uint8)
+    allgather_exact(piece, sizes2, out=buf)
+    assert torch.equal(buf[:sum(sizes2)], torch.cat([torch.full((5 + 3 * r,), r + 1, dtype=torch.uint8) for r in range(world)])) and int(buf[-7:].sum()) == 0
+    recv2, rb2 = alltoallv_bytes(send, [(rank + 1) * (d + 1) for d in range(world)], world, recv_bytes=[(s + 1) * (rank + 1) for s in range(world)])
+    assert torch.equal(recv2, want) and rb2 == rb
     assert scan_start([-1, 4, 9][:world] + [0] * (world - 3), rank) == ([-1, 4, 0][rank] if world >= 3 else [-1, 4][rank])
     dist.barrier()
     dist.destroy_process_group()
