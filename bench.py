@@ -235,6 +235,11 @@ def cpu_baseline_sample(sample):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line, the JSON: everything else that writes to file descriptor 1 -- RCCL prints a version banner
+    # there from C when a communicator is torn down -- is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -450,7 +455,7 @@ def main():
                                            "vs_one_core": out["value"] / cb["one_core"]["value"], "cpu_cores": cb["cores"],
                                            "note": "GPU value = records of ONE overlap chunk (every read pair once); the N-chunk CPU run "
                                                    "reports most pairs once per chunk, so both of its rates are given"}
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()
         dist.destroy_process_group()
