@@ -647,13 +647,14 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
 
 void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out) {
   if (n == 0) return;
-  static const long small_max = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : 13000;  // measured crossover ~14 k (tools/alignlat.py)
+  // (the knobs are read per call: the parity tests walk every kernel variant inside one process)
+  const long small_max = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : 13000;  // measured crossover ~14 k (tools/alignlat.py)
   KernelTimer tm((long)n <= small_max ? "align1" : "align", n);
   int ring = 64;
   while (ring < 2 * band + 8) ring <<= 1;
   uint32_t *counter = ws<uint32_t>("align.counter", 1);
   if ((long)n > small_max) PGX_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), ctx().stream));  // (k_align1 has no work counter)
-  static const int gl = getenv("PGX_ALIGN_GL") ? atoi(getenv("PGX_ALIGN_GL")) : 8;  // measured: 8 lanes per candidate (avg 3.6 live diagonals, <= 8 in 98.7 % of the steps) 45.6 vs 42.1 M aln/s
+  const int gl = getenv("PGX_ALIGN_GL") ? atoi(getenv("PGX_ALIGN_GL")) : 8;  // measured: 8 lanes per candidate (avg 3.6 live diagonals, <= 8 in 98.7 % of the steps) 45.6 vs 42.1 M aln/s
   // PGX_ALIGN_MODE: 8 (default) = the phase machine with 8-lane groups: at 4.5 Gbases 66.5 M alignments/s against 61.0 M of
   // k_align4 (mode 0, round 1: groups in lock-step) -- the same 39 G VALU wavefront-instructions per 2.4 M alignments, 23 % fewer
   // scalar ones, less waiting.  4 = sixteen 4-lane groups on a NARROW V ring (64 slots, 2 KiB of LDS per wavefront, full
@@ -661,7 +662,30 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
   // one (work list and count stay on the device; with nothing handed on it is an empty launch): measured and NOT chosen -- 17 %
   // fewer VALU instructions, but 57-60 M alignments/s whatever the occupancy: its probe loads touch sixteen candidates' cache
   // lines per instruction and the address pipeline, not VALU issue, becomes the limit.
-  static const int mode = getenv("PGX_ALIGN_MODE") ? atoi(getenv("PGX_ALIGN_MODE")) : 8;
+  const int mode = getenv("PGX_ALIGN_MODE") ? atoi(getenv("PGX_ALIGN_MODE")) : 8;
+  // lane-per-candidate form (round 3, pgx_align_lane.hip): bit-exact on every test set, 45 % fewer VALU wavefront-instructions than
+  // k_align_ph -- and measured SLOWER (4.68 M alignments: 93 ms + 6 ms for the 8.8 % it hands on, against 69 ms): its private LDS
+  // windows allow 3 wavefronts per SIMD, a wavefront issues one instruction per ~16 cycles of its dependent, branchy stream, and
+  // three of them cannot fill a SIMD (profiles/r03b_pmc_align_lane.txt).  Kept as an opt-in (PGX_ALIGN_LANE_MIN = smallest launch
+  // that takes it; unset / < 0: never) with its parity test; the candidates it hands on are redone by k_align_ph<8> from their list.
+  const char *lane_env = getenv("PGX_ALIGN_LANE_MIN");   // (read per call: the tools switch it between launches)
+  const long lane_min = lane_env ? atol(lane_env) : -1;
+  if ((long)n >= lane_min && lane_min >= 0 && mode == 8 && db->max_rlen <= 65535u) {
+    uint32_t *esc = dev_align_lane(db, d_keys, n, band, d_out);
+    if (getenv("PGX_TRACE")) {
+      uint32_t handed = 0;
+      PGX_HIP(hipMemcpyAsync(&handed, esc, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx().stream));
+      sync();
+      fprintf(stderr, "[pgx] align: lane kernel over %zu candidates handed %u on to k_align_ph\n", n, handed);
+    }
+    const size_t lds = (size_t)8 * ring * sizeof(uint16_t);
+    const unsigned per_cu = (unsigned)std::min<size_t>(32, (160u << 10) / lds);
+    const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>(n / 64, 64), (size_t)ctx().num_cu * per_cu);
+    hipLaunchKernelGGL((k_align_ph<8, uint16_t>), dim3(grid), dim3(64), lds, ctx().stream, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys,
+                       (uint32_t)n, band, ring, d_out, esc + 1, esc, esc + 4, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    PGX_HIP(hipGetLastError());
+    return;
+  }
   if ((long)n > small_max && (mode == 4 || mode == 8) && db->max_rlen <= 65535u) {
     auto grid_for = [&](size_t cands, int groups, int rg) {
       const size_t lds = (size_t)groups * rg * sizeof(uint16_t);
@@ -669,7 +693,7 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
       return (unsigned)std::min<size_t>((cands + groups - 1) / groups, (size_t)ctx().num_cu * per_cu);
     };
     if (mode == 4) {
-      static const int narrow = getenv("PGX_ALIGN_RING") ? atoi(getenv("PGX_ALIGN_RING")) : 64;
+      const int narrow = getenv("PGX_ALIGN_RING") ? atoi(getenv("PGX_ALIGN_RING")) : 64;
       uint32_t *esc = ws<uint32_t>("align.esc", n + 4);   // [0] handed-on count, [1] the second launch's work counter, [4..) list
       PGX_HIP(hipMemsetAsync(esc, 0, 4 * sizeof(uint32_t), ctx().stream));
       const int rg = std::min(narrow, ring);

@@ -660,6 +660,7 @@ int pgx_align_batch(pgx_seqdb *db, const pgx_align_key *keys, size_t n, int band
   DevBuf<pgx_align_key> d_keys(n);
   DevBuf<pgx_match> d_out(n);
   d_keys.upload(keys, n);
+  ++align_epoch();
   dev_align(db, d_keys.p, n, band, d_out.p);
   d_out.download(out, n);
   pgx::sync();

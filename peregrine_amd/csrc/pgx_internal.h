@@ -149,6 +149,12 @@ struct pgx_seqdb {
   ~pgx_seqdb() {
     if (borrowed) d_seq.p = nullptr, d_seq.n = 0;
   }
+  // the lane-per-candidate alignment kernel's view of the reads (pgx_align_lane.hip), rebuilt once per overlap stage:
+  mutable pgx::DevBuf<uint32_t> d_pack;          // 2-bit packs of the seqdb, both strands
+  mutable pgx::DevBuf<uint32_t> d_nflag;         // by rid: the read holds an ambiguous base
+  mutable pgx::DevBuf<uint64_t> d_roff_sorted;   // read offsets ascending + their rids (position -> read, for d_nflag)
+  mutable pgx::DevBuf<uint32_t> d_rid_sorted;
+  mutable uint64_t pack_epoch = 0;               // align_epoch() the packs were built in
   pgx::DevBuf<uint64_t> d_roff;    // indexed by rid
   pgx::DevBuf<uint32_t> d_rlen;    // indexed by rid
   std::vector<uint32_t> rid, rlen; // idx-file order
@@ -186,6 +192,12 @@ void dev_reduce(const pgx_mm128 *d_in, size_t n, int rs, DevBuf<pgx_mm128> &out,
 void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_count> &out, size_t &n_out);
 // banded O(ND) confirmation of n candidate alignments (keys on device)
 void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out);
+// one candidate per lane over 2-bit packs (pgx_align_lane.hip); returns the device escalation block: [0] number of candidates
+// handed on to the byte-wise kernel, [1] a zeroed work counter for that launch, [4..) their indices
+uint32_t *dev_align_lane(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out);
+// bumped once per overlap stage / alignment batch: the 2-bit packs are rebuilt when it changed (the packing pass belongs to the
+// timed stage, it is not kept across calls)
+uint64_t &align_epoch();
 
 // Large host arrays.  Never value-initialised (they are about to be overwritten); from 16 MiB up they are pooled anonymous
 // mappings advised to use transparent huge pages, which the allocator would not do for us (THP is in "madvise" mode on

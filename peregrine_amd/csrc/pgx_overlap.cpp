@@ -1492,6 +1492,7 @@ struct DeviceLists {
 void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
                  const pgx_overlap_params *p, OvOut &out, pgx_overlap_stats *st, const DeviceLists *dev = nullptr,
                  const pgx_pair_rec *d_recs = nullptr, size_t n_recs = 0) {
+  ++align_epoch();   // the alignment kernels' 2-bit packs of the seqdb are rebuilt once per stage, inside it (pgx_align_lane.hip)
   pgx_overlap_stats s;
   memset(&s, 0, sizeof(s));
   const double t0 = now_ms();

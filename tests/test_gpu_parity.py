@@ -620,3 +620,105 @@ def test_overlap_argument_edges(small):
     got, st = rdb.overlap(dup, dmc)
     want, ost = U.orc_overlap(db, dup, dmc)
     assert formats.ovlp_fields_equal(got, want) and st["n_align_needed"] == ost["n_align"]
+
+
+# ---- every alignment kernel variant against the oracle ------------------------------------------------------------
+def _with_long_reads():
+    """the `small` read set + two 100 kb reads of the same genome region: a read beyond 65,535 bases switches the whole stage to the
+    32-bit V rings (k_align4<8, int32_t>, pgx_align.hip)"""
+    g = simreads.make_genome(400_000, 11)
+    a = simreads.simulate_reads(g, coverage=12.0, seed=5, wrap=0)
+    b = simreads.simulate_reads(g[100_000:260_000], n_reads=2, seed=6, mean_len=100_000, sd_len=0, wrap=0)
+    seq = np.concatenate([a.seqdb, b.seqdb])
+    rlen = np.concatenate([a.rlen, b.rlen])
+    roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
+    return formats.SeqDB(seq, np.arange(len(rlen), dtype=np.uint32), rlen, roff, None)
+
+
+def _keys_of(db, rdb, n_random, seed):
+    ix = rdb.index()
+    ov, _ = rdb.overlap(ix.top, ix.top_mc)
+    keys = np.zeros(len(ov) + n_random, _lib.ALIGN_KEY_DTYPE)
+    k = keys[:len(ov)]
+    k["rid0"] = ov["y0"] >> np.uint64(32); k["rid1"] = ov["y1"] >> np.uint64(32)
+    k["q_off"] = (((ov["y0"] & np.uint64(0xFFFFFFFF)) >> np.uint64(1)) - ((ov["y1"] & np.uint64(0xFFFFFFFF)) >> np.uint64(1))).astype(np.uint32)
+    k["dir0"] = ov["strand0"]; k["dir1"] = ov["strand1"]
+    rng = np.random.default_rng(seed)
+    r = keys[len(ov):]
+    r["rid0"] = rng.integers(0, db.n_reads, n_random); r["rid1"] = rng.integers(0, db.n_reads, n_random)
+    rl = db.rlen[r["rid0"]].astype(np.int64)
+    r["q_off"] = np.where(rng.random(n_random) < 0.2, np.maximum(rl - rng.integers(0, 40, n_random), 0), rng.integers(0, rl))   # incl. queries of < 40 bases
+    r["dir0"] = rng.integers(0, 2, n_random); r["dir1"] = rng.integers(0, 2, n_random)
+    return keys, ov
+
+
+def _oracle_matches(db, keys, band):
+    out = np.zeros(len(keys), _lib.MATCH_DTYPE)
+    for i in range(len(keys)):
+        a, b = int(keys["rid0"][i]), int(keys["rid1"][i])
+        q = db.seqdb[int(db.roff[a]) + int(keys["q_off"][i]):int(db.roff[a]) + int(db.rlen[a])]
+        t = db.seqdb[int(db.roff[b]):int(db.roff[b]) + int(db.rlen[b])]
+        out[i] = U.orc_ovlp_match(q, int(keys["dir0"][i]), t, int(keys["dir1"][i]), band)
+    return out
+
+
+ALIGN_VARIANTS = [   # (id, environment, read set)
+    ("ph8", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8"), "small"),                    # k_align_ph<8, u16>: the default of large launches
+    ("lockstep8", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="0"), "small"),              # k_align4<8, u16>
+    ("lockstep16", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="0", PGX_ALIGN_GL="16"), "small"),   # k_align4<16, int32>
+    ("ph4+escalation", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="4"), "small"),         # k_align_ph<4> on the narrow ring, then k_align_ph<8> over the hand-ons
+    ("lane", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_LANE_MIN="0"), "small"),               # k_align_lane (+ k_align_ph<8> over the hand-ons)
+    ("one-per-wave", dict(PGX_ALIGN_SMALL="1000000000"), "small"),                       # k_align1 on a LARGE launch
+    ("long-reads-int32", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8"), "long"),        # a 100 kb read in the set: k_align4<8, int32>
+    ("long-reads-lane-refused", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_LANE_MIN="0"), "long"),
+]
+
+
+@pytest.fixture(scope="module")
+def variant_sets():
+    sets = {}
+    for name, db in (("small", simreads.make_workload("small")), ("long", _with_long_reads())):
+        rdb = ResidentDB(db, 0)
+        keys, ov = _keys_of(db, rdb, 3000, 17)
+        want = {band: _oracle_matches(db, keys, band) for band in (100, 20)}
+        rep = -(-20000 // len(keys))               # a launch of >= 20 k keys: beyond every small-launch threshold
+        sets[name] = (db, rdb, np.tile(keys, rep), {band: np.tile(w, rep) for band, w in want.items()})
+    yield sets
+    for _, rdb, _, _ in sets.values():
+        rdb.close()
+
+
+@pytest.mark.parametrize("vid,env,which", ALIGN_VARIANTS, ids=[v[0] for v in ALIGN_VARIANTS])
+def test_align_variants_vs_oracle(variant_sets, vid, env, which):
+    db, rdb, keys, want = variant_sets[which]
+    if which == "long":
+        assert int(db.rlen.max()) > 65535
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for band in (100, 20):
+            got = rdb.align(keys, band)
+            bad = np.flatnonzero(got != want[band])
+            assert len(bad) == 0, (vid, band, len(bad), keys[bad[:3]], got[bad[:3]], want[band][bad[:3]])
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_overlap_stage_with_long_reads_equals_oracle(variant_sets):
+    """the whole overlap stage on the set with 100 kb reads (32-bit V rings in every launch), record for record"""
+    db, rdb, _, _ = variant_sets["long"]
+    ix = rdb.index()
+    want, _ = U.orc_overlap(db, ix.top, ix.top_mc)
+    for env in (dict(), dict(PGX_ALIGN_SMALL="0"), dict(PGX_GPU_REPLAY="1", PGX_ALIGN_SMALL="0")):
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            ov, st = rdb.overlap(ix.top, ix.top_mc)
+        finally:
+            for k, v in saved.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        assert len(want) > 1000 and formats.ovlp_fields_equal(ov, want), env
