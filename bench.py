@@ -362,7 +362,7 @@ def main():
             _, _, st_x, _ = step()
             os.environ.pop("PGX_REPLAY_TIMING")
             rk = {}
-            for nm, kname in (("replay_dense", "k_eval"), ("replay_rows", "k_eval_rows"), ("replay_update", "k_update")):
+            for nm, kname in (("replay_dense", "k_eval"), ("replay_rows", "k_eval_rows"), ("replay_big", "k_eval_big"), ("replay_update", "k_update")):
                 ms, launches, units = _lib.timing(nm)
                 if launches:
                     rk[kname] = {"ms_total": ms, "launches": launches, "avg_ms": ms / launches}

@@ -130,15 +130,41 @@ void big_pool_trim() { big_pool().trim(); }
 
 // Arrays handed to the caller (released with pgx_free): large ones come from the pooled huge-page mappings too, so that
 // filling a 300 MB result does not start with 73,000 first-touch page faults; the registry tells pgx_free which is which.
+// Large result arrays are PINNED (hipHostMalloc, pooled by size class like the mappings above): the 300 MB - 3 GB of ovlp_t records
+// of an overlap chunk come down at the PCIe rate (~55 GB/s) instead of the ~16 GB/s a pageable destination gets (measured: 189 ms
+// for the 3 GB of a human-scale chunk), and the copy is truly asynchronous.  Pinning is expensive (~0.3 ms per MB), hence the pool;
+// at most PIN_CAP bytes are held back, beyond that (and when pinning fails) the array is a pageable pooled mapping as before.
 namespace {
 std::mutex g_out_mu;
-std::map<void *, size_t> g_out_big;
+std::map<void *, size_t> g_out_big;                  // pageable pooled mappings handed out
+std::map<void *, size_t> g_out_pin;                  // pinned blocks handed out (size class)
+std::multimap<size_t, void *> g_pin_free;            // pinned blocks waiting for re-use
+size_t g_pin_held = 0;
+const size_t PIN_CAP = getenv("PGX_PIN_CAP_MB") ? (size_t)atoll(getenv("PGX_PIN_CAP_MB")) << 20 : (size_t)16 << 30;
 }  // namespace
 void *out_alloc(size_t bytes) {
   if (bytes < BIG) {
     void *p = malloc(bytes ? bytes : 1);
     if (!p) throw std::bad_alloc();
     return p;
+  }
+  const size_t len = BigPool::cls(bytes);
+  if (PIN_CAP && ctx().ready) {
+    std::lock_guard<std::mutex> lk(g_out_mu);
+    auto it = g_pin_free.find(len);
+    void *p = nullptr;
+    if (it != g_pin_free.end()) {
+      p = it->second;
+      g_pin_free.erase(it);
+      g_pin_held -= len;
+    } else if (hipHostMalloc(&p, len, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      p = nullptr;
+    }
+    if (p) {
+      g_out_pin[p] = len;
+      return p;
+    }
   }
   void *p = big_alloc(bytes);
   std::lock_guard<std::mutex> lk(g_out_mu);
@@ -150,11 +176,25 @@ void out_free(void *p) {
   size_t bytes = 0;
   {
     std::lock_guard<std::mutex> lk(g_out_mu);
+    auto ip = g_out_pin.find(p);
+    if (ip != g_out_pin.end()) {
+      const size_t len = ip->second;
+      g_out_pin.erase(ip);
+      if (g_pin_held + len <= PIN_CAP && ctx().ready) g_pin_free.emplace(len, p), g_pin_held += len;
+      else (void)hipHostFree(p);
+      return;
+    }
     auto it = g_out_big.find(p);
     if (it != g_out_big.end()) bytes = it->second, g_out_big.erase(it);
   }
   if (bytes) big_free(p, bytes);
   else free(p);
+}
+static void pin_pool_trim() {
+  std::lock_guard<std::mutex> lk(g_out_mu);
+  for (auto &kv : g_pin_free) (void)hipHostFree(kv.second);
+  g_pin_free.clear();
+  g_pin_held = 0;
 }
 
 // ---- housekeeping thread -----------------------------------------------------------------------------------
@@ -404,6 +444,7 @@ void pgx_shutdown(void) {
   Context &c = ctx();
   drain_deferred();
   big_pool_trim();
+  pin_pool_trim();
   for (auto fn : shutdown_hooks()) fn();   // plan caches / held buffers of the stages (nothing may outlive the workspaces)
   g_ws.clear();
   ++index_generation();

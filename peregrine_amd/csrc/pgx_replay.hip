@@ -74,6 +74,7 @@ constexpr uint32_t LIST_CAP = 262144;    // capacity of the list (a window of a 
 constexpr uint32_t DEV_LIST = 0xFFFFFFFFu, DEV_LIST_WIN = 0xFFFFFFFEu;  // nlist: the device's list, up to SPARSE_CAP / LIST_CAP entries
 enum : uint32_t { OV_ITEMS = 1, OV_NODES = 2, OV_REQS = 4, OV_PAIRS = 8, OV_MEMO = 16, OV_QOFF = 32, OV_PASSES = 64 };  // Counters::overflow
 constexpr uint8_t F_DUP = 1, F_GUESS = 2, F_UNFILED = 4;
+constexpr uint8_t F_BIG = 8;   // a bucket of at least R::big_min entries that holds no read twice: evaluated by a whole workgroup (k_eval_big)
 
 struct alignas(64) Counters {   // three cache lines: the arenas, the dirty statistics, the totals (an atomic holds its line's L2 channel)
   uint32_t item_top, rnode_top, nreq, overflow;
@@ -114,6 +115,9 @@ struct R {
   uint32_t tail;           // != 0: the sweeps have become small: k_file also files the alignment every OTHER reader of a requested pair would ask
                            // for and the row's next `tail` partners
   int predict, predict2;   // margins of predict_contained (0: every pending alignment is guessed a plain overlap)
+  uint32_t big_min;        // buckets from this many entries on (and without a repeated read) go to k_eval_big; 0: none do
+  uint32_t dup_min;        // the same for buckets that hold a read twice (k_eval_big's LDS pair set instead of one partner at a time)
+  uint32_t wbig0;          // first wcur slot of k_eval_big's wavefronts
 };
 
 __device__ __forceinline__ uint64_t mix64(uint64_t h) {
@@ -215,7 +219,7 @@ struct Ent {
 __device__ __forceinline__ Ent entry_of(uint64_t y) { return Ent{(uint32_t)(y >> 32), (((uint32_t)y) >> 1) + 1}; }
 
 // ---- flags: buckets holding a read more than once (only those can meet a pair twice within one evaluation) ----------
-__global__ __launch_bounds__(256) void k_setup(R r) {
+__global__ __launch_bounds__(256) void k_setup(R r, uint32_t *hist) {   // hist (trace only): [dup][min(n / 8, 15)] bucket counts
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= r.nb) return;
   const uint32_t b = r.bid[j], s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
@@ -228,8 +232,9 @@ __global__ __launch_bounds__(256) void k_setup(R r) {
         break;
       }
   }
-  r.bflags[j] = dup ? F_DUP : 0;
+  r.bflags[j] = (uint8_t)((dup ? F_DUP : 0) | ((dup ? r.dup_min && n >= r.dup_min : r.big_min && n >= r.big_min) ? F_BIG : 0));
   r.dirty[j] = 1;
+  if (hist) atomicAdd(&hist[(dup ? 16 : 0) + min(n / 8, 15u)], 1u);
 }
 
 // ---- shimmer_to_overlap (shmr_overlap.c:52-180) for every dirty bucket in [lo, hi) -------------------------------------
@@ -312,7 +317,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPW + (uint32_t)(lane / GL));
   const uint32_t j = (uint32_t)jj;
-  bool alive = jj < hi && r.dirty[j] && !r.c->overflow;
+  bool alive = jj < hi && r.dirty[j] && !r.c->overflow && !(r.bflags[j] & F_BIG);   // (big buckets: k_eval_big, launched beside this kernel)
   {
     const uint64_t am = __ballot(alive);
     if (!am) return;
@@ -564,7 +569,7 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPWT + (uint32_t)(lane / GLT));
   const uint32_t j = (uint32_t)jj;
-  bool alive = jj < hi && r.dirty[j] && !r.c->overflow;
+  bool alive = jj < hi && r.dirty[j] && !r.c->overflow && !(r.bflags[j] & F_BIG);   // (big buckets: k_eval_big, launched beside this kernel)
   {
     const uint64_t am = __ballot(alive);
     if (!am) return;
@@ -836,6 +841,376 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
       any_guess |= g1 != 0, any_unfiled |= g2 != 0;
     }
   }
+}
+
+
+// ---- the same evaluation by a WHOLE WORKGROUP, for big buckets (round 3) -----------------------------------------------------------
+// A bucket of a repeat family holds ~100 entries and its walk examines ~5,000 pairs, nearly all of them "seen" skips that do not
+// count towards bestn: every row scans most of its partners.  With a wavefront per bucket (k_eval_rows: four rows x 16 partners,
+// a row that needs more continued alone, 64 partners per step) that is 100-200 dependent steps of ~20 us -- 3.4 ms per
+// evaluation, and a sparse pass lasts as long as its largest bucket: 0.47 s of a 1.07 s step at C4 scale went there
+// (profiles/r03a_kernel_stats_bench_c4s.txt), and the ~15 tail sweeps of a human-scale chunk are little else.  Here eight
+// wavefronts take FOUR rows x 128 partners per step (a bucket holds at most 128 entries, so a row is always complete within its
+// step): the rows are committed in order through masks exchanged in LDS, exactly like k_eval_rows' four-row form -- a row commits
+// while no earlier row of the step set a contained flag; the rest is looked at again with the new flags.
+constexpr int BIG_NW = 8;                       // wavefronts per bucket: rows slot = wave / 2, partner half = wave % 2
+constexpr uint32_t BIG_WG = 2048;               // workgroups of a launch (persistent: they stride over the list / the range)
+struct M128 {
+  uint64_t lo, hi;
+};
+__device__ __forceinline__ int popc128(M128 m) { return __popcll(m.lo) + __popcll(m.hi); }
+__device__ __forceinline__ bool any128(M128 m) { return (m.lo | m.hi) != 0; }
+__device__ __forceinline__ int ctz128(M128 m) { return m.lo ? __builtin_ctzll(m.lo) : 64 + __builtin_ctzll(m.hi); }   // (m != 0)
+__device__ __forceinline__ int nth128(M128 m, uint32_t nth) {   // position of the nth set bit (nth >= 1, nth <= popc128(m))
+  const uint32_t cl = (uint32_t)__popcll(m.lo);
+  uint64_t w = m.lo;
+  int base = 0;
+  if (nth > cl) w = m.hi, nth -= cl, base = 64;
+  for (uint32_t k = 1; k < nth; ++k) w &= w - 1;
+  return base + __builtin_ctzll(w);
+}
+__device__ __forceinline__ M128 upto128(int stop) {   // bits 0 .. stop (stop >= 127: all)
+  M128 m;
+  m.lo = stop >= 63 ? ~0ULL : ((2ULL << stop) - 1ULL);
+  m.hi = stop < 64 ? 0ULL : (stop >= 127 ? ~0ULL : ((2ULL << (stop - 64)) - 1ULL));
+  return m;
+}
+__device__ __forceinline__ M128 and128(M128 a, M128 b) { return M128{a.lo & b.lo, a.hi & b.hi}; }
+
+// Buckets that hold a read TWICE (tandem arrays, low-complexity runs: the same shimmer pair several times within a read) can
+// meet a read pair more than once within one evaluation, and the second meeting must see the first one's insertion.  The
+// narrower kernels therefore run them one partner at a time -- up to 5,000 dependent steps for a 100-entry bucket, and those
+// few hundred buckets were what a sparse pass at C4 scale really waited for (3.5 ms per pass, 136 passes per step).  Here the
+// pairs this evaluation has inserted so far sit in an LDS set that every probe consults, and duplicates WITHIN a step are
+// found by letting the would-be inserters claim their pair in a second LDS table: the step is cut in front of the first lane (in
+// walk order) whose pair an earlier lane of the same step claims, the cut row is continued alone from that partner in the next
+// step -- when the insertion is in the set -- and everything before the cut is exact.  Progress per step >= one new pair, so a
+// bucket of d distinct read pairs takes at most ~d steps instead of rows x partners.
+constexpr uint32_t SET_CAP = 2048, CLAIM_CAP = 1024;   // LDS tables of k_eval_big (open addressing, power-of-two sizes)
+__global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint32_t hi, uint32_t nlist) {
+  enum { MV = 0, MP, MPO, MA, MAO, MAC, MAP, MGU, MUF, NM };
+  __shared__ uint32_t s_rid[128], s_pos[128], s_rl[128];
+  __shared__ uint8_t s_dir[128];
+  __shared__ uint64_t s_m[BIG_NW][NM];
+  __shared__ uint32_t s_fresh, s_abort, s_go, s_dupstop, s_bail;
+  __shared__ unsigned long long s_setk[SET_CAP];      // pairs inserted by this evaluation (key + 1; 0: empty) ...
+  __shared__ uint8_t s_sett[SET_CAP];                 // ... and their types
+  __shared__ unsigned long long s_clk[CLAIM_CAP];     // this step's claims: pair (key + 1) ...
+  __shared__ uint32_t s_clw[CLAIM_CAP];               // ... and the lowest walk index claiming it
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t wave_id = r.wbig0 + blockIdx.x * BIG_NW + (uint32_t)w;
+  const uint4 wc = r.wcur[wave_id];
+  uint32_t rcur = wc.x, rend = wc.y;   // reader-node arena of this wavefront
+  uint32_t icur = wc.z, iend = wc.w;   // item arena of the workgroup (only thread 0's copy is used)
+  if (threadIdx.x == 0) s_abort = 0;
+  const uint32_t nl = !nlist ? hi - lo : nlist == DEV_LIST ? min(r.c->ndirty, SPARSE_CAP) : nlist == DEV_LIST_WIN ? min(r.c->ndirty, LIST_CAP) : nlist;
+  for (uint32_t g = blockIdx.x; g < nl; g += gridDim.x) {
+    const uint32_t j = nlist ? r.dlist[g] : lo + g;
+    __syncthreads();   // (the previous bucket's LDS is done with)
+    if (threadIdx.x == 0) {   // one thread decides for the workgroup (a flag another workgroup raises meanwhile must not split it)
+      if (r.c->overflow) s_abort = 1;
+      s_go = j < hi && r.dirty[j] && (r.bflags[j] & F_BIG);
+      s_bail = 0;
+    }
+    __syncthreads();
+    if (s_abort) break;
+    if (!s_go) continue;
+    const uint32_t b = r.bid[j], s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
+    const bool first_eval = r.ever[j] == 0;
+    const bool dup = (r.bflags[j] & F_DUP) != 0;
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+      const uint64_t y = r.y0[s0 + i];
+      const uint32_t rid = (uint32_t)(y >> 32);
+      s_rid[i] = rid, s_pos[i] = (((uint32_t)y) >> 1) + 1, s_dir[i] = r.dir[s0 + i], s_rl[i] = r.rlen[rid];
+    }
+    if (dup) {
+      for (uint32_t i = threadIdx.x; i < SET_CAP; i += blockDim.x) s_setk[i] = 0;
+      for (uint32_t i = threadIdx.x; i < CLAIM_CAP; i += blockDim.x) s_clk[i] = 0, s_clw[i] = 0xFFFFFFFFu;
+    }
+    __syncthreads();   // (entries staged; everybody has read ever[] / dirty[] / bflags[] before thread 0 changes them)
+    if (threadIdx.x == 0) {
+      r.dirty[j] = 0, r.evaluated[j] = 1, r.ever[j] = 1, r.parity[j] ^= 1, r.ohead[j] = r.ihead[j];
+      atomicAdd(&r.spread[(blockIdx.x % SPREAD) * 8], 1ULL);
+    }
+    // ---- workgroup-uniform state (every thread holds a copy and updates it identically) ----
+    uint64_t clo = 0, chi = 0;   // "contained" flags of the bucket's entries
+    auto cget = [&](uint32_t i) { return (((i < 64 ? clo : chi) >> (i & 63)) & 1) != 0; };
+    auto cset = [&](uint32_t i) {
+      if (i < 64) clo |= 1ULL << i;
+      else chi |= 1ULL << (i - 64);
+    };
+    uint32_t head = NIL, num = 0, lookups = 0, skips = 0, chunk = 0;
+    bool any_guess = false, any_unfiled = false;
+    int done_to = (int)n - 1;   // rows >= done_to are finished (the first row is n - 2)
+    bool row_open = false;       // one row (cur_row) is being continued alone, from partner pbase, with `got` overlaps counted so far
+    int cur_row = 0;
+    uint32_t pbase = 0, got = 0;
+    bool p_reg = false;          // this lane has a registration whose list position (p_idx) has not been looked at yet
+    uint32_t p_idx = 0, p_slot = 0;
+    auto resolve_pending = [&]() {   // as in k_eval_rows; an exhausted arena raises s_abort instead of returning
+      if (p_reg && p_idx < NIN) r.pc[p_slot].in[p_idx] = j + 1, p_reg = false;
+      const uint64_t rm = __ballot(p_reg);
+      if (rm) {
+        const uint32_t total = (uint32_t)__popcll(rm);
+        if (rcur + total > rend) {
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(&r.c->rnode_top, NCH);
+          base = (uint32_t)__shfl((int)base, 0, 64);
+          if ((uint64_t)base + NCH > r.rn_cap) {
+            atomicOr(&r.c->overflow, OV_NODES);
+            s_abort = 1;
+            p_reg = false;
+            return;
+          }
+          rcur = base, rend = base + NCH;
+        }
+        if (p_reg) {
+          const uint32_t node = rcur + lane_rank(rm);
+          const uint32_t old = atomicExch(&r.pc[p_slot].rhead, node + 1);
+          r.rn[node] = RNode{old, j};
+        }
+        rcur += total;
+        p_reg = false;
+      }
+    };
+    for (;;) {
+      // the rows of this step: the open row alone, or the next (up to four) rows that are not contained
+      int a[4] = {-1, -1, -1, -1}, nrows = 0;
+      if (row_open) {
+        a[0] = cur_row, nrows = 1;
+      } else {
+        for (int x = done_to; nrows < 4;) {
+          do --x;
+          while (x >= 0 && cget((uint32_t)x));
+          if (x < 0) break;
+          a[nrows++] = x;
+        }
+      }
+      if (nrows == 0 || r.bestn == 0) break;
+      // ---- this step's (row, partner) of the lane: slot q = wave / 2 takes row a[q], partners first + (wave % 2) * 64 + lane ----
+      const int q = w >> 1, off = (w & 1) * 64 + lane;   // off: partner offset within the row's 128 (= its bit in the row's masks)
+      const int myrow = a[q];
+      const uint32_t first = row_open ? pbase : (uint32_t)(myrow + 1);
+      const uint32_t pi = first + (uint32_t)off;
+      const uint32_t wi = (uint32_t)(q * 128 + off);     // position in walk order
+      bool valid = q < nrows && pi < n && !cget(pi);
+      uint32_t rid0 = 0, pos0 = 0, rlen0 = 0, dir0 = 0, rid1 = 0, pos1 = 0;
+      if (valid) {
+        rid0 = s_rid[myrow], pos0 = s_pos[myrow], rlen0 = s_rl[myrow], dir0 = s_dir[myrow];
+        rid1 = s_rid[pi], pos1 = s_pos[pi];
+        if (rid1 == rid0) valid = false;
+      }
+      uint32_t slot = NONE, v = 0;
+      const uint64_t pair = rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0);
+      if (valid) slot = pair_find(r, pair, &v);
+      bool present = false, accepted = false, guessed = false;
+      uint32_t ptype = 0, type = 0, mslot = NONE;
+      if (valid) {
+        present = v != 0 && own_bucket(v) < j;
+        ptype = present ? own_type(v) : 0;
+        if (!present && dup) {   // inserted earlier in THIS evaluation?
+          for (uint32_t i = (uint32_t)mix64(pair) & (SET_CAP - 1);; i = (i + 1) & (SET_CAP - 1)) {
+            const unsigned long long kk = s_setk[i];
+            if (kk == 0) break;
+            if (kk == pair + 1) {
+              present = true, ptype = s_sett[i];
+              break;
+            }
+          }
+        }
+        if (!present) {
+          const uint32_t rlen1 = s_rl[pi], dir1 = s_dir[pi];
+          const uint32_t q_off = pos0 - pos1;
+          if (q_off >= (1u << 30)) atomicOr(&r.c->overflow, OV_QOFF);
+          uint32_t req = NONE;
+          if (r.memo_used) mslot = memo_find(r, (unsigned long long)rid0 << 32 | rid1, q_off << 2 | dir0 << 1 | dir1, &req);
+          if (req < r.settled) {
+            accepted = classify(r.rq_res[req], rlen0, rlen1, q_off, &type);
+          } else {
+            accepted = true, guessed = true, type = T_OVERLAP;
+            if (r.predict && predict_contained(rlen0, rlen1, q_off, r.predict, r.predict2)) type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
+          }
+        }
+      }
+      resolve_pending();   // (the previous step's registrations: their atomics have returned behind the loads above)
+      const bool ins0 = valid && !present && accepted;
+      uint32_t my_claim = NONE;
+      if (dup) {   // would-be inserters claim their pair: the lowest walk index wins
+        if (threadIdx.x == 0) s_dupstop = 0xFFFFFFFFu;
+        if (ins0) {
+          for (uint32_t i = (uint32_t)(mix64(pair) >> 20) & (CLAIM_CAP - 1);; i = (i + 1) & (CLAIM_CAP - 1)) {
+            unsigned long long kk = s_clk[i];
+            if (kk == 0) kk = atomicCAS(&s_clk[i], 0ULL, (unsigned long long)pair + 1), kk = kk ? kk : pair + 1;
+            if (kk == pair + 1) {
+              atomicMin(&s_clw[i], wi);
+              my_claim = i;
+              break;
+            }
+          }
+        }
+      }
+      {
+        const uint64_t mv = __ballot(valid), mp = __ballot(valid && present), mpo = __ballot(valid && present && ptype == T_OVERLAP);
+        const uint64_t ma = __ballot(ins0), mao = __ballot(ins0 && type == T_OVERLAP), mac = __ballot(ins0 && type == T_CONTAINED);
+        const uint64_t map = __ballot(ins0 && type == T_CONTAINS), mgu = __ballot(ins0 && guessed), muf = __ballot(ins0 && mslot == NONE);
+        if (lane == 0)
+          s_m[w][MV] = mv, s_m[w][MP] = mp, s_m[w][MPO] = mpo, s_m[w][MA] = ma, s_m[w][MAO] = mao, s_m[w][MAC] = mac, s_m[w][MAP] = map,
+          s_m[w][MGU] = mgu, s_m[w][MUF] = muf;
+      }
+      __syncthreads();
+      if (dup) {   // the first lane (walk order) whose pair a LOWER lane of this step inserts: the step is cut in front of it.  That
+                   // holds for EVERY lane that found the pair absent, also one whose own alignment is rejected: sequentially it would
+                   // have found the pair seen and skipped it.
+        if (my_claim != NONE) {
+          if (s_clw[my_claim] < wi) atomicMin(&s_dupstop, wi);
+        } else if (valid && !present) {
+          for (uint32_t i = (uint32_t)(mix64(pair) >> 20) & (CLAIM_CAP - 1);; i = (i + 1) & (CLAIM_CAP - 1)) {
+            const unsigned long long kk = s_clk[i];
+            if (kk == 0) break;
+            if (kk == pair + 1) {
+              if (s_clw[i] < wi) atomicMin(&s_dupstop, wi);
+              break;
+            }
+          }
+        }
+        __syncthreads();
+      }
+      if (s_abort) break;
+      const uint32_t dupstop = dup ? s_dupstop : 0xFFFFFFFFu;
+      // ---- the sequential semantics over this step: the rows in order, each over its 128 partners, lowest first (uniform) ----
+      M128 proc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+      int committed = 0;         // rows completed in this step
+      bool open_next = false;    // the row after them was cut: it is continued alone
+      int open_row = 0;
+      uint32_t open_pbase = 0, open_got = 0;
+      for (int k = 0; k < nrows; ++k) {
+        if (dupstop <= (uint32_t)(k * 128)) break;   // the cut lies in front of this row
+        const M128 inc = {s_m[2 * k][MPO] | s_m[2 * k][MAO], s_m[2 * k + 1][MPO] | s_m[2 * k + 1][MAO]};
+        const M128 ac = {s_m[2 * k][MAC], s_m[2 * k + 1][MAC]}, ap = {s_m[2 * k][MAP], s_m[2 * k + 1][MAP]};
+        const uint32_t need = r.bestn - (row_open ? got : 0u);   // >= 1
+        int stop = 128;
+        if ((uint32_t)popc128(inc) >= need) stop = nth128(inc, need);
+        if (any128(ac)) stop = min(stop, ctz128(ac));
+        const int cut = dupstop < (uint32_t)(k * 128 + 128) ? (int)(dupstop - (uint32_t)(k * 128)) : 128;   // first offset of the row that may not be processed
+        const bool complete = stop < cut || (cut == 128);   // the row ends before the cut (or there is none in it)
+        proc[k] = complete ? upto128(stop) : upto128(cut - 1);   // (cut >= 1 here: cut == 0 was caught above)
+        const uint32_t first_k = row_open ? pbase : (uint32_t)(a[k] + 1);
+        const M128 apk = and128(ap, proc[k]);
+        for (uint64_t m = apk.lo; m; m &= m - 1) cset(first_k + (uint32_t)__builtin_ctzll(m));   // partners found contained
+        for (uint64_t m = apk.hi; m; m &= m - 1) cset(first_k + 64u + (uint32_t)__builtin_ctzll(m));
+        const bool rowc = any128(and128(ac, proc[k]));
+        if (rowc) cset((uint32_t)a[k]);
+        if (!complete) {
+          open_next = true, open_row = a[k], open_pbase = first_k + (uint32_t)cut, open_got = (row_open ? got : 0u) + (uint32_t)popc128(and128(inc, proc[k]));
+          break;
+        }
+        ++committed;
+        if (any128(apk) || rowc) break;   // contained flags changed: the rows below are looked at again with them
+      }
+      if (committed) done_to = a[committed - 1];
+      row_open = open_next;
+      if (open_next) cur_row = open_row, pbase = open_pbase, got = open_got;
+      // per wavefront: what the walk really visits, and the insertions in walk order (row, then partner)
+      uint32_t cins = 0, before = 0;
+      uint64_t myproc = 0;
+      for (int ww = 0; ww < BIG_NW; ++ww) {
+        const int k = ww >> 1;
+        const uint64_t pw = (ww & 1) ? proc[k].hi : proc[k].lo;
+        const uint32_t c = (uint32_t)__popcll(s_m[ww][MA] & pw);
+        if (ww < w) before += c;
+        if (ww == w) myproc = pw;
+        cins += c;
+        skips += (uint32_t)__popcll(s_m[ww][MP] & pw);
+        lookups += (uint32_t)__popcll(s_m[ww][MV] & ~s_m[ww][MP] & pw);
+        any_guess |= (s_m[ww][MGU] & pw) != 0, any_unfiled |= (s_m[ww][MUF] & pw) != 0;
+      }
+      // the item chunks this step opens (one allocation for the workgroup, by thread 0)
+      const uint32_t cur_no = num ? (num - 1) >> 4 : 0, first_new = num ? cur_no + 1 : 0;
+      const uint32_t last = num + cins - 1, last_no = last >> 4;
+      const uint32_t nnew = cins && last_no + 1 > first_new ? last_no + 1 - first_new : 0;
+      if (threadIdx.x == 0 && nnew) {
+        const uint32_t want = 16u * nnew;
+        if (icur + want > iend) {
+          const uint32_t take = want > ICH ? want : ICH;
+          const uint32_t base = atomicAdd(&r.c->item_top, take);
+          if ((uint64_t)base + take > r.item_cap) atomicOr(&r.c->overflow, OV_ITEMS), s_abort = 1;
+          icur = base, iend = base + take;
+        }
+        s_fresh = icur, icur += want;
+      }
+      const bool visited = valid && ((myproc >> lane) & 1);
+      {  // the partners the walk really examined register as readers of their pairs (as in k_eval_rows)
+        bool reg = visited;
+        if (reg && slot == NONE) slot = pair_slot(r, pair);
+        if (reg && !first_eval) {
+          const uint32_t *pw = reinterpret_cast<const uint32_t *>(&r.pc[slot]);
+          const uint4 h1 = *reinterpret_cast<const uint4 *>(pw);  // cnt, rhead, in[0], in[1]
+          const uint32_t c = min(h1.x, NIN);
+          if ((c > 0 && h1.z == j + 1) || (c > 1 && h1.w == j + 1)) reg = false;
+          for (uint32_t qq = 2; qq < c && reg; qq += 8) {
+            const uint4 xa = *reinterpret_cast<const uint4 *>(pw + 2 + qq), xb = *reinterpret_cast<const uint4 *>(pw + 6 + qq);
+            const uint32_t x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 8; ++k)
+              if (qq + k < c && x[k] == j + 1) reg = false;
+          }
+        }
+        if (reg) p_idx = atomicAdd(&r.pc[slot].cnt, 1u), p_slot = slot, p_reg = true;
+      }
+      const bool my_ins = ins0 && visited;
+      if (dup) {
+        if (my_claim != NONE) s_clk[my_claim] = 0, s_clw[my_claim] = 0xFFFFFFFFu;   // (the claim table is empty again for the next step)
+        if (my_ins) {   // this evaluation's insertions, for the probes of the steps to come
+          uint32_t tries = 0;
+          for (uint32_t i = (uint32_t)mix64(pair) & (SET_CAP - 1);; i = (i + 1) & (SET_CAP - 1)) {
+            const unsigned long long kk = atomicCAS(&s_setk[i], 0ULL, (unsigned long long)pair + 1);
+            if (kk == 0 || kk == pair + 1) {
+              s_sett[i] = (uint8_t)type;
+              break;
+            }
+            if (++tries >= SET_CAP) {   // the set is full (not with <= 128 entries and bestn <= ~8; kept as a guard): leave the bucket to k_eval_rows
+              s_bail = 1;
+              break;
+            }
+          }
+        }
+      }
+      __syncthreads();   // (s_fresh is there; nobody reads this step's masks any more; the set holds this step's insertions)
+      if (s_abort) break;
+      if (cins) {
+        const uint32_t fresh = s_fresh;
+        auto base_of = [&](uint32_t no) { return no >= first_new ? fresh + 16u * (no - first_new) : chunk; };
+        if (my_ins) {
+          const uint32_t ord = num + before + (uint32_t)__popcll(s_m[w][MA] & myproc & ((1ULL << lane) - 1ULL));   // insertion ordinal within the bucket
+          const uint32_t idx = base_of(ord >> 4) + (ord & 15);
+          uint32_t next;
+          if (ord == 0) next = NIL;
+          else if ((ord & 15) == 0) next = base_of((ord >> 4) - 1) + 16;  // the last item of the previous chunk, + 1
+          else next = idx;                                                // the item before this one, + 1
+          uint32_t info = (uint32_t)myrow | pi << 8 | type << 16;
+          if (guessed) info |= I_GUESS;
+          if (mslot == NONE) info |= I_UNFILED;
+          r.items[idx] = Item{slot, info, mslot, next};
+        }
+        chunk = base_of(last_no);
+        head = chunk + (last & 15) + 1;
+        num += cins;
+      }
+      __syncthreads();   // (s_m[w][MA] was read above: the next step may overwrite the masks now)
+      if (s_bail) break;
+    }
+    resolve_pending();
+    if (threadIdx.x == 0) {
+      if (s_bail) {   // (guard path: evaluated again by k_eval_rows, one partner at a time; the lists written so far are simply dropped)
+        r.dirty[j] = 1, r.evaluated[j] = 0, r.parity[j] ^= 1;
+        r.bflags[j] = (uint8_t)((r.bflags[j] & ~F_BIG));
+      } else {
+        r.ihead[j] = head, r.inum[j] = num, r.lookups[j] = lookups, r.skips[j] = skips;
+        r.bflags[j] = (uint8_t)(F_BIG | (dup ? F_DUP : 0) | (any_guess ? F_GUESS : 0) | (any_unfiled ? F_UNFILED : 0));
+      }
+    }
+  }
+  if (lane == 0) r.wcur[wave_id] = make_uint4(rcur, rend, icur, iend);
 }
 
 // ---- apply the evaluated buckets' lists to the pair table: a group per bucket, a lane per item ---------------------------
@@ -1222,7 +1597,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   DevBuf<PCold> pc(pcap);
   DevBuf<MSlot> mt(mcap);
   r.ph = ph.p, r.pc = pc.p, r.pmask = pcap - 1, r.mt = mt.p, r.mmask = mcap - 1;
-  r.item_cap = (uint32_t)std::min<size_t>((size_t)(ne * 6 * mult[0]) + nb * (size_t)64 + (size_t)(SPARSE_CAP + 8) * ICH + (1u << 20), 0x7FFFFFF0u);
+  r.item_cap = (uint32_t)std::min<size_t>((size_t)(ne * 6 * mult[0]) + nb * (size_t)64 + (size_t)(SPARSE_CAP + 8 + BIG_WG * BIG_NW) * ICH + (1u << 20), 0x7FFFFFF0u);
   r.rn_cap = (uint32_t)std::min<size_t>((size_t)(ne * 8 * mult[1]) + (1u << 20), 0x7FFFFFF0u);
   r.req_cap = (uint32_t)std::min<size_t>((size_t)(ne * 1 * mult[2]) + 65536, 0x7FFFFFF0u);
   DevBuf<Item> items(r.item_cap);
@@ -1234,8 +1609,11 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   DevBuf<uint32_t> words(nb * 5);
   r.dirty = bytes.p, r.evaluated = bytes.p + nb, r.parity = bytes.p + 2 * nb, r.bflags = bytes.p + 3 * nb, r.ever = bytes.p + 4 * nb;
   r.ihead = words.p, r.inum = words.p + nb, r.ohead = words.p + 2 * nb, r.lookups = words.p + 3 * nb, r.skips = words.p + 4 * nb;
-  DevBuf<uint4> wcur(nb + 2 + SPARSE_CAP + 1);  // (one slot per wavefront of k_eval: GPW buckets each)
-  r.wcur = wcur.p, r.wlist0 = (uint32_t)(nb + 2);
+  // big buckets (>= big_min entries, no read twice) are evaluated by a workgroup each: k_eval_big beside every evaluation launch
+  r.big_min = getenv("PGX_REPLAY_BIG") ? (uint32_t)std::max(0, atoi(getenv("PGX_REPLAY_BIG"))) : 48u;
+  r.dup_min = getenv("PGX_REPLAY_DUP") ? (uint32_t)std::max(0, atoi(getenv("PGX_REPLAY_DUP"))) : 12u;
+  DevBuf<uint4> wcur(nb + 2 + SPARSE_CAP + 1 + (size_t)BIG_WG * BIG_NW);  // (one slot per wavefront of k_eval: GPW buckets each; list mode; k_eval_big)
+  r.wcur = wcur.p, r.wlist0 = (uint32_t)(nb + 2), r.wbig0 = (uint32_t)(nb + 2 + SPARSE_CAP + 1);
   DevBuf<uint32_t> dlist(LIST_CAP);
   r.dlist = dlist.p;
   DevBuf<Counters> dc(1);
@@ -1256,7 +1634,21 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   PGX_HIP(hipMemsetAsync(words.p, 0, nb * 5 * sizeof(uint32_t), s));
   PGX_HIP(hipMemsetAsync(dc.p, 0, sizeof(Counters), s));
   hipLaunchKernelGGL(k_init_slots, dim3(cdiv256(wcur.n)), dim3(256), 0, s, wcur.p, (uint32_t)wcur.n, (uint32_t)(nb / GPW + 2), r.wlist0, dc.p);
-  hipLaunchKernelGGL(k_setup, dim3(cdiv256(nb)), dim3(256), 0, s, r);
+  if (trace) {
+    DevBuf<uint32_t> hist(32);
+    PGX_HIP(hipMemsetAsync(hist.p, 0, 32 * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_setup, dim3(cdiv256(nb)), dim3(256), 0, s, r, hist.p);
+    uint32_t h[32];
+    hist.download(h, 32);
+    sync();
+    fprintf(stderr, "[pgx]   buckets by entries / 8 (last class: >= 120):");
+    for (int i = 0; i < 16; ++i) fprintf(stderr, " %u", h[i]);
+    fprintf(stderr, "\n[pgx]   ... of those holding a read twice (one partner at a time):");
+    for (int i = 0; i < 16; ++i) fprintf(stderr, " %u", h[16 + i]);
+    fprintf(stderr, "\n");
+  } else {
+    hipLaunchKernelGGL(k_setup, dim3(cdiv256(nb)), dim3(256), 0, s, r, (uint32_t *)nullptr);
+  }
 
   static Counters *hc = nullptr;  // pinned mirror of the device counters
   static unsigned long long *hs = nullptr;  // pinned mirror of the spread totals
@@ -1355,6 +1747,13 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
             else if (from_list) hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST_WIN);
             else hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
             tm.reset();
+            if (r.big_min || r.dup_min) {
+              if (timed) tm.emplace("replay_big", 0);
+              const unsigned wgs = (unsigned)std::min<size_t>(BIG_WG, hi - lo);
+              if (from_list) hipLaunchKernelGGL(k_eval_big, dim3(wgs), dim3(64 * BIG_NW), 0, s, r, 0u, (uint32_t)nb, DEV_LIST_WIN);
+              else hipLaunchKernelGGL(k_eval_big, dim3(wgs), dim3(64 * BIG_NW), 0, s, r, (uint32_t)lo, hi, 0u);
+              tm.reset();
+            }
             if (deep) sync(), t_eval += now_ms() - td, td = now_ms();
             if (timed) tm.emplace("replay_update", 0);
             if (from_list) hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST_WIN);
@@ -1378,6 +1777,11 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
           if (wide) hipLaunchKernelGGL((k_eval_rows<64, 16>), dim3(cdiv256((size_t)groups * 64)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
           else hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)groups * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
           tm.reset();
+          if (r.big_min || r.dup_min) {
+            if (timed) tm.emplace("replay_big", 0);
+            hipLaunchKernelGGL(k_eval_big, dim3(std::min<unsigned>(BIG_WG, groups)), dim3(64 * BIG_NW), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
+            tm.reset();
+          }
           if (timed) tm.emplace("replay_update", 0);
           hipLaunchKernelGGL(k_update, dim3(cdiv256((size_t)groups * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
           tm.reset();

@@ -722,3 +722,28 @@ def test_overlap_stage_with_long_reads_equals_oracle(variant_sets):
             for k, v in saved.items():
                 os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
         assert len(want) > 1000 and formats.ovlp_fields_equal(ov, want), env
+
+
+def test_workgroup_evaluation_of_repeat_buckets_equals_oracle(monkeypatch):
+    """k_eval_big (round 3): a workgroup per bucket -- four rows x 128 partners per step, the rows committed in order through LDS
+    masks -- also for the buckets that hold a read TWICE (tandem arrays: a read pair met several times within one evaluation; the
+    pairs the evaluation has inserted sit in an LDS set, duplicates inside a step cut the step).  Record sequence and counters
+    against the oracle with the thresholds from "nearly every bucket" (2) to the defaults, under several schedules."""
+    g = simreads.make_genome(600_000, 9, repeat_families=2, repeat_len=4000, repeat_copies=6, tandem=60)
+    db = simreads.simulate_reads(g, seed=43, coverage=30, mean_len=9000, sd_len=1500)
+    rdb = ResidentDB(db, 0)
+    ix = rdb.index()
+    monkeypatch.setenv("PGX_GPU_REPLAY", "1")
+    rng = np.random.default_rng(3)
+    for kw in (dict(), dict(bestn=2), dict(align_bandwidth=30), dict(total_chunk=2, mychunk=2, bestn=8)):
+        okw = dict(mychunk=kw.get("mychunk", 1), total=kw.get("total_chunk", 1), bestn=kw.get("bestn", 4), band=kw.get("align_bandwidth", 100))
+        want, ost = U.orc_overlap(db, ix.top, ix.top_mc, **okw)
+        assert len(want) > 10000
+        for big, dup in ((2, 2), (5, 2), (0, 2), (2, 0), (48, 12), (0, 0)):
+            monkeypatch.setenv("PGX_REPLAY_BIG", str(big)), monkeypatch.setenv("PGX_REPLAY_DUP", str(dup))
+            monkeypatch.setenv("PGX_REPLAY_WIN", str(int(rng.choice([64, 16384, 1 << 22]))))
+            monkeypatch.setenv("PGX_REPLAY_K", str(int(rng.choice([1, 3]))))
+            got, st = rdb.overlap(ix.top, ix.top_mc, **kw)
+            assert st["device_replay"] == 1 and formats.ovlp_fields_equal(got, want), (kw, big, dup)
+            assert st["n_align_needed"] == ost["n_align"] and st["n_seen_skip"] == ost["n_seen_skip"], (kw, big, dup)
+    rdb.close()

@@ -16,7 +16,10 @@ t0 = time.time()
 for wl in wls:
     seeds = [42] if wl == "c3" else [42, 43]
     for seed in seeds:
-        if wl == "repeats":  # planted repeat families + a tandem array: buckets holding a read twice, long reader lists
+        if wl == "tandem":   # many tandem arrays and homopolymer runs: large buckets that hold a read several times
+            g = simreads.make_genome(600_000, 9, repeat_families=2, repeat_len=4000, repeat_copies=6, tandem=60)
+            db = simreads.simulate_reads(g, seed=seed, coverage=30, mean_len=9000, sd_len=1500)
+        elif wl == "repeats":  # planted repeat families + a tandem array: buckets holding a read twice, long reader lists
             g = simreads.make_genome(400_000, 5, repeat_families=3, repeat_len=5000, repeat_copies=4, tandem=1)
             db = simreads.simulate_reads(g, seed=seed, coverage=25, mean_len=9000, sd_len=1500)
         elif wl == "c3":
@@ -36,11 +39,13 @@ for wl in wls:
                 os.environ["PGX_GPU_REPLAY"] = "1"
                 os.environ["PGX_REPLAY_WIN"] = str(int(rng.choice([64, 1024, 16384, 262144, 1 << 22])))
                 os.environ["PGX_REPLAY_K"] = str(int(rng.choice([1, 2, 3, 5])))
+                os.environ["PGX_REPLAY_BIG"] = str(int(rng.choice([0, 2, 5, 24])))   # 2: nearly every bucket goes to the workgroup kernel
+                os.environ["PGX_REPLAY_DUP"] = str(int(rng.choice([0, 2, 2, 12])))   # the same for the buckets that hold a read twice
                 got, st = rdb.overlap(ix.top, ix.top_mc, **kw)
                 ok = formats.ovlp_fields_equal(got, want) and st["n_align_needed"] == wst["n_align_needed"] and st["n_seen_skip"] == wst["n_seen_skip"]
                 if not ok:
                     bad += 1
-                    print(f"MISMATCH {wl} seed {seed} {kw}: window {os.environ['PGX_REPLAY_WIN']} k {os.environ['PGX_REPLAY_K']}: {len(got)} vs {len(want)} records, {st} vs {wst}", flush=True)
+                    print(f"MISMATCH {wl} seed {seed} {kw}: window {os.environ['PGX_REPLAY_WIN']} k {os.environ['PGX_REPLAY_K']} big {os.environ['PGX_REPLAY_BIG']} dup {os.environ['PGX_REPLAY_DUP']}: {len(got)} vs {len(want)} records, {st} vs {wst}", flush=True)
             print(f"{wl} seed {seed} {kw}: {len(want)} records, ok so far ({bad} mismatches, {time.time()-t0:.0f}s)", flush=True)
 print(f"done in {time.time()-t0:.1f}s, {bad} mismatches")
 sys.exit(1 if bad else 0)
