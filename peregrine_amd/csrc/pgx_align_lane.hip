@@ -92,7 +92,12 @@ __global__ __launch_bounds__(256) void k_lane_prep(const pgx_align_key *__restri
 
 // ---- the kernel ---------------------------------------------------------------------------------------------------------------
 enum { LP_FETCH = 0, LP_DIAG = 1, LP_EXT = 2, LP_SCAN = 3, LP_DONE = 4 };
-constexpr int LANE_QD = 18;                 // dwords of a sequence window: 16 (256 bases) + 2 mirrored
+#ifndef PGX_LANE_W
+#define PGX_LANE_W 256
+#endif
+constexpr int LANE_W = PGX_LANE_W;             // bases a window holds (a power of two >= 128)
+constexpr int LANE_WD = LANE_W / 16;        // ... in dwords
+constexpr int LANE_QD = LANE_WD + 2;        // dwords of a sequence window: the ring + 2 mirrored
 constexpr int LANE_VD = 16;                 // dwords of the V ring: 32 slots of 16 bits
 constexpr int LANE_DW = 2 * LANE_QD + LANE_VD;   // 52 dwords = 208 bytes per lane, 13,312 bytes per wavefront
 constexpr int LANE_RING = 32;               // V slots
@@ -157,15 +162,15 @@ __global__ __launch_bounds__(64) void k_align_lane(const uint32_t *__restrict__ 
     // ---- A. a chunk requested three iterations ago lands in the window ------------------------------------------------------
     if (skip > 0) --skip, L.pq = L.pt = false;   // (requested for the lane's previous candidate)
     if (L.pq) {
-      const int s = (qhi >> 4) & 15;   // 4 dwords at ring dwords s..s+3 (s is a multiple of 4)
+      const int s = (qhi >> 4) & (LANE_WD - 1);   // 4 dwords at ring dwords s..s+3 (s is a multiple of 4)
       Q[(s + 0) * 64] = L.q.x, Q[(s + 1) * 64] = L.q.y, Q[(s + 2) * 64] = L.q.z, Q[(s + 3) * 64] = L.q.w;
-      if (s == 0) Q[16 * 64] = L.q.x, Q[17 * 64] = L.q.y;
+      if (s == 0) Q[LANE_WD * 64] = L.q.x, Q[(LANE_WD + 1) * 64] = L.q.y;
       qhi += 64;
     }
     if (L.pt) {
-      const int s = (thi >> 4) & 15;
+      const int s = (thi >> 4) & (LANE_WD - 1);
       T[(s + 0) * 64] = L.t.x, T[(s + 1) * 64] = L.t.y, T[(s + 2) * 64] = L.t.z, T[(s + 3) * 64] = L.t.w;
-      if (s == 0) T[16 * 64] = L.t.x, T[17 * 64] = L.t.y;
+      if (s == 0) T[LANE_WD * 64] = L.t.x, T[(LANE_WD + 1) * 64] = L.t.y;
       thi += 64;
     }
     L.pq = L.pt = false;
@@ -244,9 +249,9 @@ __global__ __launch_bounds__(64) void k_align_lane(const uint32_t *__restrict__ 
       const int rem = min(q_len - x, t_len - y);
       const int xr = x + qoff, yr = y + toff;
       const int nav = min(min(qhi - xr, thi - yr), 32);   // bases both windows hold from here on
-      hand_on = xr < qhi - 256 || yr < thi - 256;         // behind a window (the pins below make this an assertion): handed on
+      hand_on = xr < qhi - LANE_W || yr < thi - LANE_W;         // behind a window (the pins below make this an assertion): handed on
       reason = 1;
-      const int qi = (xr >> 4) & 15, ti = (yr >> 4) & 15;
+      const int qi = (xr >> 4) & (LANE_WD - 1), ti = (yr >> 4) & (LANE_WD - 1);
       const uint32_t q0 = Q[qi * 64], q1 = Q[(qi + 1) * 64], q2 = Q[(qi + 2) * 64];
       const uint32_t t0 = T[ti * 64], t1 = T[(ti + 1) * 64], t2 = T[(ti + 2) * 64];
       const int n = max(min(nav, rem), 0);
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(64) void k_align_lane(const uint32_t *__restrict__ 
       // The windows are pinned to the lowest start point of the diagonals still to come (section G), so a long match can run out
       // of them: the furthest a window gets is the first multiple of 64 above low + 192.  The diagonal is then SET ASIDE, the rest
       // of the step is done first (those diagonals sit near the old front), and it is finished when nothing else needs the old data.
-      const int qmax = ((lowx + qoff + 192) & ~63) + 64, tmax = ((lowy + toff + 192) & ~63) + 64;
+      const int qmax = ((lowx + qoff + LANE_W - 64) & ~63) + 64, tmax = ((lowy + toff + LANE_W - 64) & ~63) + 64;
       set_aside = !fin && n == 0 && (xr + m >= qmax || yr + m >= tmax);
     }
     if (set_aside) {
@@ -394,8 +399,8 @@ __global__ __launch_bounds__(64) void k_align_lane(const uint32_t *__restrict__ 
     //         unless that chunk would overwrite bases a diagonal still to come may start at -------------------------------------------
     {
       const bool active = phase != LP_FETCH && phase != LP_DONE;
-      const bool wq = active && (fx + qoff + 96 > qreq) && (qreq <= lowx + qoff + 192);
-      const bool wt = active && (fy + toff + 96 > treq) && (treq <= lowy + toff + 192);
+      const bool wq = active && (fx + qoff + 96 > qreq) && (qreq <= lowx + qoff + LANE_W - 64);
+      const bool wt = active && (fy + toff + 96 > treq) && (treq <= lowy + toff + LANE_W - 64);
       // (issued by every lane, every iteration: a lane that needs nothing re-reads its last chunk -- a cache hit -- so that the
       // number of loads in flight is the same on every path and the compiler can leave exactly two iterations' worth outstanding)
       const int qc = wq ? (qreq >> 6) : max((qreq >> 6) - 1, 0), tc = wt ? (treq >> 6) : max((treq >> 6) - 1, 0);

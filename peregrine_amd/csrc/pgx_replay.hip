@@ -80,7 +80,9 @@ struct alignas(64) Counters {   // three cache lines: the arenas, the dirty stat
   uint32_t item_top, rnode_top, nreq, overflow;
   uint32_t pad0[12];
   uint32_t ndirty, min_dirty, max_dirty, pad;
-  uint32_t pad1[12];
+  uint32_t nbig;          // big dirty buckets the narrow evaluation kernels of this pass left to k_eval_big (R::blist)
+  uint32_t nbig_total;    // buckets k_setup marked F_BIG (none: k_eval_big is never launched)
+  uint32_t pad1[10];
   unsigned long long lookups, skips, evals, records;
   unsigned long long pad2[4];
 };
@@ -107,6 +109,7 @@ struct R {
   uint8_t *dirty, *evaluated, *parity, *bflags, *ever;
   uint32_t *ihead, *inum, *ohead, *lookups, *skips;
   uint32_t *dlist;  // the dirty buckets, listed by k_count while there are at most LIST_CAP of them (the sparse passes run from the list)
+  uint32_t *blist;  // the big ones among a pass's dirty buckets (any order; Counters::nbig of them)
   uint32_t wlist0;  // first wcur slot of the list-mode wavefronts
   uint4 *wcur;  // per wavefront of k_eval: the unused rest of its arena chunks {node cur, node end, item cur, item end}, kept across launches
   Counters *c;
@@ -232,7 +235,9 @@ __global__ __launch_bounds__(256) void k_setup(R r, uint32_t *hist) {   // hist 
         break;
       }
   }
-  r.bflags[j] = (uint8_t)((dup ? F_DUP : 0) | ((dup ? r.dup_min && n >= r.dup_min : r.big_min && n >= r.big_min) ? F_BIG : 0));
+  const bool big = dup ? r.dup_min && n >= r.dup_min : r.big_min && n >= r.big_min;
+  r.bflags[j] = (uint8_t)((dup ? F_DUP : 0) | (big ? F_BIG : 0));
+  if (big) atomicAdd(&r.c->nbig_total, 1u);
   r.dirty[j] = 1;
   if (hist) atomicAdd(&hist[(dup ? 16 : 0) + min(n / 8, 15u)], 1u);
 }
@@ -317,7 +322,11 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPW + (uint32_t)(lane / GL));
   const uint32_t j = (uint32_t)jj;
-  bool alive = jj < hi && r.dirty[j] && !r.c->overflow && !(r.bflags[j] & F_BIG);   // (big buckets: k_eval_big, launched beside this kernel)
+  bool alive = jj < hi && r.dirty[j] && !r.c->overflow;
+  if (alive && (r.bflags[j] & F_BIG)) {   // a big bucket: left to k_eval_big, which runs behind this kernel from the list written here
+    if (gl == 0) r.blist[atomicAdd(&r.c->nbig, 1u)] = j;
+    alive = false;
+  }
   {
     const uint64_t am = __ballot(alive);
     if (!am) return;
@@ -569,7 +578,11 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPWT + (uint32_t)(lane / GLT));
   const uint32_t j = (uint32_t)jj;
-  bool alive = jj < hi && r.dirty[j] && !r.c->overflow && !(r.bflags[j] & F_BIG);   // (big buckets: k_eval_big, launched beside this kernel)
+  bool alive = jj < hi && r.dirty[j] && !r.c->overflow;
+  if (alive && (r.bflags[j] & F_BIG)) {   // a big bucket: left to k_eval_big, which runs behind this kernel from the list written here
+    if (gl == 0) r.blist[atomicAdd(&r.c->nbig, 1u)] = j;
+    alive = false;
+  }
   {
     const uint64_t am = __ballot(alive);
     if (!am) return;
@@ -854,7 +867,7 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
 // step): the rows are committed in order through masks exchanged in LDS, exactly like k_eval_rows' four-row form -- a row commits
 // while no earlier row of the step set a contained flag; the rest is looked at again with the new flags.
 constexpr int BIG_NW = 8;                       // wavefronts per bucket: rows slot = wave / 2, partner half = wave % 2
-constexpr uint32_t BIG_WG = 2048;               // workgroups of a launch (persistent: they stride over the list / the range)
+constexpr uint32_t BIG_WG = 512;                // workgroups of a launch (persistent: they stride over the list / the range, 512 entries at a time)
 struct M128 {
   uint64_t lo, hi;
 };
@@ -892,7 +905,7 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
   __shared__ uint32_t s_rid[128], s_pos[128], s_rl[128];
   __shared__ uint8_t s_dir[128];
   __shared__ uint64_t s_m[BIG_NW][NM];
-  __shared__ uint32_t s_fresh, s_abort, s_go, s_dupstop, s_bail;
+  __shared__ uint32_t s_fresh, s_abort, s_dupstop, s_bail;
   __shared__ unsigned long long s_setk[SET_CAP];      // pairs inserted by this evaluation (key + 1; 0: empty) ...
   __shared__ uint8_t s_sett[SET_CAP];                 // ... and their types
   __shared__ unsigned long long s_clk[CLAIM_CAP];     // this step's claims: pair (key + 1) ...
@@ -903,18 +916,20 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
   uint32_t rcur = wc.x, rend = wc.y;   // reader-node arena of this wavefront
   uint32_t icur = wc.z, iend = wc.w;   // item arena of the workgroup (only thread 0's copy is used)
   if (threadIdx.x == 0) s_abort = 0;
-  const uint32_t nl = !nlist ? hi - lo : nlist == DEV_LIST ? min(r.c->ndirty, SPARSE_CAP) : nlist == DEV_LIST_WIN ? min(r.c->ndirty, LIST_CAP) : nlist;
-  for (uint32_t g = blockIdx.x; g < nl; g += gridDim.x) {
-    const uint32_t j = nlist ? r.dlist[g] : lo + g;
+  (void)lo, (void)nlist;
+  // its buckets: the list the narrow kernels of this pass wrote (k_eval / k_eval_rows skip the big buckets they meet and note them)
+  const uint32_t nbig = min(r.c->nbig, LIST_CAP);
+  for (uint32_t g = blockIdx.x; g < nbig; g += gridDim.x) {
+  {
+    const uint32_t j = r.blist[g];
     __syncthreads();   // (the previous bucket's LDS is done with)
     if (threadIdx.x == 0) {   // one thread decides for the workgroup (a flag another workgroup raises meanwhile must not split it)
       if (r.c->overflow) s_abort = 1;
-      s_go = j < hi && r.dirty[j] && (r.bflags[j] & F_BIG);
-      s_bail = 0;
+      s_bail = 0, s_fresh = (j < hi && r.dirty[j]) ? 1u : 0u;   // (s_fresh doubles as "go": a listed bucket is dirty unless the list is stale)
     }
     __syncthreads();
     if (s_abort) break;
-    if (!s_go) continue;
+    if (!s_fresh) continue;
     const uint32_t b = r.bid[j], s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
     const bool first_eval = r.ever[j] == 0;
     const bool dup = (r.bflags[j] & F_DUP) != 0;
@@ -1210,6 +1225,8 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
       }
     }
   }
+  if (s_abort) break;
+  }
   if (lane == 0) r.wcur[wave_id] = make_uint4(rcur, rend, icur, iend);
 }
 
@@ -1238,6 +1255,7 @@ __global__ __launch_bounds__(256) void k_update(R r, uint32_t lo, uint32_t hi, u
   const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPW + (uint32_t)(lane / GL));
   const uint32_t j = (uint32_t)jj;
   const bool alive = jj < hi && r.evaluated[j] && !r.c->overflow;
+  if (blockIdx.x == 0 && threadIdx.x == 0) r.c->nbig = 0;   // (k_eval_big has consumed the pass's list; the next pass starts a new one)
   // (the dirty statistics are NOT touched here: the list-mode blocks of this very launch read ndirty as their list length, and
   // the count that follows writes absolute values)
   if (!__ballot(alive)) return;
@@ -1610,12 +1628,15 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   r.dirty = bytes.p, r.evaluated = bytes.p + nb, r.parity = bytes.p + 2 * nb, r.bflags = bytes.p + 3 * nb, r.ever = bytes.p + 4 * nb;
   r.ihead = words.p, r.inum = words.p + nb, r.ohead = words.p + 2 * nb, r.lookups = words.p + 3 * nb, r.skips = words.p + 4 * nb;
   // big buckets (>= big_min entries, no read twice) are evaluated by a workgroup each: k_eval_big beside every evaluation launch
-  r.big_min = getenv("PGX_REPLAY_BIG") ? (uint32_t)std::max(0, atoi(getenv("PGX_REPLAY_BIG"))) : 48u;
+  // (measured at C4 scale: the buckets that hold a read twice -- 7 k of 2.3 M, up to 128 entries, one partner at a time in the narrow
+  // kernels -- were what every sparse pass waited for; big buckets WITHOUT a repeated read are rare (40 of 2.3 M beyond 48 entries:
+  // the multiplicity cut-off removes the repeat families' shimmers) and stay with the narrow kernels by default)
+  r.big_min = getenv("PGX_REPLAY_BIG") ? (uint32_t)std::max(0, atoi(getenv("PGX_REPLAY_BIG"))) : 0u;
   r.dup_min = getenv("PGX_REPLAY_DUP") ? (uint32_t)std::max(0, atoi(getenv("PGX_REPLAY_DUP"))) : 12u;
   DevBuf<uint4> wcur(nb + 2 + SPARSE_CAP + 1 + (size_t)BIG_WG * BIG_NW);  // (one slot per wavefront of k_eval: GPW buckets each; list mode; k_eval_big)
   r.wcur = wcur.p, r.wlist0 = (uint32_t)(nb + 2), r.wbig0 = (uint32_t)(nb + 2 + SPARSE_CAP + 1);
-  DevBuf<uint32_t> dlist(LIST_CAP);
-  r.dlist = dlist.p;
+  DevBuf<uint32_t> dlist(LIST_CAP), blist(LIST_CAP + 64);
+  r.dlist = dlist.p, r.blist = blist.p;
   DevBuf<Counters> dc(1);
   r.c = dc.p;
   DevBuf<unsigned long long> spread(SPREAD * 8);
@@ -1650,6 +1671,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     hipLaunchKernelGGL(k_setup, dim3(cdiv256(nb)), dim3(256), 0, s, r, (uint32_t *)nullptr);
   }
 
+  bool use_big = r.big_min || r.dup_min;   // (decided below, once k_setup has counted the big buckets)
   static Counters *hc = nullptr;  // pinned mirror of the device counters
   static unsigned long long *hs = nullptr;  // pinned mirror of the spread totals
   static uint32_t *reset3 = nullptr;  // {ndirty, min_dirty, max_dirty} before a count (pinned, constant)
@@ -1673,6 +1695,10 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
 #endif
     }
   };
+  if (use_big) {   // no big bucket in this set (uniform-random genomes): none of the ~100 passes of a step launches k_eval_big
+    fetch(false);
+    use_big = hc->nbig_total != 0;
+  }
   const uint32_t nblk = (uint32_t)((nb + CB - 1) / CB);
   DevBuf<uint32_t> cblk((size_t)nblk * 3);
   auto launch_count = [&](uint32_t lo = 0, uint32_t hi = 0xFFFFFFFFu) {  // count + list of the dirty buckets of [lo, hi)
@@ -1747,7 +1773,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
             else if (from_list) hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST_WIN);
             else hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
             tm.reset();
-            if (r.big_min || r.dup_min) {
+            if (use_big) {
               if (timed) tm.emplace("replay_big", 0);
               const unsigned wgs = (unsigned)std::min<size_t>(BIG_WG, hi - lo);
               if (from_list) hipLaunchKernelGGL(k_eval_big, dim3(wgs), dim3(64 * BIG_NW), 0, s, r, 0u, (uint32_t)nb, DEV_LIST_WIN);
@@ -1777,7 +1803,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
           if (wide) hipLaunchKernelGGL((k_eval_rows<64, 16>), dim3(cdiv256((size_t)groups * 64)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
           else hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)groups * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
           tm.reset();
-          if (r.big_min || r.dup_min) {
+          if (use_big) {
             if (timed) tm.emplace("replay_big", 0);
             hipLaunchKernelGGL(k_eval_big, dim3(std::min<unsigned>(BIG_WG, groups)), dim3(64 * BIG_NW), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
             tm.reset();
