@@ -3,6 +3,7 @@
 #include <sys/mman.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -149,7 +150,15 @@ void *out_alloc(size_t bytes) {
     return p;
   }
   const size_t len = BigPool::cls(bytes);
-  if (PIN_CAP && ctx().ready) {
+  // (pinning pays from the SECOND result of a size class on -- a resident pipeline stepping over chunks; a one-shot process, the
+  // drop-in executables, gets pageable arrays: pinning 300 MB costs more than its one transfer saves)
+  static std::map<size_t, int> seen;
+  bool repeat;
+  {
+    std::lock_guard<std::mutex> lk(g_out_mu);
+    repeat = seen[len]++ > 0;
+  }
+  if (PIN_CAP && ctx().ready && repeat) {
     std::lock_guard<std::mutex> lk(g_out_mu);
     auto it = g_pin_free.find(len);
     void *p = nullptr;
@@ -419,10 +428,14 @@ int pgx_device_count(void) {
   return n;
 }
 
+static double wall_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 int pgx_init(int device) {
   PGX_GUARD_BEGIN
   Context &c = ctx();
   if (c.ready && c.device == device) return PGX_OK;
+  const double t_init = wall_ms();
   // one context per process: workspaces, the block cache and every resident seqdb live on the device of the first call
   PGX_REQUIRE(!c.ready, PGX_ESTATE, "pgx_init(%d): this process already runs on device %d (call pgx_shutdown first)", device, c.device);
   int n = 0;
@@ -437,6 +450,7 @@ int pgx_init(int device) {
   c.num_cu = prop.multiProcessorCount;
   c.device = device;
   c.ready = true;
+  if (getenv("PGX_TRACE")) fprintf(stderr, "[pgx] init: device %d (HIP runtime + context + stream) in %.1f ms\n", device, wall_ms() - t_init);
   PGX_GUARD_END
 }
 
@@ -475,41 +489,103 @@ void pgx_timing_reset(void) {
 }
 
 // ---- resident seqdb --------------------------------------------------------------------------------------
-// the seqdb file straight into HBM through two pinned staging buffers (the next piece is read while the last one uploads): the
-// host never holds more than 2 x 64 MiB of it
+// The seqdb file straight into HBM.  One thread copying out of the page cache moves ~6 GB/s, an eighth of what the host link takes
+// (round 2: 4.5 GB in 0.75 s, twice per pipeline -- each stage is its own process, as in pg_run.py), so several reader threads
+// fill a ring of pinned pieces (pread, out of order) while the calling thread uploads the pieces IN order as they complete; the
+// host never holds more than NBUF pieces.  PGX_LOAD_THREADS / PGX_LOAD_PIECE_MB: test knobs.
 static void upload_file_pieces(const char *path, uint8_t *d_dst, size_t nbytes) {
   const int fd = open(path, O_RDONLY);
   PGX_REQUIRE(fd >= 0, PGX_EIO, "cannot read %s", path);
-  const size_t P = (size_t)64 << 20;
-  uint8_t *pin[2] = {nullptr, nullptr};
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  bool used[2] = {false, false};
+  const size_t P = (size_t)(getenv("PGX_LOAD_PIECE_MB") ? std::max(1, atoi(getenv("PGX_LOAD_PIECE_MB"))) : 32) << 20;
+  const size_t npieces = (nbytes + P - 1) / P;
+  const int NT = (int)std::min<size_t>(npieces, (size_t)(getenv("PGX_LOAD_THREADS") ? std::max(1, atoi(getenv("PGX_LOAD_THREADS"))) : 6));
+  const int NBUF = (int)std::min<size_t>(npieces, (size_t)NT + 2);
+  std::vector<uint8_t *> pin(NBUF, nullptr);
+  std::vector<hipEvent_t> ev(NBUF, nullptr);
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<int> state(npieces, 0);   // 0: not read yet, 1: in its buffer, -1: read error
+  size_t next_piece = 0, uploaded = 0;  // next piece a reader takes; pieces whose upload has been issued
+  bool stop = false;
+  std::vector<std::thread> readers;
   auto cleanup = [&]() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto &t : readers) t.join();
     (void)hipStreamSynchronize(ctx().stream);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NBUF; ++k) {
       if (pin[k]) (void)hipHostFree(pin[k]);
       if (ev[k]) (void)hipEventDestroy(ev[k]);
     }
     close(fd);
   };
   try {
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < NBUF; ++k) {
       PGX_HIP(hipHostMalloc((void **)&pin[k], std::min(P, std::max<size_t>(nbytes, 1)), hipHostMallocDefault));
       PGX_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
     }
-    size_t off = 0;
-    for (int k = 0; off < nbytes; k ^= 1) {
-      const size_t n = std::min(P, nbytes - off);
-      if (used[k]) PGX_HIP(hipEventSynchronize(ev[k]));
-      for (size_t got = 0; got < n;) {
-        const ssize_t r = pread(fd, pin[k] + got, n - got, (off_t)(off + got));
-        PGX_REQUIRE(r > 0, PGX_EIO, "short read from %s (%zu of %zu bytes)", path, off + got, nbytes);
-        got += (size_t)r;
+    // a reader: take the next piece, wait until its buffer (piece % NBUF) is free -- i.e. the piece NBUF before it has been uploaded
+    // AND that upload has completed (the uploader publishes `uploaded` only after the event of that piece's copy was waited for
+    // lazily: see below) --, read it, publish it
+    std::vector<char> upload_done(npieces, 0);
+    for (int t = 0; t < NT; ++t)
+      readers.emplace_back([&]() {
+        for (;;) {
+          size_t p;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            if (stop || next_piece >= npieces) return;
+            p = next_piece++;
+            cv.wait(lk, [&] { return stop || p < (size_t)NBUF || upload_done[p - NBUF]; });
+            if (stop) return;
+          }
+          const size_t off = p * P, n = std::min(P, nbytes - off);
+          uint8_t *dst = pin[p % NBUF];
+          bool ok = true;
+          for (size_t got = 0; got < n;) {
+            const ssize_t r = pread(fd, dst + got, n - got, (off_t)(off + got));
+            if (r <= 0) {
+              ok = false;
+              break;
+            }
+            got += (size_t)r;
+          }
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            state[p] = ok ? 1 : -1;
+          }
+          cv.notify_all();
+        }
+      });
+    // the uploader (this thread): pieces in order; a piece's buffer is released to the readers once its copy has completed
+    size_t released = 0, marked = 0;   // pieces [0, released) have completed their upload; [0, marked) are published to the readers
+    for (size_t p = 0; p < npieces; ++p) {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return state[p] != 0; });
+        PGX_REQUIRE(state[p] > 0, PGX_EIO, "short read from %s (piece %zu of %zu)", path, p, npieces);
       }
-      PGX_HIP(hipMemcpyAsync(d_dst + off, pin[k], n, hipMemcpyHostToDevice, ctx().stream));
-      PGX_HIP(hipEventRecord(ev[k], ctx().stream));
-      used[k] = true;
-      off += n;
+      const size_t off = p * P, n = std::min(P, nbytes - off);
+      PGX_HIP(hipMemcpyAsync(d_dst + off, pin[p % NBUF], n, hipMemcpyHostToDevice, ctx().stream));
+      PGX_HIP(hipEventRecord(ev[p % NBUF], ctx().stream));
+      uploaded = p + 1;
+      // release every earlier piece whose copy is known to be complete (query, do not block: the readers only need the buffers NBUF pieces ahead)
+      bool any = false;
+      while (released < uploaded && hipEventQuery(ev[released % NBUF]) == hipSuccess) ++released, any = true;
+      if (!any && uploaded - released >= (size_t)NBUF - 1) {   // every buffer is in flight: wait for the oldest copy
+        PGX_HIP(hipEventSynchronize(ev[released % NBUF]));
+        ++released, any = true;
+      }
+      if (any) {
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          for (; marked < released; ++marked) upload_done[marked] = 1;
+        }
+        cv.notify_all();
+      }
     }
   } catch (...) {
     cleanup();
@@ -614,12 +690,17 @@ int pgx_seqdb_load(const char *prefix, pgx_seqdb **out) {
   std::vector<uint32_t> rid, rlen;
   std::vector<uint64_t> roff;
   std::string p(prefix);
+  const double t_load = wall_ms();
   PGX_REQUIRE(load_idx((p + ".idx").c_str(), rid, rlen, roff) == 0, PGX_EIO, "cannot open %s.idx", prefix);
+  const double t_idx = wall_ms();
   const std::string dbpath = p + ".seqdb";
   struct stat sb;
   PGX_REQUIRE(stat(dbpath.c_str(), &sb) == 0 && S_ISREG(sb.st_mode), PGX_EIO, "cannot read %s.seqdb", prefix);
   int rc = seqdb_upload_impl(nullptr, (size_t)sb.st_size, rid.data(), rlen.data(), roff.data(), (uint32_t)rid.size(), out, false, dbpath.c_str());
   if (rc) return rc;
+  if (getenv("PGX_TRACE"))
+    fprintf(stderr, "[pgx] seqdb load: idx file (%zu reads) %.1f ms, %.2f GB file -> HBM %.1f ms = %.1f GB/s\n", rid.size(), t_idx - t_load,
+            sb.st_size / 1e9, wall_ms() - t_idx, sb.st_size / 1e6 / (wall_ms() - t_idx));
   PGX_GUARD_END
 }
 

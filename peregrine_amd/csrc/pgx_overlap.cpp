@@ -23,6 +23,8 @@
 #include <mutex>
 #include <thread>
 
+#include <fcntl.h>
+#include <unistd.h>
 #include "pgx_internal.h"
 #include "pgx_khash.h"
 
@@ -1535,7 +1537,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
                     PairParams{(uint32_t)p->total_chunk, (uint32_t)p->mychunk, (uint32_t)p->mc_lower, (uint32_t)p->mc_upper,
                                (uint32_t)db->rlen_by_rid.size()},
                     pt, jflags, dev ? dev->d_top : nullptr, dev ? dev->d_mc : nullptr, gpu_replay ? &dpairs : nullptr, early);
-  sync();
+  pgx::sync();
   s.n_pair_records = pt.n_rec;
   if (gpu_replay_env < 0) gpu_replay = pt.n_rec >= gpu_replay_min;
   if (!gpu_replay) {
@@ -1598,7 +1600,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     PGX_HIP(hipMemcpyAsync(d_keys, keys, nreq * sizeof(pgx_align_key), hipMemcpyHostToDevice, ctx().stream));
     dev_align(db, d_keys, nreq, p->align_bandwidth, d_res);
     PGX_HIP(hipMemcpyAsync(res, d_res, nreq * sizeof(pgx_match), hipMemcpyDeviceToHost, ctx().stream));
-    sync();
+    pgx::sync();
     gpu_ms += now_ms() - g0;
     s.n_align_gpu += nreq;
   };
@@ -1674,7 +1676,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
         if (upto > rp.submitted) rp.submit(rp.submitted, upto);
         for (Batch &b : inflight)
           PGX_HIP(hipMemcpyAsync(rp.results.data() + b.first, b.res.p, b.n * sizeof(pgx_match), hipMemcpyDeviceToHost, ctx().stream));
-        sync();
+        pgx::sync();
         inflight.clear();
         gpu_ms += now_ms() - g0;
         if (trace) fprintf(stderr, "[pgx]   waited %.2f ms for the GPU after the sweep\n", now_ms() - g0);
@@ -1903,18 +1905,53 @@ int pgx_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, cons
     require_ready();
     PGX_REQUIRE(seqdb_prefix && shimmer_prefix && out_path, PGX_EARG, "pgx_overlap_chunk: null argument");
     check_params(p);
-    rc = pgx_seqdb_load(seqdb_prefix, &db);
-    if (rc) return rc;
+    // the shimmer / count files are read by a second thread WHILE the seqdb goes to HBM (they are independent inputs)
     std::vector<pgx_mm128> mm;
     std::vector<pgx_mm_count> mc;
-    read_counted_files(std::string(shimmer_prefix) + "-[0-9]*-of-[0-9]*.dat", mm);
-    read_counted_files(std::string(shimmer_prefix) + "-MC-[0-9]*-of-[0-9]*.dat", mc);
+    int rd_code = PGX_OK;
+    std::string rd_err;
+    std::thread reader([&] {
+      try {
+        read_counted_files(std::string(shimmer_prefix) + "-[0-9]*-of-[0-9]*.dat", mm);
+        read_counted_files(std::string(shimmer_prefix) + "-MC-[0-9]*-of-[0-9]*.dat", mc);
+      } catch (const Fail &f) {
+        rd_code = f.code, rd_err = pgx_last_error();
+      } catch (const std::bad_alloc &) {
+        rd_code = PGX_ENOMEM, rd_err = "out of host memory";
+      }
+    });
+    rc = pgx_seqdb_load(seqdb_prefix, &db);
+    const std::string load_err = rc ? pgx_last_error() : "";
+    reader.join();
+    if (rc) {
+      set_error("%s", load_err.c_str());
+      return rc;
+    }
+    PGX_REQUIRE(rd_code == PGX_OK, rd_code, "%s", rd_err.c_str());
     OvOut v;
     run_overlap(db, mm.data(), mm.size(), mc.data(), mc.size(), p, v, stats);
-    FILE *f = fopen(out_path, "wb");
-    PGX_REQUIRE(f, PGX_EIO, "file '%s' open error", out_path);
-    bool ok = v.n == 0 || fwrite(v.a, sizeof(pgx_ovlp), v.n, f) == v.n;
-    ok = (fclose(f) == 0) && ok;
+    // the records: several threads copy slices into the page cache (one thread moves ~3 GB/s: 0.1 s for the 300 MB of a 4.5 Gbase chunk)
+    const int fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    PGX_REQUIRE(fd >= 0, PGX_EIO, "file '%s' open error", out_path);
+    const size_t total = v.n * sizeof(pgx_ovlp);
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>(8, total >> 24));
+    std::vector<char> okv(nt, 1);
+    std::vector<std::thread> ws;
+    for (int t = 0; t < nt; ++t)
+      ws.emplace_back([&, t] {
+        const size_t lo = total * t / nt, hi = total * (t + 1) / nt;
+        for (size_t off = lo; off < hi;) {
+          const ssize_t w = pwrite(fd, (const char *)v.a + off, hi - off, (off_t)off);
+          if (w <= 0) {
+            okv[t] = 0;
+            return;
+          }
+          off += (size_t)w;
+        }
+      });
+    for (auto &t : ws) t.join();
+    bool ok = close(fd) == 0;
+    for (char c : okv) ok = ok && c;
     PGX_REQUIRE(ok, PGX_EIO, "short write to '%s'", out_path);
   } catch (const Fail &f) {
     rc = f.code;
