@@ -469,7 +469,7 @@ uint32_t *dev_align_lane(const pgx_seqdb *db, const pgx_align_key *d_keys, size_
   hipLaunchKernelGGL(k_lane_prep, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, d_keys, (uint32_t)n, db->d_roff.p, db->d_rlen.p,
                      db->d_nflag.p, desc);
   const size_t lds = (size_t)LANE_DW * 64 * sizeof(uint32_t);
-  static const int per_cu_env = getenv("PGX_LANE_WAVES") ? atoi(getenv("PGX_LANE_WAVES")) : 0;
+  const int per_cu_env = getenv("PGX_LANE_WAVES") ? atoi(getenv("PGX_LANE_WAVES")) : 0;
   const unsigned per_cu = per_cu_env > 0 ? (unsigned)per_cu_env : (unsigned)std::min<size_t>(16, (160u << 10) / lds);
   const unsigned grid = (unsigned)std::min<size_t>((n + 63) / 64, (size_t)ctx().num_cu * per_cu);
   uint32_t *why = nullptr;

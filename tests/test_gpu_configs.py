@@ -99,6 +99,13 @@ def test_repeat_seeded_scaled_configs_8_chunks(name):
     cnt = np.zeros(len(um), np.int64)
     np.add.at(cnt, inv, mc["count"].astype(np.int64))
     assert int(cnt.sum()) == len(mm) and int(cnt.max()) > 1000   # 300-copy families x 30x
+    # the multiplicity cut-off really bites (configs[4]'s "mc_upper stress" must not be a no-op): shimmers of the repeat
+    # content sit above the default cut-off of 240, a band of them between 120 and 240 (kept at 240, dropped at 120), and a good part
+    # of all shimmer OCCURRENCES belongs to hashes a tighter cut-off (60) removes
+    n_above, n_band = int((cnt > 240).sum()), int(((cnt > 120) & (cnt <= 240)).sum())
+    occ_above60 = int(cnt[cnt > 60].sum())
+    assert n_above > 100 and n_band > 20, (n_above, n_band)
+    assert occ_above60 > 0.01 * len(mm), occ_above60
     total = 0
     seen_pairs = []
     for c in range(1, N + 1):
@@ -109,6 +116,11 @@ def test_repeat_seeded_scaled_configs_8_chunks(name):
         if c == 3:   # idempotence of a chunk
             ov2, _ = rdb.overlap(mm, mc, total_chunk=N, mychunk=c, mc_upper=sp["mc_upper"])
             assert formats.ovlp_fields_equal(ov, ov2)
+            # ... and the same chunk under a cut-off that removes the repeat-derived shimmers (-M 60): fewer pair records, records
+            # that still re-derive from the oracle, every pair once
+            ov60, st60 = rdb.overlap(mm, mc, total_chunk=N, mychunk=c, mc_upper=60)
+            assert st60["n_pair_records"] < st["n_pair_records"] and len(ov60) > 50_000
+            _check_records(db, ov60, 100, rng, 25)
     allp = np.concatenate(seen_pairs)
     uniq = len(np.unique(allp))
     assert uniq < total and uniq > 0.15 * total              # most pairs are reported by several chunks (SURVEY 8e caveat)
