@@ -412,21 +412,29 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
 // and only the groups that need more take more iterations.  Lane utilisation is what the kernel is bound by (VALU issue):
 // sixteen 4-lane groups keep 3.6 live diagonals on 4 lanes instead of 8.
 enum { PH_FETCH = 0, PH_STEP = 1, PH_ROUND = 2, PH_SNAKE = 3, PH_END = 4, PH_BAND = 5, PH_DONE = 6 };
-template <int GL, typename VT>
+// PACKED (round 3): the reads come from the 2-bit packs of the seqdb (pgx_align_lane.hip: k_pack2, one pass per overlap stage, both
+// strands) instead of its bytes: the probe compares 16 bases with two funnel shifts, an XOR and a find-first-bit (8 codes, two
+// 64-bit shifts, XOR, AND and a 64-bit count before), an extension step 32 bases per lane = 256 per group with four funnel shifts
+// (128 with four 64-bit shift / XOR / AND / count sequences before), and fewer steps need an extension at all (a probe of 16 ends
+// 32 % of the main diagonals' matches, one of 8 only 18 %).  seq = the two packs (pack1 = seq + pack_stride dwords); candidates
+// that meet a read with ambiguous bases (nflag) are handed on to the byte-wise launch through esc_list.
+template <int GL, typename VT, bool PACKED>
 __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
                                                  const uint32_t *__restrict__ rlen, const pgx_align_key *__restrict__ keys,
                                                  uint32_t n, int band, int ring, pgx_match *__restrict__ out,
                                                  uint32_t *__restrict__ counter, const uint32_t *__restrict__ redo_n,
                                                  const uint32_t *__restrict__ redo_list, uint32_t *__restrict__ esc_n,
-                                                 uint32_t *__restrict__ esc_list) {
+                                                 uint32_t *__restrict__ esc_list, const uint32_t *__restrict__ nflag, size_t pack_stride) {
   // redo_list != nullptr: the candidates are keys[redo_list[0 .. *redo_n)] (the ones a narrow-ring launch handed on);
   // esc_list != nullptr: a candidate whose band outgrows this launch's V ring is appended there instead of being finished
   extern __shared__ int32_t Vall[];
   const int lane = threadIdx.x, gl = lane & (GL - 1), gbase = lane & ~(GL - 1);
   VT *V = reinterpret_cast<VT *>(Vall) + (lane / GL) * ring;
   const int mask = ring - 1, band_size = band * 2;
-  constexpr int SL = GL == 16 ? 8 : 16;  // codes per lane and snake iteration
+  constexpr int SL = PACKED ? 32 : (GL == 16 ? 8 : 16);  // codes per lane and snake iteration
+  constexpr int PROBE = PACKED ? 16 : 8;                   // codes of a probe
   if (redo_list) n = *redo_n;
+  uint32_t qo = 0, to = 0;   // PACKED: position of base 0 inside the dword q / t point at (q, t then address dwords of a pack)
 
   // per-candidate state, uniform within a group
   int phase = PH_FETCH;
@@ -452,8 +460,14 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
       } else {
         a = redo_list ? redo_list[na] : na;
         const pgx_align_key key = keys[a];
-        q = seq + roff[key.rid0] + key.q_off;
-        t = seq + roff[key.rid1];
+        if (PACKED) {
+          const uint64_t qg = roff[key.rid0] + key.q_off, tg = roff[key.rid1];
+          q = seq + (key.dir0 ? pack_stride * 4 : 0) + (qg >> 4) * 4, t = seq + (key.dir1 ? pack_stride * 4 : 0) + (tg >> 4) * 4;
+          qo = (uint32_t)(qg & 15), to = (uint32_t)(tg & 15);
+        } else {
+          q = seq + roff[key.rid0] + key.q_off;
+          t = seq + roff[key.rid1];
+        }
         q_len = (int)(rlen[key.rid0] - key.q_off);
         t_len = (int)rlen[key.rid1];
         qs = key.dir0 ? 4 : 0, ts = key.dir1 ? 4 : 0;
@@ -463,6 +477,10 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
         q_bgn = t_bgn = q_m_end = t_m_end = 0;
         if (gl == 0) V[1 & mask] = (VT)0;  // the only slot read before it is written (d = 0 reads V[k+1] = V[1])
         phase = PH_STEP;
+        if (PACKED && ((nflag[key.rid0] | nflag[key.rid1]) & 1u)) {   // an ambiguous base has no 2-bit code: the byte-wise launch takes it
+          if (gl == 0) esc_list[atomicAdd(esc_n, 1u)] = a;
+          phase = PH_FETCH;
+        }
       }
     }
     if (!ballot64(phase != PH_DONE)) break;
@@ -509,10 +527,19 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
         x1 = x, y1 = y;
         const int rem = min(q_len - x, t_len - y);
         if (rem > 0) {
-          int m = match8(load_u64_unaligned(q + x), load_u64_unaligned(t + y), qs, ts);
+          int m;
+          if (PACKED) {
+            const uint32_t xq = qo + (uint32_t)x, yt = to + (uint32_t)y;
+            uint2 qd, td;
+            __builtin_memcpy(&qd, q + (xq >> 4) * 4, 8), __builtin_memcpy(&td, t + (yt >> 4) * 4, 8);
+            const uint32_t df = __builtin_amdgcn_alignbit(qd.y, qd.x, (xq & 15) << 1) ^ __builtin_amdgcn_alignbit(td.y, td.x, (yt & 15) << 1);
+            m = df ? (__builtin_ctz(df) >> 1) : 16;
+          } else {
+            m = match8(load_u64_unaligned(q + x), load_u64_unaligned(t + y), qs, ts);
+          }
           m = min(m, rem);
           x += m, y += m;
-          more = (m == 8) && (rem > 8);
+          more = (m == PROBE) && (rem > PROBE);
         }
       }
     }
@@ -535,7 +562,15 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
         if (has) {
           m = 0;
           if (off < rem) {
-            if (SL == 16) {  // 16 codes with one 16-byte load per sequence (half the vector-memory instructions of two 8-byte ones)
+            if (PACKED) {   // 32 bases: three dwords of either pack (one 16-byte load at a dword address), two funnel shifts each
+              const uint32_t xq = qo + (uint32_t)(xs + off), yt = to + (uint32_t)(ys + off);
+              uint4 qd, td;
+              __builtin_memcpy(&qd, q + (xq >> 4) * 4, 16), __builtin_memcpy(&td, t + (yt >> 4) * 4, 16);
+              const uint32_t qsh = (xq & 15) << 1, tsh = (yt & 15) << 1;
+              const uint32_t d0 = __builtin_amdgcn_alignbit(qd.y, qd.x, qsh) ^ __builtin_amdgcn_alignbit(td.y, td.x, tsh);
+              const uint32_t d1 = __builtin_amdgcn_alignbit(qd.z, qd.y, qsh) ^ __builtin_amdgcn_alignbit(td.z, td.y, tsh);
+              m = d0 ? (__builtin_ctz(d0) >> 1) : d1 ? 16 + (__builtin_ctz(d1) >> 1) : 32;
+            } else if (SL == 16) {  // 16 codes with one 16-byte load per sequence (half the vector-memory instructions of two 8-byte ones)
               const U128 qa = load_u128_unaligned(q + xs + off), ta = load_u128_unaligned(t + ys + off);
               m = match8(qa.lo, ta.lo, qs, ts);
               if (m == 8) m += match8(qa.hi, ta.hi, qs, ts);
@@ -681,8 +716,8 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
     const size_t lds = (size_t)8 * ring * sizeof(uint16_t);
     const unsigned per_cu = (unsigned)std::min<size_t>(32, (160u << 10) / lds);
     const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>(n / 64, 64), (size_t)ctx().num_cu * per_cu);
-    hipLaunchKernelGGL((k_align_ph<8, uint16_t>), dim3(grid), dim3(64), lds, ctx().stream, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys,
-                       (uint32_t)n, band, ring, d_out, esc + 1, esc, esc + 4, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid), dim3(64), lds, ctx().stream, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys,
+                       (uint32_t)n, band, ring, d_out, esc + 1, esc, esc + 4, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0);
     PGX_HIP(hipGetLastError());
     return;
   }
@@ -697,17 +732,34 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
       uint32_t *esc = ws<uint32_t>("align.esc", n + 4);   // [0] handed-on count, [1] the second launch's work counter, [4..) list
       PGX_HIP(hipMemsetAsync(esc, 0, 4 * sizeof(uint32_t), ctx().stream));
       const int rg = std::min(narrow, ring);
-      hipLaunchKernelGGL((k_align_ph<4, uint16_t>), dim3(grid_for(n, 16, rg)), dim3(64), 16 * rg * sizeof(uint16_t), ctx().stream,
+      hipLaunchKernelGGL((k_align_ph<4, uint16_t, false>), dim3(grid_for(n, 16, rg)), dim3(64), 16 * rg * sizeof(uint16_t), ctx().stream,
                          db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, rg, d_out, counter,
-                         (const uint32_t *)nullptr, (const uint32_t *)nullptr, rg < ring ? esc : nullptr, rg < ring ? esc + 4 : nullptr);
+                         (const uint32_t *)nullptr, (const uint32_t *)nullptr, rg < ring ? esc : nullptr, rg < ring ? esc + 4 : nullptr, (const uint32_t *)nullptr, (size_t)0);
       if (rg < ring)
-        hipLaunchKernelGGL((k_align_ph<8, uint16_t>), dim3(grid_for(std::max<size_t>(n / 16, 8192), 8, ring)), dim3(64),
+        hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid_for(std::max<size_t>(n / 16, 8192), 8, ring)), dim3(64),
                            8 * ring * sizeof(uint16_t), ctx().stream, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band,
-                           ring, d_out, esc + 1, esc, esc + 4, (uint32_t *)nullptr, (uint32_t *)nullptr);
+                           ring, d_out, esc + 1, esc, esc + 4, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0);
     } else {
-      hipLaunchKernelGGL((k_align_ph<8, uint16_t>), dim3(grid_for(n, 8, ring)), dim3(64), 8 * ring * sizeof(uint16_t), ctx().stream,
-                         db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter,
-                         (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+      // default of the large launches (round 3): the phase machine over the 2-bit packs.  The packs are built once per overlap stage
+      // by the first launch of at least PGX_ALIGN_PACKED_MIN alignments (4.5 GB of seqdb: 1.6 ms) and serve every later launch of
+      // the stage; candidates that meet a read with ambiguous bases come back in a list and take the byte-wise form.
+      const char *pm = getenv("PGX_ALIGN_PACKED_MIN");
+      const long packed_min = pm ? atol(pm) : 100000;   // (< 0: never)
+      if (packed_min >= 0 && ((long)n >= packed_min || seq_packs_valid(db))) {
+        const uint32_t *packs = seq_packs(db);
+        uint32_t *esc = ws<uint32_t>("align.esc", n + 4);   // [0] handed-on count, [1] the second launch's work counter, [4..) list
+        PGX_HIP(hipMemsetAsync(esc, 0, 4 * sizeof(uint32_t), ctx().stream));
+        hipLaunchKernelGGL((k_align_ph<8, uint16_t, true>), dim3(grid_for(n, 8, ring)), dim3(64), 8 * ring * sizeof(uint16_t), ctx().stream,
+                           reinterpret_cast<const uint8_t *>(packs), db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter,
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, esc, esc + 4, db->d_nflag.p, seq_pack_stride(db));
+        hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid_for(std::max<size_t>(n / 64, 1024), 8, ring)), dim3(64),
+                           8 * ring * sizeof(uint16_t), ctx().stream, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band,
+                           ring, d_out, esc + 1, esc, esc + 4, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0);
+      } else {
+        hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid_for(n, 8, ring)), dim3(64), 8 * ring * sizeof(uint16_t), ctx().stream,
+                           db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter,
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0);
+      }
     }
   } else if ((long)n <= small_max) {
     hipLaunchKernelGGL(k_align1, dim3((unsigned)n), dim3(64), ring * sizeof(int32_t), ctx().stream, db->d_seq.p, db->d_roff.p,

@@ -426,6 +426,13 @@ uint64_t &align_epoch() {
 }
 
 static size_t lane_pack_stride(const pgx_seqdb *db) { return (((db->nbytes + 1024) / 16) + 3) & ~(size_t)3; }
+static void ensure_packed(const pgx_seqdb *db);
+size_t seq_pack_stride(const pgx_seqdb *db) { return lane_pack_stride(db); }
+bool seq_packs_valid(const pgx_seqdb *db) { return db->pack_epoch == align_epoch() && db->d_pack.p != nullptr; }
+const uint32_t *seq_packs(const pgx_seqdb *db) {
+  ensure_packed(db);
+  return db->d_pack.p;
+}
 
 // 2-bit packs of the whole seqdb, once per overlap stage (align_epoch): [P0 | P1], lane_pack_stride dwords each
 static void ensure_packed(const pgx_seqdb *db) {

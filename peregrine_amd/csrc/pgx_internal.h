@@ -198,6 +198,11 @@ uint32_t *dev_align_lane(const pgx_seqdb *db, const pgx_align_key *d_keys, size_
 // bumped once per overlap stage / alignment batch: the 2-bit packs are rebuilt when it changed (the packing pass belongs to the
 // timed stage, it is not kept across calls)
 uint64_t &align_epoch();
+// the 2-bit packs of a read database (pgx_align_lane.hip: [pack of the low nibbles | pack of the high nibbles], seq_pack_stride dwords
+// each; d_nflag marks the reads with ambiguous bases): built on first use within an epoch
+const uint32_t *seq_packs(const pgx_seqdb *db);
+size_t seq_pack_stride(const pgx_seqdb *db);
+bool seq_packs_valid(const pgx_seqdb *db);
 
 // Large host arrays.  Never value-initialised (they are about to be overwritten); from 16 MiB up they are pooled anonymous
 // mappings advised to use transparent huge pages, which the allocator would not do for us (THP is in "madvise" mode on

@@ -663,7 +663,9 @@ def _oracle_matches(db, keys, band):
 
 
 ALIGN_VARIANTS = [   # (id, environment, read set)
-    ("ph8", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8"), "small"),                    # k_align_ph<8, u16>: the default of large launches
+    ("ph8-packed", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8", PGX_ALIGN_PACKED_MIN="0"), "small"),   # k_align_ph<8, u16, packed>: the default of large launches
+    ("ph8-packed-ambiguous", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8", PGX_ALIGN_PACKED_MIN="0"), "withN"),   # ... reads with N: handed on to the byte-wise launch
+    ("ph8", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8", PGX_ALIGN_PACKED_MIN="-1"), "small"),          # k_align_ph<8, u16> on the seqdb bytes
     ("lockstep8", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="0"), "small"),              # k_align4<8, u16>
     ("lockstep16", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="0", PGX_ALIGN_GL="16"), "small"),   # k_align4<16, int32>
     ("ph4+escalation", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="4"), "small"),         # k_align_ph<4> on the narrow ring, then k_align_ph<8> over the hand-ons
@@ -677,7 +679,14 @@ ALIGN_VARIANTS = [   # (id, environment, read set)
 @pytest.fixture(scope="module")
 def variant_sets():
     sets = {}
-    for name, db in (("small", simreads.make_workload("small")), ("long", _with_long_reads())):
+    withn = simreads.make_workload("small")
+    sd = withn.seqdb.copy()
+    rng = np.random.default_rng(23)
+    for r in rng.choice(withn.n_reads, 40, replace=False):        # 40 reads with a few ambiguous bases (nibble 0 on both strands)
+        o, n = int(withn.roff[r]), int(withn.rlen[r])
+        sd[o + rng.integers(0, n, 3)] = 0
+    withn.seqdb = sd
+    for name, db in (("small", simreads.make_workload("small")), ("long", _with_long_reads()), ("withN", withn)):
         rdb = ResidentDB(db, 0)
         keys, ov = _keys_of(db, rdb, 3000, 17)
         want = {band: _oracle_matches(db, keys, band) for band in (100, 20)}
