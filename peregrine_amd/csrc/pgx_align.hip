@@ -77,14 +77,11 @@ __device__ __forceinline__ int wave_max_i32(int v) {  // DPP tree: 6 VALU ops, r
 
 }  // namespace
 
-__global__ __launch_bounds__(64) void k_align1(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
-                                              const uint32_t *__restrict__ rlen,
-                                              const pgx_align_key *__restrict__ keys, uint32_t n, int band,
-                                              int ring, pgx_match *__restrict__ out) {
+__device__ __forceinline__ void align_one_per_wave(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
+                                                   const uint32_t *__restrict__ rlen, const pgx_align_key *__restrict__ keys, uint32_t a, int band,
+                                                   int ring, pgx_match *__restrict__ out) {
   extern __shared__ int32_t V[];
   const int lane = threadIdx.x;
-  const uint32_t a = blockIdx.x;
-  if (a >= n) return;
   const pgx_align_key key = keys[a];
   const uint8_t *q = seq + roff[key.rid0] + key.q_off;
   const uint8_t *t = seq + roff[key.rid1];
@@ -206,6 +203,26 @@ __global__ __launch_bounds__(64) void k_align1(const uint8_t *__restrict__ seq, 
     }
     r.q_m_end = q_m_end, r.t_m_end = t_m_end;
     out[a] = r;
+  }
+}
+__global__ __launch_bounds__(64) void k_align1(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
+                                              const uint32_t *__restrict__ rlen,
+                                              const pgx_align_key *__restrict__ keys, uint32_t n, int band,
+                                              int ring, pgx_match *__restrict__ out) {
+  if (blockIdx.x < n) align_one_per_wave(seq, roff, rlen, keys, blockIdx.x, band, ring, out);
+}
+// the same over a device-resident list of candidates (the ones a grouped launch handed on: reads with ambiguous bases, and the
+// STRAGGLERS -- round 3: at C4 scale ~600 of 9 M candidates of a launch run through low-complexity sequence with a band of up to 100
+// diagonals for thousands of steps; 8 lanes take 13 rounds per step for them, and the launch waited ~100 ms for them alone
+// (profiles/r03c_align_iterations.txt).  A whole wavefront takes such a band in two rounds.)
+__global__ __launch_bounds__(64) void k_align1_list(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
+                                                   const uint32_t *__restrict__ rlen, const pgx_align_key *__restrict__ keys,
+                                                   const uint32_t *__restrict__ list_n, const uint32_t *__restrict__ list, int band, int ring,
+                                                   pgx_match *__restrict__ out) {
+  const uint32_t cnt = *list_n;
+  for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
+    __syncthreads();   // (the previous candidate's V ring is done with)
+    align_one_per_wave(seq, roff, rlen, keys, list[i], band, ring, out);
   }
 }
 
@@ -424,7 +441,9 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
                                                  uint32_t n, int band, int ring, pgx_match *__restrict__ out,
                                                  uint32_t *__restrict__ counter, const uint32_t *__restrict__ redo_n,
                                                  const uint32_t *__restrict__ redo_list, uint32_t *__restrict__ esc_n,
-                                                 uint32_t *__restrict__ esc_list, const uint32_t *__restrict__ nflag, size_t pack_stride) {
+                                                 uint32_t *__restrict__ esc_list, const uint32_t *__restrict__ nflag, size_t pack_stride,
+                                                 uint32_t iter_limit) {   // iter_limit != 0: a candidate still running after that many
+                                                                          // wavefront iterations is handed on (esc_list) at its next step
   // redo_list != nullptr: the candidates are keys[redo_list[0 .. *redo_n)] (the ones a narrow-ring launch handed on);
   // esc_list != nullptr: a candidate whose band outgrows this launch's V ring is appended there instead of being finished
   extern __shared__ int32_t Vall[];
@@ -435,6 +454,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
   constexpr int PROBE = PACKED ? 16 : 8;                   // codes of a probe
   if (redo_list) n = *redo_n;
   uint32_t qo = 0, to = 0;   // PACKED: position of base 0 inside the dword q / t point at (q, t then address dwords of a pack)
+  uint32_t iters = 0;        // wavefront iterations since the group fetched its candidate
 
   // per-candidate state, uniform within a group
   int phase = PH_FETCH;
@@ -449,15 +469,33 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
   int x = 0, y = 0, x1 = 0, y1 = 0, k = 0;
   bool active = false, more = false;
 
+#ifdef PGX_ALIGN_STATS
+  uint32_t my_iters = 0;
+  bool has_cand = false;
+#endif
   for (;;) {
+#ifdef PGX_ALIGN_STATS
+    if (phase == PH_FETCH && has_cand && gl == 0 && !redo_list) {   // (stats build: counter[1..32] / [33..64]: log2 histogram of the wavefront iterations a candidate took / their sums)
+      const uint32_t b = my_iters ? 31u - (uint32_t)__builtin_clz(my_iters) : 0u;
+      atomicAdd(counter + 1 + min(b, 31u), 1u);
+      atomicAdd(counter + 33 + min(b, 31u), my_iters);
+    }
+    if (phase == PH_FETCH) has_cand = false, my_iters = 0;
+    ++my_iters;
+#endif
     // ---- FETCH: idle groups pull the next candidate --------------------------------------------------------------
+    ++iters;
     if (phase == PH_FETCH) {
+      iters = 0;
       uint32_t na = 0;
       if (gl == 0) na = atomicAdd(counter, 1u);
       na = (uint32_t)__shfl((int)na, gbase, 64);
       if (na >= n) {
         phase = PH_DONE;
       } else {
+#ifdef PGX_ALIGN_STATS
+        has_cand = true;
+#endif
         a = redo_list ? redo_list[na] : na;
         const pgx_align_key key = keys[a];
         if (PACKED) {
@@ -487,7 +525,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
     __syncthreads();
 
     // ---- STEP: the loop conditions of a new d (DWmatch.c:118-122,196-199) -------------------------------------------
-    if (phase == PH_STEP && esc_list && max_k - min_k + 4 > ring && !(d >= max_d || max_k - min_k > band_size)) {
+    if (phase == PH_STEP && esc_list && (max_k - min_k + 4 > ring || (iter_limit && iters > iter_limit)) && !(d >= max_d || max_k - min_k > band_size)) {
       // the live diagonals k-1 .. k+1 no longer fit this launch's ring: the wide-ring launch redoes the candidate
       if (gl == 0) esc_list[atomicAdd(esc_n, 1u)] = a;
       phase = PH_FETCH;
@@ -687,8 +725,25 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
   KernelTimer tm((long)n <= small_max ? "align1" : "align", n);
   int ring = 64;
   while (ring < 2 * band + 8) ring <<= 1;
-  uint32_t *counter = ws<uint32_t>("align.counter", 1);
-  if ((long)n > small_max) PGX_HIP(hipMemsetAsync(counter, 0, sizeof(uint32_t), ctx().stream));  // (k_align1 has no work counter)
+  uint32_t *counter = ws<uint32_t>("align.counter", 72);
+  if ((long)n > small_max) PGX_HIP(hipMemsetAsync(counter, 0, 72 * sizeof(uint32_t), ctx().stream));  // (k_align1 has no work counter; [1..64]: PGX_ALIGN_STATS builds)
+#ifdef PGX_ALIGN_STATS
+  struct StatsPrinter {
+    uint32_t *c;
+    size_t n;
+    ~StatsPrinter() {
+      uint32_t h[72];
+      if (hipMemcpyAsync(h, c, sizeof(h), hipMemcpyDeviceToHost, ctx().stream) != hipSuccess) return;
+      (void)hipStreamSynchronize(ctx().stream);
+      unsigned long long tot = 0;
+      for (int i = 0; i < 32; ++i) tot += h[33 + i];
+      fprintf(stderr, "[pgx] align stats: %zu candidates; wavefront iterations per candidate (log2 classes: count, share of all iterations):", n);
+      for (int i = 0; i < 32; ++i)
+        if (h[1 + i]) fprintf(stderr, " 2^%d: %u (%.1f %%)", i, h[1 + i], tot ? 100.0 * h[33 + i] / tot : 0.0);
+      fprintf(stderr, "\n");
+    }
+  } stats_printer{counter, n};
+#endif
   const int gl = getenv("PGX_ALIGN_GL") ? atoi(getenv("PGX_ALIGN_GL")) : 8;  // measured: 8 lanes per candidate (avg 3.6 live diagonals, <= 8 in 98.7 % of the steps) 45.6 vs 42.1 M aln/s
   // PGX_ALIGN_MODE: 8 (default) = the phase machine with 8-lane groups: at 4.5 Gbases 66.5 M alignments/s against 61.0 M of
   // k_align4 (mode 0, round 1: groups in lock-step) -- the same 39 G VALU wavefront-instructions per 2.4 M alignments, 23 % fewer
@@ -717,7 +772,7 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
     const unsigned per_cu = (unsigned)std::min<size_t>(32, (160u << 10) / lds);
     const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>(n / 64, 64), (size_t)ctx().num_cu * per_cu);
     hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid), dim3(64), lds, ctx().stream, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys,
-                       (uint32_t)n, band, ring, d_out, esc + 1, esc, esc + 4, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0);
+                       (uint32_t)n, band, ring, d_out, esc + 1, esc, esc + 4, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0, 0u);
     PGX_HIP(hipGetLastError());
     return;
   }
@@ -734,15 +789,16 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
       const int rg = std::min(narrow, ring);
       hipLaunchKernelGGL((k_align_ph<4, uint16_t, false>), dim3(grid_for(n, 16, rg)), dim3(64), 16 * rg * sizeof(uint16_t), ctx().stream,
                          db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, rg, d_out, counter,
-                         (const uint32_t *)nullptr, (const uint32_t *)nullptr, rg < ring ? esc : nullptr, rg < ring ? esc + 4 : nullptr, (const uint32_t *)nullptr, (size_t)0);
+                         (const uint32_t *)nullptr, (const uint32_t *)nullptr, rg < ring ? esc : nullptr, rg < ring ? esc + 4 : nullptr, (const uint32_t *)nullptr, (size_t)0, 0u);
       if (rg < ring)
         hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid_for(std::max<size_t>(n / 16, 8192), 8, ring)), dim3(64),
                            8 * ring * sizeof(uint16_t), ctx().stream, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band,
-                           ring, d_out, esc + 1, esc, esc + 4, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0);
+                           ring, d_out, esc + 1, esc, esc + 4, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0, 0u);
     } else {
       // default of the large launches (round 3): the phase machine over the 2-bit packs.  The packs are built once per overlap stage
       // by the first launch of at least PGX_ALIGN_PACKED_MIN alignments (4.5 GB of seqdb: 1.6 ms) and serve every later launch of
       // the stage; candidates that meet a read with ambiguous bases come back in a list and take the byte-wise form.
+      const uint32_t iter_limit = getenv("PGX_ALIGN_ITER_LIMIT") ? (uint32_t)atol(getenv("PGX_ALIGN_ITER_LIMIT")) : 2500u;   // (0: no hand-on of stragglers)
       const char *pm = getenv("PGX_ALIGN_PACKED_MIN");
       const long packed_min = pm ? atol(pm) : 100000;   // (< 0: never)
       if (packed_min >= 0 && ((long)n >= packed_min || seq_packs_valid(db))) {
@@ -751,14 +807,14 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
         PGX_HIP(hipMemsetAsync(esc, 0, 4 * sizeof(uint32_t), ctx().stream));
         hipLaunchKernelGGL((k_align_ph<8, uint16_t, true>), dim3(grid_for(n, 8, ring)), dim3(64), 8 * ring * sizeof(uint16_t), ctx().stream,
                            reinterpret_cast<const uint8_t *>(packs), db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter,
-                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, esc, esc + 4, db->d_nflag.p, seq_pack_stride(db));
-        hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid_for(std::max<size_t>(n / 64, 1024), 8, ring)), dim3(64),
-                           8 * ring * sizeof(uint16_t), ctx().stream, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band,
-                           ring, d_out, esc + 1, esc, esc + 4, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0);
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, esc, esc + 4, db->d_nflag.p, seq_pack_stride(db), iter_limit);
+        // what it handed on -- reads with ambiguous bases, stragglers -- a wavefront per candidate, from the list
+        hipLaunchKernelGGL(k_align1_list, dim3((unsigned)std::min<size_t>(std::max<size_t>(n / 256, 256), (size_t)ctx().num_cu * 32)), dim3(64),
+                           ring * sizeof(int32_t), ctx().stream, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, esc, esc + 4, band, ring, d_out);
       } else {
         hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid_for(n, 8, ring)), dim3(64), 8 * ring * sizeof(uint16_t), ctx().stream,
                            db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter,
-                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0);
+                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0, 0u);
       }
     }
   } else if ((long)n <= small_max) {

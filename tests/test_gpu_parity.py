@@ -665,6 +665,8 @@ def _oracle_matches(db, keys, band):
 ALIGN_VARIANTS = [   # (id, environment, read set)
     ("ph8-packed", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8", PGX_ALIGN_PACKED_MIN="0"), "small"),   # k_align_ph<8, u16, packed>: the default of large launches
     ("ph8-packed-ambiguous", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8", PGX_ALIGN_PACKED_MIN="0"), "withN"),   # ... reads with N: handed on to the byte-wise launch
+    ("ph8-packed-stragglers", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_ITER_LIMIT="150"), "small"),   # most candidates outlast
+                                                                                    # 150 iterations: handed on to k_align1_list, a wavefront each
     ("ph8", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8", PGX_ALIGN_PACKED_MIN="-1"), "small"),          # k_align_ph<8, u16> on the seqdb bytes
     ("lockstep8", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="0"), "small"),              # k_align4<8, u16>
     ("lockstep16", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="0", PGX_ALIGN_GL="16"), "small"),   # k_align4<16, int32>

@@ -5,7 +5,7 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/fetch_calib
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/p -o p -- tools/build/fetch_calib > $OUT/cal.txt 2> $OUT/err.txt
+timeout -k 5 420 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/p -o p -- tools/build/fetch_calib > $OUT/cal.txt 2> $OUT/err.txt
 python3 - <<PY
 import csv, glob, re
 cal = {}

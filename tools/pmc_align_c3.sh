@@ -4,8 +4,8 @@ M=${1:-8}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_align_m$M
 rm -rf $OUT
-PGX_ALIGN_MODE=$M rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/a -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT.log 2>&1
-PGX_ALIGN_MODE=$M rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/b -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline >> $OUT.log 2>&1
+PGX_ALIGN_MODE=$M timeout -k 5 420 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/a -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT.log 2>&1
+PGX_ALIGN_MODE=$M timeout -k 5 420 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/b -o p -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline >> $OUT.log 2>&1
 python - <<PY
 import csv, collections, glob
 for d in ("a", "b"):

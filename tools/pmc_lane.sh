@@ -4,9 +4,9 @@ G=${1:-150}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_lane
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/t -o p -- python tools/lanecheck.py $G 0 > $OUT/trace.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/a -o p -- python tools/lanecheck.py $G 0 > $OUT/a.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_SALU SQ_INSTS_SMEM --output-format csv -d $OUT/b -o p -- python tools/lanecheck.py $G 0 > $OUT/b.log 2>&1
+timeout -k 5 420 rocprofv3 --kernel-trace --stats -d $OUT/t -o p -- python tools/lanecheck.py $G 0 > $OUT/trace.log 2>&1
+timeout -k 5 420 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/a -o p -- python tools/lanecheck.py $G 0 > $OUT/a.log 2>&1
+timeout -k 5 420 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_SALU SQ_INSTS_SMEM --output-format csv -d $OUT/b -o p -- python tools/lanecheck.py $G 0 > $OUT/b.log 2>&1
 python - <<PY
 import csv, collections, glob, sqlite3
 for db in glob.glob("$OUT/t/**/*.db", recursive=True):
