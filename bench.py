@@ -384,7 +384,7 @@ def main():
         if "align" in kern:
             k = kern["align"]
             gbs = ALIGN_BYTES_PER_PAIR * k["units"] / (k["ms_total"] * 1e-3) / 1e9
-            cands["align"] = {"kernel": "k_align_ph<8> (per-group phase machine; PGX_ALIGN_MODE=0: k_align4)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            cands["align"] = {"kernel": "k_align_ph<8, u16, packed> (per-group phase machine over the 2-bit packs; + k_pack2 once per stage, k_align1_list for the candidates it hands on)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
                               "bytes_per_unit": ALIGN_BYTES_PER_PAIR, "unit_name": "alignment",
                               "alignments_per_s": k["units"] / (k["ms_total"] * 1e-3)}
@@ -407,7 +407,7 @@ def main():
         # HBM traffic from the PMC counters: collected in separate rocprofv3 passes of this same command ON THIS WORKLOAD
         # (tools/pmc_traffic.sh <workload>) and committed under profiles/; bench.py itself cannot run under two profilers.
         # A workload without its own collection reports traffic = null.
-        tfile = os.path.join("profiles", f"r02_traffic_{a.workload}.json")
+        tfile = os.path.join("profiles", f"r03_traffic_{a.workload}.json")
         try:
             tr = json.load(open(os.path.join(ROOT, tfile)))
             if "replay" in cands and "k_update" in tr:   # a round = one evaluation kernel (k_eval or k_eval_rows) + one k_update
@@ -419,7 +419,7 @@ def main():
                 if nm in cands and kk:
                     cands[nm]["traffic"] = tr[kk]["hbm_bytes_per_launch"]
                     cands[nm]["traffic_read_side_raw"] = tr[kk].get("FETCH_SIZE_KB_per_launch", 0) * 1024 if "FETCH_SIZE_KB_per_launch" in tr[kk] else None
-                    cands[nm]["traffic_source"] = tfile + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch, read side x2 per the gfx950 note)"
+                    cands[nm]["traffic_source"] = tfile + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch; read side x2 for the streaming kernels, x1 for the alignment kernels' scattered 8- / 16-byte loads: profiles/r03_fetch_calib.txt)"
         except Exception:
             pass
         for nm in cands:

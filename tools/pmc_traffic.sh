@@ -1,12 +1,12 @@
 #!/bin/bash
 # HBM traffic of the bench's kernels from PMC counters (separate passes, kernel-trace only), per launch, ON ONE WORKLOAD.
-#   usage: tools/pmc_traffic.sh [workload=c3] [steps=2]   ->  gpurun_out/r02_traffic_<workload>.json
+#   usage: tools/pmc_traffic.sh [workload=c3] [steps=2]   ->  gpurun_out/r03_traffic_<workload>.json
 # FETCH_SIZE on gfx950 reports exactly 1/2 of a wide coalesced read stream (MI355X_MICROARCH.md, HBM): doubled below.
 W=${1:-c3}; S=${2:-2}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_bench_$W
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 5 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o p -- python bench.py --workload $W --steps $S --warmup 1 --no-cpu-baseline > $OUT.$c.log 2>&1
+  timeout -k 5 420 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -o p -- python bench.py --workload $W --steps $S --warmup 1 --no-cpu-baseline > $OUT.$c.log 2>&1
 done
 python - <<PY
 import csv, collections, json, re
@@ -21,11 +21,14 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         res.setdefault(k, {})[c + "_KB_per_launch"] = sum(v) / len(v)
         res[k]["launches"] = len(v)
 for k, v in res.items():
-    # read side doubled (gfx950 FETCH_SIZE = 1/2 of wide coalesced reads; calibrated on k_sketch_wave: the seqdb scan),
-    # write side as reported
-    v["hbm_bytes_per_launch"] = (2 * v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)) * 1024
+    # read side: FETCH_SIZE counts 64 B per fabric request; a request moves 128 B for wide coalesced streams (x2: the sketch / pack /
+    # join kernels) and 64 B for scattered 8- / 16-byte loads (x1: the alignment kernels' probes; their 16-byte extension loads are
+    # dword-aligned pieces of 2-bit packs now, no longer whole lines) -- profiles/r03_fetch_calib.txt.  Write side as reported.
+    rf = 1 if k.startswith("k_align") else 2
+    v["read_factor"] = rf
+    v["hbm_bytes_per_launch"] = (rf * v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)) * 1024
 res["_workload"] = "$W"
 res["_command"] = "rocprofv3 --kernel-trace --pmc {FETCH_SIZE|WRITE_SIZE} -- python bench.py --workload $W --steps $S --warmup 1 --no-cpu-baseline"
-json.dump(res, open("gpurun_out/r02_traffic_$W.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/r03_traffic_$W.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k in ("k_align4", "k_align1", "k_sketch_wave", "k_reduce_read", "k_eval", "k_eval_rows", "k_update")}, indent=1))
 PY

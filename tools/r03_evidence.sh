@@ -22,7 +22,10 @@ for p in $PARTS; do
     c3|c4s|c5s|ecoli)
            timeout 900 python bench.py --workload $p --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${TAG}_bench_$p.json 2> gpurun_out/${TAG}_bench_$p.err
            prof $p --workload $p --steps 2 --warmup 1 ;;
-    traffic_*) W=${p#traffic_}; timeout 1500 tools/pmc_traffic.sh $W 1 > gpurun_out/${TAG}_traffic_$W.log 2>&1; cp gpurun_out/r02_traffic_$W.json gpurun_out/${TAG}_traffic_$W.json ;;
+    traffic_*) W=${p#traffic_}; timeout 1000 tools/pmc_traffic.sh $W 1 > gpurun_out/${TAG}_traffic_$W.log 2>&1; find gpurun_out/pmc_bench_$W -type f -size +1M -delete ;;
+    pmc_lane) timeout 1300 tools/pmc_lane.sh 150 > gpurun_out/${TAG}_pmc_align_lane.txt 2>&1 ;;
+    pmc_align) timeout 900 tools/pmc_align_c3.sh 8 > gpurun_out/${TAG}_pmc_align.txt 2>&1; find gpurun_out/pmc_align_m8 -type f -size +1M -delete ;;
+    full_c3) timeout 1200 python bench.py > gpurun_out/${TAG}_bench_c3_full.json 2> gpurun_out/${TAG}_bench_c3_full.err ;;
   esac
 done
 ls -la gpurun_out | tail -30
