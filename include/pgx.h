@@ -137,6 +137,8 @@ typedef struct {
   double host_ms;            /* host orchestration time (order emulation + replay) */
   uint64_t n_evaluations;    /* bucket evaluations of the replay (>= n_buckets: the fixed point re-evaluates) */
   uint32_t device_replay;    /* 1: the greedy walk ran on the GPU (pgx_replay.hip); 0: on the host threads */
+  uint32_t device_visit;     /* 0: bucket visit order built by host threads; else 1 + the number of first-key groups a whole
+                                wavefront replayed (pgx_visit.hip; the others take a lane each) */
 } pgx_overlap_stats;
 
 /* mmers: concatenation of all index chunks' final-level lists in chunk order; counts: all MC entries */

@@ -718,6 +718,16 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
   }
 }
 
+// The 2-bit packs ahead of the first large launch of an overlap stage: run_overlap calls this while the GPU would otherwise wait
+// for the host's outer table, so k_pack2 (1.6 ms at 4.5 Gbases) is off the critical path.  Same conditions as the launch below.
+void dev_align_prepare(const pgx_seqdb *db) {
+  const int mode = getenv("PGX_ALIGN_MODE") ? atoi(getenv("PGX_ALIGN_MODE")) : 8;
+  const char *pm = getenv("PGX_ALIGN_PACKED_MIN");
+  const char *lane_env = getenv("PGX_ALIGN_LANE_MIN");
+  if (mode != 8 || db->max_rlen > 65535u || (pm && atol(pm) < 0) || (lane_env && atol(lane_env) >= 0)) return;
+  (void)seq_packs(db);
+}
+
 void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out) {
   if (n == 0) return;
   // (the knobs are read per call: the parity tests walk every kernel variant inside one process)
@@ -751,12 +761,13 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
   // occupancy) followed by a launch of the 8-lane form with the full ring over the candidates whose band outgrew the narrow
   // one (work list and count stay on the device; with nothing handed on it is an empty launch): measured and NOT chosen -- 17 %
   // fewer VALU instructions, but 57-60 M alignments/s whatever the occupancy: its probe loads touch sixteen candidates' cache
-  // lines per instruction and the address pipeline, not VALU issue, becomes the limit.
+  // lines per instruction and the address pipeline, not VALU issue, becomes the limit.  (Round 3, the same 4-lane groups over the
+  // 2-bit packs with the full ring: 70.1 M against 79.5 M alignments/s of the 8-lane form -- still not chosen.)
   const int mode = getenv("PGX_ALIGN_MODE") ? atoi(getenv("PGX_ALIGN_MODE")) : 8;
   // lane-per-candidate form (round 3, pgx_align_lane.hip): bit-exact on every test set, 45 % fewer VALU wavefront-instructions than
   // k_align_ph -- and measured SLOWER (4.68 M alignments: 93 ms + 6 ms for the 8.8 % it hands on, against 69 ms): its private LDS
   // windows allow 3 wavefronts per SIMD, a wavefront issues one instruction per ~16 cycles of its dependent, branchy stream, and
-  // three of them cannot fill a SIMD (profiles/r03b_pmc_align_lane.txt).  Kept as an opt-in (PGX_ALIGN_LANE_MIN = smallest launch
+  // three of them cannot fill a SIMD (profiles/r03d_pmc_align_lane.txt).  Kept as an opt-in (PGX_ALIGN_LANE_MIN = smallest launch
   // that takes it; unset / < 0: never) with its parity test; the candidates it hands on are redone by k_align_ph<8> from their list.
   const char *lane_env = getenv("PGX_ALIGN_LANE_MIN");   // (read per call: the tools switch it between launches)
   const long lane_min = lane_env ? atol(lane_env) : -1;

@@ -192,6 +192,7 @@ void dev_reduce(const pgx_mm128 *d_in, size_t n, int rs, DevBuf<pgx_mm128> &out,
 void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_count> &out, size_t &n_out);
 // banded O(ND) confirmation of n candidate alignments (keys on device)
 void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out);
+void dev_align_prepare(const pgx_seqdb *db);   // the 2-bit packs of this stage, ahead of the first large launch
 // one candidate per lane over 2-bit packs (pgx_align_lane.hip); returns the device escalation block: [0] number of candidates
 // handed on to the byte-wise kernel, [1] a zeroed work counter for that launch, [4..) their indices
 uint32_t *dev_align_lane(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out);
@@ -258,6 +259,8 @@ struct HostArray {
 // key0-group tables the host needs to replay the khash slot order on distinct keys
 struct PairTables {
   size_t n_rec = 0;
+  size_t n_groups = 0, n_buckets = 0;   // (always set; the arrays below only when the tables came to the host: PAIRS_DEV_TABLES)
+  bool on_host = true;
   HostArray<uint64_t> y0;        // per record
   HostArray<uint8_t> dir;        // per record
   HostArray<uint64_t> bkey1;     // per bucket
@@ -288,6 +291,8 @@ enum : unsigned {
   PAIRS_COUNTS = 4,           // also return the aggregated multiplicity table
   PAIRS_ORD_TABLES = 16,      // bkey1_ord / bn_ord / gtrail instead of bkey1 / bfirst (the overlap stage's table replay)
   PAIRS_LAZY_RECORDS = 8,     // with `keep`: leave the sorted records (y0, dir) on the device only; pairs_fetch_records downloads them
+  PAIRS_DEV_TABLES = 32,      // with `keep` + PAIRS_ORD_TABLES: leave the group / bucket tables on the device only (the visit order is
+                              // built there, pgx_visit.hip); pairs_fetch_tables downloads them for the host paths
 };
 // what the join leaves in HBM for the device replay (pgx_replay.hip): the bucket-sorted records
 struct DevicePairs {
@@ -296,7 +301,33 @@ struct DevicePairs {
   DevBuf<uint32_t> bstart;   // n_buckets + 1 record offsets
   size_t n_rec = 0, n_buckets = 0;
   bool valid = false;
+  // PAIRS_DEV_TABLES: the tables of PairTables (same names, same contents), left where the join computed them
+  bool tables = false;
+  size_t n_groups = 0;
+  DevBuf<uint32_t> gstart, gbucket;   // n_groups + 1 each (end sentinels)
+  DevBuf<uint32_t> gord, gfirst, glast, bord, bn_ord;
+  DevBuf<uint64_t> gkey0, bkey1_ord;
+  DevBuf<uint8_t> gtrail;
+  uint32_t max_group_buckets = 0;     // most buckets a first-key group holds
+  uint32_t n_big_groups = 0;          // groups with more than VISIT_LANE_MAX buckets
+  DevBuf<uint32_t> big_groups;        // their indices
+  std::vector<uint64_t> key_sample;   // gkey0[gord[i * KEY_SAMPLE_STRIDE]]: what the early outer-table keys are checked against
+  uint32_t last_gfirst = 0;           // gfirst[gord[n_groups - 1]]
 };
+constexpr uint32_t VISIT_LANE_MAX = 48;     // buckets of a group one lane replays (a 64-slot table: pgx_visit.hip)
+constexpr uint32_t VISIT_WAVE_MAX = 3153;   // ... a wavefront (a 4,096-slot table); larger groups: the host replay of the tables
+constexpr uint32_t KEY_SAMPLE_STRIDE = 997;
+void pairs_fetch_tables(const DevicePairs &dp, PairTables &out);   // (no-op when the tables are on the host already)
+// the visit order on the device (pgx_visit.hip): inner tables of every first-key group replayed by a lane / a wavefront each
+// (enqueued; runs while the host finishes the outer table), then the groups' visited buckets placed in outer-slot order
+struct DevVisit {
+  DevBuf<uint32_t> ids_all, gnb;
+  DevBuf<unsigned long long> tot;
+};
+void dev_visit_inner(const DevicePairs &dp, uint32_t ovlp_upper, DevVisit &v);
+// slots: the outer table as DistinctSlotTable leaves it (pinned host memory), ids = positions in first-insertion order
+void dev_visit_place(const DevicePairs &dp, DevVisit &v, const uint64_t *slots, uint32_t n_slots, DevBuf<uint32_t> &bid, size_t *n_buckets,
+                     size_t *n_entries);
 // The distinct first keys of the records in the order of their first insertion -- what the host replays klib's OUTER table from
 // (pgx_overlap.cpp) -- computed right after the records exist (a hash aggregation of first occurrences + an ordered select) and
 // handed to `early` while the join's sorts are still to run: the outer-table replay, the longest sequential piece of host work

@@ -98,16 +98,22 @@ struct SlotTable {
 // runs the load-factor check and may resize -- is `touch()`.
 // ---------------------------------------------------------------------------------------------------------
 struct DistinctSlotTable {
+  // One 8-byte word per slot (round 3; round 2 kept keys / ids / occupancy in three arrays, i.e. three cache misses per put on
+  // a table that has outgrown the caches): the key's 32-bit hash -- all a resize ever needs of the key, the keys being distinct
+  // and never compared -- | a 2-bit state | the 30-bit id.  State 0 = empty; 1 / 2 = occupied, the value alternating from one
+  // resize to the next, so that during a rehash "not moved yet" (the old value) and "placed" (the new one) are told apart in
+  // place, as khash does with its two flag arrays (khash.h:258-284).
+  static constexpr uint32_t ID_MASK = 0x3FFFFFFFu;
   uint32_t nb = 0, size = 0, upper = 0;
-  uint64_t *keys = nullptr;
-  uint32_t *ids = nullptr, *skip = nullptr;
-  uint8_t *used = nullptr;
-  // reserve(): all arrays at their final size from the caller's allocator (pooled huge-page mappings in the overlap stage), the
-  // occupancy / skip arrays twice (a resize builds the new ones beside the old): no realloc, no calloc, no page faults per resize
+  uint64_t *slot = nullptr;
+  uint32_t *skip = nullptr;
+  uint32_t live = 1;
+  // reserve(): the arrays at their final size from the caller's allocator (pooled huge-page mappings in the overlap stage), the
+  // skip array twice (a resize builds the new one beside the old): no realloc, no calloc, no page faults per resize
   void *(*arena_alloc)(size_t) = nullptr;
   void (*arena_free)(void *, size_t) = nullptr;
+  void (*slot_free)(void *, size_t) = nullptr;   // (the slot array may come from another allocator: pinned memory the device reads)
   uint32_t cap = 0;
-  uint8_t *ub[2] = {nullptr, nullptr};
   uint32_t *sb[2] = {nullptr, nullptr};
   int cur = 0;
   DistinctSlotTable() = default;
@@ -115,97 +121,92 @@ struct DistinctSlotTable {
   DistinctSlotTable &operator=(const DistinctSlotTable &) = delete;
   ~DistinctSlotTable() {
     if (cap) {
-      arena_free(keys, (size_t)cap * 8), arena_free(ids, (size_t)cap * 4);
-      for (int i = 0; i < 2; ++i) arena_free(ub[i], cap), arena_free(sb[i], (size_t)cap * 4);
+      slot_free(slot, (size_t)cap * 8);
+      for (int i = 0; i < 2; ++i) arena_free(sb[i], (size_t)cap * 4);
     } else {
-      free(keys), free(ids), free(used), free(skip);
+      free(slot), free(skip);
     }
   }
-  void reserve(size_t n_keys, void *(*al)(size_t), void (*fr)(void *, size_t)) {  // before the first put
+  bool is_used(uint32_t s) const { return slot[s] != 0; }   // (outside a resize every non-empty slot is live)
+  uint32_t id_at(uint32_t s) const { return (uint32_t)slot[s] & ID_MASK; }
+  void reserve(size_t n_keys, void *(*al)(size_t), void (*fr)(void *, size_t), void *(*slot_al)(size_t) = nullptr,
+               void (*slot_fr)(void *, size_t) = nullptr) {  // before the first put
     uint32_t nn = 4;
     while ((uint32_t)(nn * 0.77 + 0.5) <= n_keys && nn < (1u << 31)) nn <<= 1;   // the table stops growing once upper > size
     nn = nn < (1u << 31) ? nn * 2 : nn;   // (one spare doubling: a trailing touch() may still resize)
     arena_alloc = al, arena_free = fr, cap = nn;
-    keys = (uint64_t *)al((size_t)nn * 8), ids = (uint32_t *)al((size_t)nn * 4);
-    for (int i = 0; i < 2; ++i) ub[i] = (uint8_t *)al(nn), sb[i] = (uint32_t *)al((size_t)nn * 4);
+    slot_free = slot_al ? slot_fr : fr;
+    slot = (uint64_t *)(slot_al ? slot_al : al)((size_t)nn * 8);
+    for (int i = 0; i < 2; ++i) sb[i] = (uint32_t *)al((size_t)nn * 4);
   }
   static inline uint32_t at(uint32_t home, uint32_t step, uint32_t m) {  // position after `step` triangular increments
     return (uint32_t)((uint64_t)home + (uint64_t)step * (step + 1) / 2) & m;
   }
+  static inline uint32_t state(uint64_t e) { return (uint32_t)e >> 30; }
   void enlarge() {
     const uint32_t nn = nb ? nb * 2 : 4;
     const uint32_t thr = (uint32_t)(nn * 0.77 + 0.5);
     if (size >= thr) return;
-    uint8_t *fresh;
     uint32_t *fskip;
     if (cap && nn <= cap) {
-      fresh = ub[cur ^ 1], fskip = sb[cur ^ 1];
-      memset(fresh, 0, nn), memset(fskip, 0, (size_t)nn * 4);
+      fskip = sb[cur ^ 1];
+      memset(fskip, 0, (size_t)nn * 4);
     } else {
       if (cap) {  // grew beyond the reservation (cannot happen with a correct n_keys): fall back to the heap, keep the contents
-        uint64_t *k2 = (uint64_t *)malloc((size_t)nn * 8);
-        uint32_t *i2 = (uint32_t *)malloc((size_t)nn * 4);
-        uint8_t *u2 = (uint8_t *)malloc(nb ? nb : 1);
-        memcpy(k2, keys, (size_t)nb * 8), memcpy(i2, ids, (size_t)nb * 4), memcpy(u2, used, nb);
-        arena_free(keys, (size_t)cap * 8), arena_free(ids, (size_t)cap * 4);
-        for (int i = 0; i < 2; ++i) arena_free(ub[i], cap), arena_free(sb[i], (size_t)cap * 4);
-        keys = k2, ids = i2, used = u2, skip = nullptr, cap = 0;
+        uint64_t *s2 = (uint64_t *)malloc((size_t)nn * 8);
+        memcpy(s2, slot, (size_t)nb * 8);
+        slot_free(slot, (size_t)cap * 8);
+        for (int i = 0; i < 2; ++i) arena_free(sb[i], (size_t)cap * 4);
+        slot = s2, skip = nullptr, cap = 0;
       } else {
-        keys = (uint64_t *)realloc(keys, (size_t)nn * 8);
-        ids = (uint32_t *)realloc(ids, (size_t)nn * 4);
+        slot = (uint64_t *)realloc(slot, (size_t)nn * 8);
       }
-      fresh = (uint8_t *)calloc(nn, 1);
       fskip = (uint32_t *)calloc(nn, sizeof(uint32_t));
     }
-    const uint32_t m = nn - 1;
+    memset(slot + nb, 0, (size_t)(nn - nb) * 8);   // the new half: empty
+    const uint32_t m = nn - 1, old = live, nw = live ^ 3u;
     for (uint32_t j = 0; j < nb; ++j) {
-      if (j + 32 < nb && used[j + 32]) __builtin_prefetch(fskip + (SlotTable::h32(keys[j + 32]) & m), 1);
-      if (j + 12 < nb && used[j + 12]) {  // (fskip of that home is in the cache by now)
-        const uint32_t hh = SlotTable::h32(keys[j + 12]) & m, d = at(hh, fskip[hh], m);
-        __builtin_prefetch(fresh + d, 1), __builtin_prefetch(keys + d, 1), __builtin_prefetch(ids + d, 1);
+      if (j + 32 < nb && slot[j + 32]) __builtin_prefetch(fskip + ((uint32_t)(slot[j + 32] >> 32) & m), 1);
+      if (j + 12 < nb && slot[j + 12]) {  // (fskip of that home is in the cache by now)
+        const uint32_t hh = (uint32_t)(slot[j + 12] >> 32) & m;
+        __builtin_prefetch(slot + at(hh, fskip[hh], m), 1);
       }
-      if (!used[j]) continue;
-      uint64_t key = keys[j];
-      uint32_t id = ids[j];
-      used[j] = 0;
+      uint64_t e = slot[j];
+      if (state(e) != old) continue;   // empty, or placed here earlier in this resize
+      slot[j] = 0;
       for (;;) {  // move the element; an occupied, not yet moved destination is evicted and carried on
-        const uint32_t h = SlotTable::h32(key) & m;
+        const uint32_t h = (uint32_t)(e >> 32) & m;
         uint32_t step = fskip[h], i = at(h, step, m);
-        while (fresh[i]) i = (i + (++step)) & m;
+        while (state(slot[i]) == nw) i = (i + (++step)) & m;
         fskip[h] = step + 1;
-        fresh[i] = 1;
-        if (i < nb && used[i]) {
-          std::swap(key, keys[i]), std::swap(id, ids[i]);
-          used[i] = 0;
-        } else {
-          keys[i] = key, ids[i] = id;
-          break;
-        }
+        const uint64_t prev = slot[i];
+        slot[i] = (e & ~((uint64_t)3 << 30)) | ((uint64_t)nw << 30);
+        if (state(prev) != old) break;
+        e = prev;
       }
     }
     if (cap) cur ^= 1;
-    else free(used), free(skip);
-    used = fresh, skip = fskip, nb = nn, upper = thr;
+    else free(skip);
+    skip = fskip, nb = nn, upper = thr, live = nw;
   }
   void touch() {  // a put of a key that is already present: only the load-factor check has an effect
     if (size >= upper) enlarge();
   }
-  void put_new(uint64_t key, uint32_t id) {  // key must not be present
+  void put_new(uint64_t key, uint32_t id) {  // key must not be present; id < 2^30
     if (size >= upper) enlarge();
-    const uint32_t m = nb - 1, h = SlotTable::h32(key) & m;
+    const uint32_t hv = SlotTable::h32(key), m = nb - 1, h = hv & m;
     uint32_t step = skip[h], i = at(h, step, m);
-    while (used[i]) i = (i + (++step)) & m;
+    while (slot[i]) i = (i + (++step)) & m;
     skip[h] = step + 1;
-    used[i] = 1, keys[i] = key, ids[i] = id, ++size;
+    slot[i] = ((uint64_t)hv << 32) | ((uint64_t)live << 30) | id, ++size;
   }
   void prefetch_home(uint64_t key) const {  // first stage: the skip count of the key's home slot
     if (nb) __builtin_prefetch(skip + (SlotTable::h32(key) & (nb - 1)), 1);
   }
-  void prefetch(uint64_t key) const {  // start the misses a later put_new(key) will take
+  void prefetch(uint64_t key) const {  // start the miss a later put_new(key) will take
     if (!nb) return;
     const uint32_t m = nb - 1, h = SlotTable::h32(key) & m;
-    const uint32_t i = at(h, skip[h], m);
-    __builtin_prefetch(used + i, 1), __builtin_prefetch(keys + i, 1), __builtin_prefetch(ids + i, 1);
+    __builtin_prefetch(slot + at(h, skip[h], m), 1);
   }
 };
 

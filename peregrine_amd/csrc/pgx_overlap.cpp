@@ -366,22 +366,78 @@ void par_run(unsigned nthr, F &&fn) {
 // ids_only: leave the visit list as bucket ids (the device replay reads the records where the join left them)
 // The outer table replayed AHEAD of the join's end (EarlyFn of dev_build_pairs): ids are positions in first-insertion order,
 // i.e. id i stands for group gord[i] of the tables the join returns later.
+// pinned blocks for the outer table's slot array (the device visit uploads it, pgx_visit.hip): a few, kept while the library is up
+struct PinBlocks {
+  struct B {
+    void *p;
+    size_t n;
+    bool used;
+  };
+  std::mutex mu;
+  std::vector<B> b;
+};
+PinBlocks &pin_blocks() {
+  static PinBlocks z;
+  return z;
+}
+ShutdownHook g_pin_blocks_reset([] {
+  PinBlocks &z = pin_blocks();
+  std::lock_guard<std::mutex> lk(z.mu);
+  for (auto &x : z.b)
+    if (!x.used) (void)hipHostFree(x.p);   // (a block still in use belongs to a table that is being torn down: leaked, not freed under it)
+  z.b.clear();
+});
+void *pin_slot_alloc(size_t bytes) {
+  PinBlocks &z = pin_blocks();
+  std::lock_guard<std::mutex> lk(z.mu);
+  for (auto &x : z.b)
+    if (!x.used && x.n >= bytes && x.n <= 4 * bytes + (1u << 20)) {
+      x.used = true;
+      return x.p;
+    }
+  for (size_t i = 0; i < z.b.size(); ++i)   // the wrong size: let go of it
+    if (!z.b[i].used) {
+      (void)hipHostFree(z.b[i].p);
+      z.b.erase(z.b.begin() + i);
+      break;
+    }
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    throw std::bad_alloc();
+  }
+  z.b.push_back({p, bytes, true});
+  return p;
+}
+void pin_slot_free(void *p, size_t) {
+  PinBlocks &z = pin_blocks();
+  std::lock_guard<std::mutex> lk(z.mu);
+  for (auto &x : z.b)
+    if (x.p == p) {
+      x.used = false;
+      return;
+    }
+  (void)hipHostFree(p);   // (allocated before a pgx_shutdown)
+}
+
 struct PreOuter {
   DistinctSlotTable table;
   EarlyGroups eg;
   std::thread th;
   bool started = false;
-  double ms = 0;
+  double ms = 0, t_start = 0, t_end = 0;
   void start(EarlyGroups &&g, size_t n_rec) {
     eg = std::move(g);
-    if (eg.n < 4096) return;   // (small sets: nothing to hide)
+    const uint32_t min_n = getenv("PGX_EARLY_OUTER_MIN") ? (uint32_t)atol(getenv("PGX_EARLY_OUTER_MIN")) : 4096u;
+    if (eg.n < min_n || eg.n >= (1u << 30)) return;   // (small sets: nothing to hide)
     started = true;
-    table.reserve(eg.n, big_alloc, big_free);
+    table.reserve(eg.n, big_alloc, big_free, pin_slot_alloc, pin_slot_free);
     cpu_set_t saved, node;   // (the memory node the stage's other host threads will be pinned to: chosen from the caller's CPU)
     const bool pin = choose_node(saved, node);
     th = std::thread([this, n_rec, pin, node] {
       if (pin) (void)sched_setaffinity(0, sizeof(node), &node);
       const double t0 = now_ms();
+      t_start = t0;
       const uint64_t *k = eg.keys.data();
       const size_t n = eg.n;
       for (size_t i = 0; i < n; ++i) {
@@ -390,7 +446,8 @@ struct PreOuter {
         table.put_new(k[i], (uint32_t)i);
       }
       if ((size_t)eg.last_first + 1 < n_rec) table.touch();  // a put after the last first-insertion (khash.h:298-306)
-      ms = now_ms() - t0;
+      t_end = now_ms();
+      ms = t_end - t0;
     });
   }
   void join() {
@@ -406,6 +463,19 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
   const size_t ng = pt.gkey0.size();
   if (!ng) return;
   const bool trace = getenv("PGX_TRACE") != nullptr;
+  if (trace && getenv("PGX_TRACE_GROUPS")) {   // buckets per first-key group (log2 classes): groups, buckets
+    uint64_t hg[33] = {0}, hb[33] = {0};
+    for (size_t g = 0; g < ng; ++g) {
+      const uint32_t n = pt.gbucket[g + 1] - pt.gbucket[g];
+      int c = 0;
+      while ((1u << c) < n) ++c;
+      ++hg[c], hb[c] += n;
+    }
+    fprintf(stderr, "[pgx]   groups by buckets (<= 2^c: groups / buckets):");
+    for (int c = 0; c < 33; ++c)
+      if (hg[c]) fprintf(stderr, " 2^%d: %llu / %llu", c, (unsigned long long)hg[c], (unsigned long long)hb[c]);
+    fprintf(stderr, "\n");
+  }
   const double tv0 = now_ms();
   // The two levels are independent until the very end: the outer table only decides the ORDER in which the key0 groups
   // are visited, an inner table only the order of one group's buckets.  So one thread replays the outer table (a
@@ -446,8 +516,9 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
   }
   DistinctSlotTable local_outer;
   DistinctSlotTable &outer = pre_ok ? pre->table : local_outer;
+  PGX_REQUIRE(ng < ((size_t)1 << 30), PGX_EARG, "too many first-key groups for one overlap chunk");   // (DistinctSlotTable: 30-bit ids)
   if (!pre_ok) outer.reserve(ng, big_alloc, big_free);
-  auto gid = [&](uint32_t s0) { return pre_ok ? pt.gord[outer.ids[s0]] : outer.ids[s0]; };
+  auto gid = [&](uint32_t s0) { return pre_ok ? pt.gord[outer.id_at(s0)] : outer.id_at(s0); };
   auto outer_work = [&] {
     if (pre_ok) {
       pre->join();
@@ -509,7 +580,8 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
       }
     }
   };
-  double t_outer = 0, t_inner = 0;
+  double t_outer = 0, t_inner = 0, t_inner_only = 0;
+  std::atomic<int> inner_left{(int)nin};
   if (nin == 1) {
     outer_work();
     t_outer = now_ms() - tv0;
@@ -518,7 +590,10 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
   } else {
     par_run(nin + 1, [&](unsigned ti) {
       if (ti == 0) outer_work(), t_outer = now_ms() - tv0;
-      else inner_work(ti - 1);
+      else {
+        inner_work(ti - 1);
+        if (inner_left.fetch_sub(1) == 1) t_inner_only = now_ms() - tv0;
+      }
     });
     t_inner = now_ms() - tv0;
   }
@@ -537,14 +612,15 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
       pc.src.reserve((hi - lo) / 2 + 16), pc.cnt.reserve((hi - lo) / 2 + 16);
       for (uint32_t s0 = lo; s0 < hi; ++s0) {
         // (two dependent random reads per used slot -- the group of the slot's key, then its result -- each started ahead)
-        if (pre_ok && s0 + 32 < hi && outer.used[s0 + 32]) __builtin_prefetch(&pt.gord[outer.ids[s0 + 32]]);
-        if (s0 + 12 < hi && outer.used[s0 + 12]) __builtin_prefetch(&go[gid(s0 + 12)]);
-        if (outer.used[s0]) {
+        if (pre_ok && s0 + 32 < hi && outer.is_used(s0 + 32)) __builtin_prefetch(&pt.gord[outer.id_at(s0 + 32)]);
+        if (s0 + 12 < hi && outer.is_used(s0 + 12)) __builtin_prefetch(&go[gid(s0 + 12)]);
+        if (outer.is_used(s0)) {
           const GroupOut &o = go[gid(s0)];
           if (o.nb) pc.src.push_back(frag[o.worker].base + o.boff), pc.cnt.push_back(o.nb), pc.ne += o.ne, pc.nb += o.nb;
         }
       }
     });
+    const double tv3 = now_ms();
     std::vector<size_t> first(nin + 1, 0);
     std::vector<uint64_t> b0(nin + 1, 0);
     uint64_t ne = 0;
@@ -553,15 +629,20 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
     const size_t no = first[nin];
     v.n_buckets = b0[nin], v.n_entries = ne, v.on_device = true, v.n_groups = no;
     v.psrc.alloc(no), v.pcnt.alloc(no), v.pdst.alloc(no);
+    const double tv4 = now_ms();
     par_run(nin, [&](unsigned ti) {
       uint64_t b = b0[ti];
       size_t at = first[ti];
       const P2 &pc = piece[ti];
       for (size_t k = 0; k < pc.src.size(); ++k, ++at) v.psrc[at] = pc.src[k], v.pcnt[at] = pc.cnt[k], v.pdst[at] = b, b += pc.cnt[k];
     });
-    if (trace)
+    if (trace) {
       fprintf(stderr, "[pgx]   visit: outer table %.2f ms%s alongside %u inner-table workers (done at %.2f ms), slot scan %.2f ms\n",
               pre_ok ? pre->ms : t_outer, pre_ok ? " (started during the join)" : "", nin, t_inner, now_ms() - tv2);
+      if (pre_ok) fprintf(stderr, "[pgx]   visit: the early outer table ran from %.2f ms before to %.2f ms after the join's end; inner workers alone %.2f ms; "
+                          "slot scan: pieces %.2f ms, descriptor arrays %.2f ms, descriptors %.2f ms\n",
+                          tv0 - pre->t_start, pre->t_end - tv0, t_inner_only, tv3 - tv2, tv4 - tv3, now_ms() - tv4);
+    }
     return;
   }
   // final places: groups in ascending outer slot order
@@ -570,7 +651,7 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
   if (nin == 1 || outer.nb < (1u << 16)) {
     order.reserve(ng);
     for (uint32_t s0 = 0; s0 < outer.nb; ++s0)
-      if (outer.used[s0] && go[gid(s0)].nb) order.push_back(gid(s0));
+      if (outer.is_used(s0) && go[gid(s0)].nb) order.push_back(gid(s0));
     eat.assign(order.size() + 1, 0), bat.assign(order.size() + 1, 0);
     for (size_t i = 0; i < order.size(); ++i) eat[i + 1] = eat[i] + go[order[i]].ne, bat[i + 1] = bat[i] + go[order[i]].nb;
   } else {
@@ -585,7 +666,7 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
       Piece &pc = piece[ti];
       const uint32_t lo = (uint32_t)((uint64_t)outer.nb * ti / nin), hi = (uint32_t)((uint64_t)outer.nb * (ti + 1) / nin);
       for (uint32_t s0 = lo; s0 < hi; ++s0)
-        if (outer.used[s0]) {
+        if (outer.is_used(s0)) {
           const uint32_t g = gid(s0);
           const GroupOut &o = go[g];
           if (o.nb) pc.ids.push_back(g), pc.ne += o.ne, pc.nb += o.nb;
@@ -1526,8 +1607,11 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   const bool trace = getenv("PGX_TRACE") != nullptr;
   const bool predict = !(getenv("PGX_PREDICT") && atoi(getenv("PGX_PREDICT")) == 0);
   DevicePairs dpairs;
-  const unsigned jflags = PAIRS_ORD_TABLES | (gpu_replay ? PAIRS_LAZY_RECORDS : 0u);
   static const bool early_outer = !(getenv("PGX_EARLY_OUTER") && atoi(getenv("PGX_EARLY_OUTER")) == 0);
+  // the visit order on the device (pgx_visit.hip): the join's tables stay in HBM, the inner khash tables are replayed there, the
+  // host only replays the outer one.  PGX_DEV_VISIT=0: the round-2 form (tables downloaded, inner tables by host threads).
+  const bool dev_visit = gpu_replay && early_outer && !(getenv("PGX_DEV_VISIT") && atoi(getenv("PGX_DEV_VISIT")) == 0);
+  const unsigned jflags = PAIRS_ORD_TABLES | (gpu_replay ? PAIRS_LAZY_RECORDS : 0u) | (dev_visit ? PAIRS_DEV_TABLES : 0u);
   EarlyFn early;
   if (early_outer) early = [&](EarlyGroups &&g) { scratch->pre.start(std::move(g), pt.n_rec); };
   if (d_recs)
@@ -1541,6 +1625,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   s.n_pair_records = pt.n_rec;
   if (gpu_replay_env < 0) gpu_replay = pt.n_rec >= gpu_replay_min;
   if (!gpu_replay) {
+    pairs_fetch_tables(dpairs, pt);
     pairs_fetch_records(dpairs, pt);   // (kept on the device in case the device replay ran: the host replay reads them)
     dpairs = DevicePairs();
   }
@@ -1550,12 +1635,43 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   Visit &visit = scratch->visit;
   if (trace) fprintf(stderr, "[pgx]   pinned to a memory node at +%.2f ms after the join\n", now_ms() - t1);
   if (gpu_replay && dpairs.valid) {
-    build_visit(pt, (uint32_t)p->ovlp_upper, visit, true, &scratch->pre);
+    DevBuf<uint32_t> d_bids;
+    bool placed = false;
+    if (dpairs.tables) {
+      PreOuter &pre = scratch->pre;
+      bool ok = pre.started && pre.eg.n == dpairs.n_groups && dpairs.max_group_buckets <= VISIT_WAVE_MAX;
+      if (ok) {
+        DevVisit dv;
+        dev_visit_inner(dpairs, (uint32_t)p->ovlp_upper, dv);            // (enqueued: the GPU replays the inner tables ...
+        if (pt.n_rec >= ((size_t)2 << 20)) dev_align_prepare(db);        //  ... and packs the reads for the alignments ...
+        pre.join();                                                      //  ... while the outer table finishes here)
+        const double tw = now_ms();
+        for (size_t i = 0; ok && i < dpairs.key_sample.size(); ++i) ok = pre.eg.keys[i * KEY_SAMPLE_STRIDE] == dpairs.key_sample[i];
+        ok = ok && ((size_t)pre.eg.last_first == (size_t)dpairs.last_gfirst);
+        if (ok) {
+          size_t nbv = 0, nev = 0;
+          dev_visit_place(dpairs, dv, pre.table.slot, pre.table.nb, d_bids, &nbv, &nev);
+          visit.n_buckets = nbv, visit.n_entries = nev, visit.on_device = true, visit.n_groups = 0;
+          placed = true;
+          s.device_visit = 1 + dpairs.n_big_groups;
+          if (trace)
+            fprintf(stderr, "[pgx]   visit on the device: waited %.2f ms for the outer table (%.2f ms, %u slots), placed in %.2f ms\n", tw - t1, pre.ms,
+                    pre.table.nb, now_ms() - tw);
+        } else {
+          fprintf(stderr, "[pgx] note: the early outer-table keys do not match the join's group tables; the host builds the visit order\n");
+        }
+      } else if (trace) {
+        fprintf(stderr, "[pgx]   visit: host path (early outer table %s, largest group %u buckets)\n", pre.started ? "running" : "not started",
+                dpairs.max_group_buckets);
+      }
+      if (!placed) pairs_fetch_tables(dpairs, pt);
+    }
+    if (!placed) build_visit(pt, (uint32_t)p->ovlp_upper, visit, true, &scratch->pre);
     s.n_buckets = visit.n_buckets;
     if (trace)
       fprintf(stderr, "[pgx] GPU join: %zu records, %zu buckets, %zu key0 groups in %.2f ms; visit order (%llu buckets, ids only) in %.2f ms\n",
-              pt.n_rec, pt.bkey1_ord.size(), pt.gkey0.size(), t1 - t0, (unsigned long long)s.n_buckets, now_ms() - t1);
-    if (trace && atoi(getenv("PGX_TRACE")) >= 2 && visit.n_buckets && !visit.on_device) {  // bucket sizes: a pass of the device replay lasts as long as its largest bucket
+              pt.n_rec, pt.n_buckets, pt.n_groups, t1 - t0, (unsigned long long)s.n_buckets, now_ms() - t1);
+    if (trace && atoi(getenv("PGX_TRACE")) >= 2 && visit.n_buckets && !visit.on_device && pt.on_host) {  // bucket sizes: a pass of the device replay lasts as long as its largest bucket
       std::vector<uint32_t> sz(visit.n_buckets);
       for (size_t i = 0; i < visit.n_buckets; ++i) sz[i] = pt.bstart[visit.bids[i] + 1] - pt.bstart[visit.bids[i]];
       std::sort(sz.begin(), sz.end());
@@ -1566,8 +1682,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     size_t nrec = 0;
     pgx_overlap_stats rs;
     memset(&rs, 0, sizeof(rs));
-    DevBuf<uint32_t> d_bids;
-    if (visit.on_device)
+    if (visit.on_device && !placed)
       dev_place_bids(visit.ids_all.data(), visit.ids_all.size(), visit.psrc.data(), visit.pcnt.data(), visit.pdst.data(), visit.n_groups,
                      visit.n_buckets, d_bids);
     if (dev_replay(db, dpairs, visit.on_device ? nullptr : visit.bids.data(), visit.on_device ? d_bids.p : nullptr, visit.n_buckets,
@@ -1585,14 +1700,15 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
       if (st) *st = s;
       return;
     }
-    pairs_fetch_records(dpairs, pt);   // the device replay gave up: the host replay needs the records
+    pairs_fetch_tables(dpairs, pt);    // the device replay gave up: the host replay needs the tables and the records
+    pairs_fetch_records(dpairs, pt);
     dpairs = DevicePairs();
   }
   build_visit(pt, (uint32_t)p->ovlp_upper, visit, false, &scratch->pre);
   s.n_buckets = visit.start.size() - 1;
   if (trace)
     fprintf(stderr, "[pgx] GPU join: %zu records, %zu buckets, %zu key0 groups in %.2f ms; visit order (%llu buckets) in %.2f ms\n",
-            pt.n_rec, pt.bkey1_ord.size(), pt.gkey0.size(), t1 - t0, (unsigned long long)s.n_buckets, now_ms() - t1);
+            pt.n_rec, pt.n_buckets, pt.n_groups, t1 - t0, (unsigned long long)s.n_buckets, now_ms() - t1);
   auto align_batch = [&](const pgx_align_key *keys, size_t nreq, pgx_match *res) {  // results land in the replay's table
     const double g0 = now_ms();
     pgx_align_key *d_keys = ws<pgx_align_key>("ov.keys", nreq);
@@ -1756,7 +1872,7 @@ extern "C" {
 int pgx_khash_slot_order(const uint64_t *keys, size_t n, uint64_t *out) {
   try {
     PGX_REQUIRE((keys && out) || n == 0, PGX_EARG, "pgx_khash_slot_order: null argument");
-    PGX_REQUIRE(n < (1ULL << 31), PGX_EARG, "pgx_khash_slot_order: too many keys");
+    PGX_REQUIRE(n < (1ULL << 30), PGX_EARG, "pgx_khash_slot_order: too many keys");
     DistinctSlotTable t;
     for (size_t i = 0; i < n; ++i) {
       if (i + 8 < n) t.prefetch(keys[i + 8]);
@@ -1764,7 +1880,7 @@ int pgx_khash_slot_order(const uint64_t *keys, size_t n, uint64_t *out) {
     }
     size_t m = 0;
     for (uint32_t s0 = 0; s0 < t.nb; ++s0)
-      if (t.used[s0]) out[m++] = t.keys[s0];
+      if (t.is_used(s0)) out[m++] = keys[t.id_at(s0)];
   } catch (const Fail &f) {
     return f.code;
   }

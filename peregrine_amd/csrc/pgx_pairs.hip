@@ -578,6 +578,24 @@ void dev_pairs_scatter(const uint32_t *d_rlen, uint32_t T, int64_t start, const 
   *d_send = g_scatter.send.p;
 }
 
+void pairs_fetch_tables(const DevicePairs &dp, PairTables &out) {
+  if (out.on_host || !dp.tables) return;
+  const size_t ng = dp.n_groups, nbk = dp.n_buckets;
+  out.gord = to_host(dp.gord, ng);
+  out.bord = to_host(dp.bord, nbk);
+  out.bkey1_ord = to_host(dp.bkey1_ord, nbk);
+  out.bn_ord = to_host(dp.bn_ord, nbk);
+  out.gtrail = to_host(dp.gtrail, ng);
+  out.gkey0 = to_host(dp.gkey0, ng);
+  out.bstart = to_host(dp.bstart, nbk + 1);
+  out.gstart = to_host(dp.gstart, ng + 1);
+  out.gfirst = to_host(dp.gfirst, ng);
+  out.glast = to_host(dp.glast, ng);
+  out.gbucket = to_host(dp.gbucket, ng + 1);
+  sync();
+  out.on_host = true;
+}
+
 void pairs_fetch_records(const DevicePairs &dp, PairTables &out) {
   if (!dp.valid || out.y0.size() == dp.n_rec) return;
   out.y0 = to_host(dp.y0, dp.n_rec);
@@ -644,6 +662,23 @@ static void early_groups(const PairRecs &R, Tmp &tmp, const EarlyFn &early) {
     sync();
   }
   early(std::move(eg));
+}
+
+// PAIRS_DEV_TABLES: what the host wants to know about the groups (stats: [0] most buckets in a group, [1] groups beyond `lane_max`
+// -- listed in `big` --, [2] first insertion of the group inserted last) and every stride-th first key in first-insertion order
+__global__ void k_group_stats(const uint32_t *__restrict__ gbucket, uint32_t ng, uint32_t lane_max, uint32_t *__restrict__ stats,
+                              uint32_t *__restrict__ big, const uint64_t *__restrict__ gkey0, const uint32_t *__restrict__ gord,
+                              const uint32_t *__restrict__ gfirst, uint32_t stride, uint64_t *__restrict__ samp) {
+  const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t n = 0;
+  if (g < ng) {
+    n = gbucket[g + 1] - gbucket[g];
+    if (n > lane_max) big[atomicAdd(&stats[1], 1u)] = g;
+    if (g % stride == 0) samp[g / stride] = gkey0[gord[g]];
+    if (g == ng - 1) stats[2] = gfirst[gord[g]];
+  }
+  for (int o = 32; o; o >>= 1) n = max(n, (uint32_t)__shfl_xor((int)n, o, 64));
+  if ((threadIdx.x & 63) == 0 && n) atomicMax(&stats[0], n);
 }
 
 // OR of all keys / of all negated positions' complements: the radix sorts only visit the bits that can differ
@@ -722,7 +757,8 @@ static void bucketize(PairRecs &R, unsigned flags, PairTables &out, DevicePairs 
   PGX_HIP(hipMemcpyAsync(bstart.p + nbk, &nr, sizeof(uint32_t), hipMemcpyHostToDevice, st));
   PGX_HIP(hipMemcpyAsync(gstart.p + ng, &nr, sizeof(uint32_t), hipMemcpyHostToDevice, st));
   // first / last insertion (seq == original record index == perm value) per bucket and per key0 group
-  DevBuf<uint32_t> bfirst(nbk), gfirst(ng), glast(ng), gbucket(ng);
+  DevBuf<uint32_t> bfirst(nbk), gfirst(ng), glast(ng), gbucket((size_t)ng + 1);
+  out.n_groups = ng, out.n_buckets = nbk;
   hipLaunchKernelGGL(k_group_first_bucket, dim3(cdiv(ng, 256)), dim3(256), 0, st, gstart.p, ng, bstart.p, nbk, gbucket.p);
   {
     DevBuf<uint32_t> blast(nbk);
@@ -767,12 +803,46 @@ static void bucketize(PairRecs &R, unsigned flags, PairTables &out, DevicePairs 
     hipLaunchKernelGGL(k_gather_u64, dim3(cdiv(nr, 256)), dim3(256), 0, st, y1.p, perm_a.p, nr, sy1.p);
     out.y1 = to_host(sy1, nr);
   }
-  out.gord = to_host(gord, ng);
-  out.bord = to_host(bord, nbk);
+  const bool dev_tables = (flags & PAIRS_DEV_TABLES) && (flags & PAIRS_ORD_TABLES) && keep_dev && lazy && !(flags & PAIRS_Y1);
+  if (!dev_tables) {
+    out.gord = to_host(gord, ng);
+    out.bord = to_host(bord, nbk);
+  }
   DevBuf<uint64_t> bkey1(nbk), gkey0(ng);
   hipLaunchKernelGGL(k_gather_u64, dim3(cdiv(ng, 256)), dim3(256), 0, st, kgs.p, gstart.p, ng, gkey0.p);
   DevBuf<uint32_t> bn_o((flags & PAIRS_ORD_TABLES) ? nbk : 0);
   DevBuf<uint8_t> gtrail((flags & PAIRS_ORD_TABLES) ? ng : 0);
+  if (dev_tables) {
+    // the tables stay where they are: the visit order is built on the device (pgx_visit.hip).  What the host needs to decide
+    // that -- the largest group, the groups a lane cannot replay, a sample of the first keys in first-insertion order -- comes
+    // down with the one round trip that ends the join.
+    hipLaunchKernelGGL(k_bucket_ord, dim3(cdiv(nbk, 256)), dim3(256), 0, st, bord.p, bstart.p, sk1.p, nbk, bkey1.p, bn_o.p);
+    hipLaunchKernelGGL(k_group_trail, dim3(cdiv(ng, 256)), dim3(256), 0, st, gbucket.p, bord.p, bfirst.p, glast.p, ng, nbk, gtrail.p);
+    PGX_HIP(hipMemcpyAsync(gbucket.p + ng, &nbk, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    const uint32_t nsamp = (ng + KEY_SAMPLE_STRIDE - 1) / KEY_SAMPLE_STRIDE;
+    DevBuf<uint32_t> stats(4), big(ng);
+    DevBuf<uint64_t> samp(nsamp);
+    PGX_HIP(hipMemsetAsync(stats.p, 0, 4 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_group_stats, dim3(cdiv(ng, 256)), dim3(256), 0, st, gbucket.p, ng, VISIT_LANE_MAX, stats.p, big.p, gkey0.p, gord.p,
+                       gfirst.p, KEY_SAMPLE_STRIDE, samp.p);
+    uint32_t hst[4];
+    keep_dev->key_sample.resize(nsamp);
+    stats.download(hst, 4);
+    samp.download(keep_dev->key_sample.data(), nsamp);
+    sync();
+    keep_dev->y0 = std::move(sy0), keep_dev->dir = std::move(sdir), keep_dev->bstart = std::move(bstart);
+    keep_dev->n_rec = nr, keep_dev->n_buckets = nbk, keep_dev->valid = true;
+    keep_dev->tables = true, keep_dev->n_groups = ng;
+    keep_dev->gstart = std::move(gstart), keep_dev->gbucket = std::move(gbucket), keep_dev->gord = std::move(gord);
+    keep_dev->gfirst = std::move(gfirst), keep_dev->glast = std::move(glast), keep_dev->bord = std::move(bord);
+    keep_dev->bn_ord = std::move(bn_o), keep_dev->gkey0 = std::move(gkey0), keep_dev->bkey1_ord = std::move(bkey1);
+    keep_dev->gtrail = std::move(gtrail), keep_dev->big_groups = std::move(big);
+    keep_dev->max_group_buckets = hst[0], keep_dev->n_big_groups = hst[1], keep_dev->last_gfirst = hst[2];
+    out.on_host = false;
+    if (trace)
+      fprintf(stderr, "[pgx]   join: tables left on the device (largest group %u buckets, %u groups beyond %u)\n", hst[0], hst[1], VISIT_LANE_MAX);
+    return;
+  }
   if (flags & PAIRS_ORD_TABLES) {
     hipLaunchKernelGGL(k_bucket_ord, dim3(cdiv(nbk, 256)), dim3(256), 0, st, bord.p, bstart.p, sk1.p, nbk, bkey1.p, bn_o.p);
     hipLaunchKernelGGL(k_group_trail, dim3(cdiv(ng, 256)), dim3(256), 0, st, gbucket.p, bord.p, bfirst.p, glast.p, ng, nbk, gtrail.p);

@@ -758,3 +758,33 @@ def test_workgroup_evaluation_of_repeat_buckets_equals_oracle(monkeypatch):
             assert st["device_replay"] == 1 and formats.ovlp_fields_equal(got, want), (kw, big, dup)
             assert st["n_align_needed"] == ost["n_align"] and st["n_seen_skip"] == ost["n_seen_skip"], (kw, big, dup)
     rdb.close()
+
+
+def test_device_visit_order_equals_oracle_and_host_visit(monkeypatch):
+    """pgx_visit.hip (round 3): the inner khash tables of the first-key groups replayed on the device -- a lane per group of up
+    to 48 buckets, a wavefront (64 probe positions per step) per larger one -- and the groups' visited buckets placed in the
+    host's outer-table slot order.  A genome with one repeat family of 90 exact copies and the multiplicity cut-off lifted makes
+    first shimmers with ~100 different successors (groups well beyond 48 buckets, through several table resizes with kick-outs);
+    record SEQUENCE against the oracle, and against the host-thread form of the visit order (PGX_DEV_VISIT=0).
+    Reference: shmr_overlap.c:206-216 over khash.h:232-336."""
+    g = simreads.make_genome(1_200_000, 21, repeat_families=1, repeat_len=3000, repeat_copies=90, divergence=0.0)
+    db = simreads.simulate_reads(g, seed=5, coverage=24, mean_len=9000, sd_len=1500)
+    monkeypatch.setenv("PGX_EARLY_OUTER_MIN", "1")   # (small sets replay the outer table after the join: not here)
+    monkeypatch.setenv("PGX_GPU_REPLAY", "1")
+    rdb = ResidentDB(db, 0)
+    ix = rdb.index()
+    for kw in (dict(mc_upper=100000), dict(mc_upper=100000, ovlp_upper=60, bestn=2), dict()):
+        want, ost = U.orc_overlap(db, ix.top, ix.top_mc, mc_upper=kw.get("mc_upper", 240), ovlp_upper=kw.get("ovlp_upper", 120),
+                                  bestn=kw.get("bestn", 4))
+        assert len(want) > 5000
+        monkeypatch.setenv("PGX_DEV_VISIT", "1")
+        got, st = rdb.overlap(ix.top, ix.top_mc, **kw)
+        assert st["device_replay"] == 1 and st["device_visit"] >= 1, st
+        if "mc_upper" in kw:
+            assert st["device_visit"] > 1, st   # some groups took the wavefront kernel
+        assert formats.ovlp_fields_equal(got, want), kw
+        assert st["n_align_needed"] == ost["n_align"] and st["n_seen_skip"] == ost["n_seen_skip"], kw
+        monkeypatch.setenv("PGX_DEV_VISIT", "0")
+        got0, st0 = rdb.overlap(ix.top, ix.top_mc, **kw)
+        assert st0["device_visit"] == 0 and st0["n_buckets"] == st["n_buckets"] and formats.ovlp_fields_equal(got0, want), kw
+    rdb.close()
