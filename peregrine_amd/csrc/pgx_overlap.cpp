@@ -367,11 +367,15 @@ void par_run(unsigned nthr, F &&fn) {
 // The outer table replayed AHEAD of the join's end (EarlyFn of dev_build_pairs): ids are positions in first-insertion order,
 // i.e. id i stands for group gord[i] of the tables the join returns later.
 // pinned blocks for the outer table's slot array (the device visit uploads it, pgx_visit.hip): a few, kept while the library is up
+// Each block is a transparent-huge-page mapping registered with the HIP runtime (hipHostRegister) rather than hipHostMalloc
+// memory: the table is probed at random by the host thread that replays it, and at 8 M slots (67 MB) every probe of 4 KiB
+// pages is a TLB miss on top of the cache miss.
 struct PinBlocks {
   struct B {
     void *p;
     size_t n;
     bool used;
+    bool mapped;   // mmap + hipHostRegister (else hipHostMalloc)
   };
   std::mutex mu;
   std::vector<B> b;
@@ -380,11 +384,19 @@ PinBlocks &pin_blocks() {
   static PinBlocks z;
   return z;
 }
+void pin_block_release(void *p, size_t n, bool mapped) {
+  if (mapped) {
+    (void)hipHostUnregister(p);
+    (void)munmap(p, n);
+  } else {
+    (void)hipHostFree(p);
+  }
+}
 ShutdownHook g_pin_blocks_reset([] {
   PinBlocks &z = pin_blocks();
   std::lock_guard<std::mutex> lk(z.mu);
   for (auto &x : z.b)
-    if (!x.used) (void)hipHostFree(x.p);   // (a block still in use belongs to a table that is being torn down: leaked, not freed under it)
+    if (!x.used) pin_block_release(x.p, x.n, x.mapped);   // (a block still in use belongs to a table that is being torn down: leaked, not freed under it)
   z.b.clear();
 });
 void *pin_slot_alloc(size_t bytes) {
@@ -397,16 +409,28 @@ void *pin_slot_alloc(size_t bytes) {
     }
   for (size_t i = 0; i < z.b.size(); ++i)   // the wrong size: let go of it
     if (!z.b[i].used) {
-      (void)hipHostFree(z.b[i].p);
+      pin_block_release(z.b[i].p, z.b[i].n, z.b[i].mapped);
       z.b.erase(z.b.begin() + i);
       break;
     }
-  void *p = nullptr;
+  const size_t len = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+  void *p = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (p != MAP_FAILED) {
+    (void)madvise(p, len, MADV_HUGEPAGE);
+    memset(p, 0, len);   // (faulted in as huge pages before the runtime pins them)
+    if (hipHostRegister(p, len, hipHostRegisterDefault) == hipSuccess) {
+      z.b.push_back({p, len, true, true});
+      return p;
+    }
+    (void)hipGetLastError();
+    (void)munmap(p, len);
+  }
+  p = nullptr;
   if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess || !p) {
     (void)hipGetLastError();
     throw std::bad_alloc();
   }
-  z.b.push_back({p, bytes, true});
+  z.b.push_back({p, bytes, true, false});
   return p;
 }
 void pin_slot_free(void *p, size_t) {
@@ -417,7 +441,7 @@ void pin_slot_free(void *p, size_t) {
       x.used = false;
       return;
     }
-  (void)hipHostFree(p);   // (allocated before a pgx_shutdown)
+  // (allocated before a pgx_shutdown: the registry is gone and with it the block's kind -- leaked rather than guessed)
 }
 
 struct PreOuter {
@@ -1654,6 +1678,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
           visit.n_buckets = nbv, visit.n_entries = nev, visit.on_device = true, visit.n_groups = 0;
           placed = true;
           s.device_visit = 1 + dpairs.n_big_groups;
+          dpairs.drop_tables();
           if (trace)
             fprintf(stderr, "[pgx]   visit on the device: waited %.2f ms for the outer table (%.2f ms, %u slots), placed in %.2f ms\n", tw - t1, pre.ms,
                     pre.table.nb, now_ms() - tw);

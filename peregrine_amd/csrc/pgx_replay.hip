@@ -1648,6 +1648,9 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     r.predict = predict ? std::max(mq, 1) : 0, r.predict2 = mt;
   }
   r.bestn = bestn, r.settled = 0;
+  const bool timed_misc = getenv("PGX_REPLAY_TIMING") && atoi(getenv("PGX_REPLAY_TIMING")) != 0;   // "replay_misc" / "replay_emit" in pgx_timing_get
+  std::optional<KernelTimer> tm_setup;
+  if (timed_misc) tm_setup.emplace("replay_misc", nb);
   PGX_HIP(hipMemsetAsync(ph.p, 0, (size_t)pcap * sizeof(PHot), s));
   PGX_HIP(hipMemsetAsync(pc.p, 0, (size_t)pcap * sizeof(PCold), s));
   PGX_HIP(hipMemsetAsync(mt.p, 0, (size_t)mcap * sizeof(MSlot), s));
@@ -1670,6 +1673,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   } else {
     hipLaunchKernelGGL(k_setup, dim3(cdiv256(nb)), dim3(256), 0, s, r, (uint32_t *)nullptr);
   }
+  tm_setup.reset();
 
   bool use_big = r.big_min || r.dup_min;   // (decided below, once k_setup has counted the big buckets)
   static Counters *hc = nullptr;  // pinned mirror of the device counters
@@ -1704,6 +1708,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   auto launch_count = [&](uint32_t lo = 0, uint32_t hi = 0xFFFFFFFFu) {  // count + list of the dirty buckets of [lo, hi)
     hi = std::min<uint32_t>(hi, (uint32_t)nb);
     const uint32_t nbl = std::max<uint32_t>(1, (hi - lo + CB - 1) / CB);
+    std::optional<KernelTimer> tmc;
+    if (timed_misc) tmc.emplace("replay_misc", 0);
     hipLaunchKernelGGL(k_count_a, dim3(nbl), dim3(256), 0, s, r, lo, hi, cblk.p);
     hipLaunchKernelGGL(k_count_b, dim3(nbl), dim3(256), 0, s, r, lo, hi, cblk.p, nbl);
   };
@@ -1815,7 +1821,11 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
         }
       }
       // file what the clean buckets need (always safe), then one round trip for everything: dirty count, range, requests
-      hipLaunchKernelGGL(k_file, dim3(cdiv256(nb)), dim3(256), 0, s, r, (uint32_t)nb);
+      {
+        std::optional<KernelTimer> tmf;
+        if (timed_misc) tmf.emplace("replay_misc", 0);
+        hipLaunchKernelGGL(k_file, dim3(cdiv256(nb)), dim3(256), 0, s, r, (uint32_t)nb);
+      }
       fetch(trace);
       if (hc->overflow) goto overflowed;
       n_dirty = hc->ndirty, known = true;
@@ -1843,7 +1853,11 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     dev_align(db, r.rq_key + first_req, batch, band, r.rq_res + first_req);
     r.settled = (uint32_t)nreq;
     first_req = nreq;
-    hipLaunchKernelGGL(k_settle, dim3(cdiv256(nb)), dim3(256), 0, s, r);
+    {
+      std::optional<KernelTimer> tms;
+      if (timed_misc) tms.emplace("replay_misc", 0);
+      hipLaunchKernelGGL(k_settle, dim3(cdiv256(nb)), dim3(256), 0, s, r);
+    }
     count_dirty();
     if (batch > 100000) {  // a big batch: worth a round trip to know how many guesses were wrong (dense or sparse next)
       fetch(false);
@@ -1873,8 +1887,12 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     const size_t nrec = (size_t)last_off + last_num;
     pgx_ovlp *host = alloc_out(nrec);
     DevBuf<pgx_ovlp> d_out(std::max<size_t>(nrec, 1));
-    hipLaunchKernelGGL(k_emit, dim3(cdiv256(nb)), dim3(256), 0, s, r, off.p, d_out.p);
-    if (nrec) PGX_HIP(hipMemcpyAsync(host, d_out.p, nrec * sizeof(pgx_ovlp), hipMemcpyDeviceToHost, s));
+    {
+      std::optional<KernelTimer> tme;
+      if (timed_misc) tme.emplace("replay_emit", nrec);   // the records written and brought to the host (pinned destination)
+      hipLaunchKernelGGL(k_emit, dim3(cdiv256(nb)), dim3(256), 0, s, r, off.p, d_out.p);
+      if (nrec) PGX_HIP(hipMemcpyAsync(host, d_out.p, nrec * sizeof(pgx_ovlp), hipMemcpyDeviceToHost, s));
+    }
     if (!read_counters(false)) goto overflowed;
     *n_out = nrec;
     if (st) {

@@ -21,6 +21,14 @@ try:
             t0 = time.perf_counter()
             subprocess.run([os.path.join(exe, "shmr_overlap"), "-p", pre, "-l", os.path.join(d, "gx-L2"), "-t", "1", "-c", "1", "-o", os.path.join(d, "gov")], check=True, env=env)
             print(f"== shmr_overlap wall {time.perf_counter()-t0:.3f} s", flush=True)
+    if os.environ.get("E2E_PARENT_STEP"):   # the state bench.py's parent process is in when it times the executables
+        from peregrine_amd.shimmer import ResidentDB
+        rdb = ResidentDB(db, 0)
+        for _ in range(2):
+            ix, ov, st = rdb.index_overlap()
+        print("parent ran", len(ov), "records; affinity", len(os.sched_getaffinity(0)), "cpus", flush=True)
+        if os.environ["E2E_PARENT_STEP"] == "close":
+            rdb.close()
     for thr in (sys.argv[2:] or ["1", "4", "8", "16"]):
         env = dict(os.environ, PGX_LOAD_THREADS=thr)
         best = None

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """GPU busy / idle timeline of ONE bench step from a rocprofv3 --kernel-trace csv (memory copies are not in it: a gap
 may be a copy).  A step = the interval between the last two k_sketch_blk launches that are followed by alignment work.
-usage: tools/timeline.py p_kernel_trace.csv [min_gap_us [sequence_until_ms]]"""
+usage: tools/timeline.py p_kernel_trace.csv [min_gap_us [sequence_until_ms [sequence_from_ms]]]"""
 import csv
 import re
 import sys
@@ -50,11 +50,14 @@ def main():
             print(f"  {g/1e3:9.1f}  {at/1e6:8.2f}  {p} -> {n}")
     if len(sys.argv) > 3:   # the sequence up to this many ms: runs of the same kernel merged
         lim = float(sys.argv[3]) * 1e6
+        lo = float(sys.argv[4]) * 1e6 if len(sys.argv) > 4 else 0.0
         print("sequence: at ms, busy us, launches, kernel")
         run = None
         for s, e, n in step:
             if s - t0 > lim:
                 break
+            if s - t0 < lo:
+                continue
             if run and run[3] == n:
                 run[1] += e - s; run[2] += 1
             else:
