@@ -429,6 +429,14 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
 // and only the groups that need more take more iterations.  Lane utilisation is what the kernel is bound by (VALU issue):
 // sixteen 4-lane groups keep 3.6 live diagonals on 4 lanes instead of 8.
 enum { PH_FETCH = 0, PH_STEP = 1, PH_ROUND = 2, PH_SNAKE = 3, PH_END = 4, PH_BAND = 5, PH_DONE = 6 };
+// The V rings are exchanged between the lanes of ONE wavefront (the block is a wavefront): its LDS instructions execute in program
+// order, so all the two exchange points of an iteration need is that the compiler keeps that order -- not __syncthreads()'s
+// s_waitcnt vmcnt(0) lgkmcnt(0), which also drains the sequence loads in flight.  -DPGX_PH_BARRIER: the round-2 form.
+#ifdef PGX_PH_BARRIER
+#define PH_SYNC() __syncthreads()
+#else
+#define PH_SYNC() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"), __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
+#endif
 // PACKED (round 3): the reads come from the 2-bit packs of the seqdb (pgx_align_lane.hip: k_pack2, one pass per overlap stage, both
 // strands) instead of its bytes: the probe compares 16 bases with two funnel shifts, an XOR and a find-first-bit (8 codes, two
 // 64-bit shifts, XOR, AND and a 64-bit count before), an extension step 32 bases per lane = 256 per group with four funnel shifts
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
       }
     }
     if (!ballot64(phase != PH_DONE)) break;
-    __syncthreads();
+    PH_SYNC();
 
     // ---- STEP: the loop conditions of a new d (DWmatch.c:118-122,196-199) -------------------------------------------
     if (phase == PH_STEP && esc_list && (max_k - min_k + 4 > ring || (iter_limit && iters > iter_limit)) && !(d >= max_d || max_k - min_k > band_size)) {
@@ -693,7 +701,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
         }
       }
     }
-    __syncthreads();
+    PH_SYNC();
 
     // ---- BAND: one round of the band update (DWmatch.c:166-183) ------------------------------------------------------
     {

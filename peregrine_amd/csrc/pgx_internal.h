@@ -313,12 +313,6 @@ struct DevicePairs {
   DevBuf<uint32_t> big_groups;        // their indices
   std::vector<uint64_t> key_sample;   // gkey0[gord[i * KEY_SAMPLE_STRIDE]]: what the early outer-table keys are checked against
   uint32_t last_gfirst = 0;           // gfirst[gord[n_groups - 1]]
-  void drop_tables() {                // (the visit order is built: only the records are read from here on)
-    gstart = DevBuf<uint32_t>(), gbucket = DevBuf<uint32_t>(), gord = DevBuf<uint32_t>(), gfirst = DevBuf<uint32_t>();
-    glast = DevBuf<uint32_t>(), bord = DevBuf<uint32_t>(), bn_ord = DevBuf<uint32_t>(), big_groups = DevBuf<uint32_t>();
-    gkey0 = DevBuf<uint64_t>(), bkey1_ord = DevBuf<uint64_t>(), gtrail = DevBuf<uint8_t>();
-    tables = false;
-  }
 };
 constexpr uint32_t VISIT_LANE_MAX = 48;     // buckets of a group one lane replays (a 64-slot table: pgx_visit.hip)
 constexpr uint32_t VISIT_WAVE_MAX = 3153;   // ... a wavefront (a 4,096-slot table); larger groups: the host replay of the tables

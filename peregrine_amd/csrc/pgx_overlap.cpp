@@ -1663,7 +1663,8 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     bool placed = false;
     if (dpairs.tables) {
       PreOuter &pre = scratch->pre;
-      bool ok = pre.started && pre.eg.n == dpairs.n_groups && dpairs.max_group_buckets <= VISIT_WAVE_MAX;
+      const uint32_t wave_max = getenv("PGX_VISIT_WAVE_MAX") ? (uint32_t)std::min<long>(atol(getenv("PGX_VISIT_WAVE_MAX")), VISIT_WAVE_MAX) : VISIT_WAVE_MAX;   // (tests: force the fall-back)
+      bool ok = pre.started && pre.eg.n == dpairs.n_groups && dpairs.max_group_buckets <= wave_max;
       if (ok) {
         DevVisit dv;
         dev_visit_inner(dpairs, (uint32_t)p->ovlp_upper, dv);            // (enqueued: the GPU replays the inner tables ...
@@ -1677,8 +1678,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
           dev_visit_place(dpairs, dv, pre.table.slot, pre.table.nb, d_bids, &nbv, &nev);
           visit.n_buckets = nbv, visit.n_entries = nev, visit.on_device = true, visit.n_groups = 0;
           placed = true;
-          s.device_visit = 1 + dpairs.n_big_groups;
-          dpairs.drop_tables();
+          s.device_visit = 1 + dpairs.n_big_groups;   // (the tables stay until the device replay has succeeded: its fall-back, the host replay, fetches them)
           if (trace)
             fprintf(stderr, "[pgx]   visit on the device: waited %.2f ms for the outer table (%.2f ms, %u slots), placed in %.2f ms\n", tw - t1, pre.ms,
                     pre.table.nb, now_ms() - tw);

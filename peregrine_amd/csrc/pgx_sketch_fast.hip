@@ -42,12 +42,26 @@ __device__ __forceinline__ uint32_t lshl_add(uint32_t a, uint32_t b) {  // (a <<
   asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "n"(S), "v"(b));
   return r;
 }
+__device__ __forceinline__ uint32_t mul_lo(uint32_t a, uint32_t k) {  // (asm: the compiler would turn the multiply back into shift-adds)
+  uint32_t r;
+  asm("v_mul_lo_u32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(k));
+  return r;
+}
 __device__ __forceinline__ uint32_t mix32(uint32_t key) {  // src/mm_sketch.c:23-32 with mask = 2^32-1 (k = 16)
   key = lshl_add<21>(key, ~key);                  // ~key + (key << 21)
   key ^= key >> 24;
-  key = lshl_add<8>(key, lshl_add<3>(key, key));  // key + (key<<3) + (key<<8)   (no v_mul_lo)
+#ifdef PGX_HASH_SHIFTS
+  key = lshl_add<8>(key, lshl_add<3>(key, key));  // key + (key<<3) + (key<<8)
   key ^= key >> 14;
   key = lshl_add<4>(key, lshl_add<2>(key, key));  // key + (key<<2) + (key<<4)
+#else
+  // round 3: ONE v_mul_lo_u32 each.  profiles/r03_valu_issue.txt: on gfx950 v_mul_lo_u32 issues at the same rate as v_lshl_add_u32
+  // (0.207 / 0.243 wavefront-instructions per cycle and SIMD at 4 / 8 waves against 0.207 / 0.276) -- not the quarter-rate
+  // instruction the round-1 comment assumed -- so the two shift-adds of either step are one instruction too many.
+  key = mul_lo(key, 265u);                        // key + (key<<3) + (key<<8)
+  key ^= key >> 14;
+  key = mul_lo(key, 21u);                         // key + (key<<2) + (key<<4)
+#endif
   key ^= key >> 28;
   key = lshl_add<31>(key, key);
   return key;
@@ -64,6 +78,21 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
     const int t = __shfl_up(v, o, 64);
     if (lane >= o) v += t;
   }
+  return v;
+}
+// inclusive scan over the wavefront in six v_add_u32_dpp: Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8; lanes without a
+// source add 0), then row 0's / row 2's total into rows 1 / 3 (row_bcast:15) and lane 31's into rows 2, 3 (row_bcast:31)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add_step(int v) {
+  return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+  v = dpp_add_step<0x111, 0xf>(v);
+  v = dpp_add_step<0x112, 0xf>(v);
+  v = dpp_add_step<0x114, 0xf>(v);
+  v = dpp_add_step<0x118, 0xf>(v);
+  v = dpp_add_step<0x142, 0xa>(v);
+  v = dpp_add_step<0x143, 0xc>(v);
   return v;
 }
 __device__ __forceinline__ void lds_read16(const uint32_t *p, uint32_t (&v)[16]) {
@@ -670,10 +699,11 @@ __device__ __forceinline__ uint32_t blk_tile(BlkLds<A> &s, BlkState &st, const i
   const int x = st.x_drop;
 
   // ---- B1: window minima of the block's 16 window ends -----------------------------------------------------------------
-  uint32_t c = min3u(v[0], v[1], v[2]);
+  uint32_t pre[16];   // prefix minima of the block's own hashes (B1 needs them anyway): the last one is the block minimum
+  pre[0] = v[0];
 #pragma unroll
-  for (int o = 3; o < 15; o += 2) c = min3u(c, v[o], v[o + 1]);
-  c = min(c, v[15]);
+  for (int o = 1; o < 16; ++o) pre[o] = min(pre[o - 1], v[o]);
+  const uint32_t c = pre[15];
   lds_write16(&s.X[row_own], v);
   if (lane >= 64 - A) lds_write16(&s.Vc[par][(lane - (64 - A)) * BST], v);
   s.C[A + lane] = c;
@@ -689,10 +719,9 @@ __device__ __forceinline__ uint32_t blk_tile(BlkLds<A> &s, BlkState &st, const i
     S[16] = INF;
 #pragma unroll
     for (int o = 15; o >= 0; --o) S[o] = min(S[o + 1], u[o]);
-    uint32_t p = INF;
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
-      p = min(p, v[o]);
+      const uint32_t p = pre[o];
       if (!SPECIAL) {
         wm[o] = min3u(S[o + 1], m4, p);
       } else {
@@ -882,21 +911,12 @@ __global__ __launch_bounds__(64, 4) void k_sketch_blk(const uint8_t *__restrict_
     // ---- emission: positions in order -> queue -> one lane per emitted entry -------------------------------------------------
     if (dbg & 1) emask = 0;   // (timing experiments only: PGX_BLK_DBG)
     const int ec = __builtin_popcount(emask);
-    const uint64_t b0m = __ballot(ec & 1), b1m = __ballot(ec & 2), b2m = __ballot(ec & 4), b3m = __ballot(ec > 7);
-    if (b0m | b1m | b2m | b3m) {
-      // exclusive prefix of ec over the lanes from its bit planes (a lane emits 0.4 entries on average, eight or more only in
-      // bursts of ties): ballots + mbcnt instead of a six-step shuffle scan
-      int ex, etot;
-      if (!b3m) {
-        ex = (int)(__builtin_amdgcn_mbcnt_hi((uint32_t)(b0m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0m, 0u)) +
-                   2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1m, 0u)) +
-                   4u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b2m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b2m, 0u)));
-        etot = __builtin_popcountll(b0m) + 2 * __builtin_popcountll(b1m) + 4 * __builtin_popcountll(b2m);
-      } else {
-        const int einc = wave_incl_scan(ec, lane);
-        ex = einc - ec;
-        etot = __shfl(einc, 63, 64);
-      }
+    if (__ballot(emask != 0)) {
+      // exclusive prefix of ec over the lanes: six v_add_u32_dpp (round 2 took it from three ballots of ec's bit planes and six
+      // mbcnt: twice the instructions)
+      const int einc = wave_incl_scan_dpp(ec);
+      const int ex = einc - ec;
+      const int etot = __builtin_amdgcn_readlane(einc, 63);
       if (etot > QCAP || etot > RSTAGE) {
         st.bad |= 64;   // a burst of ties (low-complexity read): the general kernel
       } else {

@@ -787,4 +787,16 @@ def test_device_visit_order_equals_oracle_and_host_visit(monkeypatch):
         monkeypatch.setenv("PGX_DEV_VISIT", "0")
         got0, st0 = rdb.overlap(ix.top, ix.top_mc, **kw)
         assert st0["device_visit"] == 0 and st0["n_buckets"] == st["n_buckets"] and formats.ovlp_fields_equal(got0, want), kw
+        # a group beyond what a wavefront replays (here: the limit lowered): the tables left on the device are fetched and the host
+        # builds the visit order
+        monkeypatch.setenv("PGX_DEV_VISIT", "1"), monkeypatch.setenv("PGX_VISIT_WAVE_MAX", "20")
+        got1, st1 = rdb.overlap(ix.top, ix.top_mc, **kw)
+        monkeypatch.delenv("PGX_VISIT_WAVE_MAX")
+        assert st1["device_visit"] == 0 and st1["n_buckets"] == st["n_buckets"] and formats.ovlp_fields_equal(got1, want), kw
+        # the visit order built on the device, then the device replay gives up (tables far too small): the host replay takes over
+        # from the join's tables, fetched at that point
+        monkeypatch.setenv("PGX_REPLAY_PAIRS_X", "0.0002"), monkeypatch.setenv("PGX_REPLAY_MEMO_X", "0.0002")
+        got2, st2 = rdb.overlap(ix.top, ix.top_mc, **kw)
+        monkeypatch.delenv("PGX_REPLAY_PAIRS_X"), monkeypatch.delenv("PGX_REPLAY_MEMO_X")
+        assert st2["device_replay"] == 0 and formats.ovlp_fields_equal(got2, want), kw
     rdb.close()
