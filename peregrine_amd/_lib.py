@@ -70,7 +70,7 @@ EXPORTS = [
     "pgx_overlap_resident", "pgx_overlap_chunk", "pgx_index_overlap_resident", "pgx_mkseqdb", "pgx_dedup",
     "pgx_sketch_batch", "pgx_reduce_batch", "pgx_count_batch", "pgx_align_batch",
     "decode_biseq", "encode_biseq", "mm_sketch", "mm_reduce", "ovlp_match", "free_ovlp_match", "read_mmlist", "write_mmlist",
-    "pgx_map", "pgx_map_chunk", "pgx_khash_slot_order",
+    "pgx_map", "pgx_map_chunk", "pgx_khash_slot_order", "pgx_khash_slot_order_ex",
     "pgx_seqdb_upload_dev", "pgx_index_resident_dev", "pgx_pairs_prepare_dev", "pgx_pairs_scatter_dev", "pgx_overlap_records_dev",
     "pgx_overlap_resident_dev", "pgx_copy_dev", "pgx_seqdb_adopt_dev", "pgx_stream_wait", "pgx_stream_signal",
     "build_shimmer_map4py", "get_shimmers_for_read", "get_mmer_count", "get_shimmer_hits", "pgx_shimmer_map_free",
@@ -133,6 +133,7 @@ def load():
         lib.pgx_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         lib.pgx_timing_get.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pgx_khash_slot_order.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        lib.pgx_khash_slot_order_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
         lib.pgx_map.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pgx_map_chunk.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

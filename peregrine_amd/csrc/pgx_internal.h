@@ -324,10 +324,12 @@ struct DevVisit {
   DevBuf<uint32_t> ids_all, gnb;
   DevBuf<unsigned long long> tot;
 };
+// the outer table's slot layout computed on the device (pgx_khash_dev.hip); false: gave up, use the host form
+bool dev_khash_slots(const uint64_t *d_keys, size_t n_keys, bool touch, DevBuf<uint64_t> &slots, uint32_t *n_slots);
 void dev_visit_inner(const DevicePairs &dp, uint32_t ovlp_upper, DevVisit &v);
 // slots: the outer table as DistinctSlotTable leaves it (pinned host memory), ids = positions in first-insertion order
 void dev_visit_place(const DevicePairs &dp, DevVisit &v, const uint64_t *slots, uint32_t n_slots, DevBuf<uint32_t> &bid, size_t *n_buckets,
-                     size_t *n_entries);
+                     size_t *n_entries, const uint64_t *slots_on_device = nullptr);   // (slots_on_device: the same words, already in HBM)
 // The distinct first keys of the records in the order of their first insertion -- what the host replays klib's OUTER table from
 // (pgx_overlap.cpp) -- computed right after the records exist (a hash aggregation of first occurrences + an ordered select) and
 // handed to `early` while the join's sorts are still to run: the outer-table replay, the longest sequential piece of host work
@@ -336,6 +338,10 @@ struct EarlyGroups {
   HostArray<uint64_t> keys;
   uint32_t n = 0;
   uint32_t last_first = 0;   // record index of the last key's first occurrence
+  // large sets (PGX_DEV_OUTER_MIN keys and more): the outer table's slot layout, computed on the device right here
+  // (pgx_khash_dev.hip) instead of by a host thread; n_slots == 0: not computed
+  DevBuf<uint64_t> d_slots;
+  uint32_t n_slots = 0;
 };
 using EarlyFn = std::function<void(EarlyGroups &&)>;
 // d_rlen: read length by rid, on the device
