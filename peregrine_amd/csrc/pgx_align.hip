@@ -538,24 +538,22 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
       if (gl == 0) esc_list[atomicAdd(esc_n, 1u)] = a;
       phase = PH_FETCH;
     }
-    if (phase == PH_STEP) {
-      if (d >= max_d || max_k - min_k > band_size) {
-        if (gl == 0) {
-          pgx_match r;
-          r.m_size = 0, r.dist = 0, r.q_bgn = 0, r.q_end = 0, r.t_bgn = 0, r.t_end = 0;
-          r.t_m_end = t_m_end, r.q_m_end = q_m_end;
-          out[a] = r;
-        }
-        phase = PH_FETCH;
-      } else {
-        nk = max_k >= min_k ? ((max_k - min_k) >> 1) + 1 : 0;
-        base = 0;
-        if (nk == 0) {  // degenerate band: an empty k-loop, then the band update over nothing (followed literally)
-          bbase = 0, new_min = max_k, new_max = min_k;
-          phase = PH_BAND;
-        } else {
-          phase = PH_ROUND;
-        }
+    {
+      // (straight-line selects: written as nested branches the compiler kept the five step variables in copies it moved in and out of
+      //  every arm -- a fifth of the kernel's v_mov; the band scan's start values are set here for every step, END no longer does it)
+      const bool stp = phase == PH_STEP;
+      const bool term = stp && (d >= max_d || max_k - min_k > band_size);
+      if (term && gl == 0) {
+        pgx_match r;
+        r.m_size = 0, r.dist = 0, r.q_bgn = 0, r.q_end = 0, r.t_bgn = 0, r.t_end = 0;
+        r.t_m_end = t_m_end, r.q_m_end = q_m_end;
+        out[a] = r;
+      }
+      const int nk_new = max_k >= min_k ? ((max_k - min_k) >> 1) + 1 : 0;
+      if (stp) {
+        nk = nk_new, base = 0, bbase = 0, new_min = max_k, new_max = min_k;
+        // nk == 0: a degenerate band -- an empty k-loop, then the band update over nothing (followed literally)
+        phase = term ? PH_FETCH : (nk_new ? PH_ROUND : PH_BAND);
       }
     }
 
@@ -696,8 +694,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
           phase = PH_FETCH;
         } else {
           base += GL;
-          if (base >= nk) bbase = 0, new_min = max_k, new_max = min_k, phase = PH_BAND;
-          else phase = PH_ROUND;
+          phase = base >= nk ? PH_BAND : PH_ROUND;
         }
       }
     }
