@@ -6,7 +6,7 @@ T=${1:-blk}
 OUT=gpurun_out/pmc_sketch_$T
 rm -rf $OUT
 timeout -k 5 420 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/a -o p -- python tools/kbench.py 4 sketch > $OUT.log 2>&1
-timeout -k 5 420 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -o p -- python tools/kbench.py 4 sketch >> $OUT.log 2>&1
+timeout -k 5 420 rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_BUSY_CYCLES --output-format csv -d $OUT/b -o p -- python tools/kbench.py 4 sketch >> $OUT.log 2>&1
 python - <<PY
 import csv, collections, glob
 for d in ("a", "b"):
