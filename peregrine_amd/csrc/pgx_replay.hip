@@ -1731,7 +1731,10 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   const bool wide = !(getenv("PGX_REPLAY_WIDE") && atoi(getenv("PGX_REPLAY_WIDE")) == 0);  // sparse passes: a wavefront per bucket, four rows per step
   const size_t dense_den = getenv("PGX_REPLAY_DENSE") ? (size_t)std::max(1, atoi(getenv("PGX_REPLAY_DENSE"))) : 3;  // dense rounds while more than 1/dense_den of the buckets is dirty
   const bool wide_dense = getenv("PGX_REPLAY_WIDE") && atoi(getenv("PGX_REPLAY_WIDE")) >= 2;
-  const int chain = getenv("PGX_REPLAY_CHAIN") ? std::max(1, atoi(getenv("PGX_REPLAY_CHAIN"))) : 4;
+  // sparse passes per host round trip.  Round 2 measured 2 .. 8 within 1 % of each other and kept 4; with the GPU no longer waiting for the
+  // host elsewhere (round 3) the round trips and the k_file pass that precedes each one show: 8 instead of 4 = replay kernels 38.0 -> 35.5 ms
+  // and the step 113.4 -> 111.2 ms at c3, c4s 437 -> 429 ms, c5s 651 -> 639 (6), the E. coli-size set unchanged
+  const int chain = getenv("PGX_REPLAY_CHAIN") ? std::max(1, atoi(getenv("PGX_REPLAY_CHAIN"))) : 8;
   static const bool deep = getenv("PGX_TRACE") && atoi(getenv("PGX_TRACE")) >= 2;  // per-kernel wall times (synchronises after every launch)
   const bool timed = getenv("PGX_REPLAY_TIMING") && atoi(getenv("PGX_REPLAY_TIMING")) != 0;  // "replay" in pgx_timing_get
   double td = 0, t_eval = 0, t_upd = 0;
