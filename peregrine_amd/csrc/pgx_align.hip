@@ -733,10 +733,16 @@ void dev_align_prepare(const pgx_seqdb *db) {
   (void)seq_packs(db);
 }
 
-void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out) {
+void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out, bool tail_batch) {
   if (n == 0) return;
   // (the knobs are read per call: the parity tests walk every kernel variant inside one process)
-  const long small_max = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : 13000;  // measured crossover ~14 k (tools/alignlat.py)
+  // launches up to this many alignments take a wavefront per candidate (k_align1).  On uniform candidates the crossover is ~14 k
+  // (tools/alignlat.py: 13,000) -- but the mid-size launches of a stage are its TAIL sweeps (tail_batch: every request batch of the
+  // device replay after the first), and in repeat-rich sets those are mostly long, wide-band alignments that the 8-lane groups of
+  // k_align_ph first run to their iteration budget and then hand on: 60,000 for them = c4s 423 -> 417 ms per step, c5s 633 -> 628,
+  // c3 unchanged (its second batch holds 71 k).  PGX_ALIGN_SMALL / PGX_ALIGN_SMALL_TAIL override either.
+  const long small_first = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : 13000;
+  const long small_max = !tail_batch ? small_first : getenv("PGX_ALIGN_SMALL_TAIL") ? atol(getenv("PGX_ALIGN_SMALL_TAIL")) : getenv("PGX_ALIGN_SMALL") ? small_first : 60000;
   KernelTimer tm((long)n <= small_max ? "align1" : "align", n);
   int ring = 64;
   while (ring < 2 * band + 8) ring <<= 1;

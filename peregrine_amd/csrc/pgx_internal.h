@@ -191,7 +191,8 @@ void dev_reduce(const pgx_mm128 *d_in, size_t n, int rs, DevBuf<pgx_mm128> &out,
 // multiplicity of x>>8, sorted by mer
 void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_count> &out, size_t &n_out);
 // banded O(ND) confirmation of n candidate alignments (keys on device)
-void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out);
+void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out,
+               bool tail_batch = false);   // tail_batch: a later request batch of a stage (mostly hard candidates: pgx_align.hip)
 void dev_align_prepare(const pgx_seqdb *db);   // the 2-bit packs of this stage, ahead of the first large launch
 // one candidate per lane over 2-bit packs (pgx_align_lane.hip); returns the device escalation block: [0] number of candidates
 // handed on to the byte-wise kernel, [1] a zeroed work counter for that launch, [4..) their indices
