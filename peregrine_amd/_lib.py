@@ -10,7 +10,7 @@ import numpy as np
 from .formats import MC_DTYPE, MM_DTYPE, OVLP_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpgx.so")
+LIB_PATH = os.environ.get("PGX_LIB", os.path.join(_HERE, "libpgx.so"))   # (PGX_LIB: an instrumented build, e.g. -DPGX_ALIGN_STATS)
 
 MATCH_DTYPE = np.dtype([(f, "<i4") for f in ("m_size", "dist", "q_bgn", "q_end", "t_bgn", "t_end", "t_m_end", "q_m_end")])
 ALIGN_KEY_DTYPE = np.dtype([("rid0", "<u4"), ("rid1", "<u4"), ("q_off", "<u4"), ("dir0", "u1"), ("dir1", "u1"), ("pad", "u1", 2)])

@@ -479,6 +479,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
 
 #ifdef PGX_ALIGN_STATS
   uint32_t my_iters = 0;
+  int my_maxnk = 0;
   bool has_cand = false;
 #endif
   for (;;) {
@@ -486,9 +487,14 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
     if (phase == PH_FETCH && has_cand && gl == 0 && !redo_list) {   // (stats build: counter[1..32] / [33..64]: log2 histogram of the wavefront iterations a candidate took / their sums)
       const uint32_t b = my_iters ? 31u - (uint32_t)__builtin_clz(my_iters) : 0u;
       atomicAdd(counter + 1 + min(b, 31u), 1u);
+#ifdef PGX_ALIGN_STATS_NK
+      atomicAdd(counter + 33 + min((uint32_t)my_maxnk, 31u), 1u);   // (instead of the sums: candidates by the most diagonals a step of theirs had)
+#else
       atomicAdd(counter + 33 + min(b, 31u), my_iters);
+#endif
     }
-    if (phase == PH_FETCH) has_cand = false, my_iters = 0;
+    if (phase == PH_FETCH) has_cand = false, my_iters = 0, my_maxnk = 0;
+    my_maxnk = max(my_maxnk, phase == PH_ROUND || phase == PH_STEP ? nk : 0);
     ++my_iters;
 #endif
     // ---- FETCH: idle groups pull the next candidate --------------------------------------------------------------
@@ -759,8 +765,16 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
       unsigned long long tot = 0;
       for (int i = 0; i < 32; ++i) tot += h[33 + i];
       fprintf(stderr, "[pgx] align stats: %zu candidates; wavefront iterations per candidate (log2 classes: count, share of all iterations):", n);
+#ifdef PGX_ALIGN_STATS_NK
+      for (int i = 0; i < 32; ++i)
+        if (h[1 + i]) fprintf(stderr, " 2^%d: %u", i, h[1 + i]);
+      fprintf(stderr, "\n[pgx] align stats: candidates by the most diagonals a step of theirs held (31 = 31 or more):");
+      for (int i = 0; i < 32; ++i)
+        if (h[33 + i]) fprintf(stderr, " %d: %u (%.2f %%)", i, h[33 + i], tot ? 100.0 * h[33 + i] / tot : 0.0);
+#else
       for (int i = 0; i < 32; ++i)
         if (h[1 + i]) fprintf(stderr, " 2^%d: %u (%.1f %%)", i, h[1 + i], tot ? 100.0 * h[33 + i] / tot : 0.0);
+#endif
       fprintf(stderr, "\n");
     }
   } stats_printer{counter, n};
