@@ -469,9 +469,14 @@ struct PreOuter {
       t_start = t0;
       const uint64_t *k = eg.keys.data();
       const size_t n = eg.n;
+      // look-ahead of the put loop: the skip count of a key's home, then the slot it will take.  24 / 8 puts ahead while the table
+      // lives in the caches (0.75 M keys at c3: 6.6 ms whatever the distances); a table far beyond them (c5s: 4.4 M keys, 8.4 M slots
+      // = 67 MB + 34 MB of skip counts) needs the misses started ~100 ns x the puts per ns earlier: tools/khash_bench.cpp with the
+      // reference's key shape (KB_REAL=1) on the GPU box's host: 82.5 ms at 24 / 8, 58.7 at 96 / 32, 56.1 at 200 / 64
+      const size_t far = n >= ((size_t)3 << 19) ? 128 : 24, near = n >= ((size_t)3 << 19) ? 48 : 8;
       for (size_t i = 0; i < n; ++i) {
-        if (i + 24 < n) table.prefetch_home(k[i + 24]);
-        if (i + 8 < n) table.prefetch(k[i + 8]);
+        if (i + far < n) table.prefetch_home(k[i + far]);
+        if (i + near < n) table.prefetch(k[i + near]);
         table.put_new(k[i], (uint32_t)i);
       }
       if ((size_t)eg.last_first + 1 < n_rec) table.touch();  // a put after the last first-insertion (khash.h:298-306)

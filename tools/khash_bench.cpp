@@ -14,7 +14,7 @@ int main(int argc, char **argv) {
   std::vector<uint64_t> k;
   std::unordered_set<uint64_t> seen;
   while (k.size() < n) {
-    uint64_t key = ((rng() & 0xFFFFFFFFull) << 8) | (20 + rng() % 100);
+    uint64_t key = getenv("KB_REAL") ? ((((rng() & 0xFFFFFFFFull) >> 7) << 8) | 16) : (((rng() & 0xFFFFFFFFull) << 8) | (20 + rng() % 100));   // KB_REAL: the reference's keys -- hash << 8 | k, the hash a minimizer's (top bits zero)
     if (seen.insert(key).second) k.push_back(key);
   }
   for (int rep = 0; rep < 3; ++rep) {
