@@ -460,6 +460,12 @@ struct PreOuter {
     const uint32_t min_n = getenv("PGX_EARLY_OUTER_MIN") ? (uint32_t)atol(getenv("PGX_EARLY_OUTER_MIN")) : 4096u;
     if (eg.n < min_n || eg.n >= (1u << 30)) return;   // (small sets: nothing to hide)
     started = true;
+    if (const char *dump = getenv("PGX_DUMP_OUTER_KEYS")) {   // (debugging aid: the first keys in insertion order, for tools/khash_bench.cpp)
+      if (FILE *f = fopen(dump, "wb")) {
+        fwrite(eg.keys.data(), sizeof(uint64_t), eg.n, f);
+        fclose(f);
+      }
+    }
     table.reserve(eg.n, big_alloc, big_free, pin_slot_alloc, pin_slot_free);
     cpu_set_t saved, node;   // (the memory node the stage's other host threads will be pinned to: chosen from the caller's CPU)
     const bool pin = choose_node(saved, node);

@@ -13,6 +13,19 @@ int main(int argc, char **argv) {
   std::mt19937_64 rng(7);
   std::vector<uint64_t> k;
   std::unordered_set<uint64_t> seen;
+  if (const char *kf = getenv("KB_KEYS")) {   // keys dumped by the library (PGX_DUMP_OUTER_KEYS)
+    FILE *f = fopen(kf, "rb");
+    if (!f) return 1;
+    fseek(f, 0, SEEK_END);
+    n = (size_t)ftell(f) / 8;
+    fseek(f, 0, SEEK_SET);
+    k.resize(n);
+    if (fread(k.data(), 8, n, f) != n) return 1;
+    fclose(f);
+    unsigned long long orv = 0, spans = 0;
+    for (uint64_t x : k) orv |= x >> 8, spans |= 1ull << ((x & 0xFF) & 63);
+    printf("%zu keys from %s: OR of the hashes %llx, span bit set %llx\n", n, kf, orv, spans);
+  }
   while (k.size() < n) {
     uint64_t key = getenv("KB_REAL") ? ((((rng() & 0xFFFFFFFFull) >> 7) << 8) | 16) : (((rng() & 0xFFFFFFFFull) << 8) | (20 + rng() % 100));   // KB_REAL: the reference's keys -- hash << 8 | k, the hash a minimizer's (top bits zero)
     if (seen.insert(key).second) k.push_back(key);
