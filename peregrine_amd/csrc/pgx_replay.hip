@@ -1734,6 +1734,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   // sparse passes per host round trip.  Round 2 measured 2 .. 8 within 1 % of each other and kept 4; with the GPU no longer waiting for the
   // host elsewhere (round 3) the round trips and the k_file pass that precedes each one show: 8 instead of 4 = replay kernels 38.0 -> 35.5 ms
   // and the step 113.4 -> 111.2 ms at c3, c4s 437 -> 429 ms, c5s 651 -> 639 (6), the E. coli-size set unchanged
+  const int big_every = getenv("PGX_REPLAY_BIG_EVERY") ? std::max(1, atoi(getenv("PGX_REPLAY_BIG_EVERY"))) : 1;   // sparse passes per k_eval_big launch
   const int chain = getenv("PGX_REPLAY_CHAIN") ? std::max(1, atoi(getenv("PGX_REPLAY_CHAIN"))) : 8;
   static const bool deep = getenv("PGX_TRACE") && atoi(getenv("PGX_TRACE")) >= 2;  // per-kernel wall times (synchronises after every launch)
   const bool timed = getenv("PGX_REPLAY_TIMING") && atoi(getenv("PGX_REPLAY_TIMING")) != 0;  // "replay" in pgx_timing_get
@@ -1812,7 +1813,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
           if (wide) hipLaunchKernelGGL((k_eval_rows<64, 16>), dim3(cdiv256((size_t)groups * 64)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
           else hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)groups * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
           tm.reset();
-          if (use_big) {
+          if (use_big && (c % big_every == big_every - 1 || c == chain - 1)) {
             if (timed) tm.emplace("replay_big", 0);
             hipLaunchKernelGGL(k_eval_big, dim3(std::min<unsigned>(BIG_WG, groups)), dim3(64 * BIG_NW), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
             tm.reset();
