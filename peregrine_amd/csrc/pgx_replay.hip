@@ -1443,75 +1443,98 @@ __global__ __launch_bounds__(256) void k_file(R r, uint32_t limit) {
   uint32_t base = 0;
   if (lane == 63 && total) base = atomicAdd(&r.c->nreq, total);
   base = (uint32_t)__shfl((int)base, 63, 64);
-  if (!active || !cnt) {
-    if (active) r.bflags[j] &= (uint8_t)~F_UNFILED;
-    return;
-  }
+  // (from here on every lane of the wavefront stays in step: the fan-out below is done by all of them together)
+  bool run = active && cnt != 0;
+  if (active && !cnt) r.bflags[j] &= (uint8_t)~F_UNFILED;
+  if (!__ballot(run)) return;
   if ((unsigned long long)base + total > r.req_cap) {
-    atomicOr(&r.c->overflow, OV_REQS);
+    if (run) atomicOr(&r.c->overflow, OV_REQS);
     return;
   }
   uint32_t my = base + incl - cnt;
-  const uint32_t b = r.bid[j], s0 = r.bstart[b];
-  for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) {
-    Item &im = r.items[it - 1];
-    if (!(im.info & I_UNFILED)) continue;
-    const uint32_t ai = im.info & 0xFF, pi = (im.info >> 8) & 0xFF;
-    const Ent e0 = entry_of(r.y0[s0 + ai]), e1 = entry_of(r.y0[s0 + pi]);
-    const uint32_t dir0 = r.dir[s0 + ai], dir1 = r.dir[s0 + pi], q_off = e0.pos1 - e1.pos1;
-    const unsigned long long a = (unsigned long long)e0.rid << 32 | e1.rid;
-    const uint32_t bk = q_off << 2 | dir0 << 1 | dir1;
-    pgx_align_key key;
-    key.rid0 = e0.rid, key.rid1 = e1.rid, key.q_off = q_off, key.dir0 = (uint8_t)dir0, key.dir1 = (uint8_t)dir1, key.pad[0] = key.pad[1] = 0;
-    // find or insert.  Another lane may be inserting the same key right now: its `b` may still read 0, in which case this
-    // lane files a duplicate in another slot (same alignment, same result -- harmless).
-    uint32_t i = (uint32_t)mix64(a ^ mix64(bk)) & r.mmask, found = NONE;
-    bool fresh = false;
-    for (int probes = 0; probes < 1024; ++probes) {
-      unsigned long long cur = r.mt[i].a;
-      if (cur == 0) {
-        cur = atomicCAS(&r.mt[i].a, 0ULL, a);
-        if (cur == 0) {
-          r.mt[i].b = bk + 1;
-          found = i, fresh = true;
+  const uint32_t b = run ? r.bid[j] : 0u, s0 = run ? r.bstart[b] : 0u;
+  uint32_t it = run ? r.ihead[j] : NIL;
+  const bool tail = r.tail != 0;
+  for (;;) {
+    // ---- this lane's next unfiled item ----
+    bool fan = false;             // the item filed a NEW alignment (tail mode): its pair's other readers are looked at below
+    uint32_t f_slot = 0, f_a = 0, f_b = 0;
+    while (it != NIL && !fan) {
+      Item &im = r.items[it - 1];
+      const uint32_t nxt = im.next;
+      if (im.info & I_UNFILED) {
+        const uint32_t ai = im.info & 0xFF, pi = (im.info >> 8) & 0xFF;
+        const Ent e0 = entry_of(r.y0[s0 + ai]), e1 = entry_of(r.y0[s0 + pi]);
+        const uint32_t dir0 = r.dir[s0 + ai], dir1 = r.dir[s0 + pi], q_off = e0.pos1 - e1.pos1;
+        const unsigned long long a = (unsigned long long)e0.rid << 32 | e1.rid;
+        const uint32_t bk = q_off << 2 | dir0 << 1 | dir1;
+        pgx_align_key key;
+        key.rid0 = e0.rid, key.rid1 = e1.rid, key.q_off = q_off, key.dir0 = (uint8_t)dir0, key.dir1 = (uint8_t)dir1, key.pad[0] = key.pad[1] = 0;
+        // find or insert.  Another lane may be inserting the same key right now: its `b` may still read 0, in which case this
+        // lane files a duplicate in another slot (same alignment, same result -- harmless).
+        uint32_t i = (uint32_t)mix64(a ^ mix64(bk)) & r.mmask, found = NONE;
+        bool fresh = false;
+        for (int probes = 0; probes < 1024; ++probes) {
+          unsigned long long cur = r.mt[i].a;
+          if (cur == 0) {
+            cur = atomicCAS(&r.mt[i].a, 0ULL, a);
+            if (cur == 0) {
+              r.mt[i].b = bk + 1;
+              found = i, fresh = true;
+              break;
+            }
+          }
+          if (cur == a && *(volatile uint32_t *)&r.mt[i].b == bk + 1) {
+            found = i;
+            break;
+          }
+          i = (i + 1) & r.mmask;
+        }
+        if (found == NONE) {   // (this bucket stays unfiled; the overflow bit sends the walk to larger tables)
+          atomicOr(&r.c->overflow, OV_MEMO);
+          run = false, it = NIL;
           break;
         }
-      }
-      if (cur == a && *(volatile uint32_t *)&r.mt[i].b == bk + 1) {
-        found = i;
-        break;
-      }
-      i = (i + 1) & r.mmask;
-    }
-    if (found == NONE) {
-      atomicOr(&r.c->overflow, OV_MEMO);
-      return;
-    }
-    r.rq_key[my] = key;  // (a request slot whose key was already filed by someone else just repeats that alignment)
-    if (fresh) r.mt[found].req = my;
-    ++my;
-    im.mslot = found;
-    im.info &= ~I_UNFILED;
-    if (r.tail) {  // ... and the row's next partners: if this one is rejected the row goes on to them (a row of a repeat-rich
-                   // bucket can have dozens of candidates, each rejection otherwise costing a sweep)
-      const uint32_t nn = r.bstart[b + 1] - s0;
-      for (uint32_t p = pi + 1; p < nn && p <= pi + r.tail; ++p) file_entries(r, s0, ai, p);
-    }
-    if (r.tail && fresh) {  // (see file_for_reader)
-      const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[im.pslot]);
-      const uint32_t c = min(w[0], NIN);
-      for (uint32_t q = 0; q < c; ++q) {
-        const uint32_t rb = w[2 + q];
-        if (rb != 0 && rb - 1 != j && rb - 1 < r.nb) file_for_reader(r, rb - 1, e0.rid, e1.rid);
-      }
-      if (c >= NIN)
-        for (uint32_t nd = w[1]; nd != NIL; nd = r.rn[nd - 1].next) {
-          const uint32_t rb = r.rn[nd - 1].bucket;
-          if (rb != j && rb < r.nb) file_for_reader(r, rb, e0.rid, e1.rid);
+        r.rq_key[my] = key;  // (a request slot whose key was already filed by someone else just repeats that alignment)
+        if (fresh) r.mt[found].req = my;
+        ++my;
+        im.mslot = found;
+        im.info &= ~I_UNFILED;
+        if (tail) {  // ... and the row's next partners: if this one is rejected the row goes on to them (a row of a repeat-rich
+                     // bucket can have dozens of candidates, each rejection otherwise costing a sweep)
+          const uint32_t nn = r.bstart[b + 1] - s0;
+          for (uint32_t p = pi + 1; p < nn && p <= pi + r.tail; ++p) file_entries(r, s0, ai, p);
         }
+        if (tail && fresh) fan = true, f_slot = im.pslot, f_a = e0.rid, f_b = e1.rid;
+      }
+      it = nxt;
+    }
+    const uint64_t fm = __ballot(fan);
+    if (!fm && !__ballot(it != NIL)) break;
+    // ---- tail mode: the alignment every OTHER reader of a newly requested pair would ask for (file_for_reader) -- by the whole
+    // wavefront, a reader bucket per lane.  (Round 2 left this to the filing lane alone: a pair of a repeat-rich set has dozens of
+    // readers of up to 128 entries each, scanned one after the other -- k_file was 21 ms of a c4s step and 42 ms of c5s'.)
+    for (uint64_t mm = fm; mm; mm &= mm - 1) {
+      const int L = __builtin_ctzll(mm);
+      const uint32_t ps = (uint32_t)__shfl((int)f_slot, L, 64), ra = (uint32_t)__shfl((int)f_a, L, 64), rb2 = (uint32_t)__shfl((int)f_b, L, 64);
+      const uint32_t jj = (uint32_t)__shfl((int)j, L, 64);
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[ps]);
+      const uint32_t c = min(w[0], NIN);
+      for (uint32_t q = (uint32_t)lane; q < c; q += 64) {
+        const uint32_t rb = w[2 + q];
+        if (rb != 0 && rb - 1 != jj && rb - 1 < r.nb) file_for_reader(r, rb - 1, ra, rb2);
+      }
+      if (c >= NIN) {   // the overflow list: every lane walks it (one broadcast load per node), node i goes to lane i % 64
+        uint32_t idx = 0;
+        for (uint32_t nd = w[1]; nd != NIL; nd = r.rn[nd - 1].next, ++idx)
+          if ((idx & 63u) == (uint32_t)lane) {
+            const uint32_t rb = r.rn[nd - 1].bucket;
+            if (rb != jj && rb < r.nb) file_for_reader(r, rb, ra, rb2);
+          }
+      }
     }
   }
-  r.bflags[j] &= (uint8_t)~F_UNFILED;
+  if (run) r.bflags[j] &= (uint8_t)~F_UNFILED;
 }
 
 // ---- check the guesses against the results ------------------------------------------------------------------------------
