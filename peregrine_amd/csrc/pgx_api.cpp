@@ -174,6 +174,7 @@ void *out_alloc(size_t bytes) {
       g_out_pin[p] = len;
       return p;
     }
+    if (getenv("PGX_TRACE")) fprintf(stderr, "[pgx] note: no pinned block of %zu MB for a result array (held %zu MB); pageable\n", len >> 20, g_pin_held >> 20);
   }
   void *p = big_alloc(bytes);
   std::lock_guard<std::mutex> lk(g_out_mu);
