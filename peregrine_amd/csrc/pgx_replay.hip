@@ -324,7 +324,10 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
   const uint32_t j = (uint32_t)jj;
   bool alive = jj < hi && r.dirty[j] && !r.c->overflow;
   if (alive && (r.bflags[j] & F_BIG)) {   // a big bucket: left to k_eval_big, which runs behind this kernel from the list written here
-    if (gl == 0) r.blist[atomicAdd(&r.c->nbig, 1u)] = j;
+    if (gl == 0) {
+      const uint32_t at = atomicAdd(&r.c->nbig, 1u);
+      if (at < LIST_CAP) r.blist[at] = j;   // (beyond the list: the bucket stays dirty and is listed again by the next pass)
+    }
     alive = false;
   }
   {
@@ -580,7 +583,10 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
   const uint32_t j = (uint32_t)jj;
   bool alive = jj < hi && r.dirty[j] && !r.c->overflow;
   if (alive && (r.bflags[j] & F_BIG)) {   // a big bucket: left to k_eval_big, which runs behind this kernel from the list written here
-    if (gl == 0) r.blist[atomicAdd(&r.c->nbig, 1u)] = j;
+    if (gl == 0) {
+      const uint32_t at = atomicAdd(&r.c->nbig, 1u);
+      if (at < LIST_CAP) r.blist[at] = j;   // (beyond the list: the bucket stays dirty and is listed again by the next pass)
+    }
     alive = false;
   }
   {
@@ -916,12 +922,17 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
   uint32_t rcur = wc.x, rend = wc.y;   // reader-node arena of this wavefront
   uint32_t icur = wc.z, iend = wc.w;   // item arena of the workgroup (only thread 0's copy is used)
   if (threadIdx.x == 0) s_abort = 0;
-  (void)lo, (void)nlist;
-  // its buckets: the list the narrow kernels of this pass wrote (k_eval / k_eval_rows skip the big buckets they meet and note them)
+  // its buckets: the big list of the pass.  Two kinds of entries: a bucket id, noted by a narrow kernel that ran over a RANGE and met the
+  // bucket (k_eval / k_eval_rows skip big buckets); and a position in the dirty list | 2^31, noted by the count that made the list
+  // (k_count_b) -- those count only in a list-mode launch, and only below `lo` = the number of list entries the narrow kernel and the
+  // k_update of this pass cover (an evaluation k_update does not see would be lost)
+  const uint32_t list_limit = nlist ? lo : 0u;
   const uint32_t nbig = min(r.c->nbig, LIST_CAP);
   for (uint32_t g = blockIdx.x; g < nbig; g += gridDim.x) {
   {
-    const uint32_t j = r.blist[g];
+    const uint32_t e = r.blist[g];
+    if ((e & 0x80000000u) && (e & 0x7FFFFFFFu) >= list_limit) continue;   // (workgroup-uniform)
+    const uint32_t j = (e & 0x80000000u) ? (r.dlist[e & 0x7FFFFFFFu] & 0x7FFFFFFFu) : e;
     __syncthreads();   // (the previous bucket's LDS is done with)
     if (threadIdx.x == 0) {   // one thread decides for the workgroup (a flag another workgroup raises meanwhile must not split it)
       if (r.c->overflow) s_abort = 1;
@@ -1252,7 +1263,7 @@ __device__ __forceinline__ void apply_insertion(const R &r, uint32_t j, uint32_t
 __global__ __launch_bounds__(256) void k_update(R r, uint32_t lo, uint32_t hi, uint32_t nlist) {
   const int lane = threadIdx.x & 63, gl = lane & (GL - 1);
   const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPW + (uint32_t)(lane / GL));
+  const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPW + (uint32_t)(lane / GL)) & 0x7FFFFFFFull;   // (a listed big bucket: k_count_b's mark off)
   const uint32_t j = (uint32_t)jj;
   const bool alive = jj < hi && r.evaluated[j] && !r.c->overflow;
   if (blockIdx.x == 0 && threadIdx.x == 0) r.c->nbig = 0;   // (k_eval_big has consumed the pass's list; the next pass starts a new one)
@@ -1324,6 +1335,7 @@ __global__ __launch_bounds__(256) void k_count_a(R r, uint32_t rlo, uint32_t rhi
   if ((threadIdx.x & 63) == 0) s_c[w] = c, s_lo[w] = lo, s_hi[w] = hi;
   __syncthreads();
   if (threadIdx.x == 0) {
+    if (blockIdx.x == 0) r.c->nbig = 0;   // (k_count_b lists the big buckets by their POSITION in the list it writes: positions of an older list must be gone)
     blk[3 * blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
     blk[3 * blockIdx.x + 1] = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
     blk[3 * blockIdx.x + 2] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
@@ -1368,7 +1380,18 @@ __global__ __launch_bounds__(256) void k_count_b(R r, uint32_t rlo, uint32_t rhi
   if (!m) return;
   uint32_t at = s_part[0] + s_part[1] + s_part[2] + s_part[3] + incl - c;
   for (int q = 0; q < w; ++q) at += s_w[q];
-  for (uint32_t mm = m; mm && at < LIST_CAP; mm &= mm - 1, ++at) r.dlist[at] = j0 + (uint32_t)__builtin_ctz(mm);
+  // (round 3) a big bucket is marked in the list (bit 31: the narrow kernels and their wavefront slots pass it over -- its index is
+  // beyond every `hi` -- and k_update takes the mark off) and entered in the big list right here, so that k_eval_big does not have
+  // to wait for the narrow kernel of the pass to find it: the two run side by side
+  for (uint32_t mm = m; mm && at < LIST_CAP; mm &= mm - 1, ++at) {
+    const uint32_t j = j0 + (uint32_t)__builtin_ctz(mm);
+    const bool big = (r.bflags[j] & F_BIG) != 0;
+    r.dlist[at] = j | (big ? 0x80000000u : 0u);
+    if (big) {   // (listed by POSITION: k_eval_big only takes the part of the list that the pass's narrow kernel and k_update cover)
+      const uint32_t bat = atomicAdd(&r.c->nbig, 1u);
+      if (bat < LIST_CAP) r.blist[bat] = at | 0x80000000u;
+    }
+  }
 }
 
 // Tail sweeps.  A pair whose alignment is rejected is not entered in the seen-pair table, so the next bucket holding both reads
@@ -1757,6 +1780,18 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   // sparse passes per host round trip.  Round 2 measured 2 .. 8 within 1 % of each other and kept 4; with the GPU no longer waiting for the
   // host elsewhere (round 3) the round trips and the k_file pass that precedes each one show: 8 instead of 4 = replay kernels 38.0 -> 35.5 ms
   // and the step 113.4 -> 111.2 ms at c3, c4s 437 -> 429 ms, c5s 651 -> 639 (6), the E. coli-size set unchanged
+  const bool big_side = !(getenv("PGX_REPLAY_BIG_SIDE") && atoi(getenv("PGX_REPLAY_BIG_SIDE")) == 0);   // k_eval_big beside the narrow kernel of a sparse pass
+  static hipStream_t side_stream = nullptr;
+  static hipEvent_t side_ev[2] = {nullptr, nullptr};
+  if (!side_stream) {
+    PGX_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+    for (auto &e : side_ev) PGX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    static ShutdownHook h_([] {   // (a later pgx_init may choose another device)
+      if (side_stream) (void)hipStreamDestroy(side_stream), side_stream = nullptr;
+      for (auto &e : side_ev)
+        if (e) (void)hipEventDestroy(e), e = nullptr;
+    });
+  }
   const int big_every = getenv("PGX_REPLAY_BIG_EVERY") ? std::max(1, atoi(getenv("PGX_REPLAY_BIG_EVERY"))) : 1;   // sparse passes per k_eval_big launch
   const int chain = getenv("PGX_REPLAY_CHAIN") ? std::max(1, atoi(getenv("PGX_REPLAY_CHAIN"))) : 8;
   static const bool deep = getenv("PGX_TRACE") && atoi(getenv("PGX_TRACE")) >= 2;  // per-kernel wall times (synchronises after every launch)
@@ -1809,7 +1844,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
             if (use_big) {
               if (timed) tm.emplace("replay_big", 0);
               const unsigned wgs = (unsigned)std::min<size_t>(BIG_WG, hi - lo);
-              if (from_list) hipLaunchKernelGGL(k_eval_big, dim3(wgs), dim3(64 * BIG_NW), 0, s, r, 0u, (uint32_t)nb, DEV_LIST_WIN);
+              if (from_list) hipLaunchKernelGGL(k_eval_big, dim3(wgs), dim3(64 * BIG_NW), 0, s, r, (uint32_t)LIST_CAP, (uint32_t)nb, DEV_LIST_WIN);
               else hipLaunchKernelGGL(k_eval_big, dim3(wgs), dim3(64 * BIG_NW), 0, s, r, (uint32_t)lo, hi, 0u);
               tm.reset();
             }
@@ -1832,13 +1867,25 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
         const unsigned groups = (unsigned)std::min<size_t>(est, SPARSE_CAP);
         for (int c = 0; c < chain; ++c) {
           std::optional<KernelTimer> tm;
+          const bool big_now = use_big && (c % big_every == big_every - 1 || c == chain - 1);
+          // the big buckets of the pass (listed by the count, k_count_b) beside the narrow kernel, on a second stream: a launch of
+          // k_eval_big lasts as long as its longest bucket (~0.4 ms of dependent probes), whatever else the GPU could be doing
+          const bool side = big_now && big_side && !timed && !deep;
+          if (side) {
+            PGX_HIP(hipEventRecord(side_ev[0], s));
+            PGX_HIP(hipStreamWaitEvent(side_stream, side_ev[0], 0));
+            hipLaunchKernelGGL(k_eval_big, dim3(std::min<unsigned>(BIG_WG, groups)), dim3(64 * BIG_NW), 0, side_stream, r, groups, (uint32_t)nb, DEV_LIST);
+            PGX_HIP(hipEventRecord(side_ev[1], side_stream));
+          }
           if (timed) tm.emplace(wide ? "replay_rows" : "replay_dense", 0);
           if (wide) hipLaunchKernelGGL((k_eval_rows<64, 16>), dim3(cdiv256((size_t)groups * 64)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
           else hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)groups * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
           tm.reset();
-          if (use_big && (c % big_every == big_every - 1 || c == chain - 1)) {
+          if (side) {
+            PGX_HIP(hipStreamWaitEvent(s, side_ev[1], 0));
+          } else if (big_now) {
             if (timed) tm.emplace("replay_big", 0);
-            hipLaunchKernelGGL(k_eval_big, dim3(std::min<unsigned>(BIG_WG, groups)), dim3(64 * BIG_NW), 0, s, r, 0u, (uint32_t)nb, DEV_LIST);
+            hipLaunchKernelGGL(k_eval_big, dim3(std::min<unsigned>(BIG_WG, groups)), dim3(64 * BIG_NW), 0, s, r, groups, (uint32_t)nb, DEV_LIST);
             tm.reset();
           }
           if (timed) tm.emplace("replay_update", 0);
