@@ -1837,11 +1837,21 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
             // list (wavefronts full of live buckets) instead of over every bucket of the window
             const bool from_list = use_win_list && !(first_pass && k == 0) && !wide_dense && hi - lo <= LIST_CAP;
             if (from_list) launch_count((uint32_t)lo, hi);
+            const bool side = use_big && from_list && big_side && !timed && !deep;   // (the window's big buckets are in the count's list: beside k_eval)
+            if (side) {
+              PGX_HIP(hipEventRecord(side_ev[0], s));
+              PGX_HIP(hipStreamWaitEvent(side_stream, side_ev[0], 0));
+              hipLaunchKernelGGL(k_eval_big, dim3((unsigned)std::min<size_t>(BIG_WG, hi - lo)), dim3(64 * BIG_NW), 0, side_stream, r, (uint32_t)LIST_CAP,
+                                 (uint32_t)nb, DEV_LIST_WIN);
+              PGX_HIP(hipEventRecord(side_ev[1], side_stream));
+            }
             if (wide_dense) hipLaunchKernelGGL((k_eval_rows<64, 16>), dim3(cdiv256((size_t)(hi - lo) * 64)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
             else if (from_list) hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, 0u, (uint32_t)nb, DEV_LIST_WIN);
             else hipLaunchKernelGGL(k_eval, dim3(cdiv256((size_t)(hi - lo) * GL)), dim3(256), 0, s, r, (uint32_t)lo, hi, 0u);
             tm.reset();
-            if (use_big) {
+            if (side) {
+              PGX_HIP(hipStreamWaitEvent(s, side_ev[1], 0));
+            } else if (use_big) {
               if (timed) tm.emplace("replay_big", 0);
               const unsigned wgs = (unsigned)std::min<size_t>(BIG_WG, hi - lo);
               if (from_list) hipLaunchKernelGGL(k_eval_big, dim3(wgs), dim3(64 * BIG_NW), 0, s, r, (uint32_t)LIST_CAP, (uint32_t)nb, DEV_LIST_WIN);
