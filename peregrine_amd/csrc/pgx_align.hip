@@ -815,7 +815,8 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
   if ((long)n > small_max && (mode == 4 || mode == 8) && db->max_rlen <= 65535u) {
     auto grid_for = [&](size_t cands, int groups, int rg) {
       const size_t lds = (size_t)groups * rg * sizeof(uint16_t);
-      const unsigned per_cu = (unsigned)std::min<size_t>(32, (160u << 10) / lds);
+      const size_t cap_cu = getenv("PGX_ALIGN_WAVES") ? (size_t)std::max(1, atoi(getenv("PGX_ALIGN_WAVES"))) : 32;   // wavefronts per CU: 32 = all a CU holds (measured at c3, ms of alignment kernels per step: 16 -> 82.1, 20 -> 70.4, 24 -> 63.4, 28 -> 59.1, 32 -> 56.8)
+      const unsigned per_cu = (unsigned)std::min<size_t>(cap_cu, (160u << 10) / lds);
       return (unsigned)std::min<size_t>((cands + groups - 1) / groups, (size_t)ctx().num_cu * per_cu);
     };
     if (mode == 4) {
