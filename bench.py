@@ -284,9 +284,18 @@ def main():
     sp.update(simreads.STAGE_PARAMS.get(a.workload, {}))
     global LEVELS
     LEVELS = sp["levels"]
-    if a.workload in simreads.TORCH_WORKLOADS:
+    cache = os.environ.get("PGX_BENCH_CACHE")   # a directory: the simulated set is kept there (the PMC passes of the repeat-rich workloads:
+    cpath = os.path.join(cache, f"{a.workload}_r{rank}") if cache else None   # rocprofv3 --pmc aborts inside torch's generator kernels)
+    if cpath and os.path.exists(cpath + ".seqdb.npy"):
+        sq, rl = np.load(cpath + ".seqdb.npy", mmap_mode="r"), np.load(cpath + ".rlen.npy")
+        roff0 = np.concatenate([[0], np.cumsum(rl.astype(np.uint64))[:-1]]).astype(np.uint64)
+        mine = SeqDB(np.ascontiguousarray(sq), np.arange(len(rl), dtype=np.uint32), rl, roff0, None)
+    elif a.workload in simreads.TORCH_WORKLOADS:
         mine = simreads.make_workload_torch(a.workload, rank)
         mine.names = None
+        if cpath:
+            os.makedirs(cache, exist_ok=True)
+            np.save(cpath + ".seqdb.npy", np.asarray(mine.seqdb)), np.save(cpath + ".rlen.npy", np.asarray(mine.rlen))
     else:
         cfg = dict(simreads.WORKLOADS[a.workload])
         g = simreads.make_genome(cfg.pop("genome_len"), cfg.pop("genome_seed") + 7919 * rank)
