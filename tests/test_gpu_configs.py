@@ -5,7 +5,14 @@
    through size-independent properties; and a 20 Mb slice of the same recipe ("c4t") with ONE overlap chunk of 8 compared
    record for record with the oracle;
  * configs[4] scaled ("c5s"): the same reads with -l 1 (dense L1 shimmers) and mc_upper 240, 8 + 8 chunks, properties; the
-   20 Mb slice record for record."""
+   20 Mb slice record for record;
+ * round 4: ONE FULL overlap chunk (-t 8 -c 3) of c4s and of c5s at 9 Gbases, field for field and in order against the REAL
+   reference binary (oracle/_ref/shmr_overlap, ~1-2 minutes of one host core each) -- the record SEQUENCE of the repeat-rich
+   paths (k_eval_big, side stream, wavefront-visited groups) at Gbase scale, not only sampled records."""
+import os
+import shutil
+import tempfile
+
 import numpy as np
 import pytest
 
@@ -70,11 +77,21 @@ def _check_records(db, ov, band, rng, n_sample):
     return pair
 
 
+_SET = {}
+
+
+def _c4s_reads():
+    """c4s and c5s are the SAME read set (different stage parameters): simulated once per test session"""
+    if "db" not in _SET:
+        _SET["db"] = simreads.make_workload_torch("c4s")     # 300 Mb x 30x, ~600 k reads, 9 Gbases
+    return _SET["db"]
+
+
 @pytest.mark.parametrize("name", ["c4s", "c5s"])
 def test_repeat_seeded_scaled_configs_8_chunks(name):
     sp = dict(levels=2, mc_upper=240)
     sp.update(simreads.STAGE_PARAMS[name])
-    db = simreads.make_workload_torch(name)                  # 300 Mb x 30x, ~600 k reads, 9 Gbases
+    db = _c4s_reads()
     assert db.n_bases > 8.8e9
     rdb = ResidentDB(db, 0)
     rng = np.random.default_rng(17)
@@ -143,3 +160,69 @@ def test_repeat_seeded_slice_one_chunk_equals_oracle(levels, mc_upper, chunk):
     assert len(want) > 20_000 and formats.ovlp_fields_equal(ov, want)
     assert st["n_align_needed"] == ost["n_align"]
     rdb.close()
+
+
+def _scratch(need):
+    best, free = None, -1
+    for d in (os.environ.get("PGX_BENCH_TMP"), "/dev/shm", tempfile.gettempdir()):
+        if d and os.path.isdir(d):
+            st = os.statvfs(d)
+            if st.f_bavail * st.f_frsize > free:
+                best, free = d, st.f_bavail * st.f_frsize
+    return best if free >= need else None
+
+
+@pytest.mark.parametrize("name,chunk", [("c4s", 3), ("c5s", 3)])
+def test_repeat_seeded_full_chunk_equals_reference_binary(name, chunk):
+    """VERDICT r3 task 1: the whole ovlp_t stream of one overlap chunk of 8 of the 9-Gbase repeat-seeded set equals the stream the
+    REAL reference (oracle/_ref/shmr_overlap -t 8 -c 3, compiled from /root/reference/src by oracle/Makefile) writes from the same
+    files: record order = khash visit order x greedy best-n (src/shmr_overlap.c:182-231, src/khash.h:232-336) on the paths a
+    uniform-random genome never takes (buckets holding a read twice -> k_eval_big, first-key groups visited by a wavefront)."""
+    if not U.have_ref():
+        pytest.skip("oracle/_ref (the reference compiled in the build container) is not in this tree")
+    sp = dict(levels=2, mc_upper=240)
+    sp.update(simreads.STAGE_PARAMS[name])
+    db = _c4s_reads()
+    base = _scratch(int(db.seqdb.size * 1.05) + (4 << 30))
+    if base is None:
+        pytest.skip("no scratch directory with room for the 9 GB seqdb file")
+    d = tempfile.mkdtemp(prefix="pgx_cfg_", dir=base)
+    N = 8
+    try:
+        pre = os.path.join(d, "sd")
+        if "files" in _SET and os.path.exists(_SET["files"] + ".seqdb"):
+            pre = _SET["files"]
+        else:
+            formats.write_seqdb(pre, db)
+            _SET["files"], _SET["files_dir"] = pre, d
+        rdb = ResidentDB(db, 0)
+        lv = sp["levels"]
+        parts = [rdb.index(total_chunk=N, mychunk=c, levels=lv) for c in range(1, N + 1)]
+        for c, p in enumerate(parts, 1):                     # the index chunk files shmr_overlap globs (src/shmr_overlap.c:359-384)
+            formats.write_mmlist(os.path.join(d, "ix-L%d-%02d-of-%02d.dat" % (lv, c, N)), p.top)
+            formats.write_mm_count(os.path.join(d, "ix-L%d-MC-%02d-of-%02d.dat" % (lv, c, N)), p.top_mc)
+        mm = np.concatenate([p.top for p in parts])
+        mc = np.concatenate([p.top_mc for p in parts])
+        ov, st = rdb.overlap(mm, mc, total_chunk=N, mychunk=chunk, mc_upper=sp["mc_upper"])
+        rdb.close()
+        U.ref_run("shmr_overlap", "-p", pre, "-l", os.path.join(d, "ix-L%d" % lv), "-t", N, "-c", chunk, "-M", sp["mc_upper"],
+                  "-o", os.path.join(d, "ref.ovlp"))
+        want = formats.read_ovlp(os.path.join(d, "ref.ovlp"))
+        assert len(want) > 500_000 and len(ov) == len(want), (len(ov), len(want))
+        assert st["device_replay"] == 1 and st["device_visit"] >= 1
+        bad = [f for f in formats.OVLP_FIELDS if not np.array_equal(ov[f], want[f])]
+        assert not bad, (bad, int(np.flatnonzero(ov[bad[0]] != want[bad[0]])[0]))
+    finally:
+        if d != _SET.get("files_dir"):
+            shutil.rmtree(d, ignore_errors=True)
+        else:
+            for f in os.listdir(d):
+                if not f.startswith("sd."):
+                    os.remove(os.path.join(d, f))
+
+
+def test_zz_scratch_files_removed():
+    """the 9 GB seqdb file the two reference comparisons share goes away with the session"""
+    if _SET.get("files_dir"):
+        shutil.rmtree(_SET["files_dir"], ignore_errors=True)
+    _SET.clear()
