@@ -3,8 +3,15 @@
 
 One "step" = one full pass of the hot path over the synthetic read set: index stage (sketch L0 -> L1 -> L2 + counts)
 then overlap stage (pair build, bucket order, greedy best-n with GPU banded O(ND) confirmation), with the seqdb
-already resident in HBM.  N ranks = N index chunks + N overlap chunks over an N-times larger read set (weak scaling),
-the L2 lists / counts of all chunks exchanged between the stages with an RCCL all-gather.
+already resident in HBM.
+
+Two families of workloads:
+  * c4 (BASELINE configs[3] at FULL size, the configuration the metric is quoted on: a 3.1 Gb repeat-seeded genome x 30x = 93 Gbases,
+    index_nchunk = ovlp_nchunk = 8 as pg_run.py runs it): ONE read set, every rank holds the whole seqdb in HBM, the job's 8 index
+    chunks + 8 overlap chunks are dealt round-robin to the N ranks (N = 1: all 16 stages one after the other on the one GPU; N = 8: one
+    index + one overlap chunk per rank, pair records routed by the RCCL all-to-all) -- total work is fixed: "scaling": "strong";
+  * c3 / ecoli / c4s / c5s (one chunk per rank): N ranks = N index chunks + N overlap chunks over an N-times larger read set
+    ("scaling": "weak"), the count tables / pair records exchanged between the stages over RCCL.
 
   python bench.py --gpus 1 --steps 5 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -26,7 +33,10 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SKETCH_BYTES_PER_BASE = 1.04     # 1 B seqdb + 16 B/408 L2 + MC  (-m 0)
 ALIGN_BYTES_PER_PAIR = 21664.0   # 2 x 10.8 kB read + 64 B written
 LEVELS = 2
+DEFAULT_WORKLOAD = "c3"
 WORKLOAD_TEXT = {
+    "c4": "BASELINE configs[3] at FULL size (the configuration the metric is quoted on): 3.1 Gb genome seeded with 207 families of 300 copies "
+          "of a 6 kb unit at 1 % divergence, 31 k tandem arrays and 31 k homopolymer runs (CHM13 is not obtainable offline) x 30x",
     "c3": "BASELINE configs[2], uniform-random 150 Mb genome x 30x",
     "ecoli": "BASELINE configs[1], E. coli-size uniform-random genome (4,639,675 bp), 4,984 reads",
     "c4s": "BASELINE configs[3] scaled to one GPU, 300 Mb genome seeded with 6 kb x 300-copy repeat families, tandem arrays and homopolymers x 30x",
@@ -42,14 +52,23 @@ def parse():
     ap.add_argument("--two-stage", action="store_true",
                     help="N=1 only: hand the shimmer list from the index to the overlap stage through host arrays (as the "
                          "multi-GPU path must, around its all-gather) instead of leaving it in HBM")
-    ap.add_argument("--workload", default="c3",
-                    help="c3 (default; BASELINE configs[2]: 150 Mb x 30x, 4.5 Gbases, the largest single-GPU configuration, "
-                         "generated on the GPU) | ecoli (configs[1]) | c4s | c5s (repeat-seeded, scaled configs[3]/[4]) | small | tiny")
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD,
+                    help="c4 (BASELINE configs[3] at full size: 3.1 Gb repeat-seeded genome x 30x = 93 Gbases, 8 index + 8 overlap chunks; "
+                         "the configuration the metric is quoted on) | c3 (configs[2]: 150 Mb x 30x, 4.5 Gbases, one chunk) | ecoli "
+                         "(configs[1]) | c4s | c5s (repeat-seeded, scaled configs[3]/[4], one chunk) | small | tiny")
+    ap.add_argument("--chunks", type=int, default=0, help="c4 family: index_nchunk = ovlp_nchunk of the job (default 8); must be a multiple of --gpus")
+    ap.add_argument("--genome-mb", type=float, default=0, help="c4 family: genome size in Mb (default 3100; the repeat content scales with it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", default="full", choices=("full", "sample"),
-                    help="full (default): the reference binaries on the WHOLE workload -- one process on one core (its ovlp_t "
-                         "stream is compared field by field with the timed GPU output) and, beside it, N processes over N "
-                         "chunks on N = min(nproc, 24) cores; sample: a 10 Mb x 30x set of the same recipe (count check only)")
+    ap.add_argument("--cpu-baseline", default=None, choices=("full", "sample"),
+                    help="one-chunk workloads -- full (default): the reference binaries on the WHOLE workload: one process on one core (its "
+                         "ovlp_t stream is compared field by field with the timed GPU output) and N processes over N chunks for N in 24, 64, "
+                         "128; sample: a 10 Mb x 30x set of the same recipe (count check only).  c4 family -- full: the reference as 24 "
+                         "processes over 24 index chunks, then 24 overlap chunks, of the WHOLE 93 Gbases; sample (default): a bounded "
+                         "sample of it, 24 processes over chunks 1..24 of 192; either way the streams of two of those chunks are compared "
+                         "field by field with the GPU's")
+    ap.add_argument("--check-ref", action="store_true",
+                    help="c4 family, small --genome-mb only: after the timed steps every rank compares the ovlp_t stream of each of its "
+                         "chunks, field by field, with oracle/_ref/shmr_overlap -t CHUNKS -c c on files rank 0 writes")
     return ap.parse_args()
 
 
@@ -213,6 +232,204 @@ def cpu_baseline(db, ov_gpu, tag, levels=2, mc_upper=240):
         shutil.rmtree(d, ignore_errors=True)
 
 
+def attach_counters(cands, kern, workload):
+    """HBM traffic and SQ instruction counts from the PMC counters: collected in SEPARATE rocprofv3 passes of this same command ON THIS
+    WORKLOAD (tools/pmc_profile.sh <workload>: kernel-trace + one --pmc group per pass, never with the other trace domains) and committed
+    under profiles/; bench.py itself cannot run under two profilers.  A workload without its own collection reports traffic = null and
+    no `valu` object."""
+    VALU_CEILING = 0.25    # wave64 VALU instructions per cycle and SIMD for the four-cycle opcode class that dominates these kernels
+                           # (v_min / v_max / v_cmp / v_cndmask / v_alignbit / v_perm / DPP; plain adds and logic ops reach ~0.45): profiles/r03_valu_issue.txt
+    N_SIMD = 1024          # 256 CUs x 4 SIMDs
+    for tag in ("r04", "r03"):
+        tfile = os.path.join("profiles", f"{tag}_traffic_{workload}.json")
+        if os.path.exists(os.path.join(ROOT, tfile)):
+            break
+    try:
+        tr = json.load(open(os.path.join(ROOT, tfile)))
+        if "replay" in cands and "k_update" in tr:   # a round = one evaluation kernel (k_eval or k_eval_rows) + one k_update
+            tot = sum(tr[k]["hbm_bytes_per_launch"] * tr[k]["launches"] for k in ("k_eval", "k_eval_rows", "k_eval_big", "k_update") if k in tr)
+            tr["replay"] = {"hbm_bytes_per_launch": tot / tr["k_update"]["launches"]}
+        for nm, kks in (("sketch", ("k_sketch_blk", "k_sketch_wave")), ("align", ("k_align_ph", "k_align4")), ("align1", ("k_align1",)),
+                        ("replay", ("replay",))):
+            kk = next((k for k in kks if k in tr), None)
+            if nm in cands and kk:
+                cands[nm]["traffic"] = tr[kk]["hbm_bytes_per_launch"]
+                cands[nm]["traffic_read_side_raw"] = tr[kk].get("FETCH_SIZE_KB_per_launch", 0) * 1024 if "FETCH_SIZE_KB_per_launch" in tr[kk] else None
+                cands[nm]["traffic_source"] = tfile + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch; read side x2 for the streaming kernels, x1 for the alignment kernels' scattered 8- / 16-byte loads: profiles/r03_fetch_calib.txt)"
+    except Exception:
+        pass
+    # the roofline that BINDS the sketch and alignment kernels: VALU issue (VERDICT r3 task 4).  From the committed SQ passes: wave64 VALU
+    # instructions per unit and the issue rate they were executed at, against the four-cycle class's ceiling
+    for tag in ("r04", "r03"):
+        vfile = os.path.join("profiles", f"{tag}_valu_{workload}.json")
+        if os.path.exists(os.path.join(ROOT, vfile)):
+            break
+    try:
+        vv = json.load(open(os.path.join(ROOT, vfile)))
+        for nm, kks in (("sketch", ("k_sketch_blk",)), ("align", ("k_align_ph",))):
+            kk = next((k for k in kks if k in vv), None)
+            if nm in cands and kk:
+                v = vv[kk]
+                per_unit = v["SQ_INSTS_VALU"] / v["units"]
+                rate = v["SQ_INSTS_VALU"] / N_SIMD / v["SQ_BUSY_CYCLES_per_se"]
+                cands[nm]["valu"] = {"wave_instr_per_unit": per_unit, "salu_wave_instr_per_unit": v.get("SQ_INSTS_SALU", 0) / v["units"],
+                                     "issue_rate": rate, "ceiling": VALU_CEILING, "frac": rate / VALU_CEILING,
+                                     "unit": "wave64 VALU instructions per cycle and SIMD", "unit_name": cands[nm]["unit_name"],
+                                     "units_per_s_at_ceiling": VALU_CEILING * N_SIMD * v["clock_hz"] / per_unit,
+                                     "source": vfile + " (rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES ... pass of this command; ceiling: profiles/r03_valu_issue.txt)"}
+    except Exception:
+        pass
+
+
+def check_vs_reference(seq, total, db, rank, world, CH, my_chunks, streams, levels, mc_upper, multi, xdev):
+    """--check-ref (c4 family on a reduced genome; VERDICT r3 task 8): rank 0 writes the seqdb files and runs the REFERENCE index over
+    all CH chunks; every rank then runs oracle/_ref/shmr_overlap -t CH -c c for each of ITS chunks and compares its last step's
+    stream field by field, in order.  Returns (rank 0) {"all_equal": bool, "chunks": [...]}."""
+    import shutil
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_util as U
+    from peregrine_amd import formats, simreads
+    if not U.have_ref():
+        return {"all_equal": None, "error": "oracle/_ref is not in this tree"}
+    d = os.path.join(_scratch_dir(int(total * 1.2) + (2 << 30)) or tempfile.gettempdir(), "pgx_checkref_%s" % os.environ.get("MASTER_PORT", "0"))
+    if rank == 0:
+        shutil.rmtree(d, ignore_errors=True)
+        os.makedirs(d)
+        simreads.write_seqdb_from_device(os.path.join(d, "sd"), seq, total, db.rid, db.rlen, db.roff)
+        _run_many(min(CH, 24), [lambda c=c: U.ref_run("shmr_index", "-p", os.path.join(d, "sd"), "-t", CH, "-c", c, "-m", 0, "-l", levels, "-o", os.path.join(d, "ix")) for c in range(1, CH + 1)])
+    if multi:
+        dist.barrier()
+    res = []
+    for c in my_chunks:
+        U.ref_run("shmr_overlap", "-p", os.path.join(d, "sd"), "-l", os.path.join(d, "ix-L%d" % levels), "-t", CH, "-c", c, "-M", mc_upper, "-o", os.path.join(d, "ov.%03d" % c))
+        ref = formats.read_ovlp(os.path.join(d, "ov.%03d" % c))
+        res.append((c, int(len(ref)), bool(len(ref) > 0 and formats.ovlp_fields_equal(np.asarray(streams[c]), ref))))
+    flat = torch.zeros(3 * (CH // world), dtype=torch.int64, device=xdev)
+    flat[:3 * len(res)] = torch.tensor([v for r in res for v in (r[0], r[1], int(r[2]))], dtype=torch.int64)
+    if multi:
+        allr = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(allr, flat)
+        dist.barrier()
+    else:
+        allr = [flat]
+    if rank == 0:
+        shutil.rmtree(d, ignore_errors=True)
+        rows = sorted((int(t[i]), int(t[i + 1]), bool(t[i + 2])) for t in allr for i in range(0, t.numel(), 3) if int(t[i]))
+        return {"all_equal": all(r[2] for r in rows) and len(rows) == CH,
+                "chunks": [{"chunk": "%d of %d" % (r[0], CH), "records": r[1], "equal_to_reference": r[2]} for r in rows],
+                "means": "every rank's ovlp_t stream of each of its chunks == oracle/_ref/shmr_overlap -t %d -c c on the reference's own index files, field by field, in order" % CH}
+    return None
+
+
+def _run_many(n_workers, jobs):
+    """jobs: callables; run n_workers at a time (one reference process each); returns the wall time"""
+    import concurrent.futures as cf
+    t0 = time.perf_counter()
+    with cf.ThreadPoolExecutor(n_workers) as ex:
+        list(ex.map(lambda j: j(), jobs))
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, job_chunks, gpu_index_files):
+    """c4 family (one read set, CHUNKS index + overlap chunks): the REAL reference (oracle/_ref) on this box's host cores, on the same
+    bytes (the device-resident seqdb written to files), 24 processes at a time (the reference's own practical ceiling,
+    /root/reference/README.md:127-137):
+      full   -- T = 24: 24 index chunks, then 24 overlap chunks of the WHOLE read set (what VERDICT r3 task 2 asks for);
+      sample -- T = 192: index chunks 1..24 of 192 (1/8 of the reads; timed for the index rate) and overlap chunks 1..24 of 192 (1/8 of
+                the first keys) over the 8 index-chunk files of the job as the GPU wrote them (byte-identical to the reference's own:
+                tests/test_gpu_pipeline.py; shmr_overlap globs whatever index chunks exist, src/shmr_overlap.c:359-384).
+    Either way the ovlp_t streams of overlap chunks 1 and 2 of T are compared FIELD BY FIELD, in order, with the GPU's stream for the
+    same (T, c) over the same index lists -> records_match_gpu.  Checker / baseline only: nothing here is on the product path."""
+    import shutil
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_util as U
+    from peregrine_amd import _lib, formats, simreads
+    if not U.have_ref():
+        return {"value": None, "unit": "overlaps/s", "cores": 0, "kind": "none", "sample": "oracle/_ref (the compiled reference) is not in this tree"}
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    P = max(1, min(ncpu, 24))
+    T = 24 if mode == "full" else 192
+    cs = list(range(1, min(T, 24) + 1))
+    need = int(total * 1.02) + int(db.n_bases * (0.12 if mode == "full" else 0.03)) + (8 << 30)
+    base = _scratch_dir(need)
+    if base is None:
+        return {"value": None, "unit": "overlaps/s", "cores": 0, "kind": "none", "sample": f"no scratch directory with {need >> 30} GiB free"}
+    d = tempfile.mkdtemp(prefix="pgx_bench_", dir=base)
+    try:
+        pre = os.path.join(d, "sd")
+        t0 = time.perf_counter()
+        simreads.write_seqdb_from_device(pre, seq, total, db.rid, db.rlen, db.roff)
+        t_files = time.perf_counter() - t0
+        lv = "L%d" % levels
+        if mode == "full":      # the reference indexes everything itself
+            t_index = _run_many(P, [lambda c=c: U.ref_run("shmr_index", "-p", pre, "-t", T, "-c", c, "-m", 0, "-l", levels, "-o", os.path.join(d, "ix")) for c in cs])
+            lpre, index_bases, index_chunking = os.path.join(d, "ix-" + lv), db.n_bases, T
+        else:                   # the reference indexes 24 of 192 chunks (timed); the overlap sample reads the job's own index-chunk files
+            t_index = _run_many(P, [lambda c=c: U.ref_run("shmr_index", "-p", pre, "-t", T, "-c", c, "-m", 0, "-l", levels, "-o", os.path.join(d, "cx")) for c in cs])
+            index_bases = int(db.rlen[np.isin(db.rid % T, [c % T for c in cs])].sum(dtype=np.uint64))
+            gpu_index_files(os.path.join(d, "ix"))
+            lpre, index_chunking = os.path.join(d, "ix-" + lv), job_chunks
+        t_ovlp = _run_many(P, [lambda c=c: U.ref_run("shmr_overlap", "-p", pre, "-l", lpre, "-t", T, "-c", c, "-M", mc_upper, "-o", os.path.join(d, "ov.%03d" % c)) for c in cs])
+        # ---- the GPU on the same (T, c), same index chunking, for the first two chunks: field-for-field compare
+        dev = torch.device("cuda", torch.cuda.current_device())
+        tops, mcs = [], []
+        for c in range(1, index_chunking + 1):
+            _, top, mc = eng.index(index_chunking, c, levels)
+            _lib.stream_signal()
+            tops.append(top.clone()); mcs.append(mc.clone())
+        mm_all, mc_all = torch.cat(tops), torch.cat(mcs)
+        del tops, mcs
+        same_index = None
+        if mode == "full":
+            got = mm_all.cpu().numpy().view(formats.MM_DTYPE)
+            n1 = os.path.getsize(os.path.join(d, "ix-%s-01-of-%02d.dat" % (lv, T))) // 16
+            same_index = bool(np.array_equal(got[:n1], formats.read_mmlist(os.path.join(d, "ix-%s-01-of-%02d.dat" % (lv, T)))))
+            del got
+        _lib.stream_wait()
+        match, compared = True, []
+        for c in cs[:2]:
+            ov, _ = rdb.overlap_dev(mm_all.data_ptr(), mm_all.numel() // 16, mc_all.data_ptr(), mc_all.numel() // 16, total_chunk=T, mychunk=c, mc_upper=mc_upper)
+            ref = formats.read_ovlp(os.path.join(d, "ov.%03d" % c))
+            ok = bool(formats.ovlp_fields_equal(np.asarray(ov), ref))
+            compared.append({"chunk": "%d of %d" % (c, T), "records": int(len(ref)), "equal": ok})
+            match = match and ok and len(ref) > 0
+            del ov, ref
+        del mm_all, mc_all
+        raw, keys = 0, []
+        for c in cs:
+            o = formats.read_ovlp(os.path.join(d, "ov.%03d" % c))
+            raw += len(o)
+            keys.append(_pair_keys(o).view(np.int64))
+            del o
+        try:     # bookkeeping of the CPU leg's output; the whole-workload leg leaves ~0.5 G keys: sorted on the GPU
+            uniq = int(len(np.unique(np.concatenate(keys)))) if raw <= 150_000_000 else int(torch.unique(torch.cat([torch.from_numpy(k).to(dev) for k in keys])).numel())
+        except Exception:
+            uniq = None
+        del keys
+        frac = 1.0 if mode == "full" else len(cs) / T
+        out = {"value": raw / (t_index + t_ovlp), "unit": "overlaps/s", "cores": P, "kind": "reference",
+               "sample": (f"WHOLE workload {tag} ({db.n_reads} reads, {db.n_bases} bases): {P} processes over 24 index chunks, then over 24 overlap chunks"
+                          if mode == "full" else
+                          f"bounded sample of {tag} ({db.n_reads} reads, {db.n_bases} bases): {P} processes over index chunks 1..24 of 192 ({index_bases} bases) and "
+                          f"then over overlap chunks 1..24 of 192 (1/8 of the first keys; each process still loads all shimmer / count files and scans "
+                          f"the whole list, as every reference overlap chunk does)") + f"; raw ovlp_t records / wall time of both stages; host has {ncpu} usable cores",
+               "mode": mode, "chunking": T, "chunks_run": len(cs), "fraction_of_job": frac,
+               "index_s": t_index, "overlap_s": t_ovlp, "records": int(raw), "unique_pairs": uniq,
+               "index_bases_per_s": index_bases / t_index, "overlap_records_per_s": raw / t_ovlp,
+               "unique_pairs_per_s": uniq / (t_index + t_ovlp) if uniq else None,
+               "seqdb_files_written_s": t_files, "one_core": None,
+               "records_match_gpu": bool(match), "records_compared": compared, "index_list_chunk1_equals_reference": same_index,
+               "records_match_gpu_means": "every field of every ovlp_t record of overlap chunks 1 and 2 of T (the CPU leg's chunking) equals the "
+                                          "reference's stream for that chunk, in order, the GPU run on the same index lists (formats.ovlp_fields_equal; "
+                                          "padding bytes masked)"}
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def cpu_baseline_sample(sample):
     """bounded form (--cpu-baseline sample): the reference on one core on a small set of the same recipe; count only"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -250,9 +467,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
-    from peregrine_amd import _lib, simreads
+    from peregrine_amd import _lib, formats, simreads
     from peregrine_amd.formats import MC_DTYPE, MM_DTYPE, SeqDB
-    from peregrine_amd.parallel import GpuEngine, exchange_overlap, gather_seqdb
+    from peregrine_amd.parallel import GpuEngine, allgather_cat, allgather_ints, exchange_overlap, gather_seqdb
     from peregrine_amd.shimmer import ResidentDB
 
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
@@ -262,7 +479,8 @@ def main():
     backend = os.environ.get("PGX_BENCH_BACKEND", "nccl")
     dev_index = local if backend == "nccl" else local % ngpu
     torch.cuda.set_device(dev_index)
-    xdev = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
+    home = torch.device("cuda", dev_index)
+    xdev = home if backend == "nccl" else torch.device("cpu")
     # PGX_FORCE_EXCHANGE=1: a one-rank job takes the multi-rank path too -- process group over RCCL, the seqdb gathered into an
     # adopted device buffer, count all-gather + record all-to-all(v) on device views, event hand-over between the streams --
     # which is how the RCCL path is executed (and checked against the single-chunk records) on a one-GPU box
@@ -274,65 +492,138 @@ def main():
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+            dist.init_process_group("nccl", device_id=home)
         else:
             dist.init_process_group(backend)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
-    # ---- synthetic input (untimed): rank r simulates genome r; the union is the job's read set -----------------
     sp = dict(levels=2, mc_upper=240)
     sp.update(simreads.STAGE_PARAMS.get(a.workload, {}))
     global LEVELS
     LEVELS = sp["levels"]
-    cache = os.environ.get("PGX_BENCH_CACHE")   # a directory: the simulated set is kept there (the PMC passes of the repeat-rich workloads:
-    cpath = os.path.join(cache, f"{a.workload}_r{rank}") if cache else None   # rocprofv3 --pmc aborts inside torch's generator kernels)
-    if cpath and os.path.exists(cpath + ".seqdb.npy"):
-        sq, rl = np.load(cpath + ".seqdb.npy", mmap_mode="r"), np.load(cpath + ".rlen.npy")
-        roff0 = np.concatenate([[0], np.cumsum(rl.astype(np.uint64))[:-1]]).astype(np.uint64)
-        mine = SeqDB(np.ascontiguousarray(sq), np.arange(len(rl), dtype=np.uint32), rl, roff0, None)
-    elif a.workload in simreads.TORCH_WORKLOADS:
-        mine = simreads.make_workload_torch(a.workload, rank)
-        mine.names = None
-        if cpath:
-            os.makedirs(cache, exist_ok=True)
-            np.save(cpath + ".seqdb.npy", np.asarray(mine.seqdb)), np.save(cpath + ".rlen.npy", np.asarray(mine.rlen))
-    else:
-        cfg = dict(simreads.WORKLOADS[a.workload])
-        g = simreads.make_genome(cfg.pop("genome_len"), cfg.pop("genome_seed") + 7919 * rank)
-        mine = simreads.simulate_reads(g, seed=42 + rank, **cfg)
-    if multi:
-        # the job's read set = the union of the ranks' sets, replicated in every GPU's HBM: every rank's bytes are
-        # received over xGMI (RCCL) straight into their place in ONE device buffer, which the library adopts without a copy
-        home = torch.device("cuda", dev_index)
-        seq_all, total, rlen = gather_seqdb(mine.seqdb, mine.rlen, world, home)
-        roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
+    strong = a.workload in simreads.RESIDENT_WORKLOADS     # ONE read set, CHUNKS chunks dealt to the ranks; else one chunk per rank
+    seq_dev = None
+    if strong:
+        # ---- synthetic input (untimed): EVERY rank generates the same seeded read set into its own HBM (11 s for 93 Gbases) ----
+        CH = a.chunks or sp.get("chunks", 8)
+        assert CH % world == 0, f"--chunks {CH} must be a multiple of --gpus {world}"
+        my_chunks = [c for c in range(1, CH + 1) if (c - 1) % world == rank]
+        seq_dev, total, rlen = simreads.make_workload_resident(a.workload, genome_mb=a.genome_mb or None)
         rid = np.arange(len(rlen), dtype=np.uint32)
-        rdb = ResidentDB.adopt_device(seq_all, total, rid, rlen, roff, dev_index)
-        db = SeqDB(mine.seqdb if world == 1 else np.zeros(0, np.uint8), rid, rlen, roff, None)   # (sizes only when the bytes live in HBM)
-        del seq_all
+        roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
+        if world > 1:    # same generator, same seeds, same device type: the ranks' copies must be the same bytes
+            probe = [int(total), int(len(rlen)), int(seq_dev[:total:max(1, total // 65536)].to(torch.int64).sum())]
+            assert len({tuple(r) for r in allgather_ints(probe, world, device=home if backend == "nccl" else None)}) == 1, "ranks generated different read sets"
+        rdb = ResidentDB.adopt_device(seq_dev, total, rid, rlen, roff, dev_index)
+        db = SeqDB(np.zeros(0, np.uint8), rid, rlen, roff, None)   # (sizes only: the bytes live in HBM)
     else:
-        db = mine
-        rdb = ResidentDB(db, dev_index)  # H2D once; the timed region starts with the seqdb resident in HBM
-    eng = GpuEngine(rdb, torch.device("cuda", dev_index))
+        # ---- synthetic input (untimed): rank r simulates genome r; the union is the job's read set -----------------
+        CH = world
+        my_chunks = [rank + 1]
+        cache = os.environ.get("PGX_BENCH_CACHE")   # a directory: the simulated set is kept there (the PMC passes of the repeat-rich workloads:
+        cpath = os.path.join(cache, f"{a.workload}_r{rank}") if cache else None   # rocprofv3 --pmc aborts inside torch's generator kernels)
+        if cpath and os.path.exists(cpath + ".seqdb.npy"):
+            sq, rl = np.load(cpath + ".seqdb.npy", mmap_mode="r"), np.load(cpath + ".rlen.npy")
+            roff0 = np.concatenate([[0], np.cumsum(rl.astype(np.uint64))[:-1]]).astype(np.uint64)
+            mine = SeqDB(np.ascontiguousarray(sq), np.arange(len(rl), dtype=np.uint32), rl, roff0, None)
+        elif a.workload in simreads.TORCH_WORKLOADS:
+            mine = simreads.make_workload_torch(a.workload, rank)
+            mine.names = None
+            if cpath:
+                os.makedirs(cache, exist_ok=True)
+                np.save(cpath + ".seqdb.npy", np.asarray(mine.seqdb)), np.save(cpath + ".rlen.npy", np.asarray(mine.rlen))
+        else:
+            cfg = dict(simreads.WORKLOADS[a.workload])
+            g = simreads.make_genome(cfg.pop("genome_len"), cfg.pop("genome_seed") + 7919 * rank)
+            mine = simreads.simulate_reads(g, seed=42 + rank, **cfg)
+        if multi:
+            # the job's read set = the union of the ranks' sets, replicated in every GPU's HBM: every rank's bytes are
+            # received over xGMI (RCCL) straight into their place in ONE device buffer, which the library adopts without a copy
+            seq_all, total, rlen = gather_seqdb(mine.seqdb, mine.rlen, world, home)
+            roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
+            rid = np.arange(len(rlen), dtype=np.uint32)
+            rdb = ResidentDB.adopt_device(seq_all, total, rid, rlen, roff, dev_index)
+            db = SeqDB(mine.seqdb if world == 1 else np.zeros(0, np.uint8), rid, rlen, roff, None)   # (sizes only when the bytes live in HBM)
+            del seq_all
+        else:
+            db = mine
+            rdb = ResidentDB(db, dev_index)  # H2D once; the timed region starts with the seqdb resident in HBM
+    eng = GpuEngine(rdb, home)
     ov_params = dict(mc_upper=sp["mc_upper"])
+    SUM_KEYS = ("n_records", "n_pair_records", "n_buckets", "n_align_needed", "n_align_gpu", "n_seen_skip", "n_evaluations", "gpu_ms", "host_ms", "device_visit")
+    keep_streams = {}
 
-    def step():
+    def index_my_chunks():
+        """the rank's index chunks; the lists / count tables as device byte tensors (copies: the library reuses its buffers)"""
+        tops, mcs, bases, ix = [], [], 0, None
+        for c in my_chunks:
+            ix, top, mc = eng.index(CH, c, sp["levels"])
+            bases += ix.bases
+            if len(my_chunks) > 1:
+                _lib.stream_signal()
+                top, mc = top.clone(), mc.clone()
+            tops.append(top)
+            mcs.append(mc)
+        ix.bases = bases
+        return ix, tops, mcs
+
+    def step_strong():
+        """CHUNKS index chunks + CHUNKS overlap chunks of ONE read set, dealt round-robin to the ranks"""
+        s0 = time.perf_counter()
+        ix, tops, mcs = index_my_chunks()
+        s1 = time.perf_counter()
+        if world > 1 and len(my_chunks) == 1:       # one chunk per rank: count all-gather + pair-record all-to-all(v) on device views
+            (ov, st), info = exchange_overlap(eng, rank, world, tops[0], mcs[0], **ov_params)
+            st["exchange"] = info
+            if a.check_ref:
+                keep_streams[my_chunks[0]] = ov
+            return ix, len(ov), st, s1 - s0
+        if world > 1:       # several chunks per rank: the lists of ALL chunks, in chunk order, all-gathered round by round (round j = chunks j N + 1 .. j N + N)
+            mm_all = torch.cat([allgather_cat(t, world)[0] for t in tops])
+            mc_all = torch.cat([allgather_cat(t, world)[0] for t in mcs])
+        else:
+            mm_all, mc_all = (torch.cat(tops), torch.cat(mcs)) if len(tops) > 1 else (tops[0], mcs[0])
+        del tops, mcs
+        _lib.stream_wait()
+        tot, nrec = None, 0
+        for c in my_chunks:
+            ov, st = rdb.overlap_dev(mm_all.data_ptr(), mm_all.numel() // 16, mc_all.data_ptr(), mc_all.numel() // 16, total_chunk=CH, mychunk=c, **ov_params)
+            nrec += len(ov)
+            if a.check_ref:
+                keep_streams[c] = ov
+            if tot is None:
+                tot = dict(st)
+            else:
+                for k in SUM_KEYS:
+                    tot[k] += st[k]
+                tot["rounds"] = max(tot["rounds"], st["rounds"])
+                tot["device_replay"] = min(tot["device_replay"], st["device_replay"])
+            del ov
+        tot["chunks"] = len(my_chunks)
+        return ix, nrec, tot, s1 - s0
+
+    def step_one_chunk():
         """one pass of the hot path: index chunk rank+1 of world, the exchange, overlap chunk rank+1 of world.
         Returns (IndexOut, ovlp records, stats, seconds of the index stage)."""
         s0 = time.perf_counter()
         if not multi and not a.two_stage:   # one chunk: the shimmer list and its counts stay in HBM between the stages
             ix, ov, st = rdb.index_overlap(levels=sp['levels'], mc_upper=sp['mc_upper'])
-            return ix, ov, st, ix.ms * 1e-3
+            keep_streams[1] = ov
+            return ix, len(ov), st, ix.ms * 1e-3
         if not multi:
             ix = rdb.index(levels=sp['levels'])
             s1 = time.perf_counter()
             ov, st = rdb.overlap(ix.top, ix.top_mc, mc_upper=sp['mc_upper'])
-            return ix, ov, st, s1 - s0
+            keep_streams[1] = ov
+            return ix, len(ov), st, s1 - s0
         ix, top, mc = eng.index(world, rank + 1, sp['levels'])
         s1 = time.perf_counter()
         (ov, st), info = exchange_overlap(eng, rank, world, top, mc, **ov_params)   # counts all-gather + record all-to-all(v), on device
         st["exchange"] = info
-        return ix, ov, st, s1 - s0
+        keep_streams[rank + 1] = ov
+        return ix, len(ov), st, s1 - s0
+
+    step = step_strong if strong else step_one_chunk
 
     def fence():
         if multi:
@@ -347,24 +638,28 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         s0 = time.perf_counter()
-        ix, ov, st, ti = step()
+        ix, nrec, st, ti = step()
         t_index += ti
         t_ovlp += time.perf_counter() - s0 - ti
     fence()
     elapsed = time.perf_counter() - t0
 
-    tot = torch.tensor([elapsed, float(len(ov)), float(ix.bases), t_index, t_ovlp], dtype=torch.float64, device=xdev)
+    tot = torch.tensor([elapsed, float(nrec), float(ix.bases), t_index, t_ovlp], dtype=torch.float64, device=xdev)
     if multi:
         mx = tot.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = tot.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
         elapsed, t_index, t_ovlp = float(mx[0]), float(mx[3]), float(mx[4])
         records, bases = float(sm[1]), float(sm[2])
     else:
-        records, bases = float(len(ov)), float(ix.bases)
+        records, bases = float(nrec), float(ix.bases)
+
+    ref_check = None
+    if a.check_ref and strong:
+        ref_check = check_vs_reference(seq_dev, total, db, rank, world, CH, my_chunks, keep_streams, sp["levels"], sp["mc_upper"], multi, xdev)
 
     if rank == 0:
         kern = {}
-        for name in ("sketch", "sketch_literal", "sketch_gather", "reduce", "count", "pairs", "visit", "align", "align1"):
+        for name in ("sketch", "sketch_literal", "sketch_gather", "reduce", "count", "pairs", "visit", "pack", "align", "align1"):
             ms, launches, units = _lib.timing(name)
             if launches:
                 kern[name] = {"ms_total": ms, "launches": launches, "units": units, "avg_ms": ms / launches, "steps": a.steps}
@@ -387,26 +682,25 @@ def main():
                 kern["replay"] = {"ms_total": ms, "launches": launches, "units": int(st_x["n_evaluations"]), "avg_ms": ms / launches,
                                   "steps": 1, "by_kernel": rk, "max_kernel_ms": max(v["ms_total"] for v in rk.values()),
                                   "note": "one extra untimed step with PGX_REPLAY_TIMING=1; launches = evaluate/update rounds"}
-        roof = None
         cands = {}
         if "sketch" in kern:
             k = kern["sketch"]
             gbs = SKETCH_BYTES_PER_BASE * k["units"] / (k["ms_total"] * 1e-3) / 1e9
-            cands["sketch"] = {"kernel": "k_sketch_blk (+ k_sketch_wave for the reads it flags)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            cands["sketch"] = {"kernel": "k_sketch_blk (+ k_sketch_wave for the reads it flags)", "bound": "valu_issue", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
                                "bytes_per_unit": SKETCH_BYTES_PER_BASE, "unit_name": "base",
                                "gbases_per_s": k["units"] / (k["ms_total"] * 1e-3) / 1e9}
         if "align" in kern:
             k = kern["align"]
             gbs = ALIGN_BYTES_PER_PAIR * k["units"] / (k["ms_total"] * 1e-3) / 1e9
-            cands["align"] = {"kernel": "k_align_ph<8, u16, packed> (per-group phase machine over the 2-bit packs; + k_pack2 once per stage, k_align1_list for the candidates it hands on)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            cands["align"] = {"kernel": "k_align_ph<8, u16, packed> (per-group phase machine over the 2-bit packs; + k_pack2 once per stage, k_align1_list for the candidates it hands on)", "bound": "valu_issue", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
                               "bytes_per_unit": ALIGN_BYTES_PER_PAIR, "unit_name": "alignment",
                               "alignments_per_s": k["units"] / (k["ms_total"] * 1e-3)}
         if "align1" in kern:   # the one-candidate-per-wavefront form used for launches of at most 13 k alignments (tail rounds)
             k = kern["align1"]
             gbs = ALIGN_BYTES_PER_PAIR * k["units"] / (k["ms_total"] * 1e-3) / 1e9
-            cands["align1"] = {"kernel": "k_align1", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            cands["align1"] = {"kernel": "k_align1", "bound": "latency", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
                                "bytes_per_unit": ALIGN_BYTES_PER_PAIR, "unit_name": "alignment",
                                "alignments_per_s": k["units"] / (k["ms_total"] * 1e-3)}
@@ -415,48 +709,50 @@ def main():
             walk = 13 * st["n_pair_records"] + 16 * (st["n_seen_skip"] + st["n_align_needed"]) + 48 * st["n_align_needed"] + 16 * st["n_records"]
             per_eval = walk / max(1, st["n_buckets"])   # algorithmic bytes of one bucket evaluation
             gbs = per_eval * k["units"] / (k["ms_total"] * 1e-3) / 1e9
-            cands["replay"] = {"kernel": "k_eval + k_eval_rows + k_update (device replay, three kernels)", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            cands["replay"] = {"kernel": "k_eval + k_eval_rows + k_eval_big + k_update (+ counts / k_file / k_settle / k_emit: the device replay as a stage)", "bound": "latency", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
                                "bytes_per_unit": per_eval, "unit_name": "bucket evaluation",
                                "evaluations_per_s": k["units"] / (k["ms_total"] * 1e-3)}
-        # HBM traffic from the PMC counters: collected in separate rocprofv3 passes of this same command ON THIS WORKLOAD
-        # (tools/pmc_traffic.sh <workload>) and committed under profiles/; bench.py itself cannot run under two profilers.
-        # A workload without its own collection reports traffic = null.
-        tfile = os.path.join("profiles", f"r03_traffic_{a.workload}.json")
-        try:
-            tr = json.load(open(os.path.join(ROOT, tfile)))
-            if "replay" in cands and "k_update" in tr:   # a round = one evaluation kernel (k_eval or k_eval_rows) + one k_update
-                tot = sum(tr[k]["hbm_bytes_per_launch"] * tr[k]["launches"] for k in ("k_eval", "k_eval_rows", "k_update") if k in tr)
-                tr["replay"] = {"hbm_bytes_per_launch": tot / tr["k_update"]["launches"]}
-            for nm, kks in (("sketch", ("k_sketch_blk", "k_sketch_wave")), ("align", ("k_align_ph", "k_align4")), ("align1", ("k_align1",)),
-                            ("replay", ("replay",))):
-                kk = next((k for k in kks if k in tr), None)
-                if nm in cands and kk:
-                    cands[nm]["traffic"] = tr[kk]["hbm_bytes_per_launch"]
-                    cands[nm]["traffic_read_side_raw"] = tr[kk].get("FETCH_SIZE_KB_per_launch", 0) * 1024 if "FETCH_SIZE_KB_per_launch" in tr[kk] else None
-                    cands[nm]["traffic_source"] = tfile + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, bytes per launch; read side x2 for the streaming kernels, x1 for the alignment kernels' scattered 8- / 16-byte loads: profiles/r03_fetch_calib.txt)"
-        except Exception:
-            pass
+        attach_counters(cands, kern, a.workload)
         for nm in cands:
             cands[nm]["algorithmic_bytes_per_launch"] = cands[nm]["bytes_per_unit"] * kern[nm]["units"] / kern[nm]["launches"]
+            cands[nm]["stage_ms_per_step"] = kern[nm]["ms_total"] / kern[nm]["steps"]
+        roof = None
         if cands:
-            # the kernel with the most device time per step (the device replay is three kernels: its heaviest one counts)
-            dom = max(cands, key=lambda n: kern[n].get("max_kernel_ms", kern[n]["ms_total"]) / kern[n]["steps"])
-            roof = cands[dom]
+            # the STAGE with the most device time per step (the device replay counts as a whole, not by its heaviest kernel)
+            stage_ms = {n: kern[n]["ms_total"] / kern[n]["steps"] for n in cands}
+            if "align" in stage_ms and "align1" in stage_ms:
+                stage_ms["align"] += stage_ms["align1"]
+            roof = cands[max(stage_ms, key=stage_ms.get)]
+        wl = WORKLOAD_TEXT.get(a.workload, a.workload)
+        if strong:
+            gm = a.genome_mb or simreads.WORKLOADS[a.workload]["genome_len"] / 1e6
+            if a.genome_mb:
+                wl = f"the c4 recipe on a {gm:g} Mb genome (repeat content scaled with the size) x 30x"
+            workload = (f"{a.workload}: {wl}, ONE read set held by every rank, 15 kb +-1.5 kb reads, 1 % errors, k=16 w=80 r=6 l={LEVELS}, "
+                        f"index_nchunk=ovlp_nchunk={CH} dealt round-robin to {world} GPU(s) ({len(my_chunks)} index + {len(my_chunks)} overlap chunks per GPU per step), "
+                        f"bestn 4, mc 2..{sp['mc_upper']}, aln_bw 100")
+            par = f"chunks{CH}/gpus{world}" + ("+alltoall(rccl)" if world > 1 and len(my_chunks) == 1 else "+allgather(rccl)" if world > 1 else "")
+        else:
+            workload = (f"{a.workload}: {wl} per rank, 15 kb +-1.5 kb reads, 1 % errors, "
+                        f"k=16 w=80 r=6 l={LEVELS}, index_nchunk=ovlp_nchunk={world}, bestn 4, mc 2..240, aln_bw 100")
+            par = f"chunks{world}" + ("+forced-exchange(rccl)" if multi and world == 1 else "")
         out = {
             "metric": "confirmed overlaps/sec (ovlp_t records, index+overlap stages, seqdb resident in HBM)",
             "value": records * a.steps / elapsed, "unit": "overlaps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "u8/u32 integer", "data": "synthetic",
-            "config": {"workload": f"{a.workload}: {WORKLOAD_TEXT.get(a.workload, a.workload)} per rank, 15 kb +-1.5 kb reads, 1 % errors, "
-                                   f"k=16 w=80 r=6 l={LEVELS}, index_nchunk=ovlp_nchunk={world}, bestn 4, mc 2..240, aln_bw 100",
-                       "reads": int(db.n_reads), "bases": int(db.n_bases), "parallelism": f"chunks{world}" + ("+forced-exchange(rccl)" if multi and world == 1 else "")},
+            "config": {"workload": workload, "reads": int(db.n_reads), "bases": int(db.n_bases), "parallelism": par},
             "bases_per_sec_indexed": bases * a.steps / t_index if t_index else None,
             "overlap_records_per_sec": records * a.steps / t_ovlp if t_ovlp else None,
             "records_per_step": records, "index_ms_per_step": t_index / a.steps * 1e3, "overlap_ms_per_step": t_ovlp / a.steps * 1e3,
             "overlap_stats_rank0": st, "reads_literal_rank0": ix.reads_literal,
             "kernels": kern, "roofline": roof, "roofline_all": cands,
         }
+        if strong:
+            out["hbm_bytes_in_use"] = int(torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0])
+        if ref_check is not None:
+            out["check_vs_reference"] = ref_check
         # device time per step by the library's own timers (HIP events; the replay's from the extra step) against the wall clock
         ksum = sum(v["ms_total"] / v["steps"] for v in kern.values())
         out["kernel_sum_ms_per_step"] = ksum
@@ -465,18 +761,25 @@ def main():
                                   "k_file / k_settle / counts, k_emit + the records' copy to the host); not in it: the join tables' small "
                                   "copies, RCCL; tools/timeline.py on a rocprofv3 kernel trace gives the busy / idle split kernel by kernel")
         if world == 1 and not a.no_cpu_baseline:
-            if a.cpu_baseline == "sample":
+            if strong:
+                def gpu_index_files(prefix):     # the job's index chunk files, as bin/shmr_index writes them
+                    for c in range(1, CH + 1):
+                        p = rdb.index(total_chunk=CH, mychunk=c, levels=sp["levels"])
+                        formats.write_mmlist("%s-L%d-%02d-of-%02d.dat" % (prefix, sp["levels"], c, CH), p.top)
+                        formats.write_mm_count("%s-L%d-MC-%02d-of-%02d.dat" % (prefix, sp["levels"], c, CH), p.top_mc)
+                out["cpu_baseline"] = cpu_baseline_chunked(seq_dev, total, db, rdb, eng, a.workload, a.cpu_baseline or "sample", sp["levels"], sp["mc_upper"], CH, gpu_index_files)
+            elif a.cpu_baseline == "sample":
                 sample = simreads.simulate_reads_torch(10_000_000, 1003, 30.0, seed=42)
                 out["cpu_baseline"] = cpu_baseline_sample(sample)
             else:
-                out["cpu_baseline"] = cpu_baseline(db, ov, a.workload, sp["levels"], sp["mc_upper"])
-                cb = out["cpu_baseline"]
-                if cb.get("value"):
-                    out["gpu_over_cpu"] = {"vs_n_cores_raw_records": out["value"] / cb["value"],
-                                           "vs_n_cores_unique_pairs": out["value"] / cb["unique_pairs_per_s"],
-                                           "vs_one_core": out["value"] / cb["one_core"]["value"], "cpu_cores": cb["cores"],
-                                           "note": "GPU value = records of ONE overlap chunk (every read pair once); the N-chunk CPU run "
-                                                   "reports most pairs once per chunk, so both of its rates are given"}
+                out["cpu_baseline"] = cpu_baseline(db, keep_streams[1], a.workload, sp["levels"], sp["mc_upper"])
+            cb = out["cpu_baseline"]
+            if cb.get("value"):
+                out["gpu_over_cpu"] = {"vs_n_cores_raw_records": out["value"] / cb["value"],
+                                       "vs_n_cores_unique_pairs": out["value"] / cb["unique_pairs_per_s"] if cb.get("unique_pairs_per_s") else None,
+                                       "vs_one_core": out["value"] / cb["one_core"]["value"] if cb.get("one_core") else None, "cpu_cores": cb["cores"],
+                                       "note": "the N-chunk CPU run reports most pairs once per chunk, so both of its rates are given; one-chunk "
+                                               "workloads: GPU value = records of ONE overlap chunk (every read pair once)"}
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()

@@ -61,7 +61,7 @@ void run_index(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out, 
   if (!p->want_l0) {
     const pgx_mm128 *d_top = nullptr;
     size_t ntop = 0;
-    if (dev_index_fused(db, reads, p->window, p->kmer, p->reduction, p->levels, &d_top, &ntop, plan.serial)) {
+    if (dev_index_fused(db, reads, p->window, p->kmer, p->reduction, p->levels, &d_top, &ntop, plan.serial, &out->reads_literal)) {
       PGX_REQUIRE(ntop < (1ULL << 31), PGX_EARG, "chunk too large (use more index chunks)");
       DevBuf<pgx_mm_count> mc;
       size_t nmc = 0;

@@ -182,10 +182,10 @@ namespace pgx {
 void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, DevBuf<pgx_mm128> &out,
                 size_t &n_out, uint32_t *n_literal);
 // fused index path: sketch (wave kernel) -> per-read reduce x levels in LDS -> ordered gather.  Returns false (and
-// leaves the outputs untouched) when a read needs the general path (other w/k, ambiguous bases, > 1024 minimizers ...).
+// leaves the outputs untouched) when the chunk needs the general path (other w/k ...).
 // plan_serial != 0: identifies `reads` (same serial => same list as the last call: descriptors and slab offsets are still on the device)
 bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, int rs, int levels,
-                     const pgx_mm128 **d_top, size_t *n_top, uint64_t plan_serial = 0);
+                     const pgx_mm128 **d_top, size_t *n_top, uint64_t plan_serial = 0, uint32_t *n_second = nullptr);   // n_second: reads sketched run by run (ambiguous bases)
 // one mm_reduce level over a device list
 void dev_reduce(const pgx_mm128 *d_in, size_t n, int rs, DevBuf<pgx_mm128> &out, size_t &n_out);
 // multiplicity of x>>8, sorted by mer

@@ -1,8 +1,8 @@
 // pgx_kernels.hip -- gfx950 device code of libpgx.so (index stage + banded O(ND) confirmation).
 //
 // Kernels (each cites the reference routine whose results it must reproduce bit-for-bit):
-//   k_sketch_literal : mm_sketch      src/mm_sketch.c:70-151   the literal state machine, one lane per read
-//                                     (reads with ambiguous bases, slab overflow)
+//   (reads with ambiguous bases -- and whatever else a closed-form kernel flags -- are cut into runs of unambiguous bases that
+//    the same closed-form kernels sketch; pgx_sketch_n.hip)
 //   k_sketch_general : mm_sketch      closed form for any (w, k), one wavefront per read, entries in global scratch
 //   k_sketch_wave    : mm_sketch      closed form, one wavefront per read            (pgx_sketch_fast.hip)
 //   k_reduce_*       : mm_reduce      src/shmr_reduce.c:53-90
@@ -38,97 +38,6 @@ __device__ __forceinline__ int code_of_nibble(uint32_t b) {
   // seqdb low nibble is one-hot A=1 C=2 G=4 T=8 (src/shmr_utils.c:18-30); anything else decodes to 'N'
   b &= 0xF;
   return (b == 1) ? 0 : (b == 2) ? 1 : (b == 4) ? 2 : (b == 8) ? 3 : 4;
-}
-
-// =========================================================================================================
-// k_sketch_literal: the reference's streaming state machine, one lane per read.  Used for every read the
-// closed-form wave kernel does not cover.  MODE 0 counts, MODE 1 writes at out_off[slot].
-// ring_ws: per-thread ring of w entries, interleaved (slot j of thread t at j*nthreads + t).
-// =========================================================================================================
-template <int MODE>
-__global__ void k_sketch_literal(const uint8_t *__restrict__ seq, const ReadDesc *__restrict__ reads,
-                                 const uint32_t *__restrict__ list, uint32_t n_list, int w, int k,
-                                 pgx_mm128 *__restrict__ ring_ws, uint32_t *__restrict__ counts,
-                                 const uint64_t *__restrict__ out_off, pgx_mm128 *__restrict__ out) {
-  const uint32_t nthreads = gridDim.x * blockDim.x;
-  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t mask = (1ULL << (2 * k)) - 1, top = 2ULL * (uint64_t)(k - 1);
-  const uint64_t MAXV = ~0ULL;
-  for (uint32_t it = tid; it < n_list; it += nthreads) {
-    const uint32_t slot = list[it];
-    const ReadDesc rd = reads[slot];
-    const uint8_t *s = seq + rd.off;
-    pgx_mm128 *ring = ring_ws + tid;
-    for (int j = 0; j < w; ++j) ring[(size_t)j * nthreads] = pgx_mm128{MAXV, MAXV};
-    uint64_t fwd = 0, rev = 0;
-    pgx_mm128 cur{MAXV, MAXV};
-    int run = 0, ring_pos = 0, cur_pos = 0;
-    uint32_t cnt = 0;
-    pgx_mm128 *dst = MODE ? out + out_off[slot] : nullptr;
-#define PGX_EMIT(e)                  \
-  do {                               \
-    if (MODE) dst[cnt] = (e);        \
-    ++cnt;                           \
-  } while (0)
-    for (int i = 0; i < (int)rd.len; ++i) {
-      const int c = code_of_nibble(s[i]);
-      pgx_mm128 e{MAXV, MAXV};
-      if (c < 4) {
-        const int span = run + 1 < k ? run + 1 : k;
-        fwd = (fwd << 2 | (uint64_t)c) & mask;
-        rev = (rev >> 2) | (3ULL ^ (uint64_t)c) << top;
-        if (fwd == rev) continue;  // strand-ambiguous k-mer consumes no window slot (mm_sketch.c:104-105)
-        const int z = fwd < rev ? 0 : 1;
-        ++run;
-        if (run >= k) {
-          e.x = mix64(z ? rev : fwd, mask) << 8 | (uint64_t)span;
-          e.y = (uint64_t)rd.rid << 32 | (uint64_t)(uint32_t)i << 1 | (uint64_t)z;
-        }
-      } else {
-        run = 0;  // mm_sketch.c:112-113: the window state is NOT flushed
-      }
-      ring[(size_t)ring_pos * nthreads] = e;
-      if (run == w + k - 1 && cur.x != MAXV) {  // first full window: ties of the pre-update minimum
-        for (int j = ring_pos + 1; j < w; ++j) {
-          pgx_mm128 r = ring[(size_t)j * nthreads];
-          if (r.x == cur.x && r.y != cur.y) PGX_EMIT(r);
-        }
-        for (int j = 0; j < ring_pos; ++j) {
-          pgx_mm128 r = ring[(size_t)j * nthreads];
-          if (r.x == cur.x && r.y != cur.y) PGX_EMIT(r);
-        }
-      }
-      if (e.x <= cur.x) {
-        if (run >= w + k && cur.x != MAXV) PGX_EMIT(cur);
-        cur = e, cur_pos = ring_pos;
-      } else if (ring_pos == cur_pos) {
-        if (run >= w + k - 1 && cur.x != MAXV) PGX_EMIT(cur);
-        cur.x = MAXV;
-        for (int j = ring_pos + 1; j < w; ++j) {
-          pgx_mm128 r = ring[(size_t)j * nthreads];
-          if (cur.x >= r.x) cur = r, cur_pos = j;
-        }
-        for (int j = 0; j <= ring_pos; ++j) {
-          pgx_mm128 r = ring[(size_t)j * nthreads];
-          if (cur.x >= r.x) cur = r, cur_pos = j;
-        }
-        if (run >= w + k - 1 && cur.x != MAXV) {
-          for (int j = ring_pos + 1; j < w; ++j) {
-            pgx_mm128 r = ring[(size_t)j * nthreads];
-            if (cur.x == r.x && cur.y != r.y) PGX_EMIT(r);
-          }
-          for (int j = 0; j <= ring_pos; ++j) {
-            pgx_mm128 r = ring[(size_t)j * nthreads];
-            if (cur.x == r.x && cur.y != r.y) PGX_EMIT(r);
-          }
-        }
-      }
-      if (++ring_pos == w) ring_pos = 0;
-    }
-    if (cur.x != MAXV) PGX_EMIT(cur);
-#undef PGX_EMIT
-    if (!MODE) counts[slot] = cnt;
-  }
 }
 
 // =========================================================================================================
@@ -263,9 +172,7 @@ void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_cou
 }
 
 // =========================================================================================================
-// sketch driver.  Reads the closed-form wave kernel covers (w=80, k=16, no ambiguous base, slab not overflowed)
-// go through k_sketch_wave (single pass into per-read slabs, then an ordered gather); every other read goes through
-// the literal state machine (count pass, write pass).  Output: one contiguous list in `reads` order.
+// sketch driver
 // =========================================================================================================
 bool sketch_wave_eligible(const ReadDesc &rd, int w, int k);  // pgx_sketch_fast.hip
 void launch_sketch_wave(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n_list, int w,
@@ -344,7 +251,7 @@ __device__ __forceinline__ void block_running_extremum(const uint64_t *__restric
 //      fewer than w entries emits only its rightmost smallest entry.
 // O(k) work per base for the k-mers, O(1) per entry for the windows.
 // Reads with an ambiguous base (the state machine restarts there) or more minimizers than their slab holds are
-// flagged and redone by k_sketch_literal.
+// flagged; the caller cuts them into runs of unambiguous bases / gives them larger slabs (pgx_sketch_n.hip).
 // =========================================================================================================
 __global__ __launch_bounds__(64) void k_sketch_general(const uint8_t *__restrict__ seq, const ReadDesc *__restrict__ reads,
                                                        const uint32_t *__restrict__ list, uint32_t n_list, int w, int k,
@@ -356,7 +263,7 @@ __global__ __launch_bounds__(64) void k_sketch_general(const uint8_t *__restrict
   const int lane = threadIdx.x;
   const uint64_t mask = (1ULL << (2 * k)) - 1, top = 2ULL * (uint64_t)(k - 1);
   for (uint32_t it = blockIdx.x; it < n_list; it += gridDim.x) {
-    const uint32_t slot = list[it];
+    const uint32_t slot = list ? list[it] : it;
     const ReadDesc rd = reads[slot];
     const uint8_t *s = seq + rd.off;
     const int len = (int)rd.len;
@@ -491,6 +398,53 @@ __global__ __launch_bounds__(64) void k_sketch_general(const uint8_t *__restrict
   }
 }
 
+// k_sketch_general over the listed reads (d_list == nullptr: slots 0 .. lens.size()-1); lens[i] = length of the i-th listed read.
+// Entry scratch (hash, position|strand, window minimum, two running-extremum arrays: 36 B per base) in batches of at most
+// ~256 Mbases.
+void launch_sketch_general(const pgx_seqdb *db, const ReadDesc *d_reads, const std::vector<uint32_t> &lens, const uint32_t *d_list,
+                           int w, int k, pgx_mm128 *d_slab, const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags) {
+  hipStream_t st = ctx().stream;
+  const uint64_t batch_bases = 256ull << 20;
+  DevBuf<uint32_t> iota;
+  if (!d_list) {   // the kernel walks a list: the identity
+    std::vector<uint32_t> id(lens.size());
+    for (size_t i = 0; i < id.size(); ++i) id[i] = (uint32_t)i;
+    iota.alloc(id.size());
+    iota.upload(id.data(), id.size());
+    sync();
+    d_list = iota.p;
+  }
+  for (size_t b0 = 0; b0 < lens.size();) {
+    std::vector<uint64_t> so;
+    uint64_t acc = 0;
+    size_t b1 = b0;
+    while (b1 < lens.size() && (b1 == b0 || acc + lens[b1] <= batch_bases)) so.push_back(acc), acc += lens[b1], ++b1;
+    uint64_t *d_so = ws<uint64_t>("sk.gen_off", so.size());
+    uint64_t *H = ws<uint64_t>("sk.gen_h", acc), *WMv = ws<uint64_t>("sk.gen_wm", acc);
+    uint64_t *T1 = ws<uint64_t>("sk.gen_t1", acc), *T2 = ws<uint64_t>("sk.gen_t2", acc);
+    uint32_t *PY = ws<uint32_t>("sk.gen_py", acc);
+    PGX_HIP(hipMemcpyAsync(d_so, so.data(), so.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    const unsigned grid = (unsigned)std::min<size_t>(b1 - b0, (size_t)ctx().num_cu * 16);
+    hipLaunchKernelGGL(k_sketch_general, dim3(grid), dim3(64), 0, st, db->d_seq.p, d_reads, d_list + b0, (uint32_t)(b1 - b0), w, k,
+                       d_so, H, PY, WMv, T1, T2, d_slab, d_slab_off, d_counts, d_flags);
+    PGX_HIP(hipGetLastError());
+    sync();  // (so[] is reused by the next batch)
+    b0 = b1;
+  }
+}
+
+void dev_sketch_nreads(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t nn, int w, int k,
+                       DevBuf<pgx_mm128> &nl0, DevBuf<uint64_t> &nl0_off, uint64_t *n_total);   // pgx_sketch_n.hip
+void dev_reduce_nreads(const DevBuf<pgx_mm128> &nl0, const DevBuf<uint64_t> &nl0_off, uint32_t nn, uint64_t total, int rs, int levels,
+                       DevBuf<pgx_mm128> &top, DevBuf<uint32_t> &cnt);
+void dev_scatter_counts(uint32_t *d_counts_by_slot, const uint32_t *d_list, uint32_t nn, const uint64_t *d_off, const uint32_t *d_cnt);
+void dev_mark_slots(uint32_t *d_by_slot, const uint32_t *d_list, uint32_t nn, uint32_t v);
+
+// Level-0 minimizers of `reads`, one contiguous list in `reads` order.  Every read goes through the closed-form kernel of the
+// (w, k) -- k_sketch_wave for k = 16 and w in {64, 80, 96, 128}, k_sketch_general otherwise -- single pass into per-read slabs, then
+// an ordered gather; the reads it flags (an ambiguous base, a slab outgrown by low-complexity sequence) are cut into runs of
+// unambiguous bases that the same kernels sketch (pgx_sketch_n.hip: dev_sketch_nreads).  n_literal (name kept from the C-ABI's
+// reads_literal): how many reads took that second path.
 void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, DevBuf<pgx_mm128> &out,
                 size_t &n_out, uint32_t *n_literal) {
   n_out = 0;
@@ -505,76 +459,48 @@ void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, 
   PGX_HIP(hipMemsetAsync(counts.p, 0, n * sizeof(uint32_t), st));
   PGX_HIP(hipMemsetAsync(d_flag.p, 0, n * sizeof(uint32_t), st));
 
-  std::vector<uint32_t> fast, slow;
   std::vector<uint64_t> slab_off(n + 1, 0);
-  uint64_t fast_bases = 0, slow_bases = 0;
+  std::vector<uint32_t> lens(n);
+  uint64_t bases = 0;
   // (w, k) outside the specialised kernel's set: the general closed-form kernel takes the wave kernel's place
   const bool general = !(k == 16 && (w == 64 || w == 80 || w == 96 || w == 128));
   for (uint32_t i = 0; i < n; ++i) {
-    const bool f = general ? reads[i].len < (1u << 30) : sketch_wave_eligible(reads[i], w, k);
-    // slab capacity: 5x the expected density 2/(w+1); overflow (low-complexity reads) falls back to the literal kernel
-    slab_off[i + 1] = slab_off[i] + (f ? (uint64_t)reads[i].len / 8 + 64 : 0);
-    if (f) fast.push_back(i), fast_bases += reads[i].len;
-    else slow.push_back(i), slow_bases += reads[i].len;
+    PGX_REQUIRE(reads[i].len < (1u << 30), PGX_EARG, "read %u is longer than 2^30 bases", reads[i].rid);
+    // slab capacity: 5x the expected density 2/(w+1); a read that outgrows it (low complexity) takes the second path
+    slab_off[i + 1] = slab_off[i] + (uint64_t)reads[i].len / 8 + 64;
+    lens[i] = reads[i].len, bases += reads[i].len;
   }
-  DevBuf<uint32_t> d_fast(fast.size());
   DevBuf<uint64_t> d_slab_off(n + 1);
-  DevBuf<pgx_mm128> slab;
-  if (!fast.empty()) {
-    d_fast.upload(fast.data(), fast.size());
-    d_slab_off.upload(slab_off.data(), n + 1);
-    slab.alloc(slab_off[n]);
-    if (!general) {
-      KernelTimer tm("sketch", fast_bases);
-      launch_sketch_wave(db, d_reads.p, d_fast.p, (uint32_t)fast.size(), w, k, slab.p, d_slab_off.p, counts.p, d_flag.p);
-    } else {
-      // entry scratch (hash, position|strand, window minimum, two running-extremum arrays: 36 B per base), in batches of
-      // at most ~256 Mbases
-      KernelTimer tm("sketch_general", fast_bases);
-      const uint64_t batch_bases = 256ull << 20;
-      for (size_t b0 = 0; b0 < fast.size();) {
-        std::vector<uint64_t> so;
-        uint64_t acc = 0;
-        size_t b1 = b0;
-        while (b1 < fast.size() && (b1 == b0 || acc + reads[fast[b1]].len <= batch_bases)) so.push_back(acc), acc += reads[fast[b1]].len, ++b1;
-        uint64_t *d_so = ws<uint64_t>("sk.gen_off", so.size());
-        uint64_t *H = ws<uint64_t>("sk.gen_h", acc), *WMv = ws<uint64_t>("sk.gen_wm", acc);
-        uint64_t *T1 = ws<uint64_t>("sk.gen_t1", acc), *T2 = ws<uint64_t>("sk.gen_t2", acc);
-        uint32_t *PY = ws<uint32_t>("sk.gen_py", acc);
-        PGX_HIP(hipMemcpyAsync(d_so, so.data(), so.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        const unsigned grid = (unsigned)std::min<size_t>(b1 - b0, (size_t)ctx().num_cu * 16);
-        hipLaunchKernelGGL(k_sketch_general, dim3(grid), dim3(64), 0, st, db->d_seq.p, d_reads.p, d_fast.p + b0, (uint32_t)(b1 - b0), w, k,
-                           d_so, H, PY, WMv, T1, T2, slab.p, d_slab_off.p, counts.p, d_flag.p);
-        PGX_HIP(hipGetLastError());
-        sync();  // (so[] is reused by the next batch)
-        b0 = b1;
-      }
-    }
-    std::vector<uint32_t> flag(n);
-    d_flag.download(flag.data(), n);
-    sync();
-    std::vector<uint32_t> keep;
-    for (uint32_t i : fast)
-      if (flag[i]) slow.push_back(i), slow_bases += reads[i].len;
-      else keep.push_back(i);
-    if (keep.size() != fast.size()) {
-      fast.swap(keep);
-      std::sort(slow.begin(), slow.end());
-      if (!fast.empty()) d_fast.upload(fast.data(), fast.size());
-    }
+  d_slab_off.upload(slab_off.data(), n + 1);
+  DevBuf<pgx_mm128> slab(slab_off[n]);
+  if (!general) {
+    KernelTimer tm("sketch", bases);
+    launch_sketch_wave(db, d_reads.p, nullptr, n, w, k, slab.p, d_slab_off.p, counts.p, d_flag.p);
+  } else {
+    KernelTimer tm("sketch_general", bases);
+    launch_sketch_general(db, d_reads.p, lens, nullptr, w, k, slab.p, d_slab_off.p, counts.p, d_flag.p);
   }
-  // literal kernel: bounded grid, ring workspace in global memory
-  const uint32_t lit_threads = 256 * 64;
-  DevBuf<uint32_t> d_slow(slow.size());
-  DevBuf<pgx_mm128> ring;
-  if (!slow.empty()) {
-    d_slow.upload(slow.data(), slow.size());
-    ring.alloc((size_t)lit_threads * (size_t)w);
-    KernelTimer tm("sketch_literal", slow_bases);
-    hipLaunchKernelGGL(k_sketch_literal<0>, dim3(lit_threads / 64), dim3(64), 0, st, db->d_seq.p, d_reads.p, d_slow.p,
-                       (uint32_t)slow.size(), w, k, ring.p, counts.p, (const uint64_t *)nullptr, (pgx_mm128 *)nullptr);
+  std::vector<uint32_t> flag(n);
+  d_flag.download(flag.data(), n);
+  sync();
+  std::vector<uint32_t> second;
+  for (uint32_t i = 0; i < n; ++i)
+    if (flag[i]) second.push_back(i);
+  // the flagged reads: segments of unambiguous bases through the same kernels, exact slabs on demand
+  DevBuf<uint32_t> d_second(second.size()), d_skip;
+  DevBuf<pgx_mm128> nl0;
+  DevBuf<uint64_t> nl0_off;
+  if (!second.empty()) {
+    KernelTimer tm("sketch_nreads", 0);
+    d_second.upload(second.data(), second.size());
+    uint64_t tot2 = 0;
+    dev_sketch_nreads(db, d_reads.p, d_second.p, (uint32_t)second.size(), w, k, nl0, nl0_off, &tot2);
+    dev_scatter_counts(counts.p, d_second.p, (uint32_t)second.size(), nl0_off.p, nullptr);
+    d_skip.alloc(n);
+    PGX_HIP(hipMemsetAsync(d_skip.p, 0, n * sizeof(uint32_t), st));
+    dev_mark_slots(d_skip.p, d_second.p, (uint32_t)second.size(), 1u);
   }
-  if (n_literal) *n_literal = (uint32_t)slow.size();
+  if (n_literal) *n_literal = (uint32_t)second.size();
   {
     CubTemp tmp;
     size_t bytes = 0;
@@ -588,15 +514,13 @@ void dev_sketch(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, 
   }
   out.alloc(n_out);
   if (n_out == 0) return;
-  if (!fast.empty()) {
-    KernelTimer tm("sketch_gather", fast_bases);
-    hipLaunchKernelGGL(k_gather_slabs, dim3((unsigned)fast.size()), dim3(64), 0, st, slab.p, d_slab_off.p, d_fast.p,
-                       (uint32_t)fast.size(), counts.p, offs.p, out.p);
-  }
-  if (!slow.empty()) {
-    KernelTimer tm("sketch_literal", slow_bases);
-    hipLaunchKernelGGL(k_sketch_literal<1>, dim3(lit_threads / 64), dim3(64), 0, st, db->d_seq.p, d_reads.p, d_slow.p,
-                       (uint32_t)slow.size(), w, k, ring.p, counts.p, offs.p, out.p);
+  {
+    KernelTimer tm("sketch_gather", bases);
+    hipLaunchKernelGGL(k_gather_slabs, dim3(n), dim3(64), 0, st, slab.p, d_slab_off.p, (const uint32_t *)nullptr, n, counts.p, offs.p, out.p,
+                       (const uint32_t *)d_skip.p, 0);
+    if (!second.empty())
+      hipLaunchKernelGGL(k_gather_slabs, dim3((unsigned)second.size()), dim3(64), 0, st, nl0.p, nl0_off.p, (const uint32_t *)d_second.p,
+                         (uint32_t)second.size(), counts.p, offs.p, out.p, (const uint32_t *)nullptr, 1);
   }
   sync();
 }
@@ -701,7 +625,8 @@ ShutdownHook g_plan_reset([] { g_plan = FusedPlan(); });
 }  // namespace
 
 bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, int rs, int levels,
-                     const pgx_mm128 **d_top, size_t *n_top, uint64_t plan_serial) {
+                     const pgx_mm128 **d_top, size_t *n_top, uint64_t plan_serial, uint32_t *n_second) {
+  if (n_second) *n_second = 0;
   const uint32_t n = (uint32_t)reads.size();
   if (n == 0 || levels < 1 || levels > 2 || rs < 1) return false;
   const bool trace = getenv("PGX_TRACE") != nullptr;
@@ -829,6 +754,46 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
     hipLaunchKernelGGL(k_reduce_read, dim3(n), dim3(64), 0, st, slab, d_slab_off, d_reads, d_cnt, d_flags, n, rs, levels,
                        d_ctop, d_nbad);
   }
+  // Reads still flagged here hold an ambiguous base (mm_sketch.c:112-113): they are cut into runs of unambiguous bases, every run
+  // sketched by the unfused closed-form kernel, the read's list assembled and reduced per read (pgx_sketch_n.hip)
+  DevBuf<pgx_mm128> n_l0, n_toplist;
+  DevBuf<uint64_t> n_off;
+  DevBuf<uint32_t> n_cnt;
+  uint32_t n3 = 0;
+  uint32_t *d_list3 = nullptr;
+  uint32_t *d_skip = d_in2, *d_skip3 = nullptr;
+  {
+    uint32_t nb = 0;
+    PGX_HIP(hipMemcpyAsync(&nb, d_nbad, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    sync();
+    if (nb && !want_wave) {
+      KernelTimer tm("sketch_nreads", 0);
+      d_list3 = ws<uint32_t>("ix.redo3", (size_t)n + 1);
+      size_t sb = 0;
+      hipcub::CountingInputIterator<uint32_t, ptrdiff_t> iota(0);
+      PGX_HIP(hipcub::DeviceSelect::Flagged(nullptr, sb, iota, d_flags, d_list3, d_list3 + n, (int)n, st));
+      void *stmp = ws_raw("ix.sel_tmp", sb);
+      PGX_HIP(hipcub::DeviceSelect::Flagged(stmp, sb, iota, d_flags, d_list3, d_list3 + n, (int)n, st));
+      PGX_HIP(hipMemcpyAsync(&n3, d_list3 + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+      sync();
+      uint64_t tot3 = 0;
+      dev_sketch_nreads(db, d_reads, d_list3, n3, w, k, n_l0, n_off, &tot3);
+      dev_reduce_nreads(n_l0, n_off, n3, tot3, rs, levels, n_toplist, n_cnt);
+      dev_scatter_counts(d_ctop, d_list3, n3, nullptr, n_cnt.p);
+      if (!d_skip) {
+        d_skip = ws<uint32_t>("ix.in2", n);
+        PGX_HIP(hipMemsetAsync(d_skip, 0, (size_t)n * sizeof(uint32_t), st));
+      }
+      dev_mark_slots(d_skip, d_list3, n3, 1u);
+      d_skip3 = ws<uint32_t>("ix.in3", n);   // (the exact-slab gather below must step over them too: a read can be in both lists)
+      PGX_HIP(hipMemsetAsync(d_skip3, 0, (size_t)n * sizeof(uint32_t), st));
+      dev_mark_slots(d_skip3, d_list3, n3, 1u);
+      dev_mark_slots(d_flags, d_list3, n3, 0u);
+      PGX_HIP(hipMemsetAsync(d_nbad, 0, sizeof(uint32_t), st));
+      if (n_second) *n_second = n3;
+      if (trace) fprintf(stderr, "[pgx] index: %u reads with ambiguous bases sketched run by run (%llu level-0 minimizers)\n", n3, (unsigned long long)tot3);
+    }
+  }
   size_t bytes = 0;
   PGX_HIP(hipMemsetAsync(d_offs, 0, sizeof(uint64_t), st));
   PGX_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, bytes, d_ctop, d_offs + 1, (int)n, st));
@@ -854,10 +819,14 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
   if (total) {
     KernelTimer tm("sketch_gather", bases);
     hipLaunchKernelGGL(k_gather_slabs, dim3(n), dim3(64), 0, st, slab, d_slab_off, (const uint32_t *)nullptr, n, d_ctop, d_offs,
-                       top, (const uint32_t *)d_in2, 0);
+                       top, (const uint32_t *)d_skip, 0);
     if (n_redo2)
       hipLaunchKernelGGL(k_gather_slabs, dim3(n_redo2), dim3(64), 0, st, slab2, d_off2_keep, (const uint32_t *)d_list2_keep, n_redo2, d_ctop,
-                         d_offs, top, (const uint32_t *)nullptr, 1);
+                         d_offs, top, (const uint32_t *)d_skip3, 1);
+    if (n3)
+      hipLaunchKernelGGL(k_gather_slabs, dim3(n3), dim3(64), 0, st, n_toplist.p, n_off.p, (const uint32_t *)d_list3, n3, d_ctop, d_offs, top,
+                         (const uint32_t *)nullptr, 1);
+    if (n3) sync();   // (n_toplist goes back to the block cache when this function returns)
   }
   *d_top = top;
   *n_top = (size_t)total;

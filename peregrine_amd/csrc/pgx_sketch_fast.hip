@@ -334,6 +334,8 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
   uint32_t nout = 0;
   uint32_t bad = 0;
   uint32_t Fkeep = 0, Rkeep = 0;  // this lane's packs of the previous tile (lane 63's become block -1)
+  uint32_t fw_mv = 0, fw_e79 = 0;  // first window (mm_sketch.c:116-128): minimum of entries 0 .. W-2, entry W-1,
+  int fw_m = -1;                   // and the minimum's rightmost occurrence -- taken when chunk 0 is decided
 
   // fused mode: push the staged L0 minimizers through level 0 (and level 1); final-level elements go to the slab
   auto fused_flush = [&]() {
@@ -481,25 +483,33 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
         }
         if (short_read) emask = 0;
       }
-      if (q0 == 0) {  // first-window correction / short-read rule; entries 0..79 are buffer chunks 0..4 (qbase == 0)
+      if (q0 == 0) {  // first-window correction / short-read rule; entries 0..79 are buffer chunks 0..4 (qbase == 0: nothing was decided yet)
         const int lim = short_read ? E : W - 1;  // candidates are entries [0, lim)
         const uint32_t a = lane < lim ? s.H[(lane >> 4) * CST + (lane & 15)] : INF;
         const uint32_t b = lane + 64 < lim ? s.H[(4 + (lane >> 4)) * CST + (lane & 15)] : INF;  // W <= 128 = 2 x 64 lanes
         const uint32_t mv = wave_min_u32(min(a, b));
         const uint64_t mb = __ballot(lane + 64 < lim && b == mv), ma = __ballot(lane < lim && a == mv);
         const int m = mb ? 64 + (63 - __builtin_clzll(mb)) : (ma ? 63 - __builtin_clzll(ma) : -1);
+        fw_mv = mv, fw_m = m;
         if (short_read) {
           if (m >= 0 && q == m / CH) emask = 1u << (m % CH);
-        } else if (q < A && q < dlimit) {
-          const uint32_t e79 = s.H[((W - 1) >> 4) * CST + ((W - 1) & 15)];
+        } else {
+          fw_e79 = s.H[((W - 1) >> 4) * CST + ((W - 1) & 15)];
+        }
+      }
+      // The correction applies to entries 0 .. W-2, i.e. chunks 0 .. A-1 -- in WHICHEVER pass decides them.  A read whose entries
+      // are sparse (long runs of strand-ambiguous k-mers: a (GC)n array at the read start, c4s read 279,270) gets fewer than 2 A
+      // chunks out of its first tile, chunk 0 is decided alone and chunks 1 .. A-1 in a later pass, after the compaction has dropped
+      // chunk 0: hence the minimum, its rightmost occurrence and entry W-1 are kept from the pass that decides chunk 0.  (Rounds 1-3
+      // applied the correction only in that pass and emitted the rightmost tie although entry W-1 equalled it: mm_sketch.c:126-128.)
+      if (!short_read && q < A && q < dlimit) {
 #pragma unroll
-          for (int o = 0; o < 16; ++o) {
-            const int pidx = q * CH + o;
-            if (pidx <= W - 2 && v[o] == mv) {
-              if (pidx != m) emask |= 1u << o;
-              else if (e79 > mv) emask |= 1u << o;
-              else emask &= ~(1u << o);
-            }
+        for (int o = 0; o < 16; ++o) {
+          const int pidx = q * CH + o;
+          if (pidx <= W - 2 && v[o] == fw_mv) {
+            if (pidx != fw_m) emask |= 1u << o;
+            else if (fw_e79 > fw_mv) emask |= 1u << o;
+            else emask &= ~(1u << o);
           }
         }
       }

@@ -199,6 +199,87 @@ def simulate_reads_torch(genome_len: int, genome_seed: int, coverage: float, see
     return SeqDB(seqdb, np.arange(len(rlen), dtype=np.uint32), rlen, roff, None)
 
 
+def simulate_reads_resident_torch(genome_len: int, genome_seed: int, coverage: float, seed: int = 42, device: str = "cuda",
+                                  mean_len: int = 15000, sd_len: int = 1500, err: float = 0.01, wrap: int = 40000,
+                                  batch_reads: int = 16384, min_len: int = 200, progress=None, **genome_kw):
+    """The recipe of simulate_reads_torch for sets that do not fit the host comfortably (BASELINE configs[3] at full size:
+    3.1 Gb x 30x = 93 Gbases): every batch is encoded on the GPU STRAIGHT INTO one device buffer, which the library then adopts
+    without a copy (ResidentDB.adopt_device).  Returns (uint8 device tensor of >= n_bases + 1024 elements, n_bases, rlen).
+    (Batches of 16,384 reads: its own seeded stream, not simulate_reads_torch's.)"""
+    import torch
+    dev = torch.device(device)
+    genome = make_genome_torch(genome_len, genome_seed, device, **genome_kw)
+    wrap = min(wrap, genome_len)
+    ext = torch.cat([genome, genome[:wrap]])
+    del genome
+    EL = ext.numel()
+    n_reads = int(coverage * EL / mean_len)
+    cap = int(n_reads * (mean_len + 60) * 1.002 + 8 * sd_len * n_reads ** 0.5) + 2048   # (+ 8 sigma of the length sum: small sets)
+    seq = torch.empty(cap, dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    comp = torch.tensor([3, 2, 1, 0], dtype=torch.uint8, device=dev)
+    lens, done, fill = [], 0, 0
+    while done < n_reads:
+        nb = min(batch_reads, n_reads - done)
+        tl = (mean_len + sd_len * torch.randn(nb, device=dev, generator=gen)).to(torch.int64).clamp_(min_len, EL)
+        st = (torch.rand(nb, device=dev, generator=gen, dtype=torch.float64) * (EL - tl + 1).to(torch.float64)).to(torch.int64)
+        rc = torch.randint(0, 2, (nb,), device=dev, generator=gen).bool()
+        tot = int(tl.sum())
+        seg0 = torch.cumsum(tl, 0) - tl
+        src = torch.repeat_interleave(st - seg0, tl) + torch.arange(tot, device=dev)
+        base = ext[src]
+        del src
+        hit = torch.rand(tot, device=dev, generator=gen) < err
+        kind = torch.randint(0, 9, (tot,), device=dev, generator=gen, dtype=torch.int8)
+        kind = torch.where(hit, kind, torch.full_like(kind, -1))
+        del hit
+        base = torch.where((kind >= 0) & (kind < 4), kind.to(torch.uint8), base)
+        emit = torch.ones(tot, dtype=torch.int64, device=dev)
+        emit[kind == 4] = 0
+        ins = kind >= 5
+        emit[ins] = 2
+        cs = torch.cumsum(emit, 0)
+        opos = cs - emit
+        olen = cs[seg0 + tl - 1] - opos[seg0]
+        ototal = int(cs[-1])
+        raw = torch.empty(ototal, dtype=torch.uint8, device=dev)
+        keep = emit > 0
+        raw[opos[keep]] = base[keep]
+        raw[opos[ins] + 1] = (kind[ins] - 5).to(torch.uint8)
+        del base, kind, emit, cs, opos, keep, ins
+        oseg0 = torch.cumsum(olen, 0) - olen
+        seg_start = torch.repeat_interleave(oseg0, olen)
+        seg_len = torch.repeat_interleave(olen, olen)
+        mirror = 2 * seg_start + seg_len - 1 - torch.arange(ototal, device=dev)
+        del seg_start, seg_len
+        codes = torch.where(torch.repeat_interleave(rc, olen), comp[raw[mirror].long()], raw)
+        del raw
+        one = torch.ones_like(codes)
+        assert fill + ototal + 1024 <= cap
+        seq[fill:fill + ototal] = torch.bitwise_left_shift(one, codes) | torch.bitwise_left_shift(torch.bitwise_right_shift(one * 8, codes[mirror]), 4)
+        del codes, one, mirror
+        lens.append(olen.to(torch.int32).cpu().numpy().astype(np.uint32))
+        fill += ototal
+        done += nb
+        if progress:
+            progress(done, n_reads)
+    del ext
+    seq[fill:fill + 1024] = 0
+    torch.cuda.empty_cache()
+    rlen = np.concatenate(lens)
+    return seq, int(fill), rlen
+
+
+def write_seqdb_from_device(prefix: str, seq, nbytes: int, rid, rlen, roff, piece: int = 1 << 30) -> None:
+    """the files the stage executables read (formats.write_seqdb), from a seqdb that lives in a device tensor"""
+    with open(prefix + ".seqdb", "wb") as f:
+        for o in range(0, nbytes, piece):
+            seq[o:min(nbytes, o + piece)].cpu().numpy().tofile(f)
+    with open(prefix + ".idx", "w") as f:
+        f.writelines("%09d r%09d %u %u\n" % (int(r), int(r), int(n), int(o)) for r, n, o in zip(rid, rlen, roff))
+
+
 def seqdb_to_fasta(db: SeqDB, path: str) -> None:
     """Write the forward strand of every read as FASTA (for feeding the real shmr_mkseqdb in oracle tests)."""
     lut = np.full(16, ord("N"), np.uint8)
@@ -221,13 +302,32 @@ WORKLOADS = {
     # runs, 30x.  c5s is the same read set indexed with -l 1 (dense L1 shimmers) under mc_upper 240.
     "c4s": dict(genome_len=300_000_000, genome_seed=1004, coverage=30.0, **_REPEATS),
     "c5s": dict(genome_len=300_000_000, genome_seed=1004, coverage=30.0, **_REPEATS),
+    # C4 (configs[3]) at FULL size: 3.1 Gb with the same repeat content per Mb (207 families x 300 copies of a 6 kb unit, 31 k tandem
+    # arrays, 31 k homopolymer runs) x 30x = 6.2 M reads, 93 Gbases -- generated into a device buffer (RESIDENT_WORKLOADS)
+    "c4": dict(genome_len=3_100_000_000, genome_seed=1004, coverage=30.0, repeat_families=207, repeat_len=6000, repeat_copies=300,
+               divergence=0.01, tandem=31000, homopolymers=31000),
     # the same recipes on a slice small enough for the CPU oracle (parity tests)
     "c4t": dict(genome_len=20_000_000, genome_seed=1004, coverage=30.0, repeat_families=4, repeat_len=6000, repeat_copies=300,
                 divergence=0.01, tandem=200, homopolymers=200),
 }
 # stage parameters that differ from the defaults (k=16 w=80 r=6 l=2, bestn 4, mc 2..240, aln_bw 100, ovlp_upper 120)
-STAGE_PARAMS = {"c5s": dict(levels=1, mc_upper=240), "c4s": dict(levels=2, mc_upper=240)}
+STAGE_PARAMS = {"c5s": dict(levels=1, mc_upper=240), "c4s": dict(levels=2, mc_upper=240), "c4": dict(levels=2, mc_upper=240, chunks=8)}
 TORCH_WORKLOADS = ("c3", "c4s", "c5s", "c4t")   # generated on the GPU (multi-Gbase sets in seconds instead of tens of minutes)
+
+
+RESIDENT_WORKLOADS = ("c4",)                    # generated straight into ONE device buffer the library adopts (no host copy)
+
+
+def make_workload_resident(name: str, device: str = "cuda", progress=None, genome_mb: float | None = None):
+    """genome_mb: the same recipe on a smaller genome, the repeat content scaled with the size (parity / multi-rank checks)"""
+    cfg = dict(WORKLOADS[name])
+    if genome_mb:
+        f = genome_mb * 1e6 / cfg["genome_len"]
+        cfg["genome_len"] = int(genome_mb * 1e6)
+        for k in ("repeat_families", "tandem", "homopolymers"):
+            cfg[k] = max(1, round(cfg[k] * f))
+    return simulate_reads_resident_torch(cfg.pop("genome_len"), cfg.pop("genome_seed"), cfg.pop("coverage"), seed=42, device=device,
+                                         progress=progress, **cfg)
 
 
 def make_workload(name: str) -> SeqDB:

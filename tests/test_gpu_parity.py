@@ -315,6 +315,147 @@ def test_adversarial_reads_all_paths():
     rdb.close()
 
 
+def _with_ambiguous(codes, positions, both=True):
+    e = _enc(codes).copy()
+    for p in positions:
+        e[p] &= 0xF0 if not both else 0x00       # ambiguous forward base (and, `both`, its mirror image on the reverse strand's nibble)
+        if both:
+            e[len(e) - 1 - p] &= 0x0F
+    return e
+
+
+@pytest.mark.parametrize("tiny_slabs", [False, True])
+def test_reads_with_ambiguous_bases_run_by_run(monkeypatch, tiny_slabs):
+    """mm_sketch resets only its run length at an ambiguous base (src/mm_sketch.c:112-113): reads with ambiguous bases are cut into
+    runs of unambiguous bases that the closed-form kernels sketch, minus each run's pending minimum, plus the element the end of the
+    sequence emits (pgx_sketch_n.hip).  Patterns: single / many / clustered ambiguous bases, at the read ends, after strand-ambiguous
+    and low-complexity stretches (stale k-mer state), runs shorter than a window / than a k-mer, a read of ambiguous bases only; every
+    list level, both index paths, other (w, k) through the general kernel."""
+    if tiny_slabs:
+        monkeypatch.setenv("PGX_SLAB_DIV", "1000000")
+        monkeypatch.setenv("PGX_SLAB_MIN", "8")
+    rng = np.random.default_rng(2024)
+    rnd = lambda n: rng.integers(0, 4, n).astype(np.uint8)
+    at = lambda n: np.resize(np.array([0, 3], np.uint8), n)
+    enc = [
+        _with_ambiguous(rnd(7000), [10, 3000, 6990]),
+        _with_ambiguous(rnd(15000), [0]), _with_ambiguous(rnd(15000), [14999]), _with_ambiguous(rnd(15000), [14999 - 40]),
+        _with_ambiguous(rnd(12000), list(range(5000, 5040))),                            # a run of 40 ambiguous bases
+        _with_ambiguous(rnd(9000), sorted(rng.choice(9000, 60, replace=False))),        # every ~150 bases: most runs hold one window or none
+        _with_ambiguous(rnd(9000), sorted(rng.choice(9000, 400, replace=False))),       # runs shorter than a window
+        _with_ambiguous(np.concatenate([rnd(3000), at(500), rnd(3000)]), [3499, 3500, 3520]),   # stale strand-ambiguous k-mers across the break
+        _with_ambiguous(np.concatenate([rnd(2000), np.zeros(700, np.uint8), rnd(2000)]), [2300, 2350, 2699]),   # inside a homopolymer
+        _with_ambiguous(np.resize(rnd(5), 8000), [4000]),                                # inside a tandem array: bursts of ties + a break
+        _with_ambiguous(rnd(40), [20]), _with_ambiguous(rnd(16), [15]), _with_ambiguous(rnd(17), [0]), _with_ambiguous(rnd(200), [100]),
+        _with_ambiguous(rnd(300), list(range(300))),                                     # nothing but ambiguous bases
+        _with_ambiguous(rnd(15000), [7000], both=False),                                 # ambiguous on the forward strand only
+        _with_ambiguous(rnd(6000), [5999 - 90, 5999 - 30]),                              # the end element reaches back across breaks
+        _with_ambiguous(rnd(6000), [5999 - 17]), _with_ambiguous(rnd(6000), [5999 - 16]), _with_ambiguous(rnd(6000), [5999 - 15]),
+    ]
+    n_amb = len(enc)
+    enc += [_enc(rnd(int(n))) for n in rng.integers(3000, 20000, 30)]
+    order = rng.permutation(len(enc))
+    enc = [enc[i] for i in order]
+    rlen = np.array([len(e) for e in enc], np.uint32)
+    roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
+    from peregrine_amd.formats import SeqDB
+    db = SeqDB(np.concatenate(enc), np.arange(len(enc), dtype=np.uint32), rlen, roff, None)
+    rdb = ResidentDB(db, 0)
+    l0 = np.concatenate([U.orc_sketch_seqdb(e, 80, 16, i) for i, e in enumerate(enc)])
+    l1 = U.orc_reduce(l0, 6)
+    l2 = U.orc_reduce(l1, 6)
+    a = rdb.index(want_l0=True)                                   # general path (dev_sketch + list reduce)
+    assert a.reads_literal >= n_amb - 1                           # (the forward-only one included; a read of 16 bases with base 15 ambiguous too)
+    assert np.array_equal(a.l0, l0) and np.array_equal(a.top, l2)
+    f2 = rdb.index()                                              # fused path: k_sketch_blk -> flagged -> run by run + per-read reduce
+    assert np.array_equal(f2.top, l2) and f2.reads_literal >= n_amb - 1
+    assert np.array_equal(rdb.index(levels=1).top, l1)
+    sel = [i for i in range(len(enc)) if i % 3 == 2]
+    assert np.array_equal(rdb.index(total_chunk=3, mychunk=2).top,
+                          U.orc_reduce(U.orc_reduce(np.concatenate([U.orc_sketch_seqdb(enc[i], 80, 16, i) for i in sel]), 6), 6))
+    for w, k in ((64, 16), (128, 16), (24, 12), (11, 13), (80, 15), (200, 28), (5, 4)):     # wave kernel at other windows; the general kernel
+        if k < 12 or w < 24 or w <= k:
+            got = rdb.sketch(np.arange(len(enc), dtype=np.uint32), w, k)                  # (shmr_index asserts w >= 24, k >= 12; mm_sketch itself does not)
+        else:
+            got = rdb.index(window=w, kmer=k, want_l0=True).l0
+        want = np.concatenate([U.orc_sketch_seqdb(e, w, k, i) for i, e in enumerate(enc)])
+        assert np.array_equal(got, want), (w, k)
+    rdb.close()
+
+
+def test_low_complexity_read_of_the_c4s_set():
+    """read 279,270 of the c4s set (tests/golden/c4s_read_279270.npy: an (AC)n array of ~360 bases, then ~100 bases, then (AC)n again):
+    found by tools/l2diff.py -- the one read of 600,080 whose final-level list differed from the reference's file in round 3's tree"""
+    import os
+    rb = np.load(os.path.join(os.path.dirname(__file__), "golden", "c4s_read_279270.npy"))
+    enc = [rb, rb[:9000], rb[9000:], rb[2:], rb]
+    rlen = np.array([len(e) for e in enc], np.uint32)
+    roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
+    from peregrine_amd.formats import SeqDB
+    db = SeqDB(np.concatenate(enc), np.arange(len(enc), dtype=np.uint32), rlen, roff, None)
+    rdb = ResidentDB(db, 0)
+    l0 = np.concatenate([U.orc_sketch_seqdb(e, 80, 16, i) for i, e in enumerate(enc)])
+    l1 = U.orc_reduce(l0, 6)
+    l2 = U.orc_reduce(l1, 6)
+    a = rdb.index(want_l0=True)
+    assert np.array_equal(a.l0, l0) and np.array_equal(a.top, l2)
+    assert np.array_equal(rdb.index(levels=1).top, l1)
+    assert np.array_equal(rdb.index().top, l2)
+    rdb.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_sparse_entry_reads_random(seed):
+    """Reads whose ENTRY stream is sparse: self-complementary tandem arrays ((GC)n, (AT)n, (ACGT)n, (GAATTC)n ...) yield no entries at all
+    (every k-mer is its own reverse complement), so a few point mutations inside one make the first window of 80 entries span a whole
+    tile or more, repeat the same mutated k-mers (ties with entry w-1), and put drops everywhere -- the geometry of c4s read 279,270.
+    Random mixes of such arrays, plain random sequence and other short-period arrays, at many lengths, against the oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    rnd = lambda n: rng.integers(0, 4, n).astype(np.uint8)
+    units = [np.array(u, np.uint8) for u in ([2, 1], [0, 3], [0, 1, 2, 3], [2, 0, 0, 3, 3, 1], [1, 2], [3, 0], [0, 0, 3, 3], [1, 1, 2, 2])]
+
+    def piece():
+        kind = rng.integers(0, 4)
+        n = int(rng.integers(20, 2500))
+        if kind == 0:
+            return rnd(n)
+        if kind == 3:
+            return np.resize(rnd(int(rng.integers(1, 9))), n)
+        a = np.resize(units[int(rng.integers(0, len(units)))], n).copy()
+        nm = int(rng.integers(0, 1 + n // 60))
+        for p in rng.integers(0, n, nm):
+            a[p] = (a[p] + rng.integers(1, 4)) % 4
+        if nm and rng.random() < 0.5:      # the same mutation again a period multiple later: equal mutated k-mers (ties)
+            p = int(rng.integers(0, n)); d = 2 * len(units[0]) * int(rng.integers(8, 200))
+            if p + d < n:
+                a[p + d] = a[p] = (a[p] + 1) % 4
+        return a
+
+    reads = [np.concatenate([piece() for _ in range(int(rng.integers(1, 7)))]) for _ in range(260)]
+    reads += [np.resize(units[i % len(units)], int(n)) for i, n in enumerate(rng.integers(16, 3000, 16))]   # pure arrays: no entry at all
+    enc = [_enc(r) for r in reads]
+    rlen = np.array([len(e) for e in enc], np.uint32)
+    roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
+    from peregrine_amd.formats import SeqDB
+    db = SeqDB(np.concatenate(enc), np.arange(len(enc), dtype=np.uint32), rlen, roff, None)
+    rdb = ResidentDB(db, 0)
+    per = [U.orc_sketch_seqdb(e, 80, 16, i) for i, e in enumerate(enc)]
+    l0 = np.concatenate(per)
+    l1 = U.orc_reduce(l0, 6)
+    l2 = U.orc_reduce(l1, 6)
+    a = rdb.index(want_l0=True)
+    if not np.array_equal(a.l0, l0):
+        got_rid = (a.l0["y"] >> np.uint64(32)).astype(np.int64)
+        for i, w in enumerate(per):
+            g = a.l0[got_rid == i]
+            assert np.array_equal(g, w), (i, len(enc[i]), len(g), len(w))
+    assert np.array_equal(a.top, l2)
+    assert np.array_equal(rdb.index().top, l2) and np.array_equal(rdb.index(levels=1).top, l1)
+    for w in (64, 96, 128):
+        assert np.array_equal(rdb.index(window=w, want_l0=True).l0, np.concatenate([U.orc_sketch_seqdb(e, w, 16, i) for i, e in enumerate(enc)])), w
+    rdb.close()
+
+
 @pytest.mark.parametrize("tiny_slabs", [False, True])
 def test_low_complexity_reads_stay_on_the_fused_index_path(monkeypatch, tiny_slabs):
     """homopolymers and short-period tandem arrays make every position a tied minimizer (bursts of up to 1,024 per tile, thousands
