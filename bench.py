@@ -44,6 +44,16 @@ WORKLOAD_TEXT = {
 }
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (stdout carries only the JSON line)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        sys.stderr.write("[bench +%.1f s] %s\n" % (time.perf_counter() - _T0, msg))
+        sys.stderr.flush()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -363,6 +373,7 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
         t0 = time.perf_counter()
         simreads.write_seqdb_from_device(pre, seq, total, db.rid, db.rlen, db.roff)
         t_files = time.perf_counter() - t0
+        log(f"cpu baseline ({mode}): seqdb files written in {t_files:.1f} s")
         lv = "L%d" % levels
         if mode == "full":      # the reference indexes everything itself
             t_index = _run_many(P, [lambda c=c: U.ref_run("shmr_index", "-p", pre, "-t", T, "-c", c, "-m", 0, "-l", levels, "-o", os.path.join(d, "ix")) for c in cs])
@@ -372,7 +383,9 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
             index_bases = int(db.rlen[np.isin(db.rid % T, [c % T for c in cs])].sum(dtype=np.uint64))
             gpu_index_files(os.path.join(d, "ix"))
             lpre, index_chunking = os.path.join(d, "ix-" + lv), job_chunks
+        log(f"cpu baseline: reference index leg {t_index:.1f} s")
         t_ovlp = _run_many(P, [lambda c=c: U.ref_run("shmr_overlap", "-p", pre, "-l", lpre, "-t", T, "-c", c, "-M", mc_upper, "-o", os.path.join(d, "ov.%03d" % c)) for c in cs])
+        log(f"cpu baseline: reference overlap leg {t_ovlp:.1f} s")
         # ---- the GPU on the same (T, c), same index chunking, for the first two chunks: field-for-field compare
         dev = torch.device("cuda", torch.cuda.current_device())
         tops, mcs = [], []
@@ -398,6 +411,7 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
             match = match and ok and len(ref) > 0
             del ov, ref
         del mm_all, mc_all
+        log(f"cpu baseline: GPU streams of {[c['chunk'] for c in compared]} compared: {[c['equal'] for c in compared]}")
         raw, keys = 0, []
         for c in cs:
             o = formats.read_ovlp(os.path.join(d, "ov.%03d" % c))
@@ -548,6 +562,7 @@ def main():
         else:
             db = mine
             rdb = ResidentDB(db, dev_index)  # H2D once; the timed region starts with the seqdb resident in HBM
+    log(f"input ready: {db.n_reads} reads, {db.n_bases} bases")
     eng = GpuEngine(rdb, home)
     ov_params = dict(mc_upper=sp["mc_upper"])
     SUM_KEYS = ("n_records", "n_pair_records", "n_buckets", "n_align_needed", "n_align_gpu", "n_seen_skip", "n_evaluations", "gpu_ms", "host_ms", "device_visit")
@@ -632,6 +647,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    log(f"{a.warmup} warm-up step(s) done")
     _lib.timing_reset()
     t_index = t_ovlp = 0.0
     fence()
@@ -643,6 +659,7 @@ def main():
         t_ovlp += time.perf_counter() - s0 - ti
     fence()
     elapsed = time.perf_counter() - t0
+    log(f"{a.steps} timed step(s): {elapsed:.2f} s")
 
     tot = torch.tensor([elapsed, float(nrec), float(ix.bases), t_index, t_ovlp], dtype=torch.float64, device=xdev)
     if multi:
@@ -663,7 +680,7 @@ def main():
             ms, launches, units = _lib.timing(name)
             if launches:
                 kern[name] = {"ms_total": ms, "launches": launches, "units": units, "avg_ms": ms / launches, "steps": a.steps}
-        if st.get("device_replay") and not multi:
+        if st.get("device_replay") and not multi and not os.environ.get("PGX_BENCH_NO_REPLAY_TIMING"):
             # the device replay's kernels (k_eval + k_update pairs) are timed in ONE EXTRA step, outside the timed region: a HIP
             # event pair around each of their ~40 launches per step would cost ~2 % of the step
             os.environ["PGX_REPLAY_TIMING"] = "1"
@@ -732,7 +749,8 @@ def main():
             workload = (f"{a.workload}: {wl}, ONE read set held by every rank, 15 kb +-1.5 kb reads, 1 % errors, k=16 w=80 r=6 l={LEVELS}, "
                         f"index_nchunk=ovlp_nchunk={CH} dealt round-robin to {world} GPU(s) ({len(my_chunks)} index + {len(my_chunks)} overlap chunks per GPU per step), "
                         f"bestn 4, mc 2..{sp['mc_upper']}, aln_bw 100")
-            par = f"chunks{CH}/gpus{world}" + ("+alltoall(rccl)" if world > 1 and len(my_chunks) == 1 else "+allgather(rccl)" if world > 1 else "")
+            comm = "rccl" if backend == "nccl" else backend
+            par = f"chunks{CH}/gpus{world}" + (f"+alltoall({comm})" if world > 1 and len(my_chunks) == 1 else f"+allgather({comm})" if world > 1 else "")
         else:
             workload = (f"{a.workload}: {wl} per rank, 15 kb +-1.5 kb reads, 1 % errors, "
                         f"k=16 w=80 r=6 l={LEVELS}, index_nchunk=ovlp_nchunk={world}, bestn 4, mc 2..240, aln_bw 100")

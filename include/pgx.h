@@ -225,10 +225,10 @@ int pgx_align_batch(pgx_seqdb *db, const pgx_align_key *keys, size_t n, int band
  * the n keys in ascending slot order.  Runs on the host (it is the routine the overlap stage uses for its outer table). */
 int pgx_khash_slot_order(const uint64_t *keys, size_t n, uint64_t *out);
 /* the same with a trailing put of a present key (touch != 0: it only runs the load check, src/khash.h:298-306, and may resize once
- * more) and, on_device != 0, computed on the GPU (pgx_khash_dev.hip: priority insertion between the resizes, a fixed point over
- * the eviction order inside one -- the form the overlap stage uses for large outer tables).  PGX_ESTATE when the device form gives
- * up (no convergence / a degenerate probe chain): the stage then uses the host form. */
-int pgx_khash_slot_order_ex(const uint64_t *keys, size_t n, int touch, int on_device, uint64_t *out);
+ * more).  (Round 3 also offered a device form of this routine -- priority insertion + a fixed point over the eviction order of a
+ * resize; exact, and 90x slower than one host thread on the reference's keys, whose constant span byte makes 1 / 256 of the slots
+ * the home of every key: removed in round 4) */
+int pgx_khash_slot_order_ex(const uint64_t *keys, size_t n, int touch, uint64_t *out);
 
 /* ---- shimmer4py surface (py/peregrine/build_shimmer4py.py:8-84), GPU-backed single-call forms ----
  * NOT exported: shmr_aln / free_shmr_alns (build_shimmer4py.py:64-77; src/shmr_align.c is the consensus stage's aligner, out of

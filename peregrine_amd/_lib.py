@@ -133,7 +133,7 @@ def load():
         lib.pgx_align_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         lib.pgx_timing_get.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pgx_khash_slot_order.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
-        lib.pgx_khash_slot_order_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        lib.pgx_khash_slot_order_ex.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         lib.pgx_map.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_uint32,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pgx_map_chunk.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

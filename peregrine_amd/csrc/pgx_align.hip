@@ -437,7 +437,7 @@ enum { PH_FETCH = 0, PH_STEP = 1, PH_ROUND = 2, PH_SNAKE = 3, PH_END = 4, PH_BAN
 #else
 #define PH_SYNC() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"), __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront")
 #endif
-// PACKED (round 3): the reads come from the 2-bit packs of the seqdb (pgx_align_lane.hip: k_pack2, one pass per overlap stage, both
+// PACKED (round 3): the reads come from the 2-bit packs of the seqdb (pgx_pack.hip: k_pack2, one pass per read database, both
 // strands) instead of its bytes: the probe compares 16 bases with two funnel shifts, an XOR and a find-first-bit (8 codes, two
 // 64-bit shifts, XOR, AND and a 64-bit count before), an extension step 32 bases per lane = 256 per group with four funnel shifts
 // (128 with four 64-bit shift / XOR / AND / count sequences before), and fewer steps need an extension at all (a probe of 16 ends
@@ -729,16 +729,20 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
   }
 }
 
-// The 2-bit packs ahead of the first large launch of an overlap stage: run_overlap calls this while the GPU would otherwise wait
-// for the host's outer table, so k_pack2 (1.6 ms at 4.5 Gbases) is off the critical path.  Same conditions as the launch below.
+// The 2-bit packs ahead of the first large launch: run_overlap calls this while the GPU would otherwise wait for the host's outer
+// table, so the first stage's k_pack2 (1.6 ms at 4.5 Gbases) is off the critical path; later stages find the packs in place
+// (pgx_pack.hip: they are kept with the database).
 void dev_align_prepare(const pgx_seqdb *db) {
-  const int mode = getenv("PGX_ALIGN_MODE") ? atoi(getenv("PGX_ALIGN_MODE")) : 8;
   const char *pm = getenv("PGX_ALIGN_PACKED_MIN");
-  const char *lane_env = getenv("PGX_ALIGN_LANE_MIN");
-  if (mode != 8 || db->max_rlen > 65535u || (pm && atol(pm) < 0) || (lane_env && atol(lane_env) >= 0)) return;
+  if (db->max_rlen > 65535u || (pm && atol(pm) < 0)) return;
   (void)seq_packs(db);
 }
 
+// Dispatch (each form bit-exact against the oracle: tests/test_gpu_parity.py::test_align_variants_vs_oracle):
+//   n <= small     : k_align1, a wavefront per candidate -- the replay's tail rounds, where latency is everything
+//   large launches : k_align_ph<8, u16, packed> over the 2-bit packs + k_align1_list for what it hands on (reads with bytes that have no
+//                    2-bit code, stragglers past the iteration budget); without packs (no HBM for them, PGX_ALIGN_PACKED_MIN < 0)
+//                    k_align_ph<8, u16> on the seqdb bytes; with a read beyond 65,535 bases (16-bit V ring too narrow) k_align4<8, int32>
 void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out, bool tail_batch) {
   if (n == 0) return;
   // (the knobs are read per call: the parity tests walk every kernel variant inside one process)
@@ -746,133 +750,50 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
   // (tools/alignlat.py: 13,000) -- but the mid-size launches of a stage are its TAIL sweeps (tail_batch: every request batch of the
   // device replay after the first), and in repeat-rich sets those are mostly long, wide-band alignments that the 8-lane groups of
   // k_align_ph first run to their iteration budget and then hand on: 60,000 for them = c4s 423 -> 417 ms per step, c5s 633 -> 628,
-  // c3 unchanged (its second batch holds 71 k).  PGX_ALIGN_SMALL / PGX_ALIGN_SMALL_TAIL override either.
-  const long small_first = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : 13000;
-  const long small_max = !tail_batch ? small_first : getenv("PGX_ALIGN_SMALL_TAIL") ? atol(getenv("PGX_ALIGN_SMALL_TAIL")) : getenv("PGX_ALIGN_SMALL") ? small_first : 60000;
+  // c3 unchanged (its second batch holds 71 k).  PGX_ALIGN_SMALL overrides both.
+  const long small_max = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : tail_batch ? 60000 : 13000;
   KernelTimer tm((long)n <= small_max ? "align1" : "align", n);
   int ring = 64;
   while (ring < 2 * band + 8) ring <<= 1;
-  uint32_t *counter = ws<uint32_t>("align.counter", 72);
-  if ((long)n > small_max) PGX_HIP(hipMemsetAsync(counter, 0, 72 * sizeof(uint32_t), ctx().stream));  // (k_align1 has no work counter; [1..64]: PGX_ALIGN_STATS builds)
-#ifdef PGX_ALIGN_STATS
-  struct StatsPrinter {
-    uint32_t *c;
-    size_t n;
-    ~StatsPrinter() {
-      uint32_t h[72];
-      if (hipMemcpyAsync(h, c, sizeof(h), hipMemcpyDeviceToHost, ctx().stream) != hipSuccess) return;
-      (void)hipStreamSynchronize(ctx().stream);
-      unsigned long long tot = 0;
-      for (int i = 0; i < 32; ++i) tot += h[33 + i];
-      fprintf(stderr, "[pgx] align stats: %zu candidates; wavefront iterations per candidate (log2 classes: count, share of all iterations):", n);
-#ifdef PGX_ALIGN_STATS_NK
-      for (int i = 0; i < 32; ++i)
-        if (h[1 + i]) fprintf(stderr, " 2^%d: %u", i, h[1 + i]);
-      fprintf(stderr, "\n[pgx] align stats: candidates by the most diagonals a step of theirs held (31 = 31 or more):");
-      for (int i = 0; i < 32; ++i)
-        if (h[33 + i]) fprintf(stderr, " %d: %u (%.2f %%)", i, h[33 + i], tot ? 100.0 * h[33 + i] / tot : 0.0);
-#else
-      for (int i = 0; i < 32; ++i)
-        if (h[1 + i]) fprintf(stderr, " 2^%d: %u (%.1f %%)", i, h[1 + i], tot ? 100.0 * h[33 + i] / tot : 0.0);
-#endif
-      fprintf(stderr, "\n");
-    }
-  } stats_printer{counter, n};
-#endif
-  const int gl = getenv("PGX_ALIGN_GL") ? atoi(getenv("PGX_ALIGN_GL")) : 8;  // measured: 8 lanes per candidate (avg 3.6 live diagonals, <= 8 in 98.7 % of the steps) 45.6 vs 42.1 M aln/s
-  // PGX_ALIGN_MODE: 8 (default) = the phase machine with 8-lane groups: at 4.5 Gbases 66.5 M alignments/s against 61.0 M of
-  // k_align4 (mode 0, round 1: groups in lock-step) -- the same 39 G VALU wavefront-instructions per 2.4 M alignments, 23 % fewer
-  // scalar ones, less waiting.  4 = sixteen 4-lane groups on a NARROW V ring (64 slots, 2 KiB of LDS per wavefront, full
-  // occupancy) followed by a launch of the 8-lane form with the full ring over the candidates whose band outgrew the narrow
-  // one (work list and count stay on the device; with nothing handed on it is an empty launch): measured and NOT chosen -- 17 %
-  // fewer VALU instructions, but 57-60 M alignments/s whatever the occupancy: its probe loads touch sixteen candidates' cache
-  // lines per instruction and the address pipeline, not VALU issue, becomes the limit.  (Round 3, the same 4-lane groups over the
-  // 2-bit packs with the full ring: 70.1 M against 79.5 M alignments/s of the 8-lane form -- still not chosen.)
-  const int mode = getenv("PGX_ALIGN_MODE") ? atoi(getenv("PGX_ALIGN_MODE")) : 8;
-  // lane-per-candidate form (round 3, pgx_align_lane.hip): bit-exact on every test set, 45 % fewer VALU wavefront-instructions than
-  // k_align_ph -- and measured SLOWER (4.68 M alignments: 93 ms + 6 ms for the 8.8 % it hands on, against 69 ms): its private LDS
-  // windows allow 3 wavefronts per SIMD, a wavefront issues one instruction per ~16 cycles of its dependent, branchy stream, and
-  // three of them cannot fill a SIMD (profiles/r03d_pmc_align_lane.txt).  Kept as an opt-in (PGX_ALIGN_LANE_MIN = smallest launch
-  // that takes it; unset / < 0: never) with its parity test; the candidates it hands on are redone by k_align_ph<8> from their list.
-  const char *lane_env = getenv("PGX_ALIGN_LANE_MIN");   // (read per call: the tools switch it between launches)
-  const long lane_min = lane_env ? atol(lane_env) : -1;
-  if ((long)n >= lane_min && lane_min >= 0 && mode == 8 && db->max_rlen <= 65535u) {
-    uint32_t *esc = dev_align_lane(db, d_keys, n, band, d_out);
-    if (getenv("PGX_TRACE")) {
-      uint32_t handed = 0;
-      PGX_HIP(hipMemcpyAsync(&handed, esc, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx().stream));
-      sync();
-      fprintf(stderr, "[pgx] align: lane kernel over %zu candidates handed %u on to k_align_ph\n", n, handed);
-    }
-    const size_t lds = (size_t)8 * ring * sizeof(uint16_t);
-    const unsigned per_cu = (unsigned)std::min<size_t>(32, (160u << 10) / lds);
-    const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>(n / 64, 64), (size_t)ctx().num_cu * per_cu);
-    hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid), dim3(64), lds, ctx().stream, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys,
-                       (uint32_t)n, band, ring, d_out, esc + 1, esc, esc + 4, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0, 0u);
+  hipStream_t st = ctx().stream;
+  if ((long)n <= small_max) {
+    hipLaunchKernelGGL(k_align1, dim3((unsigned)n), dim3(64), ring * sizeof(int32_t), st, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys,
+                       (uint32_t)n, band, ring, d_out);
     PGX_HIP(hipGetLastError());
     return;
   }
-  if ((long)n > small_max && (mode == 4 || mode == 8) && db->max_rlen <= 65535u) {
-    auto grid_for = [&](size_t cands, int groups, int rg) {
-      const size_t lds = (size_t)groups * rg * sizeof(uint16_t);
-      const size_t cap_cu = getenv("PGX_ALIGN_WAVES") ? (size_t)std::max(1, atoi(getenv("PGX_ALIGN_WAVES"))) : 32;   // wavefronts per CU: 32 = all a CU holds (measured at c3, ms of alignment kernels per step: 16 -> 82.1, 20 -> 70.4, 24 -> 63.4, 28 -> 59.1, 32 -> 56.8)
-      const unsigned per_cu = (unsigned)std::min<size_t>(cap_cu, (160u << 10) / lds);
-      return (unsigned)std::min<size_t>((cands + groups - 1) / groups, (size_t)ctx().num_cu * per_cu);
-    };
-    if (mode == 4) {
-      const int narrow = getenv("PGX_ALIGN_RING") ? atoi(getenv("PGX_ALIGN_RING")) : 64;
-      uint32_t *esc = ws<uint32_t>("align.esc", n + 4);   // [0] handed-on count, [1] the second launch's work counter, [4..) list
-      PGX_HIP(hipMemsetAsync(esc, 0, 4 * sizeof(uint32_t), ctx().stream));
-      const int rg = std::min(narrow, ring);
-      hipLaunchKernelGGL((k_align_ph<4, uint16_t, false>), dim3(grid_for(n, 16, rg)), dim3(64), 16 * rg * sizeof(uint16_t), ctx().stream,
-                         db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, rg, d_out, counter,
-                         (const uint32_t *)nullptr, (const uint32_t *)nullptr, rg < ring ? esc : nullptr, rg < ring ? esc + 4 : nullptr, (const uint32_t *)nullptr, (size_t)0, 0u);
-      if (rg < ring)
-        hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid_for(std::max<size_t>(n / 16, 8192), 8, ring)), dim3(64),
-                           8 * ring * sizeof(uint16_t), ctx().stream, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band,
-                           ring, d_out, esc + 1, esc, esc + 4, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0, 0u);
-    } else {
-      // default of the large launches (round 3): the phase machine over the 2-bit packs.  The packs are built once per overlap stage
-      // by the first launch of at least PGX_ALIGN_PACKED_MIN alignments (4.5 GB of seqdb: 1.6 ms) and serve every later launch of
-      // the stage; candidates that meet a read with ambiguous bases come back in a list and take the byte-wise form.
-      const uint32_t iter_limit = getenv("PGX_ALIGN_ITER_LIMIT") ? (uint32_t)atol(getenv("PGX_ALIGN_ITER_LIMIT")) : 2500u;   // (0: no hand-on of stragglers)
-      const char *pm = getenv("PGX_ALIGN_PACKED_MIN");
-      const long packed_min = pm ? atol(pm) : 100000;   // (< 0: never)
-      if (packed_min >= 0 && ((long)n >= packed_min || seq_packs_valid(db))) {
-        const uint32_t *packs = seq_packs(db);
-        uint32_t *esc = ws<uint32_t>("align.esc", n + 4);   // [0] handed-on count, [1] the second launch's work counter, [4..) list
-        PGX_HIP(hipMemsetAsync(esc, 0, 4 * sizeof(uint32_t), ctx().stream));
-        hipLaunchKernelGGL((k_align_ph<8, uint16_t, true>), dim3(grid_for(n, 8, ring)), dim3(64), 8 * ring * sizeof(uint16_t), ctx().stream,
-                           reinterpret_cast<const uint8_t *>(packs), db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter,
-                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, esc, esc + 4, db->d_nflag.p, seq_pack_stride(db), iter_limit);
-        // what it handed on -- reads with ambiguous bases, stragglers -- a wavefront per candidate, from the list
-        hipLaunchKernelGGL(k_align1_list, dim3((unsigned)std::min<size_t>(std::max<size_t>(n / 256, 256), (size_t)ctx().num_cu * 32)), dim3(64),
-                           ring * sizeof(int32_t), ctx().stream, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, esc, esc + 4, band, ring, d_out);
-      } else {
-        hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid_for(n, 8, ring)), dim3(64), 8 * ring * sizeof(uint16_t), ctx().stream,
-                           db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter,
-                           (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0, 0u);
-      }
-    }
-  } else if ((long)n <= small_max) {
-    hipLaunchKernelGGL(k_align1, dim3((unsigned)n), dim3(64), ring * sizeof(int32_t), ctx().stream, db->d_seq.p, db->d_roff.p,
-                       db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out);
-  } else if (gl == 8) {
-    const size_t want = (n + 7) / 8;
-    if (db->max_rlen <= 65535u) {
-      const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * 32);
-      hipLaunchKernelGGL((k_align4<8, uint16_t>), dim3(grid), dim3(64), 8 * ring * sizeof(uint16_t), ctx().stream, db->d_seq.p,
-                         db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter);
-    } else {
-      const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * 20);
-      hipLaunchKernelGGL((k_align4<8, int32_t>), dim3(grid), dim3(64), 8 * ring * sizeof(int32_t), ctx().stream, db->d_seq.p,
-                         db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter);
-    }
+  uint32_t *counter = ws<uint32_t>("align.counter", 8);
+  PGX_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(uint32_t), st));
+  if (db->max_rlen > 65535u) {   // x <= read length must fit the V ring's element: 32-bit rings, 20 wavefronts per CU
+    const unsigned grid = (unsigned)std::min<size_t>((n + 7) / 8, (size_t)ctx().num_cu * 20);
+    hipLaunchKernelGGL((k_align4<8, int32_t>), dim3(grid), dim3(64), 8 * ring * sizeof(int32_t), st, db->d_seq.p, db->d_roff.p, db->d_rlen.p,
+                       d_keys, (uint32_t)n, band, ring, d_out, counter);
+    PGX_HIP(hipGetLastError());
+    return;
+  }
+  const size_t lds = (size_t)8 * ring * sizeof(uint16_t);
+  const unsigned per_cu = (unsigned)std::min<size_t>(32, (160u << 10) / lds);   // 32 = all the wavefronts a CU holds (measured at c3, ms of
+                                                                               // alignment kernels per step: 16 -> 82.1, 24 -> 63.4, 32 -> 56.8)
+  const unsigned grid = (unsigned)std::min<size_t>((n + 7) / 8, (size_t)ctx().num_cu * per_cu);
+  // The packs are built by the first launch of at least PGX_ALIGN_PACKED_MIN alignments (default 100,000; 4.5 GB of seqdb: 1.6 ms) and
+  // serve every later launch on this database; < 0: never.
+  const char *pm = getenv("PGX_ALIGN_PACKED_MIN");
+  const long packed_min = pm ? atol(pm) : 100000;
+  const uint32_t *packs = (packed_min >= 0 && ((long)n >= packed_min || seq_packs_valid(db))) ? seq_packs(db) : nullptr;
+  if (packs) {
+    const uint32_t iter_limit = getenv("PGX_ALIGN_ITER_LIMIT") ? (uint32_t)atol(getenv("PGX_ALIGN_ITER_LIMIT")) : 2500u;   // (0: no hand-on of stragglers)
+    uint32_t *esc = ws<uint32_t>("align.esc", n + 4);   // [0] handed-on count, [4..) list
+    PGX_HIP(hipMemsetAsync(esc, 0, 4 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL((k_align_ph<8, uint16_t, true>), dim3(grid), dim3(64), lds, st, reinterpret_cast<const uint8_t *>(packs), db->d_roff.p,
+                       db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter, (const uint32_t *)nullptr, (const uint32_t *)nullptr, esc,
+                       esc + 4, db->d_nflag.p, seq_pack_stride(db), iter_limit);
+    // what it handed on, a wavefront per candidate, from the list
+    hipLaunchKernelGGL(k_align1_list, dim3((unsigned)std::min<size_t>(std::max<size_t>(n / 256, 256), (size_t)ctx().num_cu * 32)), dim3(64),
+                       ring * sizeof(int32_t), st, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, esc, esc + 4, band, ring, d_out);
   } else {
-    const size_t want = (n + 3) / 4;
-    const unsigned grid = (unsigned)std::min<size_t>(want, (size_t)ctx().num_cu * 32);
-    hipLaunchKernelGGL((k_align4<16, int32_t>), dim3(grid), dim3(64), 4 * ring * sizeof(int32_t), ctx().stream, db->d_seq.p,
-                       db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter);
+    hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid), dim3(64), lds, st, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys,
+                       (uint32_t)n, band, ring, d_out, counter, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                       (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0, 0u);
   }
   PGX_HIP(hipGetLastError());
 }

@@ -655,8 +655,9 @@ int pgx_seqdb_upload_dev(const uint8_t *d_seqdb, size_t nbytes, const uint32_t *
 }
 int pgx_seqdb_adopt_dev(uint8_t *d_seqdb, size_t nbytes, size_t capacity, const uint32_t *rid, const uint32_t *rlen,
                         const uint64_t *roff, uint32_t nreads, pgx_seqdb **out) {
-  if (!d_seqdb || capacity < nbytes + 1024) {
-    pgx::set_error("pgx_seqdb_adopt_dev: need a device pointer with capacity >= nbytes + 1024 (the kernels' wide loads read past the last read)");
+  if (!d_seqdb || capacity < nbytes + 1024 || ((uintptr_t)d_seqdb & 15u)) {
+    pgx::set_error("pgx_seqdb_adopt_dev: need a 16-byte aligned device pointer with capacity >= nbytes + 1024 (the kernels' wide loads are "
+                   "aligned 16-byte loads and read past the last read)");
     return PGX_EARG;
   }
   return seqdb_upload_impl(d_seqdb, nbytes, rid, rlen, roff, nreads, out, true, nullptr, true);
@@ -783,7 +784,6 @@ int pgx_align_batch(pgx_seqdb *db, const pgx_align_key *keys, size_t n, int band
   DevBuf<pgx_align_key> d_keys(n);
   DevBuf<pgx_match> d_out(n);
   d_keys.upload(keys, n);
-  ++align_epoch();
   dev_align(db, d_keys.p, n, band, d_out.p);
   d_out.download(out, n);
   pgx::sync();

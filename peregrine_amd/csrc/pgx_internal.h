@@ -149,12 +149,12 @@ struct pgx_seqdb {
   ~pgx_seqdb() {
     if (borrowed) d_seq.p = nullptr, d_seq.n = 0;
   }
-  // the lane-per-candidate alignment kernel's view of the reads (pgx_align_lane.hip), rebuilt once per overlap stage:
+  // the packed alignment kernel's view of the reads (pgx_pack.hip): a cache of the immutable seqdb bytes, built on first use
   mutable pgx::DevBuf<uint32_t> d_pack;          // 2-bit packs of the seqdb, both strands
-  mutable pgx::DevBuf<uint32_t> d_nflag;         // by rid: the read holds an ambiguous base
+  mutable pgx::DevBuf<uint32_t> d_nflag;         // by rid: the read holds a byte that has no 2-bit code (an ambiguous base)
   mutable pgx::DevBuf<uint64_t> d_roff_sorted;   // read offsets ascending + their rids (position -> read, for d_nflag)
   mutable pgx::DevBuf<uint32_t> d_rid_sorted;
-  mutable uint64_t pack_epoch = 0;               // align_epoch() the packs were built in
+  mutable bool packs_built = false, packs_failed = false;   // (failed: no HBM for them -- the byte-wise kernels serve this database)
   pgx::DevBuf<uint64_t> d_roff;    // indexed by rid
   pgx::DevBuf<uint32_t> d_rlen;    // indexed by rid
   std::vector<uint32_t> rid, rlen; // idx-file order
@@ -193,15 +193,9 @@ void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_cou
 // banded O(ND) confirmation of n candidate alignments (keys on device)
 void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out,
                bool tail_batch = false);   // tail_batch: a later request batch of a stage (mostly hard candidates: pgx_align.hip)
-void dev_align_prepare(const pgx_seqdb *db);   // the 2-bit packs of this stage, ahead of the first large launch
-// one candidate per lane over 2-bit packs (pgx_align_lane.hip); returns the device escalation block: [0] number of candidates
-// handed on to the byte-wise kernel, [1] a zeroed work counter for that launch, [4..) their indices
-uint32_t *dev_align_lane(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out);
-// bumped once per overlap stage / alignment batch: the 2-bit packs are rebuilt when it changed (the packing pass belongs to the
-// timed stage, it is not kept across calls)
-uint64_t &align_epoch();
-// the 2-bit packs of a read database (pgx_align_lane.hip: [pack of the low nibbles | pack of the high nibbles], seq_pack_stride dwords
-// each; d_nflag marks the reads with ambiguous bases): built on first use within an epoch
+void dev_align_prepare(const pgx_seqdb *db);   // the database's 2-bit packs, ahead of the first large launch (no-op once they exist)
+// the 2-bit packs of a read database (pgx_pack.hip: [pack of the low nibbles | pack of the high nibbles], seq_pack_stride dwords
+// each; d_nflag marks the reads with bytes that have no 2-bit code): built on first use, kept with the database; nullptr: no HBM
 const uint32_t *seq_packs(const pgx_seqdb *db);
 size_t seq_pack_stride(const pgx_seqdb *db);
 bool seq_packs_valid(const pgx_seqdb *db);
@@ -325,12 +319,10 @@ struct DevVisit {
   DevBuf<uint32_t> ids_all, gnb;
   DevBuf<unsigned long long> tot;
 };
-// the outer table's slot layout computed on the device (pgx_khash_dev.hip); false: gave up, use the host form
-bool dev_khash_slots(const uint64_t *d_keys, size_t n_keys, bool touch, DevBuf<uint64_t> &slots, uint32_t *n_slots);
 void dev_visit_inner(const DevicePairs &dp, uint32_t ovlp_upper, DevVisit &v);
 // slots: the outer table as DistinctSlotTable leaves it (pinned host memory), ids = positions in first-insertion order
 void dev_visit_place(const DevicePairs &dp, DevVisit &v, const uint64_t *slots, uint32_t n_slots, DevBuf<uint32_t> &bid, size_t *n_buckets,
-                     size_t *n_entries, const uint64_t *slots_on_device = nullptr);   // (slots_on_device: the same words, already in HBM)
+                     size_t *n_entries);
 // The distinct first keys of the records in the order of their first insertion -- what the host replays klib's OUTER table from
 // (pgx_overlap.cpp) -- computed right after the records exist (a hash aggregation of first occurrences + an ordered select) and
 // handed to `early` while the join's sorts are still to run: the outer-table replay, the longest sequential piece of host work
@@ -339,10 +331,6 @@ struct EarlyGroups {
   HostArray<uint64_t> keys;
   uint32_t n = 0;
   uint32_t last_first = 0;   // record index of the last key's first occurrence
-  // large sets (PGX_DEV_OUTER_MIN keys and more): the outer table's slot layout, computed on the device right here
-  // (pgx_khash_dev.hip) instead of by a host thread; n_slots == 0: not computed
-  DevBuf<uint64_t> d_slots;
-  uint32_t n_slots = 0;
 };
 using EarlyFn = std::function<void(EarlyGroups &&)>;
 // d_rlen: read length by rid, on the device

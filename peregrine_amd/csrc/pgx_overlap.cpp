@@ -450,13 +450,8 @@ struct PreOuter {
   std::thread th;
   bool started = false;
   double ms = 0, t_start = 0, t_end = 0;
-  bool on_device = false;   // the layout came with the early groups (eg.d_slots): no host thread
   void start(EarlyGroups &&g, size_t n_rec) {
     eg = std::move(g);
-    if (eg.n_slots) {
-      started = on_device = true;
-      return;
-    }
     const uint32_t min_n = getenv("PGX_EARLY_OUTER_MIN") ? (uint32_t)atol(getenv("PGX_EARLY_OUTER_MIN")) : 4096u;
     if (eg.n < min_n || eg.n >= (1u << 30)) return;   // (small sets: nothing to hide)
     started = true;
@@ -1615,7 +1610,6 @@ struct DeviceLists {
 void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
                  const pgx_overlap_params *p, OvOut &out, pgx_overlap_stats *st, const DeviceLists *dev = nullptr,
                  const pgx_pair_rec *d_recs = nullptr, size_t n_recs = 0) {
-  ++align_epoch();   // the alignment kernels' 2-bit packs of the seqdb are rebuilt once per stage, inside it (pgx_align_lane.hip)
   pgx_overlap_stats s;
   memset(&s, 0, sizeof(s));
   const double t0 = now_ms();
@@ -1691,14 +1685,13 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
         ok = ok && ((size_t)pre.eg.last_first == (size_t)dpairs.last_gfirst);
         if (ok) {
           size_t nbv = 0, nev = 0;
-          if (pre.on_device) dev_visit_place(dpairs, dv, nullptr, pre.eg.n_slots, d_bids, &nbv, &nev, pre.eg.d_slots.p);
-          else dev_visit_place(dpairs, dv, pre.table.slot, pre.table.nb, d_bids, &nbv, &nev);
+          dev_visit_place(dpairs, dv, pre.table.slot, pre.table.nb, d_bids, &nbv, &nev);
           visit.n_buckets = nbv, visit.n_entries = nev, visit.on_device = true, visit.n_groups = 0;
           placed = true;
           s.device_visit = 1 + dpairs.n_big_groups;   // (the tables stay until the device replay has succeeded: its fall-back, the host replay, fetches them)
           if (trace)
-            fprintf(stderr, "[pgx]   visit on the device: waited %.2f ms for the outer table (%s %.2f ms, %u slots), placed in %.2f ms\n", tw - t1,
-                    pre.on_device ? "computed on the device during the join;" : "host thread", pre.ms, pre.on_device ? pre.eg.n_slots : pre.table.nb, now_ms() - tw);
+            fprintf(stderr, "[pgx]   visit on the device: waited %.2f ms for the outer table (host thread %.2f ms, %u slots), placed in %.2f ms\n", tw - t1,
+                    pre.ms, pre.table.nb, now_ms() - tw);
         } else {
           fprintf(stderr, "[pgx] note: the early outer-table keys do not match the join's group tables; the host builds the visit order\n");
         }
@@ -1929,33 +1922,20 @@ int pgx_khash_slot_order(const uint64_t *keys, size_t n, uint64_t *out) {
   return PGX_OK;
 }
 
-int pgx_khash_slot_order_ex(const uint64_t *keys, size_t n, int touch, int on_device, uint64_t *out) {
+int pgx_khash_slot_order_ex(const uint64_t *keys, size_t n, int touch, uint64_t *out) {
   try {
     PGX_REQUIRE((keys && out) || n == 0, PGX_EARG, "pgx_khash_slot_order_ex: null argument");
     PGX_REQUIRE(n < (1ULL << 30), PGX_EARG, "pgx_khash_slot_order_ex: too many keys");
     if (n == 0) return PGX_OK;
     size_t m = 0;
-    if (on_device) {
-      require_ready();
-      DevBuf<uint64_t> d_keys(n), d_slots;
-      d_keys.upload(keys, n);
-      uint32_t ns = 0;
-      PGX_REQUIRE(dev_khash_slots(d_keys.p, n, touch != 0, d_slots, &ns), PGX_ESTATE, "the device form of the khash layout gave up");
-      std::vector<uint64_t> sl(ns);
-      d_slots.download(sl.data(), ns);
-      pgx::sync();
-      for (uint32_t s0 = 0; s0 < ns; ++s0)
-        if (sl[s0]) out[m++] = keys[(uint32_t)sl[s0] & DistinctSlotTable::ID_MASK];
-    } else {
-      DistinctSlotTable t;
-      for (size_t i = 0; i < n; ++i) {
-        if (i + 8 < n) t.prefetch(keys[i + 8]);
-        t.put_new(keys[i], (uint32_t)i);
-      }
-      if (touch) t.touch();
-      for (uint32_t s0 = 0; s0 < t.nb; ++s0)
-        if (t.is_used(s0)) out[m++] = keys[t.id_at(s0)];
+    DistinctSlotTable t;
+    for (size_t i = 0; i < n; ++i) {
+      if (i + 8 < n) t.prefetch(keys[i + 8]);
+      t.put_new(keys[i], (uint32_t)i);
     }
+    if (touch) t.touch();
+    for (uint32_t s0 = 0; s0 < t.nb; ++s0)
+      if (t.is_used(s0)) out[m++] = keys[t.id_at(s0)];
     PGX_REQUIRE(m == n, PGX_ESTATE, "pgx_khash_slot_order_ex: %zu of %zu keys placed (are the keys distinct?)", m, n);
   } catch (const Fail &f) {
     return f.code;

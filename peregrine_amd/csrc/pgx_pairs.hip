@@ -660,12 +660,6 @@ static void early_groups(const PairRecs &R, Tmp &tmp, const EarlyFn &early) {
     eg.keys = to_host(keys, nd);
     PGX_HIP(hipMemcpyAsync(&eg.last_first, idx.p + nd - 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     sync();
-    // a large outer table: its slot layout on the device, now (pgx_khash_dev.hip); the host thread stays the fall-back
-    const long dev_min = getenv("PGX_DEV_OUTER_MIN") ? atol(getenv("PGX_DEV_OUTER_MIN")) : -1;
-    if (dev_min >= 0 && (long)nd >= dev_min) {
-      tkeys = DevBuf<unsigned long long>(), tseq = DevBuf<uint32_t>(), flag = DevBuf<uint8_t>();   // (this pass's own tables: not needed any more)
-      if (!dev_khash_slots(keys.p, nd, (size_t)eg.last_first + 1 < (size_t)nr, eg.d_slots, &eg.n_slots)) eg.n_slots = 0, eg.d_slots = DevBuf<uint64_t>();
-    }
   }
   early(std::move(eg));
 }

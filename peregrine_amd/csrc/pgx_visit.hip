@@ -229,7 +229,7 @@ void dev_visit_inner(const DevicePairs &dp, uint32_t ovlp_upper, DevVisit &v) {
 }
 
 void dev_visit_place(const DevicePairs &dp, DevVisit &v, const uint64_t *slots, uint32_t n_slots, DevBuf<uint32_t> &bid, size_t *n_buckets,
-                     size_t *n_entries, const uint64_t *slots_on_device) {
+                     size_t *n_entries) {
   hipStream_t st = ctx().stream;
   *n_buckets = *n_entries = 0;
   bid.alloc(std::max<size_t>(dp.n_buckets, 1));
@@ -238,10 +238,10 @@ void dev_visit_place(const DevicePairs &dp, DevVisit &v, const uint64_t *slots, 
   unsigned long long ne = 0;
   {
     KernelTimer tm("visit", 0);
-    DevBuf<uint64_t> d_own(slots_on_device ? 0 : n_slots);
+    DevBuf<uint64_t> d_own(n_slots);
     DevBuf<uint32_t> cnt(n_slots), off((size_t)n_slots + 1);
-    if (!slots_on_device) PGX_HIP(hipMemcpyAsync(d_own.p, slots, (size_t)n_slots * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    const uint64_t *d_slots_p = slots_on_device ? slots_on_device : d_own.p;
+    PGX_HIP(hipMemcpyAsync(d_own.p, slots, (size_t)n_slots * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    const uint64_t *d_slots_p = d_own.p;
     hipLaunchKernelGGL(k_outer_counts, dim3((n_slots + 255) / 256), dim3(256), 0, st, d_slots_p, n_slots, dp.gord.p, v.gnb.p, cnt.p);
     PGX_HIP(hipMemsetAsync(off.p, 0, sizeof(uint32_t), st));
     size_t bytes = 0;

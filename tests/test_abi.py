@@ -89,7 +89,7 @@ def test_khash_slot_order_equals_the_literal_replay(lib):
         assert np.array_equal(got, U.orc_khash_order(keys)), len(keys)
         if len(keys):   # a trailing put of a present key only runs the load check (khash.h:298-306) -- and may resize once more
             got2 = np.zeros(len(keys), np.uint64)
-            assert lib.pgx_khash_slot_order_ex(keys.ctypes.data_as(C.c_void_p), len(keys), 1, 0, got2.ctypes.data_as(C.c_void_p)) == 0
+            assert lib.pgx_khash_slot_order_ex(keys.ctypes.data_as(C.c_void_p), len(keys), 1, got2.ctypes.data_as(C.c_void_p)) == 0
             assert np.array_equal(got2, U.orc_khash_order(np.concatenate([keys, keys[:1]]))), len(keys)
     # exactly at the load-factor boundaries: the trailing put resizes iff the table is at its upper bound
     for nb in (4, 8, 16, 1024):
@@ -97,7 +97,7 @@ def test_khash_slot_order_equals_the_literal_replay(lib):
         for n in (up - 1, up, up + 1):
             keys = np.unique(rng.integers(0, 1 << 40, n + 8, dtype=np.uint64))[:n]
             got2 = np.zeros(len(keys), np.uint64)
-            assert lib.pgx_khash_slot_order_ex(keys.ctypes.data_as(C.c_void_p), len(keys), 1, 0, got2.ctypes.data_as(C.c_void_p)) == 0
+            assert lib.pgx_khash_slot_order_ex(keys.ctypes.data_as(C.c_void_p), len(keys), 1, got2.ctypes.data_as(C.c_void_p)) == 0
             assert np.array_equal(got2, U.orc_khash_order(np.concatenate([keys, keys[:1]]))), (nb, n)
 
 

@@ -803,19 +803,14 @@ def _oracle_matches(db, keys, band):
     return out
 
 
-ALIGN_VARIANTS = [   # (id, environment, read set)
-    ("ph8-packed", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8", PGX_ALIGN_PACKED_MIN="0"), "small"),   # k_align_ph<8, u16, packed>: the default of large launches
-    ("ph8-packed-ambiguous", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8", PGX_ALIGN_PACKED_MIN="0"), "withN"),   # ... reads with N: handed on to the byte-wise launch
-    ("ph8-packed-stragglers", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_ITER_LIMIT="150"), "small"),   # most candidates outlast
+ALIGN_VARIANTS = [   # (id, environment, read set): every form dev_align dispatches to (pgx_align.hip)
+    ("ph8-packed", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0"), "small"),   # k_align_ph<8, u16, packed>: the default of large launches
+    ("ph8-packed-ambiguous", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0"), "withN"),   # ... reads with N: handed on to the byte-wise launch
+    ("ph8-packed-stragglers", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_ITER_LIMIT="150"), "small"),   # most candidates outlast
                                                                                     # 150 iterations: handed on to k_align1_list, a wavefront each
-    ("ph8", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8", PGX_ALIGN_PACKED_MIN="-1"), "small"),          # k_align_ph<8, u16> on the seqdb bytes
-    ("lockstep8", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="0"), "small"),              # k_align4<8, u16>
-    ("lockstep16", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="0", PGX_ALIGN_GL="16"), "small"),   # k_align4<16, int32>
-    ("ph4+escalation", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="4"), "small"),         # k_align_ph<4> on the narrow ring, then k_align_ph<8> over the hand-ons
-    ("lane", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_LANE_MIN="0"), "small"),               # k_align_lane (+ k_align_ph<8> over the hand-ons)
-    ("one-per-wave", dict(PGX_ALIGN_SMALL="1000000000"), "small"),                       # k_align1 on a LARGE launch
-    ("long-reads-int32", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_MODE="8"), "long"),        # a 100 kb read in the set: k_align4<8, int32>
-    ("long-reads-lane-refused", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_LANE_MIN="0"), "long"),
+    ("ph8-bytes", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="-1"), "small2"),  # k_align_ph<8, u16> on the seqdb bytes (a database without packs)
+    ("one-per-wave", dict(PGX_ALIGN_SMALL="1000000000"), "small"),                  # k_align1 on a LARGE launch
+    ("long-reads-int32", dict(PGX_ALIGN_SMALL="0"), "long"),                        # a 100 kb read in the set: k_align4<8, int32>
 ]
 
 
@@ -829,7 +824,8 @@ def variant_sets():
         o, n = int(withn.roff[r]), int(withn.rlen[r])
         sd[o + rng.integers(0, n, 3)] = 0
     withn.seqdb = sd
-    for name, db in (("small", simreads.make_workload("small")), ("long", _with_long_reads()), ("withN", withn)):
+    # ("small2": the same reads as a second database -- the packs stay with a database once built, so the byte-wise form needs its own)
+    for name, db in (("small", simreads.make_workload("small")), ("small2", simreads.make_workload("small")), ("long", _with_long_reads()), ("withN", withn)):
         rdb = ResidentDB(db, 0)
         keys, ov = _keys_of(db, rdb, 3000, 17)
         want = {band: _oracle_matches(db, keys, band) for band in (100, 20)}
