@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 SKETCH_BYTES_PER_BASE = 1.04     # 1 B seqdb + 16 B/408 L2 + MC  (-m 0)
 ALIGN_BYTES_PER_PAIR = 21664.0   # 2 x 10.8 kB read + 64 B written
 LEVELS = 2
-DEFAULT_WORKLOAD = "c3"
+DEFAULT_WORKLOAD = "c4"
 WORKLOAD_TEXT = {
     "c4": "BASELINE configs[3] at FULL size (the configuration the metric is quoted on): 3.1 Gb genome seeded with 207 families of 300 copies "
           "of a 6 kb unit at 1 % divergence, 31 k tandem arrays and 31 k homopolymer runs (CHM13 is not obtainable offline) x 30x",
@@ -57,8 +57,8 @@ def log(msg):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 3 for the c4 family -- a step is 8 + 8 chunks, ~11 s -- else 10)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before them (default: 1 for the c4 family, else 2)")
     ap.add_argument("--two-stage", action="store_true",
                     help="N=1 only: hand the shimmer list from the index to the overlap stage through host arrays (as the "
                          "multi-GPU path must, around its all-gather) instead of leaving it in HBM")
@@ -79,7 +79,13 @@ def parse():
     ap.add_argument("--check-ref", action="store_true",
                     help="c4 family, small --genome-mb only: after the timed steps every rank compares the ovlp_t stream of each of its "
                          "chunks, field by field, with oracle/_ref/shmr_overlap -t CHUNKS -c c on files rank 0 writes")
-    return ap.parse_args()
+    a = ap.parse_args()
+    big = a.workload == "c4" and not a.genome_mb
+    if a.steps is None:
+        a.steps = 3 if big else 10
+    if a.warmup is None:
+        a.warmup = 1 if big else 2
+    return a
 
 
 def _pair_keys(ov):

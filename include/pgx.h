@@ -191,6 +191,12 @@ int pgx_copy_dev(void *d_dst, const void *d_src, size_t nbytes);
 /* file level: globs <shimmer_prefix>-[0-9]*-of-[0-9]*.dat and -MC- twins like shmr_overlap.c:355-384 */
 int pgx_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, const char *out_path,
                       const pgx_overlap_params *p, pgx_overlap_stats *stats);
+/* The same two stages on a read database that is ALREADY resident (pgx_seqdb_load / _upload): what a long-lived process serves
+ * several chunk commands from -- `pgx_cli serve`, which the shmr_index / shmr_overlap drop-ins attach to, INTEGRATION.md section 5 --
+ * so that a job's 8 + 8 chunk commands upload the seqdb once instead of sixteen times. */
+int pgx_index_chunk_db(pgx_seqdb *db, const char *out_prefix, const pgx_index_params *p, pgx_index_result *stats);
+int pgx_overlap_chunk_db(pgx_seqdb *db, const char *shimmer_prefix, const char *out_path, const pgx_overlap_params *p,
+                         pgx_overlap_stats *stats);
 
 /* ---- dedup (replaces shmr_dedup, src/shmr_dedup.c:32-101) ----
  * recs: the concatenated ovlp_t streams (cat ovlp*.dat).  The first record of every read pair wins; *text receives the

@@ -210,18 +210,14 @@ int pgx_index_resident_dev(pgx_seqdb *db, const pgx_index_params *p, pgx_index_r
   return PGX_OK;
 }
 
-int pgx_index_chunk(const char *seqdb_prefix, const char *out_prefix, const pgx_index_params *p,
-                    pgx_index_result *stats) {
-  pgx_seqdb *db = nullptr;
+int pgx_index_chunk_db(pgx_seqdb *db, const char *out_prefix, const pgx_index_params *p, pgx_index_result *stats) {
   pgx_index_result res;
   memset(&res, 0, sizeof(res));
   int rc = PGX_OK;
   try {
     require_ready();
-    PGX_REQUIRE(seqdb_prefix && out_prefix, PGX_EARG, "pgx_index_chunk: null prefix");
+    PGX_REQUIRE(db && out_prefix, PGX_EARG, "pgx_index_chunk_db: null argument");
     check_params(p);
-    rc = pgx_seqdb_load(seqdb_prefix, &db);
-    if (rc) return rc;
     run_index(db, p, &res);
     // file names and order of writing as in shmr_index.c:165-233
     if (p->want_l0 == 1) {
@@ -245,6 +241,22 @@ int pgx_index_chunk(const char *seqdb_prefix, const char *out_prefix, const pgx_
     stats->l0_mc = stats->top_mc = nullptr;
   }
   pgx_index_result_free(&res);
+  return rc;
+}
+
+int pgx_index_chunk(const char *seqdb_prefix, const char *out_prefix, const pgx_index_params *p,
+                    pgx_index_result *stats) {
+  pgx_seqdb *db = nullptr;
+  try {
+    require_ready();
+    PGX_REQUIRE(seqdb_prefix && out_prefix, PGX_EARG, "pgx_index_chunk: null prefix");
+    check_params(p);
+  } catch (const Fail &f) {
+    return f.code;
+  }
+  int rc = pgx_seqdb_load(seqdb_prefix, &db);
+  if (rc) return rc;
+  rc = pgx_index_chunk_db(db, out_prefix, p, stats);
   pgx_seqdb_free(db);
   return rc;
 }

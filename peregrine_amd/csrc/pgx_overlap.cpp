@@ -25,6 +25,8 @@
 
 #include <fcntl.h>
 #include <unistd.h>
+#include <sys/stat.h>
+
 #include "pgx_internal.h"
 #include "pgx_khash.h"
 
@@ -2071,6 +2073,79 @@ int pgx_overlap_records_dev(pgx_seqdb *db, const pgx_pair_rec *d_records, size_t
   return PGX_OK;
 }
 
+namespace {
+// the shimmer / count files of every index chunk, name-sorted as the reference's wordexp globs them (shmr_overlap.c:359-384)
+void read_index_files(const char *shimmer_prefix, std::vector<pgx_mm128> &mm, std::vector<pgx_mm_count> &mc) {
+  read_counted_files(std::string(shimmer_prefix) + "-[0-9]*-of-[0-9]*.dat", mm);
+  read_counted_files(std::string(shimmer_prefix) + "-MC-[0-9]*-of-[0-9]*.dat", mc);
+}
+// The records to out_path.  A regular file: several threads pwrite slices into the page cache (one thread moves ~3 GB/s: 0.1 s for the
+// 300 MB of a 4.5 Gbase chunk).  Anything that cannot seek (-o /dev/stdout, a FIFO, a process substitution -- the reference's fwrite
+// stream handles those, shmr_overlap.c:388-390): one sequential write loop.  EINTR is retried.
+void write_records(const char *out_path, const pgx_ovlp *rec, size_t n) {
+  const int fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  PGX_REQUIRE(fd >= 0, PGX_EIO, "file '%s' open error", out_path);
+  const size_t total = n * sizeof(pgx_ovlp);
+  struct stat sb;
+  const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
+  bool ok = true;
+  if (!regular) {
+    for (size_t off = 0; off < total;) {
+      const ssize_t w = write(fd, (const char *)rec + off, total - off);
+      if (w < 0 && errno == EINTR) continue;
+      if (w <= 0) {
+        ok = false;
+        break;
+      }
+      off += (size_t)w;
+    }
+  } else {
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>(8, total >> 24));
+    std::vector<char> okv(nt, 1);
+    std::vector<std::thread> ws;
+    for (int t = 0; t < nt; ++t)
+      ws.emplace_back([&, t] {
+        const size_t lo = total * t / nt, hi = total * (t + 1) / nt;
+        for (size_t off = lo; off < hi;) {
+          const ssize_t w = pwrite(fd, (const char *)rec + off, hi - off, (off_t)off);
+          if (w < 0 && errno == EINTR) continue;
+          if (w <= 0) {
+            okv[t] = 0;
+            return;
+          }
+          off += (size_t)w;
+        }
+      });
+    for (auto &t : ws) t.join();
+    for (char c : okv) ok = ok && c;
+  }
+  ok = (close(fd) == 0) && ok;
+  PGX_REQUIRE(ok, PGX_EIO, "short write to '%s'", out_path);
+}
+}  // namespace
+
+int pgx_overlap_chunk_db(pgx_seqdb *db, const char *shimmer_prefix, const char *out_path, const pgx_overlap_params *p,
+                         pgx_overlap_stats *stats) {
+  int rc = PGX_OK;
+  try {
+    require_ready();
+    PGX_REQUIRE(db && shimmer_prefix && out_path, PGX_EARG, "pgx_overlap_chunk_db: null argument");
+    check_params(p);
+    std::vector<pgx_mm128> mm;
+    std::vector<pgx_mm_count> mc;
+    read_index_files(shimmer_prefix, mm, mc);
+    OvOut v;
+    run_overlap(db, mm.data(), mm.size(), mc.data(), mc.size(), p, v, stats);
+    write_records(out_path, v.a, v.n);
+  } catch (const Fail &f) {
+    rc = f.code;
+  } catch (const std::bad_alloc &) {
+    set_error("out of host memory");
+    rc = PGX_ENOMEM;
+  }
+  return rc;
+}
+
 int pgx_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, const char *out_path,
                       const pgx_overlap_params *p, pgx_overlap_stats *stats) {
   pgx_seqdb *db = nullptr;
@@ -2086,12 +2161,13 @@ int pgx_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, cons
     std::string rd_err;
     std::thread reader([&] {
       try {
-        read_counted_files(std::string(shimmer_prefix) + "-[0-9]*-of-[0-9]*.dat", mm);
-        read_counted_files(std::string(shimmer_prefix) + "-MC-[0-9]*-of-[0-9]*.dat", mc);
+        read_index_files(shimmer_prefix, mm, mc);
       } catch (const Fail &f) {
         rd_code = f.code, rd_err = pgx_last_error();
       } catch (const std::bad_alloc &) {
         rd_code = PGX_ENOMEM, rd_err = "out of host memory";
+      } catch (...) {
+        rd_code = PGX_EIO, rd_err = "reading the shimmer files failed";
       }
     });
     rc = pgx_seqdb_load(seqdb_prefix, &db);
@@ -2104,29 +2180,7 @@ int pgx_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, cons
     PGX_REQUIRE(rd_code == PGX_OK, rd_code, "%s", rd_err.c_str());
     OvOut v;
     run_overlap(db, mm.data(), mm.size(), mc.data(), mc.size(), p, v, stats);
-    // the records: several threads copy slices into the page cache (one thread moves ~3 GB/s: 0.1 s for the 300 MB of a 4.5 Gbase chunk)
-    const int fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-    PGX_REQUIRE(fd >= 0, PGX_EIO, "file '%s' open error", out_path);
-    const size_t total = v.n * sizeof(pgx_ovlp);
-    const int nt = (int)std::max<size_t>(1, std::min<size_t>(8, total >> 24));
-    std::vector<char> okv(nt, 1);
-    std::vector<std::thread> ws;
-    for (int t = 0; t < nt; ++t)
-      ws.emplace_back([&, t] {
-        const size_t lo = total * t / nt, hi = total * (t + 1) / nt;
-        for (size_t off = lo; off < hi;) {
-          const ssize_t w = pwrite(fd, (const char *)v.a + off, hi - off, (off_t)off);
-          if (w <= 0) {
-            okv[t] = 0;
-            return;
-          }
-          off += (size_t)w;
-        }
-      });
-    for (auto &t : ws) t.join();
-    bool ok = close(fd) == 0;
-    for (char c : okv) ok = ok && c;
-    PGX_REQUIRE(ok, PGX_EIO, "short write to '%s'", out_path);
+    write_records(out_path, v.a, v.n);
   } catch (const Fail &f) {
     rc = f.code;
   } catch (const std::bad_alloc &) {

@@ -98,3 +98,63 @@ def test_pipeline_like_the_reference_test_scripts(tmp_path):
         subprocess.run([exe, "shmr_overlap", "-p", str(tmp_path / "native" / "index" / "seq_dataset"), "-l", str(tmp_path / "native" / "index" / "shmr-L2"),
                         "-t", "2", "-c", f"{c:02d}", "-o", str(o)], check=True, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert o.read_bytes() == (tmp_path / "ref" / "ovlp" / f"ovlp.{c:02d}").read_bytes(), c
+
+
+@pytest.mark.skipif(not U.have_ref(), reason="needs the prebuilt reference binaries (oracle/_ref)")
+def test_served_mode_writes_the_same_files(tmp_path):
+    """`pgx_cli serve -p <prefix>` keeps the read database in HBM; the native shmr_index / shmr_overlap drop-ins attach to it through
+    <prefix>.pgx.sock (round 4: a job's 8 + 8 chunk commands upload the seqdb once).  Files byte-identical to the reference's; a
+    command for another prefix, a replaced .seqdb file and a dead server all fall back to the stand-alone path; records also go to a
+    pipe (-o /dev/stdout: the sequential writer)."""
+    import signal
+    import time
+    g = simreads.make_genome(200_000, 23, repeat_families=1, repeat_len=3000, repeat_copies=4, divergence=0.02, tandem=2)
+    db = simreads.simulate_reads(g, coverage=12.0, seed=5, mean_len=7000, sd_len=1500)
+    pre = str(tmp_path / "sd")
+    formats.write_seqdb(pre, db)
+    other = str(tmp_path / "other")
+    formats.write_seqdb(other, simreads.simulate_reads(simreads.make_genome(60_000, 24), coverage=8.0, seed=6, mean_len=5000, sd_len=500))
+    cli = os.path.join(ROOT, "bin", "native", "pgx_cli")
+    (tmp_path / "ref").mkdir(), (tmp_path / "srv").mkdir(), (tmp_path / "alone").mkdir()
+    for c in (1, 2):
+        _ref("shmr_index", "-p", pre, "-t", 2, "-c", c, "-m", 0, "-o", tmp_path / "ref" / "ix")
+    for c in (1, 2, 3):
+        _ref("shmr_overlap", "-p", pre, "-l", tmp_path / "ref" / "ix-L2", "-t", 3, "-c", c, "-o", tmp_path / "ref" / f"ov.{c}")
+    srv = subprocess.Popen([cli, "serve", "-p", pre], stderr=subprocess.PIPE, text=True)
+    try:
+        for _ in range(600):
+            if os.path.exists(pre + ".pgx.sock") or srv.poll() is not None:
+                break
+            time.sleep(0.1)
+        assert srv.poll() is None and os.path.exists(pre + ".pgx.sock"), srv.stderr.read() if srv.poll() is not None else "no socket"
+        t0 = time.perf_counter()
+        for c in (1, 2):   # relative output paths: resolved against the CLIENT's directory
+            r = subprocess.run([cli, "shmr_index", "-p", pre, "-t", "2", "-c", str(c), "-m", "0", "-o", "ix"], cwd=tmp_path / "srv", check=True, capture_output=True, text=True)
+            assert "resident: pgx_cli serve" in r.stderr
+        for c in (1, 2, 3):
+            subprocess.run([cli, "shmr_overlap", "-p", pre, "-l", "ix-L2", "-t", "3", "-c", str(c), "-o", f"ov.{c}"], cwd=tmp_path / "srv", check=True, capture_output=True)
+        served_s = time.perf_counter() - t0
+        for c in (1, 2):
+            assert (tmp_path / "srv" / f"ix-L2-{c:02d}-of-02.dat").read_bytes() == (tmp_path / "ref" / f"ix-L2-{c:02d}-of-02.dat").read_bytes()
+        for c in (1, 2, 3):
+            assert (tmp_path / "srv" / f"ov.{c}").read_bytes() == (tmp_path / "ref" / f"ov.{c}").read_bytes()
+        # errors come back with the exit status (no index files behind that prefix)
+        bad = subprocess.run([cli, "shmr_overlap", "-p", pre, "-l", "nothing-L2", "-o", "x"], cwd=tmp_path / "srv", capture_output=True, text=True)
+        assert bad.returncode != 0 and "pgx_overlap_chunk_db failed" in bad.stderr
+        # another prefix: no socket for it -> stand-alone
+        r = subprocess.run([cli, "shmr_index", "-p", other, "-m", "0", "-o", str(tmp_path / "alone" / "o")], check=True, capture_output=True, text=True)
+        assert "resident" not in r.stderr and os.path.exists(tmp_path / "alone" / "o-L2-01-of-01.dat")
+        # the .seqdb file replaced behind the server's back (same bytes, new mtime): the server declines, the client runs alone
+        os.utime(pre + ".seqdb", ns=(1, 1))
+        r = subprocess.run([cli, "shmr_index", "-p", pre, "-t", "2", "-c", "1", "-m", "0", "-o", str(tmp_path / "alone" / "ix")], check=True, capture_output=True, text=True)
+        assert "resident" not in r.stderr
+        assert (tmp_path / "alone" / "ix-L2-01-of-02.dat").read_bytes() == (tmp_path / "ref" / "ix-L2-01-of-02.dat").read_bytes()
+    finally:
+        srv.send_signal(signal.SIGTERM)
+        srv.wait(timeout=30)
+    assert not os.path.exists(pre + ".pgx.sock")
+    # a dead server's leftovers do not matter either; and the records through a pipe (no pwrite there)
+    open(pre + ".pgx.sock", "w").close()
+    r = subprocess.run([cli, "shmr_overlap", "-p", pre, "-l", str(tmp_path / "ref" / "ix-L2"), "-t", "3", "-c", "2", "-o", "/dev/stdout"], check=True, capture_output=True)
+    assert r.stdout == (tmp_path / "ref" / "ov.2").read_bytes()
+    print(f"served: 2 index + 3 overlap commands in {served_s:.2f} s")
