@@ -55,7 +55,7 @@ struct BigPool {
     return (bytes + step - 1) / step * step;
   }
   static size_t cap() {
-    static const size_t c = getenv("PGX_HOST_POOL_GB") ? (size_t)atol(getenv("PGX_HOST_POOL_GB")) << 30 : (size_t)16 << 30;
+    static const size_t c = (size_t)16 << 30;
     return c;
   }
   void *take(std::multimap<size_t, void *> &pool, size_t len) {
@@ -141,7 +141,9 @@ std::map<void *, size_t> g_out_big;                  // pageable pooled mappings
 std::map<void *, size_t> g_out_pin;                  // pinned blocks handed out (size class)
 std::multimap<size_t, void *> g_pin_free;            // pinned blocks waiting for re-use
 size_t g_pin_held = 0;
-const size_t PIN_CAP = getenv("PGX_PIN_CAP_MB") ? (size_t)atoll(getenv("PGX_PIN_CAP_MB")) << 20 : (size_t)16 << 30;
+// pinned result blocks kept for re-use: 16 GB per NODE -- divided among the ranks of a multi-process job (torchrun's LOCAL_WORLD_SIZE),
+// as the host threads are (eight ranks used to pin up to 16 GB each)
+const size_t PIN_CAP = ((size_t)16 << 30) / (size_t)std::max(1, getenv("LOCAL_WORLD_SIZE") ? atoi(getenv("LOCAL_WORLD_SIZE")) : 1);
 }  // namespace
 void *out_alloc(size_t bytes) {
   if (bytes < BIG) {
@@ -262,7 +264,7 @@ Reaper &reaper() {
 }
 }  // namespace
 void defer_destroy(std::function<void()> fn) {
-  static const bool inline_only = getenv("PGX_DEFER") && atoi(getenv("PGX_DEFER")) == 0;
+  static const bool inline_only = false;
   if (inline_only) fn();
   else reaper().push(std::move(fn));
 }
@@ -493,11 +495,11 @@ void pgx_timing_reset(void) {
 // The seqdb file straight into HBM.  One thread copying out of the page cache moves ~6 GB/s, an eighth of what the host link takes
 // (round 2: 4.5 GB in 0.75 s, twice per pipeline -- each stage is its own process, as in pg_run.py), so several reader threads
 // fill a ring of pinned pieces (pread, out of order) while the calling thread uploads the pieces IN order as they complete; the
-// host never holds more than NBUF pieces.  PGX_LOAD_THREADS / PGX_LOAD_PIECE_MB: test knobs.
+// host never holds more than NBUF pieces.  PGX_LOAD_THREADS: test knob (tools/e2e.py).
 static void upload_file_pieces(const char *path, uint8_t *d_dst, size_t nbytes) {
   const int fd = open(path, O_RDONLY);
   PGX_REQUIRE(fd >= 0, PGX_EIO, "cannot read %s", path);
-  const size_t P = (size_t)(getenv("PGX_LOAD_PIECE_MB") ? std::max(1, atoi(getenv("PGX_LOAD_PIECE_MB"))) : 32) << 20;
+  const size_t P = (size_t)32 << 20;
   const size_t npieces = (nbytes + P - 1) / P;
   const int NT = (int)std::min<size_t>(npieces, (size_t)(getenv("PGX_LOAD_THREADS") ? std::max(1, atoi(getenv("PGX_LOAD_THREADS"))) : 6));
   const int NBUF = (int)std::min<size_t>(npieces, (size_t)NT + 2);

@@ -457,12 +457,6 @@ struct PreOuter {
     const uint32_t min_n = getenv("PGX_EARLY_OUTER_MIN") ? (uint32_t)atol(getenv("PGX_EARLY_OUTER_MIN")) : 4096u;
     if (eg.n < min_n || eg.n >= (1u << 30)) return;   // (small sets: nothing to hide)
     started = true;
-    if (const char *dump = getenv("PGX_DUMP_OUTER_KEYS")) {   // (debugging aid: the first keys in insertion order, for tools/khash_bench.cpp)
-      if (FILE *f = fopen(dump, "wb")) {
-        fwrite(eg.keys.data(), sizeof(uint64_t), eg.n, f);
-        fclose(f);
-      }
-    }
     table.reserve(eg.n, big_alloc, big_free, pin_slot_alloc, pin_slot_free);
     cpu_set_t saved, node;   // (the memory node the stage's other host threads will be pinned to: chosen from the caller's CPU)
     const bool pin = choose_node(saved, node);
@@ -500,7 +494,7 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
   const size_t ng = pt.gkey0.size();
   if (!ng) return;
   const bool trace = getenv("PGX_TRACE") != nullptr;
-  if (trace && getenv("PGX_TRACE_GROUPS")) {   // buckets per first-key group (log2 classes): groups, buckets
+  if (trace && atoi(getenv("PGX_TRACE")) >= 3) {   // buckets per first-key group (log2 classes): groups, buckets
     uint64_t hg[33] = {0}, hb[33] = {0};
     for (size_t g = 0; g < ng; ++g) {
       const uint32_t n = pt.gbucket[g + 1] - pt.gbucket[g];
@@ -522,7 +516,6 @@ void build_visit(const PairTables &pt, uint32_t ovlp_upper, Visit &v, bool ids_o
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   // inner-table workers: 48 for a lone process (2 x 64 cores), fewer per rank when several ranks share the host
   static const unsigned nin_cap = [] {
-    if (const char *e = getenv("PGX_VISIT_THREADS")) return (unsigned)std::max(1, atoi(e));
     const char *lw = getenv("LOCAL_WORLD_SIZE");
     const int world = lw ? std::max(1, atoi(lw)) : 1;
     return (unsigned)std::max(12, 48 / world);
@@ -1276,7 +1269,7 @@ struct ParReplay {
       }
     }
   }
-  bool memo_prefetch = !(getenv("PGX_MEMO_PF") && atoi(getenv("PGX_MEMO_PF")) == 0);  // (measured: first round 160 -> 156 ms at 4.5 Gbases)
+  bool memo_prefetch = true;  // (measured: first round 160 -> 156 ms at 4.5 Gbases)
 
   // The alignment memo: the request number of (rid0, rid1, q_off, dir0, dir1), filing the request if it is new.
   uint32_t request_of(TL &t, uint32_t rid0, uint32_t rid1, uint32_t q_off, uint8_t dir0, uint8_t dir1) {
@@ -1638,12 +1631,12 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   // 1 Mb 11.8 vs 9.8 ms, 0.3 Mb 10.9 vs 6.1 ms).  PGX_GPU_REPLAY=1 / 0 forces either one; the host replay is also the
   // fallback for jobs the device tables' encodings do not hold.
   const int gpu_replay_env = getenv("PGX_GPU_REPLAY") ? atoi(getenv("PGX_GPU_REPLAY")) : -1;
-  static const size_t gpu_replay_min = getenv("PGX_GPU_REPLAY_MIN") ? (size_t)atoll(getenv("PGX_GPU_REPLAY_MIN")) : (size_t)200000;
+  static const size_t gpu_replay_min = 200000;   // pair records from which the device replay wins (tools/crossover.py)
   bool gpu_replay = gpu_replay_env != 0;  // (decided once the join has counted the records)
   const bool trace = getenv("PGX_TRACE") != nullptr;
-  const bool predict = !(getenv("PGX_PREDICT") && atoi(getenv("PGX_PREDICT")) == 0);
+  const bool predict = true;   // the type of a pending alignment is guessed from the geometry (predict_contained)
   DevicePairs dpairs;
-  static const bool early_outer = !(getenv("PGX_EARLY_OUTER") && atoi(getenv("PGX_EARLY_OUTER")) == 0);
+  static const bool early_outer = true;   // the outer khash table is replayed by a host thread DURING the join
   // the visit order on the device (pgx_visit.hip): the join's tables stay in HBM, the inner khash tables are replayed there, the
   // host only replays the outer one.  PGX_DEV_VISIT=0: the round-2 form (tables downloaded, inner tables by host threads).
   const bool dev_visit = gpu_replay && early_outer && !(getenv("PGX_DEV_VISIT") && atoi(getenv("PGX_DEV_VISIT")) == 0);

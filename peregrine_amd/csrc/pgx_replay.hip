@@ -1689,8 +1689,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   r.spread = spread.p;
   PGX_HIP(hipMemsetAsync(spread.p, 0, SPREAD * 8 * sizeof(unsigned long long), s));
   {
-    static const int mq = getenv("PGX_PREDICT_MQ") ? atoi(getenv("PGX_PREDICT_MQ")) : END_FUZZ * 2 - 8;
-    static const int mt = getenv("PGX_PREDICT_MT") ? atoi(getenv("PGX_PREDICT_MT")) : END_FUZZ * 2 - 8;
+    const int mq = END_FUZZ * 2 - 8, mt = END_FUZZ * 2 - 8;
     r.predict = predict ? std::max(mq, 1) : 0, r.predict2 = mt;
   }
   r.bestn = bestn, r.settled = 0;
@@ -1767,20 +1766,23 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     return hc->overflow == 0;
   };
   const size_t window = getenv("PGX_REPLAY_WIN") ? (size_t)atoll(getenv("PGX_REPLAY_WIN")) : (size_t)262144;
-  const size_t win0 = getenv("PGX_REPLAY_WIN0") ? (size_t)std::max(64ll, atoll(getenv("PGX_REPLAY_WIN0")) & ~63ll) : (size_t)16384;
-  const size_t win1 = getenv("PGX_REPLAY_WIN1") ? (size_t)std::max(64ll, atoll(getenv("PGX_REPLAY_WIN1")) & ~63ll) : (size_t)131072;  // largest window of the first pass
-  const size_t dense_min = getenv("PGX_REPLAY_DENSE_MIN") ? (size_t)atoll(getenv("PGX_REPLAY_DENSE_MIN")) : (size_t)SPARSE_CAP;  // dense rounds from this many dirty buckets
-  const size_t tail_max = getenv("PGX_REPLAY_TAIL") ? (size_t)atoll(getenv("PGX_REPLAY_TAIL")) : (size_t)4000;  // tail mode (file_for_reader, look-ahead) once a sweep asks for at most this many alignments, or 1/256 of the first sweep's
-  const uint32_t ahead = getenv("PGX_REPLAY_AHEAD") ? (uint32_t)std::max(1, atoi(getenv("PGX_REPLAY_AHEAD"))) : 24u;   // tail mode: partners of a row filed ahead
-  const bool use_win_list = !(getenv("PGX_REPLAY_WINLIST") && atoi(getenv("PGX_REPLAY_WINLIST")) == 0);
+  // The schedule's constants.  Every one of them was an environment knob through round 3; tools/knob_sweep.sh (profiles/r04f_knob_sweep_c4s.txt)
+  // moved each over its plausible range on the repeat-rich 9-Gbase set: 391-405 ms per step whatever the setting (only k_eval_big behind
+  // instead of beside the narrow kernel is worse, 417 ms), so they are constants now; PGX_REPLAY_WIN / _K stay because the parity
+  // tests randomise the schedule with them.
+  const size_t win0 = 16384, win1 = 131072;   // the first pass ramps its window from win0 up to win1
+  const size_t dense_min = SPARSE_CAP;        // dense rounds from this many dirty buckets
+  const size_t tail_max = 4000;               // tail mode (file_for_reader, look-ahead) once a sweep asks for at most this many alignments, or 1/256 of the first sweep's
+  const uint32_t ahead = 24u;                 // tail mode: partners of a row filed ahead
+  const bool use_win_list = true;
   const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 3;
-  const bool wide = !(getenv("PGX_REPLAY_WIDE") && atoi(getenv("PGX_REPLAY_WIDE")) == 0);  // sparse passes: a wavefront per bucket, four rows per step
-  const size_t dense_den = getenv("PGX_REPLAY_DENSE") ? (size_t)std::max(1, atoi(getenv("PGX_REPLAY_DENSE"))) : 3;  // dense rounds while more than 1/dense_den of the buckets is dirty
-  const bool wide_dense = getenv("PGX_REPLAY_WIDE") && atoi(getenv("PGX_REPLAY_WIDE")) >= 2;
+  const bool wide = true;          // sparse passes: a wavefront per bucket, four rows per step
+  const size_t dense_den = 3;      // dense rounds while more than 1/dense_den of the buckets is dirty
+  const bool wide_dense = false;   // (the dense rounds keep 16 lanes per bucket: measured)
   // sparse passes per host round trip.  Round 2 measured 2 .. 8 within 1 % of each other and kept 4; with the GPU no longer waiting for the
   // host elsewhere (round 3) the round trips and the k_file pass that precedes each one show: 8 instead of 4 = replay kernels 38.0 -> 35.5 ms
   // and the step 113.4 -> 111.2 ms at c3, c4s 437 -> 429 ms, c5s 651 -> 639 (6), the E. coli-size set unchanged
-  const bool big_side = !(getenv("PGX_REPLAY_BIG_SIDE") && atoi(getenv("PGX_REPLAY_BIG_SIDE")) == 0);   // k_eval_big beside the narrow kernel of a sparse pass
+  const bool big_side = true;   // k_eval_big beside the narrow kernel of a pass, on a second stream
   static hipStream_t side_stream = nullptr;
   static hipEvent_t side_ev[2] = {nullptr, nullptr};
   if (!side_stream) {
@@ -1792,8 +1794,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
         if (e) (void)hipEventDestroy(e), e = nullptr;
     });
   }
-  const int big_every = getenv("PGX_REPLAY_BIG_EVERY") ? std::max(1, atoi(getenv("PGX_REPLAY_BIG_EVERY"))) : 1;   // sparse passes per k_eval_big launch
-  const int chain = getenv("PGX_REPLAY_CHAIN") ? std::max(1, atoi(getenv("PGX_REPLAY_CHAIN"))) : 8;
+  const int big_every = 1;   // sparse passes per k_eval_big launch
+  const int chain = 8;       // sparse passes per host round trip
   static const bool deep = getenv("PGX_TRACE") && atoi(getenv("PGX_TRACE")) >= 2;  // per-kernel wall times (synchronises after every launch)
   const bool timed = getenv("PGX_REPLAY_TIMING") && atoi(getenv("PGX_REPLAY_TIMING")) != 0;  // "replay" in pgx_timing_get
   double td = 0, t_eval = 0, t_upd = 0;

@@ -1017,7 +1017,7 @@ bool sketch_blk_supported(int w, int k, int rs, int levels) { return k == K && s
 void launch_sketch_blk(const pgx_seqdb *db, const ReadDesc *d_reads, uint32_t n, int rs, int levels, pgx_mm128 *d_slab,
                        const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags) {
   if (!n) return;
-  static const int dbg = getenv("PGX_BLK_DBG") ? atoi(getenv("PGX_BLK_DBG")) : 0;   // timing experiments (wrong results when set)
+  const int dbg = 0;   // (round 2's timing experiments: bit 1 no emission, 2 no reduce, 4 no edge variants)
   hipLaunchKernelGGL((k_sketch_blk<5>), dim3(n), dim3(64), 0, ctx().stream, db->d_seq.p, d_reads, n, d_slab, d_slab_off, d_counts,
                      d_flags, rs, levels, dbg);
   PGX_HIP(hipGetLastError());

@@ -39,7 +39,6 @@ for wl in wls:
                 os.environ["PGX_GPU_REPLAY"] = "1"
                 os.environ["PGX_REPLAY_WIN"] = str(int(rng.choice([64, 1024, 16384, 262144, 1 << 22])))
                 os.environ["PGX_REPLAY_K"] = str(int(rng.choice([1, 2, 3, 5])))
-                os.environ["PGX_REPLAY_CHAIN"] = str(int(rng.choice([1, 4, 8, 13])))   # sparse passes per host round trip
                 os.environ["PGX_REPLAY_BIG"] = str(int(rng.choice([0, 2, 5, 24])))   # 2: nearly every bucket goes to the workgroup kernel
                 os.environ["PGX_REPLAY_DUP"] = str(int(rng.choice([0, 2, 2, 12])))   # the same for the buckets that hold a read twice
                 got, st = rdb.overlap(ix.top, ix.top_mc, **kw)

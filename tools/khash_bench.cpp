@@ -13,7 +13,7 @@ int main(int argc, char **argv) {
   std::mt19937_64 rng(7);
   std::vector<uint64_t> k;
   std::unordered_set<uint64_t> seen;
-  if (const char *kf = getenv("KB_KEYS")) {   // keys dumped by the library (PGX_DUMP_OUTER_KEYS)
+  if (const char *kf = getenv("KB_KEYS")) {   // keys dumped by the library (a debugging dump that round 3 had)
     FILE *f = fopen(kf, "rb");
     if (!f) return 1;
     fseek(f, 0, SEEK_END);

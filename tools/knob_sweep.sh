@@ -1,5 +1,6 @@
 #!/bin/bash
-# replay schedule knobs on one workload: ms per step of bench.py under each setting (the simulated set is cached once)
+# replay schedule knobs on one workload: ms per step of bench.py under each setting (the simulated set is cached once).  Round 4 ran it with
+# every schedule knob of round 3 (profiles/r04f_knob_sweep_c4s.txt: all within noise) and then turned all but the ones below into constants.
 #   usage: tools/knob_sweep.sh [workload=c4s] [steps=3]  -> gpurun_out/knob_sweep_<workload>.txt
 W=${1:-c4s}; S=${2:-3}
 export PGX_BENCH_CACHE=/dev/shm/pgx_bench_cache PGX_BENCH_NO_REPLAY_TIMING=1
@@ -21,18 +22,10 @@ PY
 }
 run baseline X=1
 run baseline-again X=1
-run DENSE_MIN=1e9 PGX_REPLAY_DENSE_MIN=1000000000
-run DENSE=2 PGX_REPLAY_DENSE=2
-run DENSE=6 PGX_REPLAY_DENSE=6
-run CHAIN=4 PGX_REPLAY_CHAIN=4
-run CHAIN=16 PGX_REPLAY_CHAIN=16
 run WIN=524288 PGX_REPLAY_WIN=524288
 run WIN=131072 PGX_REPLAY_WIN=131072
 run K=2 PGX_REPLAY_K=2
 run K=4 PGX_REPLAY_K=4
-run TAIL=20000 PGX_REPLAY_TAIL=20000
-run AHEAD=48 PGX_REPLAY_AHEAD=48
-run BIG_SIDE=0 PGX_REPLAY_BIG_SIDE=0
 run DUP=24 PGX_REPLAY_DUP=24
 run DUP=6 PGX_REPLAY_DUP=6
 run BIG=48 PGX_REPLAY_BIG=48
