@@ -101,7 +101,7 @@ typedef struct {
   pgx_mm128 *top; size_t n_top;         /* L1 (levels==1) or L2 */
   pgx_mm_count *top_mc; size_t n_top_mc;/* sorted by mer (the reference writes khash slot order; consumers only aggregate) */
   uint64_t bases; uint32_t reads;       /* what this chunk sketched */
-  uint32_t reads_literal;               /* reads routed to the literal-state-machine kernel (N, short, k>16 ...) */
+  uint32_t reads_literal;               /* reads sketched run by run (ambiguous bases, or flagged by a closed-form kernel: pgx_sketch_n.hip); the name is round 1's */
   double gpu_ms;                        /* device time of this call */
 } pgx_index_result;
 

@@ -2117,6 +2117,29 @@ void write_records(const char *out_path, const pgx_ovlp *rec, size_t n) {
 }
 }  // namespace
 
+namespace {
+// The index files a served job's overlap commands read are the SAME for all of them (every chunk globs every index chunk,
+// shmr_overlap.c:359-384): the resident form keeps the lists of the last shimmer prefix, as long as the files behind it have not
+// changed (names, sizes, mtimes).
+struct ListCache {
+  std::string prefix;
+  std::vector<std::pair<std::string, std::pair<long long, long long>>> files;   // path -> (size, mtime ns)
+  std::vector<pgx_mm128> mm;
+  std::vector<pgx_mm_count> mc;
+};
+void glob_identity(const std::string &pat, std::vector<std::pair<std::string, std::pair<long long, long long>>> &out) {
+  glob_t g;
+  if (glob(pat.c_str(), 0, nullptr, &g) == 0) {
+    for (size_t i = 0; i < g.gl_pathc; ++i) {
+      struct stat sb;
+      if (stat(g.gl_pathv[i], &sb) == 0)
+        out.push_back({g.gl_pathv[i], {(long long)sb.st_size, (long long)sb.st_mtim.tv_sec * 1000000000LL + sb.st_mtim.tv_nsec}});
+    }
+    globfree(&g);
+  }
+}
+}  // namespace
+
 int pgx_overlap_chunk_db(pgx_seqdb *db, const char *shimmer_prefix, const char *out_path, const pgx_overlap_params *p,
                          pgx_overlap_stats *stats) {
   int rc = PGX_OK;
@@ -2124,12 +2147,24 @@ int pgx_overlap_chunk_db(pgx_seqdb *db, const char *shimmer_prefix, const char *
     require_ready();
     PGX_REQUIRE(db && shimmer_prefix && out_path, PGX_EARG, "pgx_overlap_chunk_db: null argument");
     check_params(p);
-    std::vector<pgx_mm128> mm;
-    std::vector<pgx_mm_count> mc;
-    read_index_files(shimmer_prefix, mm, mc);
+    const bool trace = getenv("PGX_TRACE") != nullptr;
+    const double t0 = now_ms();
+    static ListCache cache;
+    std::vector<std::pair<std::string, std::pair<long long, long long>>> ident;
+    glob_identity(std::string(shimmer_prefix) + "-[0-9]*-of-[0-9]*.dat", ident);
+    glob_identity(std::string(shimmer_prefix) + "-MC-[0-9]*-of-[0-9]*.dat", ident);
+    if (cache.prefix != shimmer_prefix || cache.files != ident || ident.empty()) {
+      cache.prefix.clear();
+      cache.mm.clear(), cache.mc.clear();
+      read_index_files(shimmer_prefix, cache.mm, cache.mc);
+      cache.prefix = shimmer_prefix, cache.files = ident;
+    }
+    const double t1 = now_ms();
     OvOut v;
-    run_overlap(db, mm.data(), mm.size(), mc.data(), mc.size(), p, v, stats);
+    run_overlap(db, cache.mm.data(), cache.mm.size(), cache.mc.data(), cache.mc.size(), p, v, stats);
+    const double t2 = now_ms();
     write_records(out_path, v.a, v.n);
+    if (trace) fprintf(stderr, "[pgx] overlap chunk (resident database): index files %.1f ms, stage %.1f ms, %zu records written in %.1f ms\n", t1 - t0, t2 - t1, v.n, now_ms() - t2);
   } catch (const Fail &f) {
     rc = f.code;
   } catch (const std::bad_alloc &) {

@@ -221,6 +221,90 @@ def test_repeat_seeded_full_chunk_equals_reference_binary(name, chunk):
                     os.remove(os.path.join(d, f))
 
 
+def test_configs3_at_full_size_on_one_gpu():
+    """BASELINE configs[3] at its STATED size: a 3.1 Gb repeat-seeded genome x 30x = 6.2 M reads, 93 Gbases, generated
+    into one device buffer the library adopts; index_nchunk = ovlp_nchunk = 8 run one after the other on the one GPU (bench.py's default
+    workload).  Properties on every chunk, the record count of the whole job (pinned: the generator is seeded), and ONE overlap chunk of
+    192 -- 2.8 M records -- field for field against the real reference binary on the same files (~2 minutes of one host core)."""
+    import torch
+    if torch.cuda.mem_get_info()[1] < 280e9:
+        pytest.skip("needs a GPU with 288 GB of HBM")
+    base = _scratch(115 << 30)
+    if base is None or not U.have_ref():
+        pytest.skip("needs 115 GB of scratch space and oracle/_ref")
+    rng = np.random.default_rng(5)
+    torch.cuda.empty_cache()
+    seq, total, rlen = simreads.make_workload_resident("c4")
+    assert len(rlen) == 6_200_080 and total > 93e9
+    rid = np.arange(len(rlen), dtype=np.uint32)
+    roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
+    rdb = ResidentDB.adopt_device(seq, total, rid, rlen, roff, 0)
+
+    def read_bytes(r):
+        return seq[int(roff[r]):int(roff[r]) + int(rlen[r])].cpu().numpy()
+
+    from peregrine_amd import _lib
+    from peregrine_amd.parallel import GpuEngine
+    eng = GpuEngine(rdb, torch.device("cuda", 0))
+    N = 8
+    tops, mcs = [], []
+    for c in range(1, N + 1):
+        ix, top, mc = eng.index(N, c, 2)
+        _lib.stream_signal()
+        tops.append(top.clone()), mcs.append(mc.clone())
+        t = tops[-1].cpu().numpy().view(formats.MM_DTYPE)
+        r_ = (t["y"] >> np.uint64(32)).astype(np.int64)
+        assert np.all(r_ % N == c % N) and np.all(np.diff(r_) >= 0)
+        starts = np.searchsorted(r_, np.arange(len(rlen) + 1))
+        for r in rng.choice(np.flatnonzero(rid % N == c % N), 3, replace=False):
+            want = U.orc_reduce(U.orc_reduce(U.orc_sketch_seqdb(read_bytes(r), 80, 16, int(r)), 6), 6)
+            assert np.array_equal(t[starts[r]:starts[r + 1]], want), (c, int(r))
+        if c == 1:
+            keep_chunk1 = t.copy()
+        del t
+    mm, mc = torch.cat(tops), torch.cat(mcs)
+    del tops, mcs
+    _lib.stream_wait()
+    total_records = 0
+    for c in range(1, N + 1):
+        ov, st = rdb.overlap_dev(mm.data_ptr(), mm.numel() // 16, mc.data_ptr(), mc.numel() // 16, total_chunk=N, mychunk=c)
+        assert st["device_replay"] == 1 and st["n_records"] == len(ov)
+        r0 = (ov["y0"] >> np.uint64(32)).astype(np.int64)
+        r1 = (ov["y1"] >> np.uint64(32)).astype(np.int64)
+        pair = np.minimum(r0, r1) << 32 | np.maximum(r0, r1)
+        assert len(np.unique(pair)) == len(pair)             # a read pair once per chunk
+        for i in rng.integers(0, len(ov), 6):
+            o = ov[i]
+            p0 = ((int(o["y0"]) & 0xFFFFFFFF) >> 1) + 1
+            p1 = ((int(o["y1"]) & 0xFFFFFFFF) >> 1) + 1
+            m = U.orc_ovlp_match(read_bytes(r0[i])[p0 - p1:], int(o["strand0"]), read_bytes(r1[i]), int(o["strand1"]), 100)
+            assert m == tuple(int(o[f]) for f in formats.MATCH_FIELDS), (c, int(i))
+        total_records += len(ov)
+        del ov, r0, r1, pair
+    assert total_records == 366_003_067, total_records           # (profiles/r04d_bench_c4_sample.json: records_per_step)
+    # one chunk of 192 against the reference binary, on files
+    d = tempfile.mkdtemp(prefix="pgx_c4_", dir=base)
+    try:
+        pre = os.path.join(d, "sd")
+        simreads.write_seqdb_from_device(pre, seq, total, rid, rlen, roff)
+        for c in range(1, N + 1):
+            p = rdb.index(total_chunk=N, mychunk=c, levels=2)
+            formats.write_mmlist(os.path.join(d, "ix-L2-%02d-of-%02d.dat" % (c, N)), p.top)
+            formats.write_mm_count(os.path.join(d, "ix-L2-MC-%02d-of-%02d.dat" % (c, N)), p.top_mc)
+            if c == 1:
+                assert np.array_equal(p.top, keep_chunk1)
+        T, c = 192, 7
+        U.ref_run("shmr_overlap", "-p", pre, "-l", os.path.join(d, "ix-L2"), "-t", T, "-c", c, "-o", os.path.join(d, "ref.ovlp"))
+        want = formats.read_ovlp(os.path.join(d, "ref.ovlp"))
+        ov, st = rdb.overlap_dev(mm.data_ptr(), mm.numel() // 16, mc.data_ptr(), mc.numel() // 16, total_chunk=T, mychunk=c)
+        assert len(want) > 2_000_000 and formats.ovlp_fields_equal(np.asarray(ov), want)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+        rdb.close()
+        del seq, mm, mc
+        torch.cuda.empty_cache()
+
+
 def test_zz_scratch_files_removed():
     """the 9 GB seqdb file the two reference comparisons share goes away with the session"""
     if _SET.get("files_dir"):

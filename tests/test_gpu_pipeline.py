@@ -138,8 +138,8 @@ def test_served_mode_writes_the_same_files(tmp_path):
             assert (tmp_path / "srv" / f"ix-L2-{c:02d}-of-02.dat").read_bytes() == (tmp_path / "ref" / f"ix-L2-{c:02d}-of-02.dat").read_bytes()
         for c in (1, 2, 3):
             assert (tmp_path / "srv" / f"ov.{c}").read_bytes() == (tmp_path / "ref" / f"ov.{c}").read_bytes()
-        # errors come back with the exit status (no index files behind that prefix)
-        bad = subprocess.run([cli, "shmr_overlap", "-p", pre, "-l", "nothing-L2", "-o", "x"], cwd=tmp_path / "srv", capture_output=True, text=True)
+        # errors come back with the exit status and the library's message (chunk 7 of 3)
+        bad = subprocess.run([cli, "shmr_overlap", "-p", pre, "-l", "ix-L2", "-t", "3", "-c", "7", "-o", "x"], cwd=tmp_path / "srv", capture_output=True, text=True)
         assert bad.returncode != 0 and "pgx_overlap_chunk_db failed" in bad.stderr
         # another prefix: no socket for it -> stand-alone
         r = subprocess.run([cli, "shmr_index", "-p", other, "-m", "0", "-o", str(tmp_path / "alone" / "o")], check=True, capture_output=True, text=True)

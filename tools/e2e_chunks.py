@@ -42,7 +42,8 @@ try:
     res["stand_alone"] = commands("alone")
     print("stand-alone:", res["stand_alone"], flush=True)
     t0 = time.perf_counter()
-    srv = subprocess.Popen([cli, "serve", "-p", pre], stderr=subprocess.DEVNULL)
+    srv_log = open(os.path.join(ROOT, "gpurun_out", "e2e_server_trace.log"), "w") if os.environ.get("E2E_SERVER_TRACE") else subprocess.DEVNULL
+    srv = subprocess.Popen([cli, "serve", "-p", pre], stderr=srv_log, env=dict(os.environ, PGX_TRACE="1") if os.environ.get("E2E_SERVER_TRACE") else None)
     while not os.path.exists(pre + ".pgx.sock") and srv.poll() is None:
         time.sleep(0.05)
     t_up = time.perf_counter() - t0
