@@ -68,6 +68,9 @@ def parse():
                          "(configs[1]) | c4s | c5s (repeat-seeded, scaled configs[3]/[4], one chunk) | small | tiny")
     ap.add_argument("--chunks", type=int, default=0, help="c4 family: index_nchunk = ovlp_nchunk of the job (default 8); must be a multiple of --gpus")
     ap.add_argument("--genome-mb", type=float, default=0, help="c4 family: genome size in Mb (default 3100; the repeat content scales with it)")
+    ap.add_argument("--ambiguous-frac", type=float, default=0.0,
+                    help="one-chunk workloads: this fraction of the reads gets 1-3 ambiguous bases (both strands' nibbles zeroed, seeded): the index "
+                         "stage then takes those reads run by run (pgx_sketch_n.hip), the packed alignment kernel hands their candidates on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", default=None, choices=("full", "sample"),
                     help="one-chunk workloads -- full (default): the reference binaries on the WHOLE workload: one process on one core (its "
@@ -556,6 +559,17 @@ def main():
             cfg = dict(simreads.WORKLOADS[a.workload])
             g = simreads.make_genome(cfg.pop("genome_len"), cfg.pop("genome_seed") + 7919 * rank)
             mine = simreads.simulate_reads(g, seed=42 + rank, **cfg)
+        if a.ambiguous_frac > 0:
+            rng = np.random.default_rng(777 + rank)
+            sq = np.array(mine.seqdb, copy=True)
+            picked = rng.choice(mine.n_reads, max(1, int(a.ambiguous_frac * mine.n_reads)), replace=False)
+            for r in picked:
+                o, n = int(mine.roff[r]), int(mine.rlen[r])
+                for ppos in rng.integers(0, n, int(rng.integers(1, 4))):
+                    sq[o + ppos] = 0                      # ambiguous on the forward strand ...
+                    sq[o + n - 1 - ppos] &= 0x0F          # ... and its mirror image on the reverse strand's nibble
+            mine = SeqDB(sq, mine.rid, mine.rlen, mine.roff, None)
+            log(f"{len(picked)} reads with ambiguous bases")
         if multi:
             # the job's read set = the union of the ranks' sets, replicated in every GPU's HBM: every rank's bytes are
             # received over xGMI (RCCL) straight into their place in ONE device buffer, which the library adopts without a copy
@@ -759,7 +773,8 @@ def main():
             par = f"chunks{CH}/gpus{world}" + (f"+alltoall({comm})" if world > 1 and len(my_chunks) == 1 else f"+allgather({comm})" if world > 1 else "")
         else:
             workload = (f"{a.workload}: {wl} per rank, 15 kb +-1.5 kb reads, 1 % errors, "
-                        f"k=16 w=80 r=6 l={LEVELS}, index_nchunk=ovlp_nchunk={world}, bestn 4, mc 2..240, aln_bw 100")
+                        f"k=16 w=80 r=6 l={LEVELS}, index_nchunk=ovlp_nchunk={world}, bestn 4, mc 2..240, aln_bw 100"
+                        + (f", {a.ambiguous_frac:g} of the reads with 1-3 ambiguous bases" if a.ambiguous_frac > 0 else ""))
             par = f"chunks{world}" + ("+forced-exchange(rccl)" if multi and world == 1 else "")
         out = {
             "metric": "confirmed overlaps/sec (ovlp_t records, index+overlap stages, seqdb resident in HBM)",
