@@ -37,6 +37,7 @@ DEFAULT_WORKLOAD = "c4"
 WORKLOAD_TEXT = {
     "c4": "BASELINE configs[3] at FULL size (the configuration the metric is quoted on): 3.1 Gb genome seeded with 207 families of 300 copies "
           "of a 6 kb unit at 1 % divergence, 31 k tandem arrays and 31 k homopolymer runs (CHM13 is not obtainable offline) x 30x",
+    "c5": "BASELINE configs[4] at FULL size: the configs[3] read set (3.1 Gb repeat-seeded genome x 30x) with -l 1 (dense L1 shimmers) and mc_upper 240",
     "c3": "BASELINE configs[2], uniform-random 150 Mb genome x 30x",
     "ecoli": "BASELINE configs[1], E. coli-size uniform-random genome (4,639,675 bp), 4,984 reads",
     "c4s": "BASELINE configs[3] scaled to one GPU, 300 Mb genome seeded with 6 kb x 300-copy repeat families, tandem arrays and homopolymers x 30x",
@@ -83,7 +84,7 @@ def parse():
                     help="c4 family, small --genome-mb only: after the timed steps every rank compares the ovlp_t stream of each of its "
                          "chunks, field by field, with oracle/_ref/shmr_overlap -t CHUNKS -c c on files rank 0 writes")
     a = ap.parse_args()
-    big = a.workload == "c4" and not a.genome_mb
+    big = a.workload in ("c4", "c5") and not a.genome_mb
     if a.steps is None:
         a.steps = 3 if big else 10
     if a.warmup is None:
@@ -351,7 +352,7 @@ def _run_many(n_workers, jobs):
     return time.perf_counter() - t0
 
 
-def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, job_chunks, gpu_index_files):
+def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, job_chunks, gpu_index_files, job_lists):
     """c4 family (one read set, CHUNKS index + overlap chunks): the REAL reference (oracle/_ref) on this box's host cores, on the same
     bytes (the device-resident seqdb written to files), 24 processes at a time (the reference's own practical ceiling,
     /root/reference/README.md:127-137):
@@ -397,13 +398,18 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
         log(f"cpu baseline: reference overlap leg {t_ovlp:.1f} s")
         # ---- the GPU on the same (T, c), same index chunking, for the first two chunks: field-for-field compare
         dev = torch.device("cuda", torch.cuda.current_device())
-        tops, mcs = [], []
-        for c in range(1, index_chunking + 1):
-            _, top, mc = eng.index(index_chunking, c, levels)
-            _lib.stream_signal()
-            tops.append(top.clone()); mcs.append(mc.clone())
-        mm_all, mc_all = torch.cat(tops), torch.cat(mcs)
-        del tops, mcs
+        if index_chunking == job_chunks and job_lists.get("mm") is not None:
+            mm_all, mc_all = job_lists["mm"], job_lists["mc"]      # the timed steps' own lists (still in HBM)
+        else:
+            job_lists.clear()                                       # (their HBM is needed: 276-285 of 288 GB are in use at full size)
+            torch.cuda.empty_cache()
+            tops, mcs = [], []
+            for c in range(1, index_chunking + 1):
+                _, top, mc = eng.index(index_chunking, c, levels)
+                _lib.stream_signal()
+                tops.append(top.clone()); mcs.append(mc.clone())
+            mm_all, mc_all = torch.cat(tops), torch.cat(mcs)
+            del tops, mcs
         same_index = None
         if mode == "full":
             got = mm_all.cpu().numpy().view(formats.MM_DTYPE)
@@ -588,18 +594,30 @@ def main():
     SUM_KEYS = ("n_records", "n_pair_records", "n_buckets", "n_align_needed", "n_align_gpu", "n_seen_skip", "n_evaluations", "gpu_ms", "host_ms", "device_visit")
     keep_streams = {}
 
+    held = {}   # N = 1, several chunks: the concatenated lists live in ONE pair of buffers kept across the steps (sizes repeat)
+
     def index_my_chunks():
         """the rank's index chunks; the lists / count tables as device byte tensors (copies: the library reuses its buffers)"""
         tops, mcs, bases, ix = [], [], 0, None
+        om = oc = 0
         for c in my_chunks:
             ix, top, mc = eng.index(CH, c, sp["levels"])
             bases += ix.bases
             if len(my_chunks) > 1:
                 _lib.stream_signal()
-                top, mc = top.clone(), mc.clone()
+                if "mm" in held and om + top.numel() <= held["mm"].numel() and oc + mc.numel() <= held["mc"].numel():
+                    held["mm"][om:om + top.numel()].copy_(top), held["mc"][oc:oc + mc.numel()].copy_(mc)   # straight into place
+                    top, mc = held["mm"][om:om + top.numel()], held["mc"][oc:oc + mc.numel()]
+                else:
+                    held.clear()
+                    top, mc = top.clone(), mc.clone()
+                om, oc = om + top.numel(), oc + mc.numel()
             tops.append(top)
             mcs.append(mc)
         ix.bases = bases
+        if held and (om != held["mm"].numel() or oc != held["mc"].numel()):
+            held.clear()
+            tops, mcs = [t.clone() for t in tops], [t.clone() for t in mcs]
         return ix, tops, mcs
 
     def step_strong():
@@ -616,8 +634,16 @@ def main():
         if world > 1:       # several chunks per rank: the lists of ALL chunks, in chunk order, all-gathered round by round (round j = chunks j N + 1 .. j N + N)
             mm_all = torch.cat([allgather_cat(t, world)[0] for t in tops])
             mc_all = torch.cat([allgather_cat(t, world)[0] for t in mcs])
+        elif held:
+            mm_all, mc_all = held["mm"], held["mc"]
+        elif len(tops) > 1:      # the first step: concatenate, keep the buffers, give the pieces back to the driver
+            mm_all, mc_all = torch.cat(tops), torch.cat(mcs)
+            held["mm"], held["mc"] = mm_all, mc_all
+            del tops, mcs
+            tops = mcs = None
+            torch.cuda.empty_cache()
         else:
-            mm_all, mc_all = (torch.cat(tops), torch.cat(mcs)) if len(tops) > 1 else (tops[0], mcs[0])
+            mm_all, mc_all = tops[0], mcs[0]
         del tops, mcs
         _lib.stream_wait()
         tot, nrec = None, 0
@@ -765,7 +791,7 @@ def main():
         if strong:
             gm = a.genome_mb or simreads.WORKLOADS[a.workload]["genome_len"] / 1e6
             if a.genome_mb:
-                wl = f"the c4 recipe on a {gm:g} Mb genome (repeat content scaled with the size) x 30x"
+                wl = f"the {a.workload} recipe on a {gm:g} Mb genome (repeat content scaled with the size) x 30x"
             workload = (f"{a.workload}: {wl}, ONE read set held by every rank, 15 kb +-1.5 kb reads, 1 % errors, k=16 w=80 r=6 l={LEVELS}, "
                         f"index_nchunk=ovlp_nchunk={CH} dealt round-robin to {world} GPU(s) ({len(my_chunks)} index + {len(my_chunks)} overlap chunks per GPU per step), "
                         f"bestn 4, mc 2..{sp['mc_upper']}, aln_bw 100")
@@ -806,7 +832,7 @@ def main():
                         p = rdb.index(total_chunk=CH, mychunk=c, levels=sp["levels"])
                         formats.write_mmlist("%s-L%d-%02d-of-%02d.dat" % (prefix, sp["levels"], c, CH), p.top)
                         formats.write_mm_count("%s-L%d-MC-%02d-of-%02d.dat" % (prefix, sp["levels"], c, CH), p.top_mc)
-                out["cpu_baseline"] = cpu_baseline_chunked(seq_dev, total, db, rdb, eng, a.workload, a.cpu_baseline or "sample", sp["levels"], sp["mc_upper"], CH, gpu_index_files)
+                out["cpu_baseline"] = cpu_baseline_chunked(seq_dev, total, db, rdb, eng, a.workload, a.cpu_baseline or "sample", sp["levels"], sp["mc_upper"], CH, gpu_index_files, held)
             elif a.cpu_baseline == "sample":
                 sample = simreads.simulate_reads_torch(10_000_000, 1003, 30.0, seed=42)
                 out["cpu_baseline"] = cpu_baseline_sample(sample)

@@ -530,7 +530,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
         if (gl == 0) V[1 & mask] = (VT)0;  // the only slot read before it is written (d = 0 reads V[k+1] = V[1])
         phase = PH_STEP;
         if (PACKED && ((nflag[key.rid0] | nflag[key.rid1]) & 1u)) {   // an ambiguous base has no 2-bit code: the byte-wise launch takes it
-          if (gl == 0) esc_list[atomicAdd(esc_n, 1u)] = a;
+          if (gl == 0) esc_list[n + atomicAdd(esc_n + 1, 1u)] = a;      // (second list of the escalation block: [4 + n ..), count at [1])
           phase = PH_FETCH;
         }
       }
@@ -782,12 +782,21 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
   const uint32_t *packs = (packed_min >= 0 && ((long)n >= packed_min || seq_packs_valid(db))) ? seq_packs(db) : nullptr;
   if (packs) {
     const uint32_t iter_limit = getenv("PGX_ALIGN_ITER_LIMIT") ? (uint32_t)atol(getenv("PGX_ALIGN_ITER_LIMIT")) : 2500u;   // (0: no hand-on of stragglers)
-    uint32_t *esc = ws<uint32_t>("align.esc", n + 4);   // [0] handed-on count, [4..) list
+    // escalation block: [0] stragglers handed on, [1] candidates that touch a read without 2-bit codes, [2] the byte-wise launch's work
+    // counter, [4 .. 4 + n) the stragglers, [4 + n .. 4 + 2 n) the others
+    uint32_t *esc = ws<uint32_t>("align.esc", 2 * n + 4);
     PGX_HIP(hipMemsetAsync(esc, 0, 4 * sizeof(uint32_t), st));
     hipLaunchKernelGGL((k_align_ph<8, uint16_t, true>), dim3(grid), dim3(64), lds, st, reinterpret_cast<const uint8_t *>(packs), db->d_roff.p,
                        db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter, (const uint32_t *)nullptr, (const uint32_t *)nullptr, esc,
                        esc + 4, db->d_nflag.p, seq_pack_stride(db), iter_limit);
-    // what it handed on, a wavefront per candidate, from the list
+    // candidates on reads with ambiguous bases: the same phase machine on the seqdb bytes, eight per wavefront, from their list (round 3 gave
+    // each a wavefront of its own through k_align1_list: 5 % of the reads flagged = +64 % alignment time at c3).  Only when the database
+    // holds such a read at all.
+    if (db->n_flagged_reads)
+      hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3((unsigned)std::min<size_t>(n / 64 + 64, (size_t)ctx().num_cu * per_cu)), dim3(64), lds, st,
+                         db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, esc + 2, esc + 1, esc + 4 + n, esc, esc + 4,
+                         (const uint32_t *)nullptr, (size_t)0, iter_limit);
+    // the stragglers of either launch, a wavefront per candidate, from the list
     hipLaunchKernelGGL(k_align1_list, dim3((unsigned)std::min<size_t>(std::max<size_t>(n / 256, 256), (size_t)ctx().num_cu * 32)), dim3(64),
                        ring * sizeof(int32_t), st, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, esc, esc + 4, band, ring, d_out);
   } else {

@@ -155,6 +155,7 @@ struct pgx_seqdb {
   mutable pgx::DevBuf<uint64_t> d_roff_sorted;   // read offsets ascending + their rids (position -> read, for d_nflag)
   mutable pgx::DevBuf<uint32_t> d_rid_sorted;
   mutable bool packs_built = false, packs_failed = false;   // (failed: no HBM for them -- the byte-wise kernels serve this database)
+  mutable uint32_t n_flagged_reads = 0;                     // reads marked in d_nflag (known once the packs are built)
   pgx::DevBuf<uint64_t> d_roff;    // indexed by rid
   pgx::DevBuf<uint32_t> d_rlen;    // indexed by rid
   std::vector<uint32_t> rid, rlen; // idx-file order

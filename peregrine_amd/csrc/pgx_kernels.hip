@@ -603,6 +603,17 @@ __global__ __launch_bounds__(64) void k_reduce_read(pgx_mm128 *__restrict__ slab
   if (lane == 0) counts_top[slot] = (uint32_t)ncur;
 }
 
+__global__ void k_set_aside_ambiguous(uint32_t *__restrict__ flags, uint32_t n, uint32_t *__restrict__ mark) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t f = flags[i];
+  mark[i] = (f & 2u) ? 1u : 0u;   // k_sketch_blk's "ambiguous base" bit
+  if (f & 2u) flags[i] = 0;
+}
+__global__ void k_restore_marks(uint32_t *__restrict__ flags, uint32_t n, const uint32_t *__restrict__ mark) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && mark[i]) flags[i] |= 2u;
+}
 __global__ void k_count_flags(const uint32_t *__restrict__ flags, uint32_t n, uint32_t *__restrict__ nbad) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && flags[i]) atomicAdd(nbad, 1u);
@@ -687,6 +698,10 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
       KernelTimer tm("sketch", bases);
       launch_sketch_blk(db, d_reads, n, rs, levels, slab, d_slab_off, d_ctop, d_flags);
     }
+    // reads with an ambiguous base (flag bit 2) skip the two redo passes below -- the fused wave kernel would walk them whole only to flag
+    // them again -- and go straight to the run-by-run path at the end (their mark is put back once the passes are through)
+    uint32_t *d_nmark = ws<uint32_t>("ix.nmark", n);
+    hipLaunchKernelGGL(k_set_aside_ambiguous, dim3(cdiv(n, 256)), dim3(256), 0, st, d_flags, n, d_nmark);
     // the flagged reads, once more on the general closed-form kernel
     uint32_t *d_list = ws<uint32_t>("ix.redo", (size_t)n + 1);
     size_t sbytes = 0;
@@ -740,6 +755,7 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
         if (trace) fprintf(stderr, "[pgx] index: %u reads outgrew their slabs and were redone into exact ones (%llu elements)\n", n_redo2, (unsigned long long)total2);
       }
     }
+    hipLaunchKernelGGL(k_restore_marks, dim3(cdiv(n, 256)), dim3(256), 0, st, d_flags, n, d_nmark);
     hipLaunchKernelGGL(k_count_flags, dim3(cdiv(n, 256)), dim3(256), 0, st, d_flags, n, d_nbad);
   } else if (want_fuse && sketch_fused_supported(w, rs, levels)) {
     KernelTimer tm("sketch", bases);

@@ -9,6 +9,8 @@
 // in every overlap stage): built by the first large alignment launch -- 1.6 ms per 4.5 GB, at the memory roofline -- and reused by
 // every later stage on the same database, on every rank of a multi-GPU job (whose seqdb replica grows with the job while its chunk
 // does not).  If their HBM (seqdb / 2) cannot be had, the alignment launches stay on the byte-wise kernels.
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 
 #include "pgx_internal.h"
@@ -96,6 +98,16 @@ const uint32_t *seq_packs(const pgx_seqdb *db) {
   hipLaunchKernelGGL(k_pack2, dim3(grid), dim3(256), 0, st, reinterpret_cast<const uint4 *>(db->d_seq.p), nwords, db->d_pack.p, db->d_pack.p + stride,
                      db->d_roff_sorted.p, db->d_rid_sorted.p, (uint32_t)db->rid.size(), db->nbytes, db->d_nflag.p);
   PGX_HIP(hipGetLastError());
+  {   // how many reads hold a byte without a 2-bit code (0 for everything the reference's encoder wrote from ACGT reads): the alignment
+      // launches only start their byte-wise second launch when there is one
+    uint32_t *d_cnt = ws<uint32_t>("pack.nflag_count", 1);
+    size_t rb = 0;
+    PGX_HIP(hipcub::DeviceReduce::Sum(nullptr, rb, db->d_nflag.p, d_cnt, (int)nr, st));
+    void *rt = ws_raw("pack.red_tmp", rb);
+    PGX_HIP(hipcub::DeviceReduce::Sum(rt, rb, db->d_nflag.p, d_cnt, (int)nr, st));
+    PGX_HIP(hipMemcpyAsync(&db->n_flagged_reads, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    sync();
+  }
   db->packs_built = true;
   return db->d_pack.p;
 }

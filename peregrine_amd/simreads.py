@@ -306,16 +306,21 @@ WORKLOADS = {
     # arrays, 31 k homopolymer runs) x 30x = 6.2 M reads, 93 Gbases -- generated into a device buffer (RESIDENT_WORKLOADS)
     "c4": dict(genome_len=3_100_000_000, genome_seed=1004, coverage=30.0, repeat_families=207, repeat_len=6000, repeat_copies=300,
                divergence=0.01, tandem=31000, homopolymers=31000),
+    # C5 (configs[4]) at full size: the SAME read set as c4, indexed with -l 1 (dense L1 shimmers, ~3.2x the L2 list) under mc_upper 240
+    "c5": dict(genome_len=3_100_000_000, genome_seed=1004, coverage=30.0, repeat_families=207, repeat_len=6000, repeat_copies=300,
+               divergence=0.01, tandem=31000, homopolymers=31000),
     # the same recipes on a slice small enough for the CPU oracle (parity tests)
     "c4t": dict(genome_len=20_000_000, genome_seed=1004, coverage=30.0, repeat_families=4, repeat_len=6000, repeat_copies=300,
                 divergence=0.01, tandem=200, homopolymers=200),
 }
 # stage parameters that differ from the defaults (k=16 w=80 r=6 l=2, bestn 4, mc 2..240, aln_bw 100, ovlp_upper 120)
-STAGE_PARAMS = {"c5s": dict(levels=1, mc_upper=240), "c4s": dict(levels=2, mc_upper=240), "c4": dict(levels=2, mc_upper=240, chunks=8)}
+STAGE_PARAMS = {"c5s": dict(levels=1, mc_upper=240), "c4s": dict(levels=2, mc_upper=240), "c4": dict(levels=2, mc_upper=240, chunks=8),
+                # (16 chunks on ONE GPU: an l = 1 chunk of 8 would need twice the HBM the seqdb and its packs leave for a chunk's tables)
+                "c5": dict(levels=1, mc_upper=240, chunks=16)}
 TORCH_WORKLOADS = ("c3", "c4s", "c5s", "c4t")   # generated on the GPU (multi-Gbase sets in seconds instead of tens of minutes)
 
 
-RESIDENT_WORKLOADS = ("c4",)                    # generated straight into ONE device buffer the library adopts (no host copy)
+RESIDENT_WORKLOADS = ("c4", "c5")                   # generated straight into ONE device buffer the library adopts (no host copy)
 
 
 def make_workload_resident(name: str, device: str = "cuda", progress=None, genome_mb: float | None = None):
