@@ -315,8 +315,10 @@ WORKLOADS = {
 }
 # stage parameters that differ from the defaults (k=16 w=80 r=6 l=2, bestn 4, mc 2..240, aln_bw 100, ovlp_upper 120)
 STAGE_PARAMS = {"c5s": dict(levels=1, mc_upper=240), "c4s": dict(levels=2, mc_upper=240), "c4": dict(levels=2, mc_upper=240, chunks=8),
-                # (16 chunks on ONE GPU: an l = 1 chunk of 8 would need twice the HBM the seqdb and its packs leave for a chunk's tables)
-                "c5": dict(levels=1, mc_upper=240, chunks=16)}
+                # (24 chunks on ONE GPU: an l = 1 chunk of 8 would need twice the HBM the seqdb and its packs leave for a chunk's tables.  With 16
+                #  chunks one pass ran in 23.2 s with 285 of 288 GB in use -- profiles/r04k_bench_c5_full_size_1step_nocpu.json -- and a second
+                #  run, with the reference's 24 processes beside it, lost the box: not a configuration to leave as a default)
+                "c5": dict(levels=1, mc_upper=240, chunks=24)}
 TORCH_WORKLOADS = ("c3", "c4s", "c5s", "c4t")   # generated on the GPU (multi-Gbase sets in seconds instead of tens of minutes)
 
 

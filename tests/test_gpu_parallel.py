@@ -201,6 +201,30 @@ def test_rccl_exchange_as_one_rank_job(tmp_path):
     assert formats.ovlp_fields_equal(direct, want)
 
 
+@pytest.mark.skipif(not U.have_ref(), reason="needs the prebuilt reference binaries (oracle/_ref)")
+@pytest.mark.parametrize("ranks,chunks", [(1, 4), (2, 2), (2, 4)])
+def test_bench_strong_scaling_form_of_configs3_against_the_reference(ranks, chunks):
+    """bench.py's c4 family (BASELINE configs[3] AS STATED: one read set on every rank, the job's chunks dealt to the ranks, strong
+    scaling) on a 12 Mb genome of the same recipe: one rank with 4 chunks; two ranks sharing the GPU under gloo with 2 chunks (one
+    chunk per rank: count all-gather + pair-record all-to-all) and with 4 (two per rank: lists all-gathered round by round).  Every rank
+    compares the ovlp_t stream of each of its chunks with oracle/_ref/shmr_overlap -t C -c c on files (--check-ref)."""
+    import json
+    import subprocess
+    cmd = [sys.executable]
+    env = dict(os.environ)
+    if ranks > 1:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port", str(_free_port())]
+        env["PGX_BENCH_BACKEND"] = "gloo"
+    cmd += [os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--workload", "c4", "--genome-mb", "12", "--chunks", str(chunks), "--check-ref",
+            "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    chk = line["check_vs_reference"]
+    assert chk["all_equal"] is True and len(chk["chunks"]) == chunks and all(c["records"] > 50_000 for c in chk["chunks"]), chk
+    assert line["scaling"] == "strong" and line["n_gpus"] == ranks and line["records_per_step"] == sum(c["records"] for c in chk["chunks"])
+
+
 def test_shutdown_forgets_device_state():
     """pgx_shutdown() must reset the plan caches / held buffers, or a pgx_seqdb that outlives a shutdown + init runs the
     sketch kernels on freed descriptors.  Runs in its own process (one context per process)."""
