@@ -647,9 +647,12 @@ def main():
         del tops, mcs
         _lib.stream_wait()
         tot, nrec = None, 0
+        was_async = _lib.results_async(True)    # a chunk's records travel to the host while the next chunk's join and first sweep run
+        prev = None                             # (the array of the chunk before: freeing it would wait for its copy)
         for c in my_chunks:
             ov, st = rdb.overlap_dev(mm_all.data_ptr(), mm_all.numel() // 16, mc_all.data_ptr(), mc_all.numel() // 16, total_chunk=CH, mychunk=c, **ov_params)
             nrec += len(ov)
+            prev = ov
             if a.check_ref:
                 keep_streams[c] = ov
             if tot is None:
@@ -660,6 +663,9 @@ def main():
                 tot["rounds"] = max(tot["rounds"], st["rounds"])
                 tot["device_replay"] = min(tot["device_replay"], st["device_replay"])
             del ov
+        _lib.results_wait()                     # the last chunk's records have arrived: the step is complete
+        _lib.results_async(was_async)
+        del prev
         tot["chunks"] = len(my_chunks)
         return ix, nrec, tot, s1 - s0
 

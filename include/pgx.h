@@ -191,6 +191,14 @@ int pgx_copy_dev(void *d_dst, const void *d_src, size_t nbytes);
 /* file level: globs <shimmer_prefix>-[0-9]*-of-[0-9]*.dat and -MC- twins like shmr_overlap.c:355-384 */
 int pgx_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, const char *out_path,
                       const pgx_overlap_params *p, pgx_overlap_stats *stats);
+/* Asynchronous delivery of the overlap records (resident pipelines that run several chunks in one process).  pgx_results_async(1): the
+ * pgx_overlap_*resident* entry points return once the copy of their records to the host array is ENQUEUED (on a stream of its own,
+ * behind the kernel that writes them) instead of finished; *n_records, the statistics and the array's address are valid at once, the
+ * array's CONTENT only after pgx_results_wait() -- which the next overlap stage, pgx_free of the array and pgx_results_async(0) also
+ * imply.  Returns the previous setting.  Off by default: every call returns finished arrays. */
+int pgx_results_async(int on);
+int pgx_results_wait(void);
+
 /* The same two stages on a read database that is ALREADY resident (pgx_seqdb_load / _upload): what a long-lived process serves
  * several chunk commands from -- `pgx_cli serve`, which the shmr_index / shmr_overlap drop-ins attach to, INTEGRATION.md section 5 --
  * so that a job's 8 + 8 chunk commands upload the seqdb once instead of sixteen times. */

@@ -64,7 +64,7 @@ class OverlapStats(C.Structure):
 # every symbol include/pgx.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "pgx_init", "pgx_shutdown", "pgx_last_error", "pgx_device_count", "pgx_version", "pgx_free",
-    "pgx_timing_get", "pgx_timing_reset",
+    "pgx_timing_get", "pgx_timing_reset", "pgx_results_async", "pgx_results_wait",
     "pgx_seqdb_upload", "pgx_seqdb_load", "pgx_seqdb_free", "pgx_seqdb_bases", "pgx_seqdb_reads",
     "pgx_index_resident", "pgx_index_result_free", "pgx_index_chunk",
     "pgx_overlap_resident", "pgx_overlap_chunk", "pgx_index_chunk_db", "pgx_overlap_chunk_db", "pgx_index_overlap_resident", "pgx_mkseqdb", "pgx_dedup",
@@ -233,6 +233,16 @@ def take(ptr, n: int, dtype: np.dtype) -> np.ndarray:
     out = np.frombuffer(buf, dtype=dtype)
     weakref.finalize(buf, load().pgx_free, C.c_void_p(ptr))
     return out
+
+
+def results_async(on: bool) -> bool:
+    """overlap records on their way to the host while the next chunk already runs (include/pgx.h: pgx_results_async); returns the
+    previous setting.  With it on, call results_wait() before reading a returned record array."""
+    return bool(load().pgx_results_async(1 if on else 0))
+
+
+def results_wait():
+    check(load().pgx_results_wait(), "pgx_results_wait")
 
 
 def timing(name: str):

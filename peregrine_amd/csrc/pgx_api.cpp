@@ -145,6 +145,55 @@ size_t g_pin_held = 0;
 // as the host threads are (eight ranks used to pin up to 16 GB each)
 const size_t PIN_CAP = ((size_t)16 << 30) / (size_t)std::max(1, getenv("LOCAL_WORLD_SIZE") ? atoi(getenv("LOCAL_WORLD_SIZE")) : 1);
 }  // namespace
+namespace {
+struct PendingCopy {
+  DevBuf<pgx_ovlp> dev;
+  const void *host = nullptr;
+  hipEvent_t ready = nullptr, done = nullptr;
+  hipStream_t stream = nullptr;
+  bool active = false;
+} g_copy;
+bool g_results_async = false;
+ShutdownHook g_copy_reset([] {
+  if (g_copy.active) (void)hipEventSynchronize(g_copy.done);
+  g_copy.dev.release();
+  g_copy.active = false, g_copy.host = nullptr;
+  if (g_copy.ready) (void)hipEventDestroy(g_copy.ready), g_copy.ready = nullptr;
+  if (g_copy.done) (void)hipEventDestroy(g_copy.done), g_copy.done = nullptr;
+  if (g_copy.stream) (void)hipStreamDestroy(g_copy.stream), g_copy.stream = nullptr;
+});
+}  // namespace
+bool &results_async() { return g_results_async; }
+void results_wait() {
+  if (!g_copy.active) return;
+  g_copy.active = false;
+  const hipError_t e = hipEventSynchronize(g_copy.done);
+  g_copy.dev.release();
+  g_copy.host = nullptr;
+  PGX_HIP(e);
+}
+void results_wait_if(const void *host) {
+  if (g_copy.active && g_copy.host == host) {
+    try {
+      results_wait();
+    } catch (const Fail &) {
+    }
+  }
+}
+void results_copy_async(pgx_ovlp *host, DevBuf<pgx_ovlp> &&dev, size_t n) {
+  results_wait();   // (one copy in flight)
+  if (!g_copy.stream) {
+    PGX_HIP(hipStreamCreateWithFlags(&g_copy.stream, hipStreamNonBlocking));
+    PGX_HIP(hipEventCreateWithFlags(&g_copy.ready, hipEventDisableTiming));
+    PGX_HIP(hipEventCreateWithFlags(&g_copy.done, hipEventDisableTiming));
+  }
+  PGX_HIP(hipEventRecord(g_copy.ready, ctx().stream));
+  PGX_HIP(hipStreamWaitEvent(g_copy.stream, g_copy.ready, 0));
+  PGX_HIP(hipMemcpyAsync(host, dev.p, n * sizeof(pgx_ovlp), hipMemcpyDeviceToHost, g_copy.stream));
+  PGX_HIP(hipEventRecord(g_copy.done, g_copy.stream));
+  g_copy.dev = std::move(dev), g_copy.host = host, g_copy.active = true;
+}
+
 void *out_alloc(size_t bytes) {
   if (bytes < BIG) {
     void *p = malloc(bytes ? bytes : 1);
@@ -185,6 +234,7 @@ void *out_alloc(size_t bytes) {
 }
 void out_free(void *p) {
   if (!p) return;
+  results_wait_if(p);   // (an array still being written by the pending record copy)
   size_t bytes = 0;
   {
     std::lock_guard<std::mutex> lk(g_out_mu);
@@ -424,6 +474,20 @@ extern "C" {
 const char *pgx_last_error(void) { return pgx::g_err.c_str(); }
 const char *pgx_version(void) { return "pgx 0.1 (gfx950)"; }
 void pgx_free(void *p) { pgx::out_free(p); }
+int pgx_results_async(int on) {
+  const int was = pgx::results_async() ? 1 : 0;
+  if (!on) pgx::results_wait();
+  pgx::results_async() = on != 0;
+  return was;
+}
+int pgx_results_wait(void) {
+  try {
+    pgx::results_wait();
+  } catch (const pgx::Fail &f) {
+    return f.code;
+  }
+  return PGX_OK;
+}
 
 int pgx_device_count(void) {
   int n = 0;

@@ -373,6 +373,15 @@ struct DeviceIndex {
 // the index stage; keep != nullptr: leave the final list + counts on the device too; host_arrays == false: do not download them
 void index_stage(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out, DeviceIndex *keep, bool host_arrays);
 
+// Records on their way to the host while the caller already works on the next chunk (pgx_results_async, include/pgx.h): the overlap
+// stage's device replay hands its record buffer to a copy on a second stream and returns; results_wait() -- called by
+// pgx_results_wait, by the next stage before it allocates its own buffer, by pgx_free of that array and by every entry point that
+// reads the records itself -- waits for the copy and gives the device buffer back.
+bool &results_async();
+void results_wait();
+void results_wait_if(const void *host);   // only if `host` is the array the pending copy writes
+void results_copy_async(pgx_ovlp *host, DevBuf<pgx_ovlp> &&dev, size_t n);   // after what is enqueued on ctx().stream
+
 // Runs fn on the library's housekeeping thread: tearing down GB-sized host tables (munmap, free) takes tens of
 // milliseconds that the caller does not have to wait for.  At most a few jobs are queued; beyond that fn runs inline.
 void defer_destroy(std::function<void()> fn);

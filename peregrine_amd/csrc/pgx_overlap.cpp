@@ -2162,6 +2162,7 @@ int pgx_overlap_chunk_db(pgx_seqdb *db, const char *shimmer_prefix, const char *
     const double t1 = now_ms();
     OvOut v;
     run_overlap(db, cache.mm.data(), cache.mm.size(), cache.mc.data(), cache.mc.size(), p, v, stats);
+    results_wait();
     const double t2 = now_ms();
     write_records(out_path, v.a, v.n);
     if (trace) fprintf(stderr, "[pgx] overlap chunk (resident database): index files %.1f ms, stage %.1f ms, %zu records written in %.1f ms\n", t1 - t0, t2 - t1, v.n, now_ms() - t2);
@@ -2208,6 +2209,7 @@ int pgx_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, cons
     PGX_REQUIRE(rd_code == PGX_OK, rd_code, "%s", rd_err.c_str());
     OvOut v;
     run_overlap(db, mm.data(), mm.size(), mc.data(), mc.size(), p, v, stats);
+    results_wait();
     write_records(out_path, v.a, v.n);
   } catch (const Fail &f) {
     rc = f.code;

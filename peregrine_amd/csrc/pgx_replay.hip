@@ -1971,13 +1971,17 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     PGX_HIP(hipMemcpyAsync(&last_num, r.inum + nb - 1, 4, hipMemcpyDeviceToHost, s));
     sync();
     const size_t nrec = (size_t)last_off + last_num;
+    results_wait();   // (pgx_results_async: the previous stage's record copy -- long finished -- gives its device buffer back first)
     pgx_ovlp *host = alloc_out(nrec);
     DevBuf<pgx_ovlp> d_out(std::max<size_t>(nrec, 1));
     {
       std::optional<KernelTimer> tme;
       if (timed_misc) tme.emplace("replay_emit", nrec);   // the records written and brought to the host (pinned destination)
       hipLaunchKernelGGL(k_emit, dim3(cdiv256(nb)), dim3(256), 0, s, r, off.p, d_out.p);
-      if (nrec) PGX_HIP(hipMemcpyAsync(host, d_out.p, nrec * sizeof(pgx_ovlp), hipMemcpyDeviceToHost, s));
+      // pgx_results_async: the copy runs on its own stream behind k_emit and this call returns without it -- the 2.9 GB of a human-scale
+      // chunk (55 ms over PCIe) overlap the NEXT chunk's join and first sweep; the caller waits (pgx_results_wait) before it reads
+      if (nrec && results_async() && !timed_misc) results_copy_async(host, std::move(d_out), nrec);
+      else if (nrec) PGX_HIP(hipMemcpyAsync(host, d_out.p, nrec * sizeof(pgx_ovlp), hipMemcpyDeviceToHost, s));
     }
     if (!read_counters(false)) goto overflowed;
     *n_out = nrec;

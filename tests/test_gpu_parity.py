@@ -667,6 +667,33 @@ def test_device_replay_equals_oracle(small, monkeypatch):
     rdb2.close()
 
 
+def test_asynchronous_record_delivery(small, monkeypatch):
+    """pgx_results_async (round 4): the overlap stage returns once the copy of its records is enqueued on a stream of its own; the NEXT
+    stage, pgx_free of the array and pgx_results_wait wait for it.  Two chunks back to back, arrays read after the wait, equal to the
+    oracle's; an array dropped while its copy may be in flight; the setting restored."""
+    db, rdb = small
+    ix = rdb.index()
+    l2, mc = ix.top, ix.top_mc
+    monkeypatch.setenv("PGX_GPU_REPLAY", "1")
+    want = [U.orc_overlap(db, l2, mc, mychunk=c, total=2)[0] for c in (1, 2)]
+    assert _lib.results_async(True) is False
+    try:
+        for rep in range(3):                                   # (from the second use of a size class on the result arrays are pinned)
+            a, _ = rdb.overlap(l2, mc, total_chunk=2, mychunk=1)
+            b, _ = rdb.overlap(l2, mc, total_chunk=2, mychunk=2)   # (its emit waited for a's copy)
+            _lib.results_wait()
+            assert formats.ovlp_fields_equal(a, want[0]) and formats.ovlp_fields_equal(b, want[1]), rep
+            c, _ = rdb.overlap(l2, mc, total_chunk=2, mychunk=1)
+            del c                                              # freed right away: pgx_free waits for the copy before the block is reused
+            d, _ = rdb.overlap(l2, mc, total_chunk=2, mychunk=2)
+            _lib.results_wait()
+            assert formats.ovlp_fields_equal(d, want[1]), rep
+    finally:
+        assert _lib.results_async(False) is True
+    e, _ = rdb.overlap(l2, mc, total_chunk=2, mychunk=1)       # synchronous again
+    assert formats.ovlp_fields_equal(e, want[0])
+
+
 def test_query_and_map_edge_cases(tmp_path):
     """rows f3/f4 at the edges: unrelated contigs (no line), a chunk that owns nothing, reads unknown to the index (error, not a
     crash), an empty shimmer list, repeated / interleaved queries on one map"""
