@@ -830,7 +830,9 @@ def main():
         out["kernel_sum_over_step"] = ksum / (elapsed / a.steps * 1e3) if elapsed else None
         out["kernel_sum_note"] = ("sum of the `kernels` entries per step (sketch .. visit, alignment launches, every replay kernel incl. clears, "
                                   "k_file / k_settle / counts, k_emit + the records' copy to the host); not in it: the join tables' small "
-                                  "copies, RCCL; tools/timeline.py on a rocprofv3 kernel trace gives the busy / idle split kernel by kernel")
+                                  "copies, RCCL; the replay's kernels are timed in an extra step WITHOUT their second stream and the record copy of a multi-chunk "
+                                  "step overlaps the next chunk, so the sum can exceed the step; tools/timeline.py / chunk_timeline.py on a rocprofv3 "
+                                  "kernel trace give the busy / idle split kernel by kernel")
         if world == 1 and not a.no_cpu_baseline:
             if strong:
                 def gpu_index_files(prefix):     # the job's index chunk files, as bin/shmr_index writes them
