@@ -83,6 +83,24 @@ __device__ __forceinline__ Kmers kmers_before(const uint8_t *s, uint32_t at, int
 }
 
 // ---- segments: maximal runs of unambiguous bases, a wavefront per read ------------------------------------------------------------
+// A tile of 1 KiB per step: lane l loads the 16 bytes [16 l, 16 l + 16) of the tile with one aligned 16-byte load (the read's first tile
+// starts at the 16-byte boundary below the read; bytes outside the read count as ambiguous) and turns them into a 16-bit mask of
+// unambiguous positions.  A segment starts where a set bit follows a clear one and ends (exclusively) where a clear bit follows a set
+// one -- across lanes through the neighbour's top bit, across tiles through a carried bit.  Counting pass, then (FILL) the same walk
+// writes starts / ends at the offsets a wave prefix sum of the per-lane counts gives.  (The first version walked 64 BYTES per step:
+// 235 dependent steps for a 15 kb read, 1 ms per pass for 15 k reads.)
+__device__ __forceinline__ uint32_t valid16(uint4 v) {   // bit i: byte i holds a one-hot low nibble (exactly one of its four bits set)
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  uint32_t m = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint32_t n = (w[d] >> (8 * b)) & 0xFu;
+      m |= ((n != 0 && (n & (n - 1)) == 0) ? 1u : 0u) << (4 * d + b);
+    }
+  return m;
+}
 template <bool FILL>
 __global__ __launch_bounds__(64) void k_nseg_scan(const uint8_t *__restrict__ seq, const ReadDesc *__restrict__ reads,
                                                   const uint32_t *__restrict__ list, uint32_t nn, uint64_t *__restrict__ seg_cnt,
@@ -91,31 +109,43 @@ __global__ __launch_bounds__(64) void k_nseg_scan(const uint8_t *__restrict__ se
   const uint32_t it = blockIdx.x;
   if (it >= nn) return;
   const ReadDesc rd = reads[list[it]];
-  const uint8_t *s = seq + rd.off;
-  const uint32_t len = rd.len;
+  const int lead = (int)(rd.off & 15);
+  const uint8_t *base = seq + (rd.off - (uint64_t)lead);   // (the seqdb buffer is 16-byte aligned and padded: pgx_seqdb_adopt_dev / _upload)
+  const int len = (int)rd.len, span = lead + len;
   const int lane = threadIdx.x;
-  const uint64_t below = (1ULL << lane) - 1;
-  const uint64_t base = FILL ? seg_off[it] : 0;
+  const uint64_t out0 = FILL ? seg_off[it] : 0;
   uint64_t nstart = 0, nend = 0;
-  bool prev = false;   // position p0 - 1 is an unambiguous base (wave-uniform)
-  for (uint32_t p0 = 0; p0 < len; p0 += 64) {
-    const uint32_t p = p0 + lane;
-    const bool v = p < len && base_code(s[p]) < 4;
-    const uint64_t vm = __ballot(v);
-    const uint64_t pm = (vm << 1) | (prev ? 1ULL : 0ULL);   // bit l: position p0 + l - 1 is unambiguous
-    const uint64_t starts = vm & ~pm, ends = ~vm & pm;      // an end bit sits on the first position AFTER the segment (<= len)
-    if (FILL) {
-      if (starts >> lane & 1) {
-        const uint64_t i = base + nstart + (uint64_t)__builtin_popcountll(starts & below);
-        seg_s[i] = p, seg_read[i] = it;
-      }
-      if (ends >> lane & 1) seg_e[base + nend + (uint64_t)__builtin_popcountll(ends & below)] = p;
+  uint32_t carry = 0;   // the position before the tile is an unambiguous base (wave-uniform)
+  for (int b0 = 0; b0 < span; b0 += 1024) {
+    const int mine = b0 + lane * 16;              // byte offset (from base) of this lane's 16 bytes
+    uint32_t m = 0;
+    if (mine < span) {
+      m = valid16(*reinterpret_cast<const uint4 *>(base + mine));
+      const int lo = lead - mine, hi = span - mine;   // bytes [lo, hi) of the 16 belong to the read
+      if (lo > 0) m &= ~((1u << (lo > 16 ? 16 : lo)) - 1u);
+      if (hi < 16) m &= (1u << (hi < 0 ? 0 : hi)) - 1u;
     }
-    nstart += (uint64_t)__builtin_popcountll(starts), nend += (uint64_t)__builtin_popcountll(ends);
-    prev = (vm >> 63) & 1;
+    uint32_t prevtop = (uint32_t)__shfl_up((int)(m >> 15), 1, 64);
+    if (lane == 0) prevtop = carry;
+    const uint32_t pm = ((m << 1) | (prevtop & 1u)) & 0xFFFFu;   // bit i: the position before byte i is unambiguous
+    const uint32_t st = m & ~pm, en = ~m & pm & 0xFFFFu;          // (an end bit sits on the first position after a segment)
+    const int cs = __builtin_popcount(st), ce = __builtin_popcount(en);
+    int is = cs, ie = ce;                                        // inclusive scans over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int ts = __shfl_up(is, o, 64), te = __shfl_up(ie, o, 64);
+      if (lane >= o) is += ts, ie += te;
+    }
+    if (FILL) {
+      uint64_t ws = out0 + nstart + (uint64_t)(is - cs), we = out0 + nend + (uint64_t)(ie - ce);
+      for (uint32_t x = st; x; x &= x - 1) seg_s[ws] = (uint32_t)(mine + __builtin_ctz(x) - lead), seg_read[ws] = it, ++ws;
+      for (uint32_t x = en; x; x &= x - 1) seg_e[we++] = (uint32_t)(mine + __builtin_ctz(x) - lead);
+    }
+    nstart += (uint64_t)__shfl(is, 63, 64), nend += (uint64_t)__shfl(ie, 63, 64);
+    carry = (uint32_t)__shfl((int)(m >> 15), 63, 64) & 1u;
   }
-  if (prev) {   // the read ends inside a segment and on a strip boundary: its end was not seen
-    if (FILL && lane == 0) seg_e[base + nend] = len;
+  if (carry) {   // the read ends inside a segment exactly on a tile boundary: its end was not seen
+    if (FILL && lane == 0) seg_e[out0 + nend] = (uint32_t)len;
     ++nend;
   }
   if (!FILL && lane == 0) seg_cnt[it] = nstart;
