@@ -728,7 +728,7 @@ def main():
 
     if rank == 0:
         kern = {}
-        for name in ("sketch", "sketch_literal", "sketch_gather", "reduce", "count", "pairs", "visit", "pack", "align", "align1"):
+        for name in ("sketch", "sketch_redo", "sketch_nreads", "sketch_general", "sketch_gather", "reduce", "count", "pairs", "visit", "pack", "align", "align1"):
             ms, launches, units = _lib.timing(name)
             if launches:
                 kern[name] = {"ms_total": ms, "launches": launches, "units": units, "avg_ms": ms / launches, "steps": a.steps}
