@@ -3,7 +3,9 @@
 parameter set, the GPU's ovlp_t stream against oracle/_ref/shmr_overlap with the same flags on the same files, field by field.
 (The suite pins the default parameters at this size; this hunts the dispatch corners: bestn 1 / 8, narrow and wide bands -- other V-ring
 sizes --, small and large ovlp_upper, a low multiplicity cut-off, mc_lower 1.)
-  python tools/ovlp_param_hunt_c4.py [T=384] [genome_mb=3100]"""
+  python tools/ovlp_param_hunt_c4.py [T=384] [genome_mb=3100 (0: full)] [levels=2] [first n sets]
+(levels = 1: BASELINE configs[4]'s dense L1 shimmers at full size -- 776 M of them; two sets are plenty there: each reference process
+loads all of them)"""
 import os, sys, tempfile, shutil, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,7 +18,9 @@ from peregrine_amd.parallel import GpuEngine
 from peregrine_amd.shimmer import ResidentDB
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 384
-gmb = float(sys.argv[2]) if len(sys.argv) > 2 else None
+gmb = (float(sys.argv[2]) or None) if len(sys.argv) > 2 else None
+LV = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+NSETS = int(sys.argv[4]) if len(sys.argv) > 4 else 99
 SETS = [   # (chunk, reference flags, library keywords)
     (5, ["-b", 1], dict(bestn=1)),
     (11, ["-b", 8], dict(bestn=8)),
@@ -27,6 +31,7 @@ SETS = [   # (chunk, reference flags, library keywords)
     (41, ["-M", 60], dict(mc_upper=60)),
     (47, ["-m", 1, "-b", 2, "-w", 60], dict(mc_lower=1, bestn=2, align_bandwidth=60)),
 ]
+SETS = SETS[:NSETS]
 seq, total, rlen = simreads.make_workload_resident("c4", genome_mb=gmb)
 rid = np.arange(len(rlen), dtype=np.uint32)
 roff = np.concatenate([[0], np.cumsum(rlen.astype(np.uint64))[:-1]]).astype(np.uint64)
@@ -39,15 +44,15 @@ try:
     N = 8
     tops, mcs = [], []
     for c in range(1, N + 1):
-        p = rdb.index(total_chunk=N, mychunk=c, levels=2)
-        formats.write_mmlist(os.path.join(d, "ix-L2-%02d-of-%02d.dat" % (c, N)), p.top)
-        formats.write_mm_count(os.path.join(d, "ix-L2-MC-%02d-of-%02d.dat" % (c, N)), p.top_mc)
+        p = rdb.index(total_chunk=N, mychunk=c, levels=LV)
+        formats.write_mmlist(os.path.join(d, "ix-L%d-%02d-of-%02d.dat" % (LV, c, N)), p.top)
+        formats.write_mm_count(os.path.join(d, "ix-L%d-MC-%02d-of-%02d.dat" % (LV, c, N)), p.top_mc)
         tops.append(torch.from_numpy(p.top.view(np.uint8)).cuda()); mcs.append(torch.from_numpy(p.top_mc.view(np.uint8)).cuda())
     mm, mc = torch.cat(tops), torch.cat(mcs)
     del tops, mcs
     t = time.time()
     with cf.ThreadPoolExecutor(len(SETS)) as ex:
-        list(ex.map(lambda s: U.ref_run("shmr_overlap", "-p", pre, "-l", os.path.join(d, "ix-L2"), "-t", T, "-c", s[0], *s[1], "-o", os.path.join(d, "ref.%d" % s[0])), SETS))
+        list(ex.map(lambda s: U.ref_run("shmr_overlap", "-p", pre, "-l", os.path.join(d, "ix-L%d" % LV), "-t", T, "-c", s[0], *s[1], "-o", os.path.join(d, "ref.%d" % s[0])), SETS))
     print("reference: %d overlap chunks of %d in %.0f s" % (len(SETS), T, time.time() - t), flush=True)
     _lib.stream_wait()
     bad = 0
