@@ -60,7 +60,7 @@ const char *pgx_version(void);
 void pgx_free(void *p);              /* releases any host array returned by this library */
 
 /* per-kernel device time (HIP events on the library's stream), accumulated since the last reset.
- * names: "sketch", "sketch_general", "sketch_literal", "sketch_gather", "reduce", "count", "pairs", "replay_dense" / "replay_rows" / "replay_update" (k_eval, k_eval_rows, k_update of the device replay; only with PGX_REPLAY_TIMING=1), "align" (k_align4), "align1" (k_align1: launches of
+ * names: "sketch", "sketch_general", "sketch_redo", "sketch_nreads", "sketch_gather", "pack", "reduce", "count", "pairs", "replay_dense" / "replay_rows" / "replay_update" (k_eval, k_eval_rows, k_update of the device replay; only with PGX_REPLAY_TIMING=1), "align" (k_align4), "align1" (k_align1: launches of
  * at most 13 k alignments), "encode", "dedup", "map". */
 int pgx_timing_get(const char *kernel, double *total_ms, uint64_t *launches, uint64_t *units);
 void pgx_timing_reset(void);

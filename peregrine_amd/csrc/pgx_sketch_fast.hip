@@ -534,7 +534,7 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
               out[w++] = e;
             }
           } else {
-            bad |= 1;  // slab overflow: the literal kernel redoes this read
+            bad |= 1;  // slab overflow: redone with a larger slab (exact-slab pass of the index stage / the run-by-run path)
           }
           nout += (uint32_t)etot;
         } else {

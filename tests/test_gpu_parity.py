@@ -285,7 +285,7 @@ def test_adversarial_reads_all_paths():
     ]
     enc = [_enc(r) for r in reads]
     amb = _enc(rnd(7000)).copy()
-    amb[[10, 3000, 6990]] &= 0xF0                                        # ambiguous forward bases -> literal kernel
+    amb[[10, 3000, 6990]] &= 0xF0                                        # ambiguous forward bases -> run by run (pgx_sketch_n.hip)
     enc.append(amb)
     enc += [_enc(rnd(int(n))) for n in rng.integers(5000, 20000, 40)]
     rlen = np.array([len(e) for e in enc], np.uint32)
@@ -460,7 +460,7 @@ def test_sparse_entry_reads_random(seed):
 def test_low_complexity_reads_stay_on_the_fused_index_path(monkeypatch, tiny_slabs):
     """homopolymers and short-period tandem arrays make every position a tied minimizer (bursts of up to 1,024 per tile, thousands
     of top-level shimmers per read): the fused index path stages the bursts in pieces and redoes reads that outgrow their slab
-    into exact slabs -- no read is handed to the literal kernel, and the lists equal the oracle's"""
+    into exact slabs -- no read leaves the fused index path, and the lists equal the oracle's"""
     if tiny_slabs:   # 8 elements per read: nearly every read outgrows its slab and goes through the exact-slab pass
         monkeypatch.setenv("PGX_SLAB_DIV", "1000000")
         monkeypatch.setenv("PGX_SLAB_MIN", "8")
