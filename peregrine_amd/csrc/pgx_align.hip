@@ -896,40 +896,24 @@ __global__ __launch_bounds__(64) void k_align_q(const uint8_t *__restrict__ seq,
       acta = j0 < nk, actb = j0 + 1 < nk;
       morea = false, moreb = false;
       xa = 0, ya = 0, xa1 = 0, xb = 0, yb = 0, xb1 = 0;
-      // (two arms, not branch-free selects with all four loads leaving together: measured 60.8 -> 91 ms at c3 -- the loads of the idle
-      //  diagonals cost the texture path more than the second arm's wait costs the wavefront)
-      if (acta) {
-        const int k = k0;
-        xa = (k == min_k || (k != max_k && v0 < v1)) ? v1 : v0 + 1;
-        ya = xa - k, xa1 = xa;
-        const int rem = min(q_len - xa, t_len - ya);
-        if (rem > 0) {
-          const uint32_t xq = qo + (uint32_t)xa, yt = to + (uint32_t)ya;
-          uint32_t qd[2], td[2];
-          pack_dwords<2>(QW, wqe, q, xq, WIN, qd), pack_dwords<2>(TW, wte, t, yt, WIN, td);
-          const uint32_t df = __builtin_amdgcn_alignbit(qd[1], qd[0], (xq & 15) << 1) ^ __builtin_amdgcn_alignbit(td[1], td[0], (yt & 15) << 1);
-          int m = df ? (__builtin_ctz(df) >> 1) : 16;
-          m = min(m, rem);
-          xa += m, ya += m;
-          morea = (m == 16) && (rem > 16);
-        }
-      }
-      if (actb) {
-        const int k = k0 + 2;
-        xb = (k != max_k && v1 < v2) ? v2 : v1 + 1;   // (k == min_k cannot be: the lane's first diagonal is below it)
-        yb = xb - k, xb1 = xb;
-        const int rem = min(q_len - xb, t_len - yb);
-        if (rem > 0) {
-          const uint32_t xq = qo + (uint32_t)xb, yt = to + (uint32_t)yb;
-          uint32_t qd[2], td[2];
-          pack_dwords<2>(QW, wqe, q, xq, WIN, qd), pack_dwords<2>(TW, wte, t, yt, WIN, td);
-          const uint32_t df = __builtin_amdgcn_alignbit(qd[1], qd[0], (xq & 15) << 1) ^ __builtin_amdgcn_alignbit(td[1], td[0], (yt & 15) << 1);
-          int m = df ? (__builtin_ctz(df) >> 1) : 16;
-          m = min(m, rem);
-          xb += m, yb += m;
-          moreb = (m == 16) && (rem > 16);
-        }
-      }
+      // (start points by selects, then the probe loads of BOTH diagonals under their predicates before either is used: under two
+      //  `if (active) { start; load; compare }` arms the second diagonal's loads waited for the first's, and by then the other wavefronts had
+      //  pushed the shared lines out of L1 (hit rate 17 %); loading for the idle diagonals as well costs the texture path more than it saves)
+      xa = acta ? ((k0 == min_k || (k0 != max_k && v0 < v1)) ? v1 : v0 + 1) : 0;
+      xb = actb ? ((k0 + 2 != max_k && v1 < v2) ? v2 : v1 + 1) : 0;   // (k == min_k cannot be: the lane's first diagonal is below it)
+      ya = acta ? xa - k0 : 0, yb = actb ? xb - (k0 + 2) : 0;
+      xa1 = xa, xb1 = xb;
+      const int rema = acta ? min(q_len - xa, t_len - ya) : 0, remb = actb ? min(q_len - xb, t_len - yb) : 0;
+      const bool pa = rema > 0, pb = remb > 0;
+      const uint32_t xqa = qo + (uint32_t)xa, yta = to + (uint32_t)ya, xqb = qo + (uint32_t)xb, ytb = to + (uint32_t)yb;
+      uint32_t qda[2] = {0, 0}, tda[2] = {0, 0}, qdb[2] = {0, 0}, tdb[2] = {0, 0};
+      if (pa) pack_dwords<2>(QW, wqe, q, xqa, WIN, qda), pack_dwords<2>(TW, wte, t, yta, WIN, tda);
+      if (pb) pack_dwords<2>(QW, wqe, q, xqb, WIN, qdb), pack_dwords<2>(TW, wte, t, ytb, WIN, tdb);
+      const uint32_t dfa = __builtin_amdgcn_alignbit(qda[1], qda[0], (xqa & 15) << 1) ^ __builtin_amdgcn_alignbit(tda[1], tda[0], (yta & 15) << 1);
+      const uint32_t dfb = __builtin_amdgcn_alignbit(qdb[1], qdb[0], (xqb & 15) << 1) ^ __builtin_amdgcn_alignbit(tdb[1], tdb[0], (ytb & 15) << 1);
+      const int ma = pa ? min(dfa ? (__builtin_ctz(dfa) >> 1) : 16, rema) : 0, mb = pb ? min(dfb ? (__builtin_ctz(dfb) >> 1) : 16, remb) : 0;
+      xa += ma, ya += ma, xb += mb, yb += mb;
+      morea = ma == 16 && rema > 16, moreb = mb == 16 && remb > 16;
     }
 
     // ---- SNAKE: one 128-base extension of the group's lowest unfinished diagonal ------------------------------------------------
