@@ -729,330 +729,6 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
   }
 }
 
-// ---- sixteen candidates per wavefront, TWO diagonals per lane (round 4) -----------------------------------------------------------
-// k_align_ph is bound by VALU issue, and most of what it issues is per-GROUP bookkeeping (phase selects, the step variables, ballots and
-// their mask arithmetic) that eight candidates share a wavefront instruction for.  Here a group is a DPP quad: four lanes, each holding
-// the diagonals 2 gl and 2 gl + 1 of a round of eight, so the same bookkeeping instruction serves sixteen candidates and only the
-// per-diagonal work (start point, probe, V write) is issued twice.  Everything "lowest diagonal with property P" becomes a min over the
-// quad of (P ? diagonal index : 8): two v_min with quad_perm DPP operands instead of ballot + mask + shift + find-first-bit, and a value
-// of the chosen diagonal is one ds_bpermute of the owner lane's own pick (a lane's lower diagonal comes first in k order, so its pick is
-// right whenever the lane is the owner).  Packs only; same phases, same escalation lists as k_align_ph<8, u16, true>.
-template <int CTRL>
-__device__ __forceinline__ int dpp_quad(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
-__device__ __forceinline__ int quad_min(int v) {
-  v = min(v, dpp_quad<0xB1>(v));   // quad_perm [1,0,3,2]
-  return min(v, dpp_quad<0x4E>(v));   // quad_perm [2,3,0,1]
-}
-__device__ __forceinline__ int quad_max(int v) {
-  v = max(v, dpp_quad<0xB1>(v));
-  return max(v, dpp_quad<0x4E>(v));
-}
-
-// WIN: every group keeps a 512-base WINDOW of either sequence's pack in LDS (32 dwords as a ring over the dword index, its first four
-// mirrored behind the end so that three consecutive dwords are always contiguous), filled at FETCH and moved on by one 32-byte block
-// (eight dwords, two a lane) whenever the front of the alignment comes within 224 bases of its end: the load leaves at the top of an
-// iteration and lands at its end.  Probes and extensions read the window (LDS latency, no texture-path work); a position outside it (a
-// diagonal that lags far behind, a match that outruns the refills) takes the global load as before, so the policy never decides a result.
-// Measured why: with sixteen candidates a wavefront the scattered 8- / 16-byte loads made the texture path the bound (TA busy 88 %, L1 hit
-// rate 17 %: tools/sq_ab.sh), and k_align_ph<8> sat at 65 % of it beside 99 % VALU.
-constexpr int QW_DW = 32, QW_PAD = 4, QW_BLOCK = 8, QW_AHEAD = 224;
-template <int N>
-__device__ __forceinline__ void pack_dwords(const uint32_t *__restrict__ W, int we, const uint8_t *__restrict__ g, uint32_t pos, bool win, uint32_t (&dst)[N]) {
-  const uint32_t r = pos >> 4;
-  if (win && (uint32_t)((int)r - (we - QW_DW)) <= (uint32_t)(QW_DW - N)) {
-    const uint32_t s0 = r & (QW_DW - 1);
-#pragma unroll
-    for (int i = 0; i < N; ++i) dst[i] = W[s0 + i];
-  } else {
-    __builtin_memcpy(dst, g + (size_t)r * 4, 4 * N);
-  }
-}
-
-template <bool WIN>
-__global__ __launch_bounds__(64) void k_align_q(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
-                                                const uint32_t *__restrict__ rlen, const pgx_align_key *__restrict__ keys, uint32_t n,
-                                                int band, int ring, pgx_match *__restrict__ out, uint32_t *__restrict__ counter,
-                                                uint32_t *__restrict__ esc_n, uint32_t *__restrict__ esc_list,
-                                                const uint32_t *__restrict__ nflag, size_t pack_stride, uint32_t iter_limit) {
-  extern __shared__ int32_t Vall[];
-  constexpr int GD = 8;   // diagonals of a round
-  const int lane = threadIdx.x, gl = lane & 3, gbase = lane & ~3;
-  const int i0 = 2 * gl, i1 = i0 + 1;   // this lane's diagonals within a round
-  const int gstride = ring * 2 + (WIN ? 2 * (QW_DW + QW_PAD) * 4 : 0);   // bytes of LDS a group owns: V ring, then the two windows
-  uint8_t *G = reinterpret_cast<uint8_t *>(Vall) + (lane >> 2) * gstride;
-  uint16_t *V = reinterpret_cast<uint16_t *>(G);
-  uint32_t *QW = reinterpret_cast<uint32_t *>(G + ring * 2), *TW = QW + QW_DW + QW_PAD;
-  const int mask = ring - 1, band_size = band * 2;
-  uint32_t qo = 0, to = 0, iters = 0;
-
-  int phase = PH_FETCH;
-  uint32_t a = 0;
-  const uint8_t *q = seq, *t = seq;
-  int q_len = 0, t_len = 0, max_d = 0, d = 0;
-  int best_m = -1, min_k = 0, max_k = 0, nk = 0, base = 0, bbase = 0, new_min = 0, new_max = 0;
-  uint32_t longest = 0;
-  bool started = false;
-  int q_bgn = 0, t_bgn = 0, q_m_end = 0, t_m_end = 0;
-  int wqe = 0, wte = 0;   // WIN: the windows hold the dwords [w?e - 32, w?e) of the packs, counted from q / t
-  // the lane's two diagonals of the running round
-  int xa = 0, ya = 0, xa1 = 0, xb = 0, yb = 0, xb1 = 0, k0 = 0;   // (y1 = x1 - k: not kept)
-  bool acta = false, actb = false, morea = false, moreb = false;
-
-  for (;;) {
-    ++iters;
-    if (phase == PH_FETCH) {
-      iters = 0;
-      uint32_t na = 0;
-      if (gl == 0) na = atomicAdd(counter, 1u);
-      na = (uint32_t)__shfl((int)na, gbase, 64);
-      if (na >= n) {
-        phase = PH_DONE;
-      } else {
-        a = na;
-        const pgx_align_key key = keys[a];
-        const uint64_t qg = roff[key.rid0] + key.q_off, tg = roff[key.rid1];
-        q = seq + (key.dir0 ? pack_stride * 4 : 0) + (qg >> 4) * 4, t = seq + (key.dir1 ? pack_stride * 4 : 0) + (tg >> 4) * 4;
-        qo = (uint32_t)(qg & 15), to = (uint32_t)(tg & 15);
-        q_len = (int)(rlen[key.rid0] - key.q_off);
-        t_len = (int)rlen[key.rid1];
-        max_d = (int)(0.3 * (double)(q_len + t_len));  // DWmatch.c:96
-        d = 0, best_m = -1, min_k = 0, max_k = 0, longest = 0;
-        started = false;
-        q_bgn = t_bgn = q_m_end = t_m_end = 0;
-        if (gl == 0) V[1 & mask] = (uint16_t)0;
-        phase = PH_STEP;
-        if ((nflag[key.rid0] | nflag[key.rid1]) & 1u) {
-          if (gl == 0) esc_list[n + atomicAdd(esc_n + 1, 1u)] = a;
-          phase = PH_FETCH;
-        } else if (WIN) {
-          // q / t back to a 32-byte boundary (the blocks of the window are sectors), the first 32 dwords of either into the windows
-          const uint32_t phq = (uint32_t)(reinterpret_cast<uintptr_t>(q) >> 2) & 7u, pht = (uint32_t)(reinterpret_cast<uintptr_t>(t) >> 2) & 7u;
-          q -= phq * 4, qo += phq * 16, t -= pht * 4, to += pht * 16;
-#pragma unroll
-          for (int b = 0; b < QW_DW / QW_BLOCK; ++b) {
-            uint2 vq, vt;
-            __builtin_memcpy(&vq, q + (b * QW_BLOCK + 2 * gl) * 4, 8), __builtin_memcpy(&vt, t + (b * QW_BLOCK + 2 * gl) * 4, 8);
-            QW[b * QW_BLOCK + 2 * gl] = vq.x, QW[b * QW_BLOCK + 2 * gl + 1] = vq.y;
-            TW[b * QW_BLOCK + 2 * gl] = vt.x, TW[b * QW_BLOCK + 2 * gl + 1] = vt.y;
-            if (b == 0 && gl < 2) {
-              QW[QW_DW + 2 * gl] = vq.x, QW[QW_DW + 2 * gl + 1] = vq.y;
-              TW[QW_DW + 2 * gl] = vt.x, TW[QW_DW + 2 * gl + 1] = vt.y;
-            }
-          }
-          wqe = QW_DW, wte = QW_DW;
-        }
-      }
-    }
-    if (!ballot64(phase != PH_DONE)) break;
-    // WIN: the next block of a window leaves now and lands at the end of this iteration (upper bounds of the front: x <= (best + max_k) / 2,
-    // y <= (best - min_k) / 2 on every live diagonal)
-    bool nq = false, nt = false;
-    uint2 rq = make_uint2(0, 0), rt = make_uint2(0, 0);
-    if (WIN) {
-      const bool run = phase != PH_FETCH && phase != PH_DONE;
-      nq = run && (int)((qo + (uint32_t)(((best_m + max_k) >> 1) + QW_AHEAD)) >> 4) >= wqe;
-      nt = run && (int)((to + (uint32_t)(((best_m - min_k) >> 1) + QW_AHEAD)) >> 4) >= wte;
-      if (ballot64(nq || nt)) {
-        if (nq) __builtin_memcpy(&rq, q + (size_t)(wqe + 2 * gl) * 4, 8);
-        if (nt) __builtin_memcpy(&rt, t + (size_t)(wte + 2 * gl) * 4, 8);
-      }
-    }
-    PH_SYNC();
-
-    // ---- STEP (DWmatch.c:118-122,196-199) ---------------------------------------------------------------------------------
-    if (phase == PH_STEP && !(d >= max_d || max_k - min_k > band_size)) {
-      // hand-ons: a band that outgrows this launch's (narrow) ring -> the wide-ring launch of k_align_ph redoes the candidate (third list of
-      // the escalation block, count at [3]); one past the iteration budget -> k_align1_list, a wavefront of its own (first list, count at [0])
-      const bool wide = max_k - min_k + 4 > ring, late = iter_limit && iters > iter_limit;
-      if (wide || late) {
-        if (gl == 0) {
-          if (late) esc_list[atomicAdd(esc_n, 1u)] = a;
-          else esc_list[2 * (size_t)n + atomicAdd(esc_n + 3, 1u)] = a;
-        }
-        phase = PH_FETCH;
-      }
-    }
-    {
-      const bool stp = phase == PH_STEP;
-      const bool term = stp && (d >= max_d || max_k - min_k > band_size);
-      if (term && gl == 0) {
-        pgx_match r;
-        r.m_size = 0, r.dist = 0, r.q_bgn = 0, r.q_end = 0, r.t_bgn = 0, r.t_end = 0;
-        r.t_m_end = t_m_end, r.q_m_end = q_m_end;
-        out[a] = r;
-      }
-      const int nk_new = max_k >= min_k ? ((max_k - min_k) >> 1) + 1 : 0;
-      if (stp) {
-        nk = nk_new, base = 0, bbase = 0, new_min = max_k, new_max = min_k;
-        phase = term ? PH_FETCH : (nk_new ? PH_ROUND : PH_BAND);
-      }
-    }
-
-    // ---- ROUND: start points and the 16-base probe of the lane's two diagonals (DWmatch.c:124-140) ----------------------------
-    if (phase == PH_ROUND) {
-      const int j0 = base + i0;
-      k0 = min_k + 2 * j0;
-      const int v0 = (int)V[(k0 - 1) & mask], v1 = (int)V[(k0 + 1) & mask], v2 = (int)V[(k0 + 3) & mask];
-      acta = j0 < nk, actb = j0 + 1 < nk;
-      morea = false, moreb = false;
-      xa = 0, ya = 0, xa1 = 0, xb = 0, yb = 0, xb1 = 0;
-      // (start points by selects, then the probe loads of BOTH diagonals under their predicates before either is used: under two
-      //  `if (active) { start; load; compare }` arms the second diagonal's loads waited for the first's, and by then the other wavefronts had
-      //  pushed the shared lines out of L1 (hit rate 17 %); loading for the idle diagonals as well costs the texture path more than it saves)
-      xa = acta ? ((k0 == min_k || (k0 != max_k && v0 < v1)) ? v1 : v0 + 1) : 0;
-      xb = actb ? ((k0 + 2 != max_k && v1 < v2) ? v2 : v1 + 1) : 0;   // (k == min_k cannot be: the lane's first diagonal is below it)
-      ya = acta ? xa - k0 : 0, yb = actb ? xb - (k0 + 2) : 0;
-      xa1 = xa, xb1 = xb;
-      const int rema = acta ? min(q_len - xa, t_len - ya) : 0, remb = actb ? min(q_len - xb, t_len - yb) : 0;
-      const bool pa = rema > 0, pb = remb > 0;
-      const uint32_t xqa = qo + (uint32_t)xa, yta = to + (uint32_t)ya, xqb = qo + (uint32_t)xb, ytb = to + (uint32_t)yb;
-      uint32_t qda[2] = {0, 0}, tda[2] = {0, 0}, qdb[2] = {0, 0}, tdb[2] = {0, 0};
-      if (pa) pack_dwords<2>(QW, wqe, q, xqa, WIN, qda), pack_dwords<2>(TW, wte, t, yta, WIN, tda);
-      if (pb) pack_dwords<2>(QW, wqe, q, xqb, WIN, qdb), pack_dwords<2>(TW, wte, t, ytb, WIN, tdb);
-      const uint32_t dfa = __builtin_amdgcn_alignbit(qda[1], qda[0], (xqa & 15) << 1) ^ __builtin_amdgcn_alignbit(tda[1], tda[0], (yta & 15) << 1);
-      const uint32_t dfb = __builtin_amdgcn_alignbit(qdb[1], qdb[0], (xqb & 15) << 1) ^ __builtin_amdgcn_alignbit(tdb[1], tdb[0], (ytb & 15) << 1);
-      const int ma = pa ? min(dfa ? (__builtin_ctz(dfa) >> 1) : 16, rema) : 0, mb = pb ? min(dfb ? (__builtin_ctz(dfb) >> 1) : 16, remb) : 0;
-      xa += ma, ya += ma, xb += mb, yb += mb;
-      morea = ma == 16 && rema > 16, moreb = mb == 16 && remb > 16;
-    }
-
-    // ---- SNAKE: one 128-base extension of the group's lowest unfinished diagonal ------------------------------------------------
-    {
-      const bool rs = phase == PH_ROUND || phase == PH_SNAKE;
-      int L = quad_min(rs ? (morea ? i0 : moreb ? i1 : GD) : GD);
-      if (rs) phase = L < GD ? PH_SNAKE : PH_END;
-      if (ballot64(L < GD)) {
-        const bool has = L < GD;
-        const int own = gbase + ((L >> 1) & 3);
-        const int xs = __shfl(morea ? xa : xb, own, 64), ys = __shfl(morea ? ya : yb, own, 64);
-        const int rem = min(q_len - xs, t_len - ys);
-        const int off = gl * 32;
-        int m = 32;
-        if (has) {
-          m = 0;
-          if (off < rem) {
-            const uint32_t xq = qo + (uint32_t)(xs + off), yt = to + (uint32_t)(ys + off);
-            uint32_t qd[3], td[3];
-            pack_dwords<3>(QW, wqe, q, xq, WIN, qd), pack_dwords<3>(TW, wte, t, yt, WIN, td);
-            const uint32_t qsh = (xq & 15) << 1, tsh = (yt & 15) << 1;
-            const uint32_t d0 = __builtin_amdgcn_alignbit(qd[1], qd[0], qsh) ^ __builtin_amdgcn_alignbit(td[1], td[0], tsh);
-            const uint32_t d1 = __builtin_amdgcn_alignbit(qd[2], qd[1], qsh) ^ __builtin_amdgcn_alignbit(td[2], td[1], tsh);
-            m = d0 ? (__builtin_ctz(d0) >> 1) : d1 ? 16 + (__builtin_ctz(d1) >> 1) : 32;
-            m = min(m, rem - off);
-          }
-        }
-        // the first lane that stops short decides: its 32 gl + m is the smallest of the quad
-        const int ext = quad_min(m < 32 ? off + m : 128);
-        if (has && lane == own) {
-          const bool done = ext < 128 || ext >= rem;   // mismatch found or an end reached: this diagonal is done
-          if (L & 1) {
-            xb += ext, yb += ext;
-            if (done) moreb = false;
-          } else {
-            xa += ext, ya += ext;
-            if (done) morea = false;
-          }
-        }
-        L = quad_min(has ? (morea ? i0 : moreb ? i1 : GD) : GD);
-        if (has && L == GD) phase = PH_END;
-      }
-    }
-
-    // ---- END of the round: the order-dependent side results, lowest k first (DWmatch.c:142-164) ---------------------------------
-    {
-      const bool e = phase == PH_END;
-      const int exta = xa - xa1, extb = xb - xb1;
-      const bool hita = e && acta && (xa >= q_len || ya >= t_len), hitb = e && actb && (xb >= q_len || yb >= t_len);
-      const int hl = quad_min(hita ? i0 : hitb ? i1 : GD);
-      const bool vala = e && acta && i0 <= hl, valb = e && actb && i1 <= hl;
-      if (ballot64(e && !started)) {   // first extension > 16 fixes q_bgn / t_bgn once (DWmatch.c:142-146)
-        const bool sa = vala && exta > 16, sb = valb && extb > 16;
-        const int sl = quad_min(!started ? (sa ? i0 : sb ? i1 : GD) : GD);
-        const int own = gbase + ((sl >> 1) & 3);
-        const int bx = __shfl(sa ? xa1 : xb1, own, 64), bk = __shfl(sa ? k0 : k0 + 2, own, 64);
-        if (sl < GD) q_bgn = bx, t_bgn = bx - bk, started = true;
-      }
-      const int eva = vala ? exta : -1, evb = valb ? extb : -1;
-      if (ballot64(max(eva, evb) > (int)longest)) {   // strictly longer extension (DWmatch.c:148-152), the first of equals
-        const int mx = quad_max(max(eva, evb));
-        const bool la = eva == mx, lb = evb == mx;
-        const int l = quad_min(la ? i0 : lb ? i1 : GD);
-        const int own = gbase + ((l >> 1) & 3);
-        const int ex = __shfl(la ? xa : xb, own, 64), ey = __shfl(la ? ya : yb, own, 64);
-        if (e && mx >= 0 && (uint32_t)mx > longest) longest = (uint32_t)mx, q_m_end = ex, t_m_end = ey;
-      }
-      if (vala) V[k0 & mask] = (uint16_t)xa;
-      if (valb) V[(k0 + 2) & mask] = (uint16_t)xb;
-      {
-        const int s = quad_max(max(vala ? xa + ya : -1, valb ? xb + yb : -1));
-        if (e) best_m = max(best_m, s);
-      }
-      bool matched = false;
-      if (ballot64(hl < GD)) {
-        const int own = gbase + ((hl >> 1) & 3);
-        const int ex = __shfl(hita ? xa : xb, own, 64), ey = __shfl(hita ? ya : yb, own, 64);
-        if (hl < GD) {  // DWmatch.c:185-194  (hl < GD implies e)
-          matched = true;
-          if (gl == 0) {
-            pgx_match r;
-            r.q_bgn = q_bgn, r.t_bgn = t_bgn, r.q_end = ex, r.t_end = ey, r.dist = d;
-            r.m_size = (ex - q_bgn + ey - t_bgn + 2 * d) / 2;
-            r.t_m_end = t_m_end, r.q_m_end = q_m_end;
-            out[a] = r;
-          }
-        }
-      }
-      if (e) {
-        if (matched) {
-          phase = PH_FETCH;
-        } else {
-          base += GD;
-          phase = base >= nk ? PH_BAND : PH_ROUND;
-        }
-      }
-    }
-    if (WIN && ballot64(nq || nt)) {   // the block requested at the top lands: it replaces the oldest one of the ring
-      if (nq) {
-        const int s0 = (wqe & (QW_DW - 1)) + 2 * gl;
-        QW[s0] = rq.x, QW[s0 + 1] = rq.y;
-        if (s0 < QW_PAD) QW[QW_DW + s0] = rq.x, QW[QW_DW + s0 + 1] = rq.y;
-        wqe += QW_BLOCK;
-      }
-      if (nt) {
-        const int s0 = (wte & (QW_DW - 1)) + 2 * gl;
-        TW[s0] = rt.x, TW[s0 + 1] = rt.y;
-        if (s0 < QW_PAD) TW[QW_DW + s0] = rt.x, TW[QW_DW + s0 + 1] = rt.y;
-        wte += QW_BLOCK;
-      }
-    }
-    PH_SYNC();
-
-    // ---- BAND: one round of the band update (DWmatch.c:166-183) -------------------------------------------------------------------
-    {
-      const bool bnd = phase == PH_BAND;
-      if (ballot64(bnd)) {
-        const int thr = best_m - band;
-        const int j0 = bbase + i0;
-        const int ka = min_k + 2 * j0;
-        const bool ina = bnd && j0 < nk, inb = bnd && j0 + 1 < nk;
-        int ua = INT32_MIN, ub = INT32_MIN;
-        if (ina) ua = (nk <= GD) ? xa + ya : 2 * (int)V[ka & mask] - ka;
-        if (inb) ub = (nk <= GD) ? xb + yb : 2 * (int)V[(ka + 2) & mask] - (ka + 2);
-        const bool pa = ina && ua >= thr, pb = inb && ub >= thr;
-        const int lo = quad_min(pa ? i0 : pb ? i1 : 99), hi = quad_max(pb ? i1 : pa ? i0 : -1);
-        if (bnd) {
-          if (lo < 99) {
-            new_min = min(new_min, min_k + 2 * (bbase + lo));
-            new_max = max(new_max, min_k + 2 * (bbase + hi));
-          }
-          bbase += GD;
-          if (bbase >= nk) max_k = new_max + 1, min_k = new_min - 1, ++d, phase = PH_STEP;
-        }
-      }
-    }
-  }
-}
-
 // The 2-bit packs ahead of the first large launch: run_overlap calls this while the GPU would otherwise wait for the host's outer
 // table, so the first stage's k_pack2 (1.6 ms at 4.5 Gbases) is off the critical path; later stages find the packs in place
 // (pgx_pack.hip: they are kept with the database).
@@ -1108,28 +784,8 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
     const uint32_t iter_limit = getenv("PGX_ALIGN_ITER_LIMIT") ? (uint32_t)atol(getenv("PGX_ALIGN_ITER_LIMIT")) : 2500u;   // (0: no hand-on of stragglers)
     // escalation block: [0] stragglers handed on, [1] candidates that touch a read without 2-bit codes, [2] the byte-wise launch's work
     // counter, [4 .. 4 + n) the stragglers, [4 + n .. 4 + 2 n) the others
-    uint32_t *esc = ws<uint32_t>("align.esc", 3 * n + 4);
+    uint32_t *esc = ws<uint32_t>("align.esc", 2 * n + 4);
     PGX_HIP(hipMemsetAsync(esc, 0, 4 * sizeof(uint32_t), st));
-    const bool quad = getenv("PGX_ALIGN_Q") && atoi(getenv("PGX_ALIGN_Q"));
-    if (quad) {
-      // k_align_q with rings of at most 128 entries (4 KiB of LDS a wavefront: all 32 wavefronts of a CU); the candidates whose band outgrows
-      // them go through k_align_ph with the full ring, from the third list of the block
-      const int ringq = std::min(ring, getenv("PGX_ALIGN_Q_RING") ? atoi(getenv("PGX_ALIGN_Q_RING")) : 128);
-      const bool win = atoi(getenv("PGX_ALIGN_Q")) == 2;
-      const size_t ldsq = (size_t)16 * (ringq * sizeof(uint16_t) + (win ? 2 * (QW_DW + QW_PAD) * 4 : 0));
-      const unsigned pcq = (unsigned)std::min<size_t>(getenv("PGX_ALIGN_Q_WAVES") ? atoi(getenv("PGX_ALIGN_Q_WAVES")) : 32, (160u << 10) / ldsq);
-      const dim3 gq((unsigned)std::min<size_t>((n + 15) / 16, (size_t)ctx().num_cu * pcq));
-      if (win)
-        hipLaunchKernelGGL(k_align_q<true>, gq, dim3(64), ldsq, st, reinterpret_cast<const uint8_t *>(packs), db->d_roff.p, db->d_rlen.p, d_keys,
-                           (uint32_t)n, band, ringq, d_out, counter, esc, esc + 4, db->d_nflag.p, seq_pack_stride(db), iter_limit);
-      else
-        hipLaunchKernelGGL(k_align_q<false>, gq, dim3(64), ldsq, st, reinterpret_cast<const uint8_t *>(packs), db->d_roff.p, db->d_rlen.p, d_keys,
-                           (uint32_t)n, band, ringq, d_out, counter, esc, esc + 4, db->d_nflag.p, seq_pack_stride(db), iter_limit);
-      if (ringq < ring)
-        hipLaunchKernelGGL((k_align_ph<8, uint16_t, true>), dim3((unsigned)std::min<size_t>(n / 64 + 64, (size_t)ctx().num_cu * per_cu)), dim3(64), lds, st,
-                           reinterpret_cast<const uint8_t *>(packs), db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter + 1, esc + 3,
-                           esc + 4 + 2 * n, esc, esc + 4, db->d_nflag.p, seq_pack_stride(db), iter_limit);
-    } else
     hipLaunchKernelGGL((k_align_ph<8, uint16_t, true>), dim3(grid), dim3(64), lds, st, reinterpret_cast<const uint8_t *>(packs), db->d_roff.p,
                        db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter, (const uint32_t *)nullptr, (const uint32_t *)nullptr, esc,
                        esc + 4, db->d_nflag.p, seq_pack_stride(db), iter_limit);

@@ -835,15 +835,6 @@ ALIGN_VARIANTS = [   # (id, environment, read set): every form dev_align dispatc
     ("ph8-packed-ambiguous", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0"), "withN"),   # ... reads with N: handed on to the byte-wise launch
     ("ph8-packed-stragglers", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_ITER_LIMIT="150"), "small"),   # most candidates outlast
                                                                                     # 150 iterations: handed on to k_align1_list, a wavefront each
-    ("quad-packed", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_Q="1"), "small"),   # k_align_q: sixteen per wavefront, two diagonals a lane
-    ("quad-packed-ambiguous", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_Q="1"), "withN"),
-    ("quad-packed-stragglers", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_ITER_LIMIT="150", PGX_ALIGN_Q="1"), "small"),
-    ("quad-packed-narrow-ring", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_Q="1", PGX_ALIGN_Q_RING="64"), "small"),   # bands beyond
-                                                                                    # 60 diagonals: redone by k_align_ph with the full ring
-    ("quad-window", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_Q="2"), "small"),   # k_align_q<WIN>: the packs through LDS windows
-    ("quad-window-ambiguous", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_Q="2"), "withN"),
-    ("quad-window-stragglers", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_ITER_LIMIT="150", PGX_ALIGN_Q="2"), "small"),
-    ("quad-window-narrow-ring", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_Q="2", PGX_ALIGN_Q_RING="64"), "small"),
     ("ph8-bytes", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="-1"), "small2"),  # k_align_ph<8, u16> on the seqdb bytes (a database without packs)
     ("one-per-wave", dict(PGX_ALIGN_SMALL="1000000000"), "small"),                  # k_align1 on a LARGE launch
     ("long-reads-int32", dict(PGX_ALIGN_SMALL="0"), "long"),                        # a 100 kb read in the set: k_align4<8, int32>
