@@ -84,7 +84,12 @@ struct alignas(64) Counters {   // three cache lines: the arenas, the dirty stat
   uint32_t nbig_total;    // buckets k_setup marked F_BIG (none: k_eval_big is never launched)
   uint32_t pad1[10];
   unsigned long long lookups, skips, evals, records;
+#ifdef PGX_BIG_STATS
+  uint32_t big_max_steps, big_long, big_long_n, big_evals;
+  unsigned long long pad2[2];
+#else
   unsigned long long pad2[4];
+#endif
 };
 
 struct R {
@@ -895,6 +900,13 @@ __device__ __forceinline__ M128 upto128(int stop) {   // bits 0 .. stop (stop >=
   return m;
 }
 __device__ __forceinline__ M128 and128(M128 a, M128 b) { return M128{a.lo & b.lo, a.hi & b.hi}; }
+__device__ __forceinline__ M128 andn128(M128 a, M128 b) { return M128{a.lo & ~b.lo, a.hi & ~b.hi}; }   // a & ~b
+__device__ __forceinline__ M128 shr128(M128 m, uint32_t s) {   // m >> s, s <= 128
+  if (s >= 128) return M128{0, 0};
+  if (s >= 64) return M128{m.hi >> (s - 64), 0};
+  if (s == 0) return m;
+  return M128{m.lo >> s | m.hi << (64 - s), m.hi >> s};
+}
 
 // Buckets that hold a read TWICE (tandem arrays, low-complexity runs: the same shimmer pair several times within a read) can
 // meet a read pair more than once within one evaluation, and the second meeting must see the first one's insertion.  The
@@ -907,11 +919,11 @@ __device__ __forceinline__ M128 and128(M128 a, M128 b) { return M128{a.lo & b.lo
 // bucket of d distinct read pairs takes at most ~d steps instead of rows x partners.
 constexpr uint32_t SET_CAP = 2048, CLAIM_CAP = 1024;   // LDS tables of k_eval_big (open addressing, power-of-two sizes)
 __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint32_t hi, uint32_t nlist) {
-  enum { MV = 0, MP, MPO, MA, MAO, MAC, MAP, MGU, MUF, NM };
+  enum { MV = 0, MP, MPO, MA, MAO, MAC, MAP, MGU, MUF, MDF, NM };
   __shared__ uint32_t s_rid[128], s_pos[128], s_rl[128];
   __shared__ uint8_t s_dir[128];
   __shared__ uint64_t s_m[BIG_NW][NM];
-  __shared__ uint32_t s_fresh, s_abort, s_dupstop, s_bail;
+  __shared__ uint32_t s_fresh, s_abort, s_bail;
   __shared__ unsigned long long s_setk[SET_CAP];      // pairs inserted by this evaluation (key + 1; 0: empty) ...
   __shared__ uint8_t s_sett[SET_CAP];                 // ... and their types
   __shared__ unsigned long long s_clk[CLAIM_CAP];     // this step's claims: pair (key + 1) ...
@@ -999,6 +1011,9 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
         p_reg = false;
       }
     };
+#ifdef PGX_BIG_STATS
+    uint32_t st_steps = 0, st_rows = 0, st_cut = 0, st_cont = 0, st_full = 0;
+#endif
     for (;;) {
       // the rows of this step: the open row alone, or the next (up to four) rows that are not contained
       int a[4] = {-1, -1, -1, -1}, nrows = 0;
@@ -1062,7 +1077,6 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
       const bool ins0 = valid && !present && accepted;
       uint32_t my_claim = NONE;
       if (dup) {   // would-be inserters claim their pair: the lowest walk index wins
-        if (threadIdx.x == 0) s_dupstop = 0xFFFFFFFFu;
         if (ins0) {
           for (uint32_t i = (uint32_t)(mix64(pair) >> 20) & (CLAIM_CAP - 1);; i = (i + 1) & (CLAIM_CAP - 1)) {
             unsigned long long kk = s_clk[i];
@@ -1081,28 +1095,30 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
         const uint64_t map = __ballot(ins0 && type == T_CONTAINS), mgu = __ballot(ins0 && guessed), muf = __ballot(ins0 && mslot == NONE);
         if (lane == 0)
           s_m[w][MV] = mv, s_m[w][MP] = mp, s_m[w][MPO] = mpo, s_m[w][MA] = ma, s_m[w][MAO] = mao, s_m[w][MAC] = mac, s_m[w][MAP] = map,
-          s_m[w][MGU] = mgu, s_m[w][MUF] = muf;
+          s_m[w][MGU] = mgu, s_m[w][MUF] = muf, s_m[w][MDF] = 0;
       }
       __syncthreads();
-      if (dup) {   // the first lane (walk order) whose pair a LOWER lane of this step inserts: the step is cut in front of it.  That
+      if (dup) {   // a lane whose pair a LOWER lane of this step would insert is FLAGGED: its row is cut in front of it (below).  That
                    // holds for EVERY lane that found the pair absent, also one whose own alignment is rejected: sequentially it would
                    // have found the pair seen and skipped it.
+        bool dflag = false;
         if (my_claim != NONE) {
-          if (s_clw[my_claim] < wi) atomicMin(&s_dupstop, wi);
+          dflag = s_clw[my_claim] < wi;
         } else if (valid && !present) {
           for (uint32_t i = (uint32_t)(mix64(pair) >> 20) & (CLAIM_CAP - 1);; i = (i + 1) & (CLAIM_CAP - 1)) {
             const unsigned long long kk = s_clk[i];
             if (kk == 0) break;
             if (kk == pair + 1) {
-              if (s_clw[i] < wi) atomicMin(&s_dupstop, wi);
+              dflag = s_clw[i] < wi;
               break;
             }
           }
         }
+        const uint64_t mdf = __ballot(dflag);
+        if (lane == 0) s_m[w][MDF] = mdf;
         __syncthreads();
       }
       if (s_abort) break;
-      const uint32_t dupstop = dup ? s_dupstop : 0xFFFFFFFFu;
       // ---- the sequential semantics over this step: the rows in order, each over its 128 partners, lowest first (uniform) ----
       M128 proc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
       int committed = 0;         // rows completed in this step
@@ -1110,17 +1126,26 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
       int open_row = 0;
       uint32_t open_pbase = 0, open_got = 0;
       for (int k = 0; k < nrows; ++k) {
-        if (dupstop <= (uint32_t)(k * 128)) break;   // the cut lies in front of this row
-        const M128 inc = {s_m[2 * k][MPO] | s_m[2 * k][MAO], s_m[2 * k + 1][MPO] | s_m[2 * k + 1][MAO]};
-        const M128 ac = {s_m[2 * k][MAC], s_m[2 * k + 1][MAC]}, ap = {s_m[2 * k][MAP], s_m[2 * k + 1][MAP]};
+        // A partner that an EARLIER row of this step found contained (or that was such a row) is not examined by this row: its lane is dropped
+        // from the row's masks right here.  (Round 3 ended the step at the first row that changed a flag and looked at the rows below again
+        // in the next one.  Rows themselves are never flagged by an earlier row of the step: a row's partners lie above it.)
+        const uint32_t first_k = row_open ? pbase : (uint32_t)(a[k] + 1);
+        const M128 gone = shr128(M128{clo, chi}, first_k);
+        const M128 inc = andn128(M128{s_m[2 * k][MPO] | s_m[2 * k][MAO], s_m[2 * k + 1][MPO] | s_m[2 * k + 1][MAO]}, gone);
+        const M128 ac = andn128(M128{s_m[2 * k][MAC], s_m[2 * k + 1][MAC]}, gone), ap = andn128(M128{s_m[2 * k][MAP], s_m[2 * k + 1][MAP]}, gone);
+        // the row's cut: its first flagged lane.  (Round 3 took ONE cut for the step, the lowest flagged lane of all rows -- which most often lay
+        // beyond the stop of its row, among lanes the walk never visits, and still ended the step there: 69 % of all steps ended with rows left,
+        // 1.5 of 4 rows committed per step, profiles/r04w_big_stats_c4s.txt.  A flag whose lower claimant turns out unvisited is void but harmless:
+        // the lane is looked at again in the next step.)
+        const M128 df = andn128(M128{s_m[2 * k][MDF], s_m[2 * k + 1][MDF]}, gone);
+        const int cut = any128(df) ? ctz128(df) : 128;   // first offset of the row that may not be processed
+        if (cut == 0) break;                             // the cut lies in front of this row
         const uint32_t need = r.bestn - (row_open ? got : 0u);   // >= 1
         int stop = 128;
         if ((uint32_t)popc128(inc) >= need) stop = nth128(inc, need);
         if (any128(ac)) stop = min(stop, ctz128(ac));
-        const int cut = dupstop < (uint32_t)(k * 128 + 128) ? (int)(dupstop - (uint32_t)(k * 128)) : 128;   // first offset of the row that may not be processed
         const bool complete = stop < cut || (cut == 128);   // the row ends before the cut (or there is none in it)
-        proc[k] = complete ? upto128(stop) : upto128(cut - 1);   // (cut >= 1 here: cut == 0 was caught above)
-        const uint32_t first_k = row_open ? pbase : (uint32_t)(a[k] + 1);
+        proc[k] = andn128(complete ? upto128(stop) : upto128(cut - 1), gone);
         const M128 apk = and128(ap, proc[k]);
         for (uint64_t m = apk.lo; m; m &= m - 1) cset(first_k + (uint32_t)__builtin_ctzll(m));   // partners found contained
         for (uint64_t m = apk.hi; m; m &= m - 1) cset(first_k + 64u + (uint32_t)__builtin_ctzll(m));
@@ -1131,8 +1156,11 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
           break;
         }
         ++committed;
-        if (any128(apk) || rowc) break;   // contained flags changed: the rows below are looked at again with them
       }
+#ifdef PGX_BIG_STATS
+      ++st_steps, st_rows += (uint32_t)committed, st_cut += open_next ? 1u : 0u, st_full += (committed == nrows) ? 1u : 0u;
+      st_cont += (!open_next && committed < nrows) ? 1u : 0u;
+#endif
       if (committed) done_to = a[committed - 1];
       row_open = open_next;
       if (open_next) cur_row = open_row, pbase = open_pbase, got = open_got;
@@ -1226,6 +1254,16 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
       if (s_bail) break;
     }
     resolve_pending();
+#ifdef PGX_BIG_STATS
+    if (threadIdx.x == 0) {   // [3] steps, [4] rows committed, [5] steps cut at a duplicate, [6] steps ended by a containment, [7] steps that committed all their rows
+      unsigned long long *line = r.spread + (blockIdx.x % SPREAD) * 8;
+      atomicAdd(line + 3, (unsigned long long)st_steps), atomicAdd(line + 4, (unsigned long long)st_rows), atomicAdd(line + 5, (unsigned long long)st_cut);
+      atomicAdd(line + 6, (unsigned long long)st_cont), atomicAdd(line + 7, (unsigned long long)st_full);
+      atomicMax(&r.c->big_max_steps, st_steps);
+      if (st_steps >= 64) atomicAdd(&r.c->big_long, 1u), atomicAdd(&r.c->big_long_n, n);
+      atomicAdd(&r.c->big_evals, 1u);
+    }
+#endif
     if (threadIdx.x == 0) {
       if (s_bail) {   // (guard path: evaluated again by k_eval_rows, one partner at a time; the lists written so far are simply dropped)
         r.dirty[j] = 1, r.evaluated[j] = 0, r.parity[j] ^= 1;
@@ -1737,6 +1775,14 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     if (totals) {
       hc->evals = hc->lookups = hc->skips = 0;
       for (uint32_t i = 0; i < SPREAD; ++i) hc->evals += hs[i * 8], hc->lookups += hs[i * 8 + 1], hc->skips += hs[i * 8 + 2];
+#ifdef PGX_BIG_STATS
+      {
+        unsigned long long b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
+        for (uint32_t i = 0; i < SPREAD; ++i) b3 += hs[i * 8 + 3], b4 += hs[i * 8 + 4], b5 += hs[i * 8 + 5], b6 += hs[i * 8 + 6], b7 += hs[i * 8 + 7];
+        fprintf(stderr, "[pgx]   k_eval_big so far: %u evaluations, %llu steps, %llu rows committed; steps cut at a duplicate %llu, ended by a containment %llu, all rows %llu; longest %u steps, %u evaluations of >= 64 steps (entries %u)\n",
+                hc->big_evals, b3, b4, b5, b6, b7, hc->big_max_steps, hc->big_long, hc->big_long_n);
+      }
+#endif
 #ifdef PGX_SETTLE_STATS
       unsigned long long c3 = 0, c4 = 0, c5 = 0, c6 = 0;
       for (uint32_t i = 0; i < SPREAD; ++i) c3 += hs[i * 8 + 3], c4 += hs[i * 8 + 4], c5 += hs[i * 8 + 5], c6 += hs[i * 8 + 6];
