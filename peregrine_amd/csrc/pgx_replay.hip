@@ -571,6 +571,37 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
   }
 }
 
+// 128-bit masks over a row's partners / a bucket's entries (k_eval_rows, k_eval_big)
+struct M128 {
+  uint64_t lo, hi;
+};
+__device__ __forceinline__ int popc128(M128 m) { return __popcll(m.lo) + __popcll(m.hi); }
+__device__ __forceinline__ bool any128(M128 m) { return (m.lo | m.hi) != 0; }
+__device__ __forceinline__ int ctz128(M128 m) { return m.lo ? __builtin_ctzll(m.lo) : 64 + __builtin_ctzll(m.hi); }   // (m != 0)
+__device__ __forceinline__ int nth128(M128 m, uint32_t nth) {   // position of the nth set bit (nth >= 1, nth <= popc128(m))
+  const uint32_t cl = (uint32_t)__popcll(m.lo);
+  uint64_t w = m.lo;
+  int base = 0;
+  if (nth > cl) w = m.hi, nth -= cl, base = 64;
+  for (uint32_t k = 1; k < nth; ++k) w &= w - 1;
+  return base + __builtin_ctzll(w);
+}
+__device__ __forceinline__ M128 upto128(int stop) {   // bits 0 .. stop (stop >= 127: all)
+  M128 m;
+  m.lo = stop >= 63 ? ~0ULL : ((2ULL << stop) - 1ULL);
+  m.hi = stop < 64 ? 0ULL : (stop >= 127 ? ~0ULL : ((2ULL << (stop - 64)) - 1ULL));
+  return m;
+}
+__device__ __forceinline__ M128 and128(M128 a, M128 b) { return M128{a.lo & b.lo, a.hi & b.hi}; }
+__device__ __forceinline__ M128 andn128(M128 a, M128 b) { return M128{a.lo & ~b.lo, a.hi & ~b.hi}; }   // a & ~b
+__device__ __forceinline__ M128 shr128(M128 m, uint32_t s) {   // m >> s, s <= 128
+  if (s >= 128) return M128{0, 0};
+  if (s >= 64) return M128{m.hi >> (s - 64), 0};
+  if (s == 0) return m;
+  return M128{m.lo >> s | m.hi << (64 - s), m.hi >> s};
+}
+
+
 // ---- the same evaluation with FOUR ROWS PER STEP, for the sparse passes (a wavefront per bucket: lanes are plentiful there and
 // a pass lasts as long as its longest bucket's chain of rows).  Lane l works row l / PW, partner l % PW; the rows are committed
 // in order while each one is complete within its PW partners and no earlier row of the step set a contained flag (then the
@@ -764,12 +795,16 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
       else pbase += step;
     } else if (alive) {
       int committed = 0;
-      bool flagged = false;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (k >= nrows || flagged || committed != k) continue;
+        if (k >= nrows || committed != k) continue;
         const int row = k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : a3;
-        const uint32_t inc_k = (uint32_t)((inc >> (PW * k)) & RM), ac_k = (uint32_t)((AC >> (PW * k)) & RM), ap_k = (uint32_t)((AP >> (PW * k)) & RM);
+        // partners an EARLIER row of this step found contained (or that were such a row) are not examined by this row: their lanes are
+        // dropped from its masks here (round 3 ended the step at the first row that changed a flag; a row's partners lie above it, so
+        // the rows themselves are never flagged by an earlier row of the step)
+        const uint32_t gone = (uint32_t)shr128(M128{clo, chi}, (uint32_t)row + 1).lo & (uint32_t)RM;
+        const uint32_t inc_k = (uint32_t)((inc >> (PW * k)) & RM) & ~gone, ac_k = (uint32_t)((AC >> (PW * k)) & RM) & ~gone,
+                       ap_k = (uint32_t)((AP >> (PW * k)) & RM) & ~gone;
         int stop = PW;
         if ((uint32_t)__popc(inc_k) >= r.bestn) {
           uint32_t m = inc_k;
@@ -778,18 +813,11 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
         }
         if (ac_k) stop = min(stop, (int)__builtin_ctz(ac_k));
         if (stop == PW && (uint32_t)row + 1 + PW < n) continue;  // the row needs more partners: it is continued alone (committed stays k)
-        const uint32_t proc_k = stop < PW ? (2u << stop) - 1u : (uint32_t)RM;
+        const uint32_t proc_k = (stop < PW ? (2u << stop) - 1u : (uint32_t)RM) & ~gone;
         proc |= (uint64_t)proc_k << (PW * k);
         ++committed;
-        if ((ap_k | ac_k) & proc_k) flagged = true;  // contained flags change: the rows below are looked at again with them
-      }
-      for (uint64_t m = AP & proc; m; m &= m - 1) {
-        const int l = __builtin_ctzll(m), k = l >> SH;
-        cset((uint32_t)((k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : a3) + 1 + (l & (PW - 1))));
-      }
-      for (uint64_t m = AC & proc; m; m &= m - 1) {
-        const int k = __builtin_ctzll(m) >> SH;
-        cset((uint32_t)(k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : a3));
+        for (uint32_t m = ap_k & proc_k; m; m &= m - 1) cset((uint32_t)row + 1 + (uint32_t)__builtin_ctz(m));   // partners found contained
+        if (ac_k & proc_k) cset((uint32_t)row);
       }
       if (committed == 0) cur_row = a0, got = 0, pbase = (uint32_t)a0 + 1, row_open = true;  // (nothing done in this step)
       else done_to = committed == 1 ? a0 : committed == 2 ? a1 : committed == 3 ? a2 : a3;
@@ -875,39 +903,14 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
 // evaluation, and a sparse pass lasts as long as its largest bucket: 0.47 s of a 1.07 s step at C4 scale went there
 // (profiles/r03a_kernel_stats_bench_c4s.txt), and the ~15 tail sweeps of a human-scale chunk are little else.  Here eight
 // wavefronts take FOUR rows x 128 partners per step (a bucket holds at most 128 entries, so a row is always complete within its
-// step): the rows are committed in order through masks exchanged in LDS, exactly like k_eval_rows' four-row form -- a row commits
-// while no earlier row of the step set a contained flag; the rest is looked at again with the new flags.
-constexpr int BIG_NW = 8;                       // wavefronts per bucket: rows slot = wave / 2, partner half = wave % 2
+// step): the rows are committed in order through masks exchanged in LDS, exactly like k_eval_rows' four-row form; a partner that an
+// earlier row of the step found contained is dropped from the later rows' masks in place (round 4).
+#ifndef PGX_BIG_NW
+#define PGX_BIG_NW 8
+#endif
+constexpr int BIG_NW = PGX_BIG_NW;              // wavefronts per bucket: rows slot = wave / 2, partner half = wave % 2
+constexpr int BIG_NR = BIG_NW / 2;              // rows of a step
 constexpr uint32_t BIG_WG = 512;                // workgroups of a launch (persistent: they stride over the list / the range, 512 entries at a time)
-struct M128 {
-  uint64_t lo, hi;
-};
-__device__ __forceinline__ int popc128(M128 m) { return __popcll(m.lo) + __popcll(m.hi); }
-__device__ __forceinline__ bool any128(M128 m) { return (m.lo | m.hi) != 0; }
-__device__ __forceinline__ int ctz128(M128 m) { return m.lo ? __builtin_ctzll(m.lo) : 64 + __builtin_ctzll(m.hi); }   // (m != 0)
-__device__ __forceinline__ int nth128(M128 m, uint32_t nth) {   // position of the nth set bit (nth >= 1, nth <= popc128(m))
-  const uint32_t cl = (uint32_t)__popcll(m.lo);
-  uint64_t w = m.lo;
-  int base = 0;
-  if (nth > cl) w = m.hi, nth -= cl, base = 64;
-  for (uint32_t k = 1; k < nth; ++k) w &= w - 1;
-  return base + __builtin_ctzll(w);
-}
-__device__ __forceinline__ M128 upto128(int stop) {   // bits 0 .. stop (stop >= 127: all)
-  M128 m;
-  m.lo = stop >= 63 ? ~0ULL : ((2ULL << stop) - 1ULL);
-  m.hi = stop < 64 ? 0ULL : (stop >= 127 ? ~0ULL : ((2ULL << (stop - 64)) - 1ULL));
-  return m;
-}
-__device__ __forceinline__ M128 and128(M128 a, M128 b) { return M128{a.lo & b.lo, a.hi & b.hi}; }
-__device__ __forceinline__ M128 andn128(M128 a, M128 b) { return M128{a.lo & ~b.lo, a.hi & ~b.hi}; }   // a & ~b
-__device__ __forceinline__ M128 shr128(M128 m, uint32_t s) {   // m >> s, s <= 128
-  if (s >= 128) return M128{0, 0};
-  if (s >= 64) return M128{m.hi >> (s - 64), 0};
-  if (s == 0) return m;
-  return M128{m.lo >> s | m.hi << (64 - s), m.hi >> s};
-}
-
 // Buckets that hold a read TWICE (tandem arrays, low-complexity runs: the same shimmer pair several times within a read) can
 // meet a read pair more than once within one evaluation, and the second meeting must see the first one's insertion.  The
 // narrower kernels therefore run them one partner at a time -- up to 5,000 dependent steps for a 100-entry bucket, and those
@@ -1016,11 +1019,13 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
 #endif
     for (;;) {
       // the rows of this step: the open row alone, or the next (up to four) rows that are not contained
-      int a[4] = {-1, -1, -1, -1}, nrows = 0;
+      int a[BIG_NR], nrows = 0;
+#pragma unroll
+      for (int k = 0; k < BIG_NR; ++k) a[k] = -1;
       if (row_open) {
         a[0] = cur_row, nrows = 1;
       } else {
-        for (int x = done_to; nrows < 4;) {
+        for (int x = done_to; nrows < BIG_NR;) {
           do --x;
           while (x >= 0 && cget((uint32_t)x));
           if (x < 0) break;
@@ -1120,7 +1125,9 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
       }
       if (s_abort) break;
       // ---- the sequential semantics over this step: the rows in order, each over its 128 partners, lowest first (uniform) ----
-      M128 proc[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+      M128 proc[BIG_NR];
+#pragma unroll
+      for (int k = 0; k < BIG_NR; ++k) proc[k] = M128{0, 0};
       int committed = 0;         // rows completed in this step
       bool open_next = false;    // the row after them was cut: it is continued alone
       int open_row = 0;
@@ -1516,11 +1523,13 @@ __global__ __launch_bounds__(256) void k_file(R r, uint32_t limit) {
   const uint32_t b = run ? r.bid[j] : 0u, s0 = run ? r.bstart[b] : 0u;
   uint32_t it = run ? r.ihead[j] : NIL;
   const bool tail = r.tail != 0;
+  const uint32_t nn = run ? r.bstart[b + 1] - s0 : 0u;
   for (;;) {
     // ---- this lane's next unfiled item ----
     bool fan = false;             // the item filed a NEW alignment (tail mode): its pair's other readers are looked at below
-    uint32_t f_slot = 0, f_a = 0, f_b = 0;
-    while (it != NIL && !fan) {
+    bool ah = false;              // the item was filed in tail mode: its row's next partners are filed ahead below
+    uint32_t f_slot = 0, f_a = 0, f_b = 0, ah_ai = 0, ah_pi = 0;
+    while (it != NIL && !fan && !ah) {
       Item &im = r.items[it - 1];
       const uint32_t nxt = im.next;
       if (im.info & I_UNFILED) {
@@ -1561,17 +1570,22 @@ __global__ __launch_bounds__(256) void k_file(R r, uint32_t limit) {
         ++my;
         im.mslot = found;
         im.info &= ~I_UNFILED;
-        if (tail) {  // ... and the row's next partners: if this one is rejected the row goes on to them (a row of a repeat-rich
-                     // bucket can have dozens of candidates, each rejection otherwise costing a sweep)
-          const uint32_t nn = r.bstart[b + 1] - s0;
-          for (uint32_t p = pi + 1; p < nn && p <= pi + r.tail; ++p) file_entries(r, s0, ai, p);
-        }
+        if (tail) ah = true, ah_ai = ai, ah_pi = pi;   // ... and the row's next partners (below)
         if (tail && fresh) fan = true, f_slot = im.pslot, f_a = e0.rid, f_b = e1.rid;
       }
       it = nxt;
     }
-    const uint64_t fm = __ballot(fan);
-    if (!fm && !__ballot(it != NIL)) break;
+    const uint64_t fm = __ballot(fan), am = __ballot(ah);
+    if (!fm && !am && !__ballot(it != NIL)) break;
+    // ---- tail mode: the row's next partners -- if this candidate is rejected the row goes on to them (a row of a repeat-rich bucket can
+    // have dozens of candidates, each rejection otherwise costing a sweep) -- a partner per lane.  (Through round 3 the filing lane walked
+    // its r.tail partners itself, a dependent memo probe each, item after item: the tail sweeps' k_file launches took up to 7 ms at c4s.)
+    for (uint64_t mm = am; mm; mm &= mm - 1) {
+      const int L = __builtin_ctzll(mm);
+      const uint32_t sL = (uint32_t)__shfl((int)s0, L, 64), aL = (uint32_t)__shfl((int)ah_ai, L, 64), pL = (uint32_t)__shfl((int)ah_pi, L, 64);
+      const uint32_t nL = (uint32_t)__shfl((int)nn, L, 64);
+      for (uint32_t p = pL + 1 + (uint32_t)lane; p < nL && p <= pL + r.tail; p += 64) file_entries(r, sL, aL, p);
+    }
     // ---- tail mode: the alignment every OTHER reader of a newly requested pair would ask for (file_for_reader) -- by the whole
     // wavefront, a reader bucket per lane.  (Round 2 left this to the filing lane alone: a pair of a repeat-rich set has dozens of
     // readers of up to 128 entries each, scanned one after the other -- k_file was 21 ms of a c4s step and 42 ms of c5s'.)
@@ -1715,7 +1729,10 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   // (measured at C4 scale: the buckets that hold a read twice -- 7 k of 2.3 M, up to 128 entries, one partner at a time in the narrow
   // kernels -- were what every sparse pass waited for; big buckets WITHOUT a repeated read are rare (40 of 2.3 M beyond 48 entries:
   // the multiplicity cut-off removes the repeat families' shimmers) and stay with the narrow kernels by default)
-  r.big_min = getenv("PGX_REPLAY_BIG") ? (uint32_t)std::max(0, atoi(getenv("PGX_REPLAY_BIG"))) : 0u;
+  // (round 4: 48 -- with k_eval_big's walk a third shorter the long buckets WITHOUT a repeated read are better off there too: k_eval_rows 38 -> 22 ms
+  //  per c4s step, hidden behind k_eval_big as it is: 360 -> 354 ms; from 24 entries on k_eval_big doubles, 411 ms.  Sixteen wavefronts = eight
+  //  rows a step (-DPGX_BIG_NW=16): k_eval_big 56 -> 186 ms.)
+  r.big_min = getenv("PGX_REPLAY_BIG") ? (uint32_t)std::max(0, atoi(getenv("PGX_REPLAY_BIG"))) : 48u;
   r.dup_min = getenv("PGX_REPLAY_DUP") ? (uint32_t)std::max(0, atoi(getenv("PGX_REPLAY_DUP"))) : 12u;
   DevBuf<uint4> wcur(nb + 2 + SPARSE_CAP + 1 + (size_t)BIG_WG * BIG_NW);  // (one slot per wavefront of k_eval: GPW buckets each; list mode; k_eval_big)
   r.wcur = wcur.p, r.wlist0 = (uint32_t)(nb + 2), r.wbig0 = (uint32_t)(nb + 2 + SPARSE_CAP + 1);
