@@ -55,6 +55,19 @@ template <int GL>
 __device__ __forceinline__ uint32_t group_bits(uint64_t wave_mask, int gbase) {
   return (uint32_t)(wave_mask >> gbase) & ((1u << GL) - 1u);
 }
+template <int CTRL>
+__device__ __forceinline__ int dpp_min(int v) {
+  return min(v, __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true));   // (one v_min_i32_dpp)
+}
+// minimum over the 8 lanes of a group, result in every lane (same butterfly as group_max_i32<8>)
+__device__ __forceinline__ int group_min8_i32(int v) {
+  v = dpp_min<0xB1>(v);
+  v = dpp_min<0x4E>(v);
+  return dpp_min<0x141>(v);
+}
+// value of lane l of the caller's group: gb4 = byte address of the group's lane 0 (ds_bpermute addresses lanes by 4 l).  __shfl computes
+// ((l & 63) | (self & ~63)) << 2 in front of every call -- three instructions of a kernel that is bound by their issue
+__device__ __forceinline__ int group_lane(int v, int gb4, int l) { return __builtin_amdgcn_ds_bpermute(gb4 + (l << 2), v); }
 
 // ---- one candidate per wavefront: all per-candidate state is wave-uniform (scalar registers, readlane instead of
 // cross-lane permutes, no predicated bookkeeping), so a d-step costs roughly half the instructions of the grouped kernel.
@@ -455,7 +468,8 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
   // redo_list != nullptr: the candidates are keys[redo_list[0 .. *redo_n)] (the ones a narrow-ring launch handed on);
   // esc_list != nullptr: a candidate whose band outgrows this launch's V ring is appended there instead of being finished
   extern __shared__ int32_t Vall[];
-  const int lane = threadIdx.x, gl = lane & (GL - 1), gbase = lane & ~(GL - 1);
+  static_assert(GL == 8, "the group operations below are written for 8-lane groups (half a DPP row)");
+  const int lane = threadIdx.x, gl = lane & (GL - 1), gbase = lane & ~(GL - 1), gb4 = gbase << 2;
   VT *V = reinterpret_cast<VT *>(Vall) + (lane / GL) * ring;
   const int mask = ring - 1, band_size = band * 2;
   constexpr int SL = PACKED ? 32 : (GL == 16 ? 8 : 16);  // codes per lane and snake iteration
@@ -463,6 +477,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
   if (redo_list) n = *redo_n;
   uint32_t qo = 0, to = 0;   // PACKED: position of base 0 inside the dword q / t point at (q, t then address dwords of a pack)
   uint32_t iters = 0;        // wavefront iterations since the group fetched its candidate
+  uint32_t c_next = 0, c_end = 0;   // the wavefront's chunk of the work counter (uniform over the wavefront)
 
   // per-candidate state, uniform within a group
   int phase = PH_FETCH;
@@ -475,7 +490,8 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
   int q_bgn = 0, t_bgn = 0, q_m_end = 0, t_m_end = 0;
   // per-lane state of the running round
   int x = 0, y = 0, x1 = 0, y1 = 0, k = 0;
-  bool active = false, more = false;
+  bool active = false;
+  uint32_t gm = 0;   // SNAKE: the lanes of the group whose diagonal still has codes to compare (bit gl; uniform within the group)
 
 #ifdef PGX_ALIGN_STATS
   uint32_t my_iters = 0;
@@ -499,11 +515,43 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
 #endif
     // ---- FETCH: idle groups pull the next candidate --------------------------------------------------------------
     ++iters;
-    if (phase == PH_FETCH) {
+#ifdef PGX_PAD_VALU   // (experiment: what the kernel is bound by -- N extra full-rate / half-rate VALU or SALU instructions per iteration)
+    { int pad = lane; for (int i_ = 0; i_ < PGX_PAD_VALU; ++i_) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(pad) : "v"(lane)); }
+#endif
+#ifdef PGX_PAD_VMIN
+    { int pad = lane; for (int i_ = 0; i_ < PGX_PAD_VMIN; ++i_) asm volatile("v_min_i32 %0, %0, %1" : "+v"(pad) : "v"(lane)); }
+#endif
+#ifdef PGX_PAD_SALU
+    { int pad = 1; for (int i_ = 0; i_ < PGX_PAD_SALU; ++i_) asm volatile("s_add_u32 %0, %0, 1" : "+s"(pad) : : "scc"); }
+#endif
+    // The work counter is ONE address: an L2 channel serves same-address atomics one wavefront-instruction at a time, ~12 ns each
+    // (measured on k_keep) -- with an add per candidate a launch of 4.66 M candidates cannot finish in under 56 ms whatever
+    // the kernel does, and that is exactly where rounds 3 and 4 stood (84 M alignments/s at c3 for every form of the kernel; 24 more
+    // VALU or 40 more SALU instructions per iteration changed nothing).  A wavefront therefore takes CHUNK candidates per add and hands
+    // them to its groups as they come free; the launch's tail grows by at most CHUNK / 8 candidates per group.
+    const bool fetching = phase == PH_FETCH;
+    const uint64_t fw = ballot64(fetching);
+    uint32_t na = 0;
+    if (fw) {   // (wave-uniform; ~3 % of the iterations)
+      constexpr uint32_t CHUNK = 16;
+      const uint64_t need = fw & 0x0101010101010101ULL;   // the first lanes of the fetching groups
+      const uint32_t cnt = (uint32_t)__builtin_popcountll(need);
+      const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));   // such lanes below this one
+      const uint32_t avail = __builtin_amdgcn_readfirstlane(c_end - c_next);
+      na = c_next + r;
+      if (avail < cnt) {   // a new chunk; what is left of the old one goes out first
+        uint32_t got = 0;
+        if (lane == 0) got = atomicAdd(counter, CHUNK);
+        got = __builtin_amdgcn_readfirstlane(got);
+        if (r >= avail) na = got + (r - avail);
+        c_next = got + (cnt - avail), c_end = got + CHUNK;
+      } else {
+        c_next += cnt;
+      }
+    }
+    if (fetching) {
       iters = 0;
-      uint32_t na = 0;
-      if (gl == 0) na = atomicAdd(counter, 1u);
-      na = (uint32_t)__shfl((int)na, gbase, 64);
+      na = (uint32_t)group_lane((int)na, gb4, 0);
       if (na >= n) {
         phase = PH_DONE;
       } else {
@@ -564,12 +612,12 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
     }
 
     // ---- ROUND: start points and the 8-code probe of GL diagonals ----------------------------------------------------
+    int probe_full = 0;   // >= PROBE: the lane's probe matched throughout and its diagonal has more codes to compare
     if (phase == PH_ROUND) {
       const int j = base + gl;
       active = j < nk;
       k = min_k + 2 * j;
       x = 0, y = 0, x1 = 0, y1 = 0;
-      more = false;
       if (active) {
         const int va = (int)V[(k - 1) & mask], vb = (int)V[(k + 1) & mask];
         x = (k == min_k || (k != max_k && va < vb)) ? vb : va + 1;
@@ -587,31 +635,35 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
           } else {
             m = match8(load_u64_unaligned(q + x), load_u64_unaligned(t + y), qs, ts);
           }
+          probe_full = min(m, rem - 1);   // (m <= PROBE: >= PROBE iff m == PROBE and rem > PROBE)
           m = min(m, rem);
           x += m, y += m;
-          more = (m == PROBE) && (rem > PROBE);
         }
       }
     }
     {
-      const uint32_t gm = group_bits<GL>(ballot64(more && phase == PH_ROUND), gbase);
-      if (phase == PH_ROUND) phase = gm ? PH_SNAKE : PH_END;
+      // (a ballot of ONE integer compare is one v_cmp; of a bool the compiler materialises 0 / 1 and compares again.  Lanes outside
+      //  ROUND hold 0.)  The group's mask is STATE from here on: SNAKE clears a bit per finished diagonal, no ballot of its own.
+      asm volatile("" : "+v"(probe_full));   // (kept a VGPR value: as a bool the compiler carries it as a lane mask and the ballot costs a select + a compare on top)
+      const uint32_t g = group_bits<GL>(ballot64(probe_full >= PROBE), gbase);
+      if (phase == PH_ROUND) gm = g, phase = g ? PH_SNAKE : PH_END;
     }
 
     // ---- SNAKE: one extension of the group's lowest unfinished diagonal ----------------------------------------------
     {
-      const uint64_t mw = ballot64(more && phase == PH_SNAKE);
-      if (mw) {
-        const uint32_t gm = group_bits<GL>(mw, gbase);
-        const bool has = gm != 0 && phase == PH_SNAKE;
-        const int L = has ? __builtin_ctz(gm) : 0;
-        const int xs = __shfl(x, gbase + L, 64), ys = __shfl(y, gbase + L, 64);
+      const bool sn = phase == PH_SNAKE;
+      if (ballot64(sn)) {
+        const int L = __builtin_ctz(gm | 0x100u);   // (groups outside SNAKE: lane 8 = the next group's lane 0, looked at and dropped)
+        const int xs = group_lane(x, gb4, L), ys = group_lane(y, gb4, L);
         const int rem = min(q_len - xs, t_len - ys);
         const int off = gl * SL;
-        int m = SL;
-        if (has) {
-          m = 0;
+        // e = length of the run if it ends inside this lane's piece (a mismatch, or the end of a sequence), GL * SL if it does not:
+        // the run's length is the minimum over the group (the pieces before the first such lane match throughout)
+        int e = GL * SL;
+        if (sn) {
+          e = off;   // (a piece beyond the end of a sequence: the run ends at its start at the latest)
           if (off < rem) {
+            int m;
             if (PACKED) {   // 32 bases: three dwords of either pack (one 16-byte load at a dword address), two funnel shifts each
               const uint32_t xq = qo + (uint32_t)(xs + off), yt = to + (uint32_t)(ys + off);
               uint4 qd, td;
@@ -619,29 +671,25 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
               const uint32_t qsh = (xq & 15) << 1, tsh = (yt & 15) << 1;
               const uint32_t d0 = __builtin_amdgcn_alignbit(qd.y, qd.x, qsh) ^ __builtin_amdgcn_alignbit(td.y, td.x, tsh);
               const uint32_t d1 = __builtin_amdgcn_alignbit(qd.z, qd.y, qsh) ^ __builtin_amdgcn_alignbit(td.z, td.y, tsh);
-              m = d0 ? (__builtin_ctz(d0) >> 1) : d1 ? 16 + (__builtin_ctz(d1) >> 1) : 32;
-            } else if (SL == 16) {  // 16 codes with one 16-byte load per sequence (half the vector-memory instructions of two 8-byte ones)
+              // (one find-first-bit over both halves: written as d0 ? .. : d1 ? .. the compiler loads the third dwords only behind the
+              //  test of d0 -- a second, dependent trip to the cache in most extensions, in a kernel whose wavefronts wait 60 % of their time)
+              const uint64_t dd = ((uint64_t)d1 << 32) | d0;
+              m = dd ? (__builtin_ctzll(dd) >> 1) : 32;
+            } else {  // 16 codes with one 16-byte load per sequence (half the vector-memory instructions of two 8-byte ones)
               const U128 qa = load_u128_unaligned(q + xs + off), ta = load_u128_unaligned(t + ys + off);
               m = match8(qa.lo, ta.lo, qs, ts);
               if (m == 8) m += match8(qa.hi, ta.hi, qs, ts);
-            } else {
-              m = match8(load_u64_unaligned(q + xs + off), load_u64_unaligned(t + ys + off), qs, ts);
             }
             m = min(m, rem - off);
+            e = m < SL ? off + m : GL * SL;
           }
         }
-        const uint32_t sg = group_bits<GL>(ballot64(m < SL), gbase);   // (m == SL wherever !has: one compare, no mask logic)
-        int ext = GL * SL;
-        if (sg) {
-          const int f = __builtin_ctz(sg);
-          ext = SL * f + __shfl(m, gbase + f, 64);
+        const int ext = group_min8_i32(e);
+        if (sn) {
+          if (gl == L) x += ext, y += ext;
+          if (ext < GL * SL || ext >= rem) gm &= gm - 1;  // mismatch found or an end reached: this diagonal is done
+          if (!gm) phase = PH_END;
         }
-        if (has && gl == L) {
-          x += ext, y += ext;
-          if (sg || ext >= rem) more = false;  // mismatch found or an end reached: this diagonal is done
-        }
-        const uint32_t gm2 = group_bits<GL>(ballot64(more && phase == PH_SNAKE), gbase);
-        if (phase == PH_SNAKE && !gm2) phase = PH_END;
       }
     }
 
@@ -653,9 +701,10 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
       const uint64_t hitw = ballot64(hit);
       int hl = GL;
       uint32_t hitm = 0;
-      if (hitw) {
+      if (hitw) {   // (once per candidate)
         hitm = group_bits<GL>(hitw, gbase);
         if (hitm) hl = __builtin_ctz(hitm);
+        asm volatile("" : "+v"(hl));   // (keeps the branch: folded into selects the four instructions run in every iteration)
       }
       const bool valid = e && active && gl <= hl;
       {  // first extension > 16 fixes q_bgn/t_bgn once (DWmatch.c:142-146)
@@ -664,7 +713,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
         if (sw) {
           const uint32_t m = group_bits<GL>(sw, gbase);
           const int l = m ? __builtin_ctz(m) : 0;
-          const int bx = __shfl(x1, gbase + l, 64), by = __shfl(y1, gbase + l, 64);
+          const int bx = group_lane(x1, gb4, l), by = group_lane(y1, gb4, l);
           if (m) q_bgn = bx, t_bgn = by, started = true;
         }
       }
@@ -673,17 +722,18 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
         const int mx = group_max_i32<GL>(ev);
         const uint32_t m = group_bits<GL>(ballot64(valid && ext == mx), gbase);
         const int l = m ? __builtin_ctz(m) : 0;
-        const int ex = __shfl(x, gbase + l, 64), ey = __shfl(y, gbase + l, 64);
+        const int ex = group_lane(x, gb4, l), ey = group_lane(y, gb4, l);
         if (e && mx >= 0 && (uint32_t)mx > longest) longest = (uint32_t)mx, q_m_end = ex, t_m_end = ey;
       }
       if (valid) V[k & mask] = (VT)x;
+      const int u = x + y;
       {
-        const int s = group_max_i32<GL>(valid ? x + y : -1);
+        const int s = group_max_i32<GL>(valid ? u : -1);
         if (e) best_m = max(best_m, s);
       }
       bool matched = false;
       if (hitw) {
-        const int ex = __shfl(x, gbase + (hl & (GL - 1)), 64), ey = __shfl(y, gbase + (hl & (GL - 1)), 64);
+        const int ex = group_lane(x, gb4, hl & (GL - 1)), ey = group_lane(y, gb4, hl & (GL - 1));
         if (e && hitm) {  // DWmatch.c:185-194
           matched = true;
           if (gl == 0) {
@@ -695,9 +745,16 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
           }
         }
       }
+      // The band update (DWmatch.c:166-183) of a step whose diagonals all sat in this one round -- 98.7 % of the steps -- right here, from
+      // the registers: U = x + y of the group's lanes, the qualifying diagonals as a mask, its lowest and highest bit.  (hit lanes: the
+      // candidate is finished, the update is not looked at.)  Wider bands go through BAND below, a round of GL diagonals per iteration.
+      const uint32_t qm = group_bits<GL>(ballot64((e && active ? u : INT32_MIN) >= best_m - band), gbase);
       if (e) {
         if (matched) {
           phase = PH_FETCH;
+        } else if (nk <= GL) {
+          const int lo = qm ? min_k + 2 * __builtin_ctz(qm) : max_k, hi = qm ? min_k + 2 * (31 - __builtin_clz(qm)) : min_k;
+          max_k = hi + 1, min_k = lo - 1, ++d, phase = PH_STEP;
         } else {
           base += GL;
           phase = base >= nk ? PH_BAND : PH_ROUND;
@@ -714,7 +771,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
         const int j = bbase + gl;
         const int k2 = min_k + 2 * j;
         int u = 0;
-        if (bnd && j < nk) u = (nk <= GL) ? x + y : 2 * (int)V[k2 & mask] - k2;
+        if (bnd && j < nk) u = 2 * (int)V[k2 & mask] - k2;   // (nk > GL: U of the earlier rounds' diagonals is not in the registers)
         const uint32_t m = group_bits<GL>(ballot64((bnd && j < nk ? u : INT32_MIN) >= thr), gbase);
         if (bnd) {
           if (m) {
