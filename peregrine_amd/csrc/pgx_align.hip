@@ -528,12 +528,17 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
     // (measured on k_keep) -- with an add per candidate a launch of 4.66 M candidates cannot finish in under 56 ms whatever
     // the kernel does, and that is exactly where rounds 3 and 4 stood (84 M alignments/s at c3 for every form of the kernel; 24 more
     // VALU or 40 more SALU instructions per iteration changed nothing).  A wavefront therefore takes CHUNK candidates per add and hands
-    // them to its groups as they come free; the launch's tail grows by at most CHUNK / 8 candidates per group.
+    // them to its groups as they come free.  What a wavefront holds back at the end of a launch is other wavefronts' idle time: alignment
+    // kernels per c3 / c4s step with CHUNK 8: 45.5 / 123.8 ms, 16: 46.0 / 127.3, 64: 49.0 / 157.4 (c4s's last candidates are its longest);
+    // the last 32 candidates per wavefront taken one by one again: 48.5 / 128.5 (the tail is then the old floor).
     const bool fetching = phase == PH_FETCH;
     const uint64_t fw = ballot64(fetching);
     uint32_t na = 0;
     if (fw) {   // (wave-uniform; ~3 % of the iterations)
-      constexpr uint32_t CHUNK = 16;
+#ifndef PGX_ALIGN_CHUNK
+#define PGX_ALIGN_CHUNK 8
+#endif
+      constexpr uint32_t CHUNK = PGX_ALIGN_CHUNK;
       const uint64_t need = fw & 0x0101010101010101ULL;   // the first lanes of the fetching groups
       const uint32_t cnt = (uint32_t)__builtin_popcountll(need);
       const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));   // such lanes below this one

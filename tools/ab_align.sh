@@ -8,7 +8,10 @@ fi
 export PGX_BENCH_CACHE=/dev/shm/pgx_bench_cache
 for w in ${WL:-c3 c4s}; do
 for lib in ${LIBS:-base new}; do
+  unset PGX_ALIGN_Q
   if [ $lib = new ]; then unset PGX_LIB; else export PGX_LIB=$PWD/peregrine_amd/libpgx_$lib.so; fi
+  if [ $lib = q ]; then export PGX_ALIGN_Q=1; fi
+  if [ $lib = qw ]; then export PGX_LIB=$PWD/peregrine_amd/libpgx_q.so PGX_ALIGN_Q=2; fi
   timeout 400 python bench.py --workload $w --steps ${STEPS:-6} --warmup 2 --no-cpu-baseline > gpurun_out/ab_${w}_$lib.json 2> gpurun_out/ab_${w}_$lib.err
   python - <<P
 import json
