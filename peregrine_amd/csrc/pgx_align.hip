@@ -475,6 +475,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
   constexpr int SL = PACKED ? 32 : (GL == 16 ? 8 : 16);  // codes per lane and snake iteration
   constexpr int PROBE = PACKED ? 16 : 8;                   // codes of a probe
   if (redo_list) n = *redo_n;
+  const uint32_t iter_budget = esc_list && iter_limit ? iter_limit : 0xFFFFFFFFu;
   uint32_t qo = 0, to = 0;   // PACKED: position of base 0 inside the dword q / t point at (q, t then address dwords of a pack)
   uint32_t iters = 0;        // wavefront iterations since the group fetched its candidate
   uint32_t c_next = 0, c_end = 0;   // the wavefront's chunk of the work counter (uniform over the wavefront)
@@ -592,27 +593,26 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
     PH_SYNC();
 
     // ---- STEP: the loop conditions of a new d (DWmatch.c:118-122,196-199) -------------------------------------------
-    if (phase == PH_STEP && esc_list && (max_k - min_k + 4 > ring || (iter_limit && iters > iter_limit)) && !(d >= max_d || max_k - min_k > band_size)) {
-      // the live diagonals k-1 .. k+1 no longer fit this launch's ring: the wide-ring launch redoes the candidate
+    // (the V ring holds every live diagonal of a band that passes the width test below: ring >= 2 band + 8 by dev_align, so the only
+    //  hand-on left is the iteration budget -- round 2's narrow-ring launches are gone)
+    if (iters > iter_budget && phase == PH_STEP && !(d >= max_d || max_k - min_k > band_size)) {   // a straggler: k_align1_list takes it, a wavefront of its own
       if (gl == 0) esc_list[atomicAdd(esc_n, 1u)] = a;
       phase = PH_FETCH;
     }
-    {
-      // (straight-line selects: written as nested branches the compiler kept the five step variables in copies it moved in and out of
-      //  every arm -- a fifth of the kernel's v_mov; the band scan's start values are set here for every step, END no longer does it)
-      const bool stp = phase == PH_STEP;
-      const bool term = stp && (d >= max_d || max_k - min_k > band_size);
-      if (term && gl == 0) {
-        pgx_match r;
-        r.m_size = 0, r.dist = 0, r.q_bgn = 0, r.q_end = 0, r.t_bgn = 0, r.t_end = 0;
-        r.t_m_end = t_m_end, r.q_m_end = q_m_end;
-        out[a] = r;
-      }
-      const int nk_new = max_k >= min_k ? ((max_k - min_k) >> 1) + 1 : 0;
-      if (stp) {
-        nk = nk_new, base = 0, bbase = 0, new_min = max_k, new_max = min_k;
-        // nk == 0: a degenerate band -- an empty k-loop, then the band update over nothing (followed literally)
-        phase = term ? PH_FETCH : (nk_new ? PH_ROUND : PH_BAND);
+    if (phase == PH_STEP) {
+      const int width = max_k - min_k;
+      if (d >= max_d || width > band_size) {   // the end of the d-loop without a match
+        if (gl == 0) {
+          pgx_match r;
+          r.m_size = 0, r.dist = 0, r.q_bgn = 0, r.q_end = 0, r.t_bgn = 0, r.t_end = 0;
+          r.t_m_end = t_m_end, r.q_m_end = q_m_end;
+          out[a] = r;
+        }
+        phase = PH_FETCH;
+      } else if (width < 0) {   // a degenerate band: an empty k-loop, then the band update over nothing (followed literally)
+        nk = 0, base = 0, bbase = 0, new_min = max_k, new_max = min_k, phase = PH_BAND;
+      } else {
+        nk = (width >> 1) + 1, base = 0, phase = PH_ROUND;
       }
     }
 
@@ -762,7 +762,8 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
           max_k = hi + 1, min_k = lo - 1, ++d, phase = PH_STEP;
         } else {
           base += GL;
-          phase = base >= nk ? PH_BAND : PH_ROUND;
+          phase = PH_ROUND;
+          if (base >= nk) bbase = 0, new_min = max_k, new_max = min_k, phase = PH_BAND;
         }
       }
     }
