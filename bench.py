@@ -257,8 +257,10 @@ def attach_counters(cands, kern, workload):
     WORKLOAD (tools/pmc_profile.sh <workload>: kernel-trace + one --pmc group per pass, never with the other trace domains) and committed
     under profiles/; bench.py itself cannot run under two profilers.  A workload without its own collection reports traffic = null and
     no `valu` object."""
-    VALU_CEILING = 0.25    # wave64 VALU instructions per cycle and SIMD for the four-cycle opcode class that dominates these kernels
-                           # (v_min / v_max / v_cmp / v_cndmask / v_alignbit / v_perm / DPP; plain adds and logic ops reach ~0.45): profiles/r03_valu_issue.txt
+    VALU_CEILING = 0.5     # wave64 VALU instructions per cycle and SIMD: a SIMD is 32 lanes wide, a wave64 add / logic / shift holds it two cycles (measured
+                           # 0.45-0.48); the four-cycle class (v_min / v_max / v_cmp / v_cndmask / v_alignbit / v_perm / DPP / SDWA) tops out at 0.23-0.32
+                           # (profiles/r03_valu_issue.txt).  Rounds 3-4 priced the alignment kernel against 0.25 and read 0.22 as "93 % of the ceiling": it was
+                           # the work counter's same-address atomic that held it there (round 4: DESIGN 4.4); with chunks of 8 it issues 0.31.
     N_SIMD = 1024          # 256 CUs x 4 SIMDs
     for tag in ("r04", "r03"):
         tfile = os.path.join("profiles", f"{tag}_traffic_{workload}.json")
@@ -293,7 +295,7 @@ def attach_counters(cands, kern, workload):
                 per_unit = v["SQ_INSTS_VALU"] / v["units"]
                 rate = v["SQ_INSTS_VALU"] / N_SIMD / v["SQ_BUSY_CYCLES_per_se"]
                 cands[nm]["valu"] = {"wave_instr_per_unit": per_unit, "salu_wave_instr_per_unit": v.get("SQ_INSTS_SALU", 0) / v["units"],
-                                     "issue_rate": rate, "ceiling": VALU_CEILING, "frac": rate / VALU_CEILING,
+                                     "issue_rate": rate, "ceiling": VALU_CEILING, "ceiling_four_cycle_opcodes": 0.25, "frac": rate / VALU_CEILING,
                                      "unit": "wave64 VALU instructions per cycle and SIMD", "unit_name": cands[nm]["unit_name"],
                                      "units_per_s_at_ceiling": VALU_CEILING * N_SIMD * v["clock_hz"] / per_unit,
                                      "source": vfile + " (rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES ... pass of this command; ceiling: profiles/r03_valu_issue.txt)"}

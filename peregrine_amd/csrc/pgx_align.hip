@@ -622,7 +622,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
       const int j = base + gl;
       active = j < nk;
       k = min_k + 2 * j;
-      x = 0, y = 0, x1 = 0, y1 = 0;
+      // (x, y, x1, y1 of the lanes beyond the band keep whatever they held: every use below is behind `active`)
       if (active) {
         const int va = (int)V[(k - 1) & mask], vb = (int)V[(k + 1) & mask];
         x = (k == min_k || (k != max_k && va < vb)) ? vb : va + 1;
@@ -835,7 +835,11 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
     return;
   }
   const size_t lds = (size_t)8 * ring * sizeof(uint16_t);
-  const unsigned per_cu = (unsigned)std::min<size_t>(32, (160u << 10) / lds);   // 32 = all the wavefronts a CU holds (measured at c3, ms of
+#ifdef PGX_ALIGN_WAVES_ENV   // (experiment builds: the persistent wavefronts per CU from the environment)
+  const unsigned per_cu = (unsigned)std::min<size_t>(getenv("PGX_ALIGN_WAVES") ? atoi(getenv("PGX_ALIGN_WAVES")) : 32, (160u << 10) / lds);
+#else
+  const unsigned per_cu = (unsigned)std::min<size_t>(32, (160u << 10) / lds);
+#endif   // 32 = all the wavefronts a CU holds (measured at c3, ms of
                                                                                // alignment kernels per step: 16 -> 82.1, 24 -> 63.4, 32 -> 56.8)
   const unsigned grid = (unsigned)std::min<size_t>((n + 7) / 8, (size_t)ctx().num_cu * per_cu);
   // The packs are built by the first launch of at least PGX_ALIGN_PACKED_MIN alignments (default 100,000; 4.5 GB of seqdb: 1.6 ms) and
