@@ -516,15 +516,6 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
 #endif
     // ---- FETCH: idle groups pull the next candidate --------------------------------------------------------------
     ++iters;
-#ifdef PGX_PAD_VALU   // (experiment: what the kernel is bound by -- N extra full-rate / half-rate VALU or SALU instructions per iteration)
-    { int pad = lane; for (int i_ = 0; i_ < PGX_PAD_VALU; ++i_) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(pad) : "v"(lane)); }
-#endif
-#ifdef PGX_PAD_VMIN
-    { int pad = lane; for (int i_ = 0; i_ < PGX_PAD_VMIN; ++i_) asm volatile("v_min_i32 %0, %0, %1" : "+v"(pad) : "v"(lane)); }
-#endif
-#ifdef PGX_PAD_SALU
-    { int pad = 1; for (int i_ = 0; i_ < PGX_PAD_SALU; ++i_) asm volatile("s_add_u32 %0, %0, 1" : "+s"(pad) : : "scc"); }
-#endif
     // The work counter is ONE address: an L2 channel serves same-address atomics one wavefront-instruction at a time, ~12 ns each
     // (measured on k_keep) -- with an add per candidate a launch of 4.66 M candidates cannot finish in under 56 ms whatever
     // the kernel does, and that is exactly where rounds 3 and 4 stood (84 M alignments/s at c3 for every form of the kernel; 24 more
@@ -835,12 +826,8 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
     return;
   }
   const size_t lds = (size_t)8 * ring * sizeof(uint16_t);
-#ifdef PGX_ALIGN_WAVES_ENV   // (experiment builds: the persistent wavefronts per CU from the environment)
-  const unsigned per_cu = (unsigned)std::min<size_t>(getenv("PGX_ALIGN_WAVES") ? atoi(getenv("PGX_ALIGN_WAVES")) : 32, (160u << 10) / lds);
-#else
-  const unsigned per_cu = (unsigned)std::min<size_t>(32, (160u << 10) / lds);
-#endif   // 32 = all the wavefronts a CU holds (measured at c3, ms of
-                                                                               // alignment kernels per step: 16 -> 82.1, 24 -> 63.4, 32 -> 56.8)
+  const unsigned per_cu = (unsigned)std::min<size_t>(32, (160u << 10) / lds);   // 32 = all the wavefronts a CU holds; alignment kernels per c3 step
+                                                                               // with the chunked work counter: 16 -> 65.3 ms, 20 -> 55.9, 24 -> 50.1, 28 -> 46.3, 32 -> 43.7
   const unsigned grid = (unsigned)std::min<size_t>((n + 7) / 8, (size_t)ctx().num_cu * per_cu);
   // The packs are built by the first launch of at least PGX_ALIGN_PACKED_MIN alignments (default 100,000; 4.5 GB of seqdb: 1.6 ms) and
   // serve every later launch on this database; < 0: never.

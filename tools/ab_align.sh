@@ -10,8 +10,6 @@ for w in ${WL:-c3 c4s}; do
 for lib in ${LIBS:-base new}; do
   unset PGX_ALIGN_Q
   if [ $lib = new ]; then unset PGX_LIB; else export PGX_LIB=$PWD/peregrine_amd/libpgx_$lib.so; fi
-  unset PGX_ALIGN_WAVES
-  case $lib in w[0-9]*) export PGX_LIB=$PWD/peregrine_amd/libpgx_w.so PGX_ALIGN_WAVES=${lib#w};; esac   # (a -DPGX_ALIGN_WAVES_ENV build: persistent wavefronts per CU)
   timeout 400 python bench.py --workload $w --steps ${STEPS:-6} --warmup 2 --no-cpu-baseline > gpurun_out/ab_${w}_$lib.json 2> gpurun_out/ab_${w}_$lib.err
   python - <<P
 import json
