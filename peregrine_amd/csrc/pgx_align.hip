@@ -253,6 +253,7 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
   VT *V = reinterpret_cast<VT *>(Vall) + (lane / GL) * ring;
   const int mask = ring - 1, band_size = band * 2;
 
+  uint32_t c_next = 0, c_end = 0;   // the wavefront's chunk of the work counter
   // per-candidate state, uniform within a 16-lane group
   bool alive = false, exhausted = false;
   uint32_t a = 0;
@@ -265,9 +266,30 @@ __global__ __launch_bounds__(64) void k_align4(const uint8_t *__restrict__ seq, 
 
   for (;;) {
     // ---- idle groups pull the next candidate ---------------------------------------------------------------
-    if (!alive && !exhausted) {
-      uint32_t na = 0;
-      if (gl == 0) na = atomicAdd(counter, 1u);
+    // (the work counter in chunks of 8 per wavefront, as in k_align_ph below: one address, ~12 ns per same-address atomic)
+    const bool fetching = !alive && !exhausted;
+    const uint64_t fw = ballot64(fetching);
+    uint32_t na = 0;
+    if (fw) {
+      constexpr uint32_t CHUNK = 8;
+      uint64_t need = 0;
+      for (int g = 0; g < 64; g += GL) need |= 1ULL << g;   // the first lanes of the groups
+      need &= fw;
+      const uint32_t cnt = (uint32_t)__builtin_popcountll(need);
+      const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+      const uint32_t avail = __builtin_amdgcn_readfirstlane(c_end - c_next);
+      na = c_next + r;
+      if (avail < cnt) {
+        uint32_t got = 0;
+        if (lane == 0) got = atomicAdd(counter, CHUNK);
+        got = __builtin_amdgcn_readfirstlane(got);
+        if (r >= avail) na = got + (r - avail);
+        c_next = got + (cnt - avail), c_end = got + CHUNK;
+      } else {
+        c_next += cnt;
+      }
+    }
+    if (fetching) {
       na = (uint32_t)__shfl((int)na, gbase, 64);
       if (na >= n) {
         exhausted = true;
