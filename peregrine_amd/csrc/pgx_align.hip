@@ -65,6 +65,13 @@ __device__ __forceinline__ int group_min8_i32(int v) {
   v = dpp_min<0x4E>(v);
   return dpp_min<0x141>(v);
 }
+// v_ffbl_b32 as the hardware defines it: the position of the lowest set bit, 0xFFFFFFFF for 0 (__builtin_ctz leaves 0 undefined and the
+// guarded form costs a compare and a select)
+__device__ __forceinline__ uint32_t ffbl_or_ones(uint32_t v) {
+  uint32_t r;
+  asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
 // value of lane l of the caller's group: gb4 = byte address of the group's lane 0 (ds_bpermute addresses lanes by 4 l).  __shfl computes
 // ((l & 63) | (self & ~63)) << 2 in front of every call -- three instructions of a kernel that is bound by their issue
 __device__ __forceinline__ int group_lane(int v, int gb4, int l) { return __builtin_amdgcn_ds_bpermute(gb4 + (l << 2), v); }
@@ -649,12 +656,12 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
             uint2 qd, td;
             __builtin_memcpy(&qd, q + (xq >> 4) * 4, 8), __builtin_memcpy(&td, t + (yt >> 4) * 4, 8);
             const uint32_t df = __builtin_amdgcn_alignbit(qd.y, qd.x, (xq & 15) << 1) ^ __builtin_amdgcn_alignbit(td.y, td.x, (yt & 15) << 1);
-            m = df ? (__builtin_ctz(df) >> 1) : 16;
+            m = (int)min(ffbl_or_ones(df) >> 1, 16u);   // (no test of df: the instruction answers ~0 for 0, and the minimum folds into the ones below)
           } else {
             m = match8(load_u64_unaligned(q + x), load_u64_unaligned(t + y), qs, ts);
           }
-          probe_full = min(m, rem - 1);   // (m <= PROBE: >= PROBE iff m == PROBE and rem > PROBE)
-          m = min(m, rem);
+          probe_full = (int)min((uint32_t)m, (uint32_t)(rem - 1));   // (m <= PROBE: >= PROBE iff m == PROBE and rem > PROBE; rem >= 1: unsigned, so that the
+          m = (int)min((uint32_t)m, (uint32_t)rem);                  //  minimum with 16 above folds into v_min3_u32)
           x += m, y += m;
         }
       }
@@ -689,16 +696,15 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
               const uint32_t qsh = (xq & 15) << 1, tsh = (yt & 15) << 1;
               const uint32_t d0 = __builtin_amdgcn_alignbit(qd.y, qd.x, qsh) ^ __builtin_amdgcn_alignbit(td.y, td.x, tsh);
               const uint32_t d1 = __builtin_amdgcn_alignbit(qd.z, qd.y, qsh) ^ __builtin_amdgcn_alignbit(td.z, td.y, tsh);
-              // (one find-first-bit over both halves: written as d0 ? .. : d1 ? .. the compiler loads the third dwords only behind the
-              //  test of d0 -- a second, dependent trip to the cache in most extensions, in a kernel whose wavefronts wait 60 % of their time)
-              const uint64_t dd = ((uint64_t)d1 << 32) | d0;
-              m = dd ? (__builtin_ctzll(dd) >> 1) : 32;
+              // (both halves at once: written as d0 ? .. : d1 ? .. the compiler loads the third dwords only behind the test of d0 -- a
+              //  second, dependent trip to the cache in most extensions, in a kernel whose wavefronts wait 60 % of their time)
+              m = (int)min(min(ffbl_or_ones(d0), ffbl_or_ones(d1) | 32u) >> 1, 32u);   // (both halves looked at, no test of either)
             } else {  // 16 codes with one 16-byte load per sequence (half the vector-memory instructions of two 8-byte ones)
               const U128 qa = load_u128_unaligned(q + xs + off), ta = load_u128_unaligned(t + ys + off);
               m = match8(qa.lo, ta.lo, qs, ts);
               if (m == 8) m += match8(qa.hi, ta.hi, qs, ts);
             }
-            m = min(m, rem - off);
+            m = (int)min((uint32_t)m, (uint32_t)(rem - off));   // (off < rem)
             e = m < SL ? off + m : GL * SL;
           }
         }
