@@ -825,15 +825,19 @@ void dev_align_prepare(const pgx_seqdb *db) {
 //   large launches : k_align_ph<8, u16, packed> over the 2-bit packs + k_align1_list for what it hands on (reads with bytes that have no
 //                    2-bit code, stragglers past the iteration budget); without packs (no HBM for them, PGX_ALIGN_PACKED_MIN < 0)
 //                    k_align_ph<8, u16> on the seqdb bytes; with a read beyond 65,535 bases (16-bit V ring too narrow) k_align4<8, int32>
-void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out, bool tail_batch) {
+void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out, int tail_batch) {
   if (n == 0) return;
   // (the knobs are read per call: the parity tests walk every kernel variant inside one process)
   // launches up to this many alignments take a wavefront per candidate (k_align1).  On uniform candidates the crossover is ~14 k
   // (tools/alignlat.py: 13,000) -- but the mid-size launches of a stage are its TAIL sweeps (tail_batch: every request batch of the
   // device replay after the first), and in repeat-rich sets those are mostly long, wide-band alignments that the 8-lane groups of
   // k_align_ph first run to their iteration budget and then hand on: 60,000 for them = c4s 423 -> 417 ms per step, c5s 633 -> 628,
-  // c3 unchanged (its second batch holds 71 k).  PGX_ALIGN_SMALL overrides both.
-  const long small_max = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : tail_batch ? 60000 : 13000;
+  // c3 unchanged (its second batch holds 71 k).  With the work counter's floor gone (round 4) re-swept on c4s: 13,000 -> 315.0 ms per step,
+  // 30,000 -> 313.3, 60,000 -> 307.2, 120,000 -> 303.3, 250,000 and more -> 300.4-302.9 (its largest tail batch); full-size c4: 60,000 -> 8.56 s,
+  // 250,000 -> 8.51, 1,000,000 -> 8.67 (the sweep-2 batches of ~0.8 M belong to the grouped kernel) -- but c3, whose SECOND batch is 71 k ordinary
+  // candidates (wrong type guesses, not stragglers), loses 2 ms of 100 with them on k_align1: 250,000 from the third batch on, 60,000 for the
+  // second.  PGX_ALIGN_SMALL overrides all three.
+  const long small_max = getenv("PGX_ALIGN_SMALL") ? atol(getenv("PGX_ALIGN_SMALL")) : tail_batch >= 2 ? 250000 : tail_batch ? 60000 : 13000;
   KernelTimer tm((long)n <= small_max ? "align1" : "align", n);
   int ring = 64;
   while (ring < 2 * band + 8) ring <<= 1;

@@ -193,7 +193,7 @@ void dev_reduce(const pgx_mm128 *d_in, size_t n, int rs, DevBuf<pgx_mm128> &out,
 void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_count> &out, size_t &n_out);
 // banded O(ND) confirmation of n candidate alignments (keys on device)
 void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out,
-               bool tail_batch = false);   // tail_batch: a later request batch of a stage (mostly hard candidates: pgx_align.hip)
+               int tail_batch = 0);   // tail_batch: 1 = the second request batch of a stage, 2 = a later one (mostly hard candidates: pgx_align.hip)
 void dev_align_prepare(const pgx_seqdb *db);   // the database's 2-bit packs, ahead of the first large launch (no-op once they exist)
 // the 2-bit packs of a read database (pgx_pack.hip: [pack of the low nibbles | pack of the high nibbles], seq_pack_stride dwords
 // each; d_nflag marks the reads with bytes that have no 2-bit code): built on first use, kept with the database; nullptr: no HBM

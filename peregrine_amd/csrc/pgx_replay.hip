@@ -2009,7 +2009,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     const size_t batch = nreq - first_req;
     if (sweeps == 1) first_batch = batch;
     r.tail = tail_max && batch <= std::max(tail_max, first_batch / 256) ? ahead : 0u;   // (the NEXT sweep's k_file)
-    dev_align(db, r.rq_key + first_req, batch, band, r.rq_res + first_req, sweeps > 1);
+    dev_align(db, r.rq_key + first_req, batch, band, r.rq_res + first_req, sweeps > 2 ? 2 : sweeps > 1 ? 1 : 0);
     r.settled = (uint32_t)nreq;
     first_req = nreq;
     {

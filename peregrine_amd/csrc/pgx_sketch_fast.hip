@@ -870,9 +870,6 @@ __global__ __launch_bounds__(64, 4) void k_sketch_blk(const uint8_t *__restrict_
   uint4 raw_next = make_uint4(0, 0, 0, 0);
   if (lane * 16 < span) raw_next = *reinterpret_cast<const uint4 *>(base + lane * 16);
   for (int t = 0; t < ntiles; ++t) {
-#ifdef PGX_PAD_SKETCH   // (experiment: N extra VALU instructions per tile)
-    { int pad = lane; for (int i_ = 0; i_ < PGX_PAD_SKETCH; ++i_) asm volatile("v_min_i32 %0, %0, %1" : "+v"(pad) : "v"(lane)); }
-#endif
     const int G = t * 64 + lane;
     const int b0 = t * TILE + lane * 16;   // byte offset of the block from `base`
     const int ibase = b0 - lead;           // read position of its first base
