@@ -910,10 +910,7 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
 #endif
 constexpr int BIG_NW = PGX_BIG_NW;              // wavefronts per bucket: rows slot = wave / 2, partner half = wave % 2
 constexpr int BIG_NR = BIG_NW / 2;              // rows of a step
-#ifndef PGX_BIG_WG
-#define PGX_BIG_WG 512
-#endif
-constexpr uint32_t BIG_WG = PGX_BIG_WG;                // workgroups of a launch (persistent: they stride over the list / the range, 512 entries at a time)
+constexpr uint32_t BIG_WG = 512;                // workgroups of a launch (persistent: they stride over the list / the range, 512 entries at a time; 1024 / 2048: c4s 302-305 ms against 306, c4 unchanged)
 // Buckets that hold a read TWICE (tandem arrays, low-complexity runs: the same shimmer pair several times within a read) can
 // meet a read pair more than once within one evaluation, and the second meeting must see the first one's insertion.  The
 // narrower kernels therefore run them one partner at a time -- up to 5,000 dependent steps for a 100-entry bucket, and those
