@@ -556,10 +556,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
     const uint64_t fw = ballot64(fetching);
     uint32_t na = 0;
     if (fw) {   // (wave-uniform; ~3 % of the iterations)
-#ifndef PGX_ALIGN_CHUNK
-#define PGX_ALIGN_CHUNK 8
-#endif
-      constexpr uint32_t CHUNK = PGX_ALIGN_CHUNK;
+      constexpr uint32_t CHUNK = 8;
       const uint64_t need = fw & 0x0101010101010101ULL;   // the first lanes of the fetching groups
       const uint32_t cnt = (uint32_t)__builtin_popcountll(need);
       const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));   // such lanes below this one
@@ -656,12 +653,12 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
             uint2 qd, td;
             __builtin_memcpy(&qd, q + (xq >> 4) * 4, 8), __builtin_memcpy(&td, t + (yt >> 4) * 4, 8);
             const uint32_t df = __builtin_amdgcn_alignbit(qd.y, qd.x, (xq & 15) << 1) ^ __builtin_amdgcn_alignbit(td.y, td.x, (yt & 15) << 1);
-            m = (int)min(ffbl_or_ones(df) >> 1, 16u);   // (no test of df: the instruction answers ~0 for 0, and the minimum folds into the ones below)
+            m = (int)min(ffbl_or_ones(df) >> 1, 16u);   // (no test of df: the instruction answers ~0 for 0)
           } else {
             m = match8(load_u64_unaligned(q + x), load_u64_unaligned(t + y), qs, ts);
           }
-          probe_full = (int)min((uint32_t)m, (uint32_t)(rem - 1));   // (m <= PROBE: >= PROBE iff m == PROBE and rem > PROBE; rem >= 1: unsigned, so that the
-          m = (int)min((uint32_t)m, (uint32_t)rem);                  //  minimum with 16 above folds into v_min3_u32)
+          probe_full = (int)min((uint32_t)m, (uint32_t)(rem - 1));   // (m <= PROBE: >= PROBE iff m == PROBE and rem > PROBE; rem >= 1, so unsigned
+          m = (int)min((uint32_t)m, (uint32_t)rem);                  //  minima like the one with 16 above: three v_min_u32 in a row)
           x += m, y += m;
         }
       }
