@@ -767,7 +767,10 @@ def main():
             cands["align"] = {"kernel": "k_align_ph<8, u16, packed> (per-group phase machine over the 2-bit packs; + k_pack2 once per stage, k_align1_list for the candidates it hands on)", "bound": "valu_issue", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": k["avg_ms"],
                               "bytes_per_unit": ALIGN_BYTES_PER_PAIR, "unit_name": "alignment",
-                              "alignments_per_s": k["units"] / (k["ms_total"] * 1e-3)}
+                              "alignments_per_s": k["units"] / (k["ms_total"] * 1e-3),
+                              "bound_note": "instruction issue AND the wavefront's own dependent chain per d-step, at the hardware's 8 wavefronts per SIMD (DESIGN 4.4 round 4 (c): "
+                                            "+10 % VALU = +16 % time, +46 % SALU = +8.5 %, 28 instead of 32 wavefronts per CU = +6 %); through round 4 the work counter's "
+                                            "same-address atomic (12 ns per candidate) was the floor, not the instructions"}
         if "align1" in kern:   # the one-candidate-per-wavefront form used for launches of at most 13 k alignments (tail rounds)
             k = kern["align1"]
             gbs = ALIGN_BYTES_PER_PAIR * k["units"] / (k["ms_total"] * 1e-3) / 1e9
