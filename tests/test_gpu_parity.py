@@ -883,6 +883,24 @@ def test_align_variants_vs_oracle(variant_sets, vid, env, which):
                 os.environ[k] = v
 
 
+@pytest.mark.parametrize("env,which", [(dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0"), "small"), (dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0"), "withN"),
+                                       (dict(PGX_ALIGN_SMALL="0"), "long")], ids=["ph8", "ph8-ambiguous", "align4"])
+def test_grouped_alignment_launches_of_every_size(variant_sets, env, which):
+    """The grouped kernels take the work counter in chunks of 8 per wavefront (round 4: the per-candidate add on one address was their
+    floor): launches smaller than a chunk, one past a chunk, around a wavefront's 8 groups and around 64, each candidate exactly once."""
+    db, rdb, keys, want = variant_sets[which]
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        for n in (1, 3, 7, 8, 9, 15, 16, 17, 63, 64, 65, 127, 513, 4099):
+            got = rdb.align(keys[:n], 100)
+            bad = np.flatnonzero(got != want[100][:n])
+            assert len(bad) == 0, (which, n, len(bad), keys[bad[:3]], got[bad[:3]], want[100][bad[:3]])
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
 def test_overlap_stage_with_long_reads_equals_oracle(variant_sets):
     """the whole overlap stage on the set with 100 kb reads (32-bit V rings in every launch), record for record"""
     db, rdb, _, _ = variant_sets["long"]
