@@ -139,6 +139,11 @@ typedef struct {
   uint32_t device_replay;    /* 1: the greedy walk ran on the GPU (pgx_replay.hip); 0: on the host threads */
   uint32_t device_visit;     /* 0: bucket visit order built by host threads; else 1 + the number of first-key groups a whole
                                 wavefront replayed (pgx_visit.hip; the others take a lane each) */
+  uint32_t replay_attempts;  /* device replay: attempts until the tables were large enough (1: the first sizes held; the sizes a
+                                stage needed are where the next stage of the process starts) */
+  uint32_t reserved0;
+  uint64_t stream_checksum;  /* order-sensitive 64-bit checksum of the records' fields (padding bytes excluded), computed where the
+                                records are written: two stages with equal checksums produced the same stream (0: not computed) */
 } pgx_overlap_stats;
 
 /* mmers: concatenation of all index chunks' final-level lists in chunk order; counts: all MC entries */

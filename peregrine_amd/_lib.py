@@ -55,7 +55,8 @@ class OverlapStats(C.Structure):
     _fields_ = [("n_records", C.c_uint64), ("n_pair_records", C.c_uint64), ("n_buckets", C.c_uint64),
                 ("n_align_needed", C.c_uint64), ("n_align_gpu", C.c_uint64), ("n_seen_skip", C.c_uint64),
                 ("rounds", C.c_uint32), ("gpu_ms", C.c_double), ("host_ms", C.c_double),
-                ("n_evaluations", C.c_uint64), ("device_replay", C.c_uint32), ("device_visit", C.c_uint32)]
+                ("n_evaluations", C.c_uint64), ("device_replay", C.c_uint32), ("device_visit", C.c_uint32),
+                ("replay_attempts", C.c_uint32), ("reserved0", C.c_uint32), ("stream_checksum", C.c_uint64)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -382,6 +382,24 @@ void results_wait();
 void results_wait_if(const void *host);   // only if `host` is the array the pending copy writes
 void results_copy_async(pgx_ovlp *host, DevBuf<pgx_ovlp> &&dev, size_t n);   // after what is enqueued on ctx().stream
 
+// pgx_overlap_stats::stream_checksum: the sum over the records of a 64-bit mix of every field (padding bytes excluded) and the record's
+// position in the stream -- the same on the device (k_emit adds it up while it writes the records) and on the host
+__host__ __device__ inline uint64_t checksum_mix(uint64_t h) {
+  h ^= h >> 33, h *= 0xff51afd7ed558ccdULL, h ^= h >> 33, h *= 0xc4ceb9fe1a85ec53ULL, h ^= h >> 33;
+  return h;
+}
+__host__ __device__ inline uint64_t record_checksum(const pgx_ovlp &o, uint64_t pos) {
+  uint64_t h = checksum_mix(o.y0 + 0x9E3779B97F4A7C15ULL * (pos + 1));
+  h = checksum_mix(h ^ o.y1);
+  h = checksum_mix(h ^ ((uint64_t)o.rl0 | (uint64_t)o.rl1 << 32));
+  h = checksum_mix(h ^ ((uint64_t)o.strand0 | (uint64_t)o.strand1 << 8 | (uint64_t)o.ovlp_type << 16));
+  h = checksum_mix(h ^ ((uint64_t)(uint32_t)o.match.m_size | (uint64_t)(uint32_t)o.match.dist << 32));
+  h = checksum_mix(h ^ ((uint64_t)(uint32_t)o.match.q_bgn | (uint64_t)(uint32_t)o.match.q_end << 32));
+  h = checksum_mix(h ^ ((uint64_t)(uint32_t)o.match.t_bgn | (uint64_t)(uint32_t)o.match.t_end << 32));
+  h = checksum_mix(h ^ ((uint64_t)(uint32_t)o.match.t_m_end | (uint64_t)(uint32_t)o.match.q_m_end << 32));
+  return h;
+}
+
 // Runs fn on the library's housekeeping thread: tearing down GB-sized host tables (munmap, free) takes tens of
 // milliseconds that the caller does not have to wait for.  At most a few jobs are queued; beyond that fn runs inline.
 void defer_destroy(std::function<void()> fn);

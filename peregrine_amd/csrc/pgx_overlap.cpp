@@ -1721,6 +1721,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
                    [&](size_t n) { out.alloc(n); return out.a; }, &nrec, &rs, trace)) {
       s.n_align_needed = rs.n_align_needed, s.n_seen_skip = rs.n_seen_skip, s.n_align_gpu = rs.n_align_gpu, s.rounds = rs.rounds;
       s.n_evaluations = rs.n_evaluations, s.device_replay = 1;
+      s.replay_attempts = rs.replay_attempts, s.stream_checksum = rs.stream_checksum;
       gpu_ms += now_ms() - r0;
       timing_flush();
       if (trace) fprintf(stderr, "[pgx] stage total %.2f ms\n", now_ms() - t0);
@@ -1863,6 +1864,7 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   timing_flush();
   if (trace) fprintf(stderr, "[pgx] stage total %.2f ms (timing flush %.2f ms)\n", now_ms() - t0, now_ms() - tf0);
   s.n_records = out.n;
+  for (size_t i = 0; i < out.n; ++i) s.stream_checksum += record_checksum(out.a[i], i);   // (the host replay serves small sets)
   s.gpu_ms = gpu_ms;
   s.host_ms = now_ms() - t0 - gpu_ms;
   if (st) *st = s;

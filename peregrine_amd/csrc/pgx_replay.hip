@@ -1659,7 +1659,7 @@ __global__ __launch_bounds__(256) void k_settle(R r) {
 // ---- the ovlp_t records, bucket by bucket in visit order, each bucket's in evaluation order ---------------------------
 __global__ __launch_bounds__(256) void k_emit(R r, const uint32_t *__restrict__ off, pgx_ovlp *__restrict__ out) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long lk = 0, sk = 0;
+  unsigned long long lk = 0, sk = 0, ck = 0;
   if (j < r.nb) {
     lk = r.lookups[j], sk = r.skips[j];
     const uint32_t num = r.inum[j];
@@ -1677,6 +1677,7 @@ __global__ __launch_bounds__(256) void k_emit(R r, const uint32_t *__restrict__ 
         o.match = r.rq_res[r.mt[im.mslot].req];
         o.pad1 = 0;
         out[(size_t)off[j] + (num - 1 - k)] = o;
+        ck += record_checksum(o, (uint64_t)off[j] + (num - 1 - k));
       }
     }
   }
@@ -1684,11 +1685,15 @@ __global__ __launch_bounds__(256) void k_emit(R r, const uint32_t *__restrict__ 
   for (int o = 32; o; o >>= 1) {
     lk += (unsigned long long)__shfl_xor((int)(lk >> 32), o, 64) << 32 | (uint32_t)__shfl_xor((int)lk, o, 64);
     sk += (unsigned long long)__shfl_xor((int)(sk >> 32), o, 64) << 32 | (uint32_t)__shfl_xor((int)sk, o, 64);
+    ck += (unsigned long long)__shfl_xor((int)(ck >> 32), o, 64) << 32 | (uint32_t)__shfl_xor((int)ck, o, 64);
   }
-  if ((threadIdx.x & 63) == 0 && (lk | sk)) {
+  if ((threadIdx.x & 63) == 0 && (lk | sk | ck)) {
     unsigned long long *line = r.spread + ((j >> 6) % SPREAD) * 8;
     atomicAdd(line + 1, lk);
     atomicAdd(line + 2, sk);
+#if !defined(PGX_BIG_STATS) && !defined(PGX_SETTLE_STATS)   // (the statistics builds count in the same words)
+    atomicAdd(line + 7, ck);
+#endif
   }
 }
 
@@ -1801,7 +1806,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     sync();
     if (totals) {
       hc->evals = hc->lookups = hc->skips = 0;
-      for (uint32_t i = 0; i < SPREAD; ++i) hc->evals += hs[i * 8], hc->lookups += hs[i * 8 + 1], hc->skips += hs[i * 8 + 2];
+      hc->records = 0;   // (re-used as the stream checksum k_emit adds up in word 7 of every line)
+      for (uint32_t i = 0; i < SPREAD; ++i) hc->evals += hs[i * 8], hc->lookups += hs[i * 8 + 1], hc->skips += hs[i * 8 + 2], hc->records += hs[i * 8 + 7];
 #ifdef PGX_BIG_STATS
       {
         unsigned long long b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
@@ -2062,6 +2068,9 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
       st->n_align_needed = hc->lookups, st->n_seen_skip = hc->skips, st->n_align_gpu = first_req;
       st->rounds = sweeps;
       st->n_evaluations = hc->evals;
+#if !defined(PGX_BIG_STATS) && !defined(PGX_SETTLE_STATS)
+      st->stream_checksum = hc->records;
+#endif
     }
     if (trace)
       fprintf(stderr, "[pgx] device replay: %u sweeps, %u rounds, %llu evaluations, %zu records; emit %.2f ms; alignments %.2f ms; total %.2f ms\n",
@@ -2123,15 +2132,35 @@ bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visi
       }
     }
   }
-  double mult[5] = {1, 1, 1, 1, 1};  // items, reader nodes, requests, pair table, memo table
+  // Table sizes are multiples of the defaults: items, reader nodes, requests, pair table, memo table.  What an overflowing attempt costs is a whole
+  // first sweep (the request / memo overflow is only seen when k_file runs: ~100 ms of a full-size configs[3] chunk), so the multiples the
+  // LAST stage of this process needed are where the next one starts (round 5: every one of the 8 chunks of a c4 step used to run two attempts
+  // in vain -- requests 1.72 x the entries, then the memo table -- 205 of its 1,103 ms; profiles/r05a_chunk_timeline_c4.txt).  The
+  // chunks of a job are alike; a stage that needs less keeps the larger tables (their cost is the clears).
+  static double learned[5] = {1, 1, 1, 1, 1};
+  static ShutdownHook h_learn([] {
+    for (double &m : learned) m = 1;
+  });
+  double mult[5];
+  for (int k = 0; k < 5; ++k) mult[k] = learned[k];
   if (getenv("PGX_REPLAY_PAIRS_X")) mult[3] = atof(getenv("PGX_REPLAY_PAIRS_X"));
   if (getenv("PGX_REPLAY_MEMO_X")) mult[4] = atof(getenv("PGX_REPLAY_MEMO_X"));
-  for (int attempt = 0; attempt < 3; ++attempt) {
+  for (int attempt = 0; attempt < 5; ++attempt) {
     const uint32_t ov = replay_attempt(db, dp, visit_bids, d_bids, nb, n_entries, bestn, band, predict, alloc_out, n_out, st, trace, mult);
-    if (!ov) return true;
+    if (!ov) {
+      for (int k = 0; k < 5; ++k) learned[k] = std::max(learned[k], mult[k]);
+      if (st) st->replay_attempts = (uint32_t)attempt + 1;
+      return true;
+    }
     if (ov & (OV_QOFF | OV_PASSES)) break;  // not a matter of table sizes
+    // unusual data (repeat-rich sets): the same walk again with larger tables.  The pair and memo tables are powers of two: doubling is a
+    // real step there (x 4 made the pair table's cold part 34 GB at c4); the arenas grow by 2 as well.  Requests and memo entries are the
+    // same alignments: when the request array was too small the memo table of the same size class is too, and k_file stopped before it
+    // could say so -- grow both
     for (int k = 0; k < 5; ++k)
-      if (ov & (1u << k)) mult[k] *= 4;  // unusual data (repeat-rich sets): the same walk again with larger tables
+      if (ov & (1u << k)) mult[k] *= 2;
+    if ((ov & OV_REQS) && !(ov & OV_MEMO)) mult[4] = std::max(mult[4], mult[2]);
+    if (trace) fprintf(stderr, "[pgx]   next attempt with items x %g, reader nodes x %g, requests x %g, pair table x %g, memo table x %g\n", mult[0], mult[1], mult[2], mult[3], mult[4]);
   }
   fprintf(stderr, "[pgx] note: the device replay's tables overflowed; the host replay takes over\n");
   return false;

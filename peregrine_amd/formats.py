@@ -124,6 +124,49 @@ def ovlp_fields_equal(a: np.ndarray, b: np.ndarray) -> bool:
     return all(np.array_equal(a[f], b[f]) for f in OVLP_FIELDS)
 
 
+def _mix64(h: np.ndarray) -> np.ndarray:
+    h = h ^ (h >> np.uint64(33))
+    h = h * np.uint64(0xff51afd7ed558ccd)
+    h = h ^ (h >> np.uint64(33))
+    h = h * np.uint64(0xc4ceb9fe1a85ec53)
+    return h ^ (h >> np.uint64(33))
+
+
+def stream_checksum(ov: np.ndarray, block: int = 1 << 22) -> int:
+    """pgx_overlap_stats.stream_checksum (pgx_internal.h::record_checksum) in numpy: the sum over the records of a 64-bit mix of every
+    field -- padding bytes excluded -- and the record's position in the stream (order-sensitive; arithmetic modulo 2^64)."""
+    total = np.uint64(0)
+    u = lambda a: a.astype(np.uint32).astype(np.uint64)   # noqa: E731  (two's complement of the int32 fields)
+    with np.errstate(over="ignore"):
+        for s in range(0, len(ov), block):
+            o = ov[s:s + block]
+            pos = np.arange(s, s + len(o), dtype=np.uint64)
+            h = _mix64(o["y0"] + np.uint64(0x9E3779B97F4A7C15) * (pos + np.uint64(1)))
+            h = _mix64(h ^ o["y1"])
+            h = _mix64(h ^ (o["rl0"].astype(np.uint64) | (o["rl1"].astype(np.uint64) << np.uint64(32))))
+            h = _mix64(h ^ (o["strand0"].astype(np.uint64) | (o["strand1"].astype(np.uint64) << np.uint64(8)) | (o["ovlp_type"].astype(np.uint64) << np.uint64(16))))
+            for a, b in (("m_size", "dist"), ("q_bgn", "q_end"), ("t_bgn", "t_end"), ("t_m_end", "q_m_end")):
+                h = _mix64(h ^ (u(o[a]) | (u(o[b]) << np.uint64(32))))
+            total = total + h.sum(dtype=np.uint64)
+    return int(total)
+
+
+def masked_stream_sha256(ov, block: int = 1 << 20) -> str:
+    """SHA-256 of an ovlp_t stream with the padding bytes (27 and 60..63 of every 64-byte record: the reference writes whatever its
+    stack held there) zeroed.  ov: a record array or a file path.  `cat stream | zero those bytes | sha256sum`."""
+    import hashlib
+    h = hashlib.sha256()
+    if isinstance(ov, (str, bytes)):
+        ov = np.memmap(ov, dtype=np.uint8, mode="r")
+    raw = np.asarray(ov).view(np.uint8).reshape(-1, 64)
+    for s in range(0, len(raw), block):
+        b = np.array(raw[s:s + block], copy=True)
+        b[:, 27] = 0
+        b[:, 60:64] = 0
+        h.update(b.tobytes() if not b.flags.c_contiguous else memoryview(b.reshape(-1)))
+    return h.hexdigest()
+
+
 def mc_as_sorted_pairs(arr: np.ndarray) -> np.ndarray:
     """MC parity is the multiset of (mer, count) -- slot order and padding carry no meaning."""
     out = np.stack([arr["mer"].astype(np.uint64), arr["count"].astype(np.uint64)], axis=1)

@@ -202,11 +202,13 @@ def test_rccl_exchange_as_one_rank_job(tmp_path):
 
 
 @pytest.mark.skipif(not U.have_ref(), reason="needs the prebuilt reference binaries (oracle/_ref)")
-@pytest.mark.parametrize("ranks,chunks", [(1, 4), (2, 2), (2, 4)])
+@pytest.mark.parametrize("ranks,chunks", [(1, 4), (2, 2), (2, 4), (4, 8), (8, 8)])
 def test_bench_strong_scaling_form_of_configs3_against_the_reference(ranks, chunks):
     """bench.py's c4 family (BASELINE configs[3] AS STATED: one read set on every rank, the job's chunks dealt to the ranks, strong
     scaling) on a 12 Mb genome of the same recipe: one rank with 4 chunks; two ranks sharing the GPU under gloo with 2 chunks (one
-    chunk per rank: count all-gather + pair-record all-to-all) and with 4 (two per rank: lists all-gathered round by round).  Every rank
+    chunk per rank: count all-gather + pair-record all-to-all) and with 4 (two per rank: lists all-gathered round by round); and the
+    dress rehearsal of an 8-GPU node (VERDICT r4 task 2): EIGHT ranks x 8 chunks -- one index + one overlap chunk per rank, records routed by
+    the all-to-all, exactly what `bench.py --gpus 8` runs -- and four ranks x 8 chunks, all sharing the one GPU under gloo.  Every rank
     compares the ovlp_t stream of each of its chunks with oracle/_ref/shmr_overlap -t C -c c on files (--check-ref)."""
     import json
     import subprocess
@@ -223,6 +225,11 @@ def test_bench_strong_scaling_form_of_configs3_against_the_reference(ranks, chun
     chk = line["check_vs_reference"]
     assert chk["all_equal"] is True and len(chk["chunks"]) == chunks and all(c["records"] > 50_000 for c in chk["chunks"]), chk
     assert line["scaling"] == "strong" and line["n_gpus"] == ranks and line["records_per_step"] == sum(c["records"] for c in chk["chunks"])
+    assert line["world_size"] == ranks and len(line["per_rank"]) == ranks and all(r["hbm_bytes_in_use"] > 0 for r in line["per_rank"])
+    assert line["read_set_hash_equal_on_all_ranks"] is True
+    if ranks > 1 and chunks == ranks:   # the all-to-all form: every record sent is received, and they are the records the overlap stages consumed
+        sent, recv = sum(r["sent_records"] for r in line["per_rank"]), sum(r["received_records"] for r in line["per_rank"])
+        assert sent == recv > 0
 
 
 def test_shutdown_forgets_device_state():

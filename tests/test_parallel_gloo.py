@@ -1,4 +1,4 @@
-"""Multi-rank exchange on CPU (gloo, world_size 2 and 3).
+"""Multi-rank exchange on CPU (gloo, world_size 2, 3 and 8 -- the one-chunk-per-rank form an 8-GPU node runs).
 
 The reference's "every overlap chunk globs every index chunk's files" step (src/shmr_overlap.c:359-384) is, in the multi-GPU
 form, the exchange of peregrine_amd/parallel.py: count tables all-gathered, pair records routed to their owner chunk.  Here
@@ -72,7 +72,7 @@ def _pipeline_worker(rank, world, port, out_dir, lower, upper):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,lower,upper", [(2, 2, 240), (3, 2, 240), (2, 1, 30), (3, 2, "first"), (3, 2, "empty0")])
+@pytest.mark.parametrize("world,lower,upper", [(2, 2, 240), (3, 2, 240), (2, 1, 30), (3, 2, "first"), (3, 2, "empty0"), (8, 2, 240), (8, 2, "empty0")])
 def test_two_rank_pipeline(tmp_path, world, lower, upper):
     sys.path.insert(0, HERE)
     import oracle_util as U
@@ -141,12 +141,12 @@ def _worker(rank, world, port, out_dir):
     assert torch.equal(buf[:sum(sizes2)], torch.cat([torch.full((5 + 3 * r,), r + 1, dtype=torch.uint8) for r in range(world)])) and int(buf[-7:].sum()) == 0
     recv2, rb2 = alltoallv_bytes(send, [(rank + 1) * (d + 1) for d in range(world)], world, recv_bytes=[(s + 1) * (rank + 1) for s in range(world)])
     assert torch.equal(recv2, want) and rb2 == rb
-    assert scan_start([-1, 4, 9][:world] + [0] * (world - 3), rank) == ([-1, 4, 0][rank] if world >= 3 else [-1, 4][rank])
+    assert scan_start([-1, 4, 9][:world] + [0] * (world - 3), rank) == ([-1, 4][rank] if rank < 2 else 0)   # ranks behind the first holder start at 0
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_collectives_order_by_chunk(tmp_path, world):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
