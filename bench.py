@@ -649,10 +649,13 @@ def main():
         del tops, mcs
         _lib.stream_wait()
         tot, nrec = None, 0
-        was_async = _lib.results_async(True)    # a chunk's records travel to the host while the next chunk's join and first sweep run
+        was_async = _lib.results_async(os.environ.get("PGX_BENCH_SYNC_RESULTS") != "1")    # a chunk's records travel to the host beside the next chunk's main alignment launch
         prev = None                             # (the array of the chunk before: freeing it would wait for its copy)
         for c in my_chunks:
+            tc0 = time.perf_counter()
             ov, st = rdb.overlap_dev(mm_all.data_ptr(), mm_all.numel() // 16, mc_all.data_ptr(), mc_all.numel() // 16, total_chunk=CH, mychunk=c, **ov_params)
+            if os.environ.get("PGX_BENCH_CHUNK_TIMES"):
+                log("chunk %d: call %.1f ms (library: gpu %.1f + host %.1f), %d records, attempts %d" % (c, (time.perf_counter() - tc0) * 1e3, st["gpu_ms"], st["host_ms"], len(ov), st["replay_attempts"]))
             nrec += len(ov)
             prev = ov
             if a.check_ref:
@@ -827,6 +830,14 @@ def main():
         }
         if strong:
             out["hbm_bytes_in_use"] = int(torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0])
+        # the HBM ledger (VERDICT r4 task 5): the library's device memory by owner at the moment its live total peaked, what its block cache
+        # holds beside that, and torch's side (the adopted seqdb, the lists held between the stages)
+        led = _lib.mem_ledger()
+        led["torch_allocated_bytes"] = int(torch.cuda.memory_allocated())
+        led["torch_reserved_bytes"] = int(torch.cuda.memory_reserved())
+        if seq_dev is not None:
+            led["seqdb_bytes_adopted_from_torch"] = int(seq_dev.numel())
+        out["hbm_ledger"] = led
         if ref_check is not None:
             out["check_vs_reference"] = ref_check
         # device time per step by the library's own timers (HIP events; the replay's from the extra step) against the wall clock

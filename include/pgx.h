@@ -64,6 +64,10 @@ void pgx_free(void *p);              /* releases any host array returned by this
  * at most 13 k alignments), "encode", "dedup", "map". */
 int pgx_timing_get(const char *kernel, double *total_ms, uint64_t *launches, uint64_t *units);
 void pgx_timing_reset(void);
+/* HBM ledger: JSON text of the library's device memory -- live bytes, bytes held in the block cache, and the live bytes BY OWNER (seqdb,
+ * packs, index workspaces, join tables, replay tables ...) at the moment the live total peaked; the named workspaces; what the driver
+ * reports as used.  Returns the length of the text (buf may be NULL to ask for it).  reset_peak != 0: the peak starts again from now. */
+int pgx_mem_ledger(char *buf, size_t cap, int reset_peak);
 
 /* ---- resident read database ---- */
 /* rid/rlen/roff: the idx file's columns in file order (src/shmr_mkseqdb.c:111-112); copies to HBM. */

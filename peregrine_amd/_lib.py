@@ -65,7 +65,7 @@ class OverlapStats(C.Structure):
 # every symbol include/pgx.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "pgx_init", "pgx_shutdown", "pgx_last_error", "pgx_device_count", "pgx_version", "pgx_free",
-    "pgx_timing_get", "pgx_timing_reset", "pgx_results_async", "pgx_results_wait",
+    "pgx_timing_get", "pgx_timing_reset", "pgx_mem_ledger", "pgx_results_async", "pgx_results_wait",
     "pgx_seqdb_upload", "pgx_seqdb_load", "pgx_seqdb_free", "pgx_seqdb_bases", "pgx_seqdb_reads",
     "pgx_index_resident", "pgx_index_result_free", "pgx_index_chunk",
     "pgx_overlap_resident", "pgx_overlap_chunk", "pgx_index_chunk_db", "pgx_overlap_chunk_db", "pgx_index_overlap_resident", "pgx_mkseqdb", "pgx_dedup",
@@ -254,3 +254,14 @@ def timing(name: str):
 
 def timing_reset():
     load().pgx_timing_reset()
+
+
+def mem_ledger(reset_peak: bool = False) -> dict:
+    """the library's device memory by owner at its peak (pgx_mem_ledger)"""
+    import json
+    lib = load()
+    lib.pgx_mem_ledger.argtypes = [C.c_char_p, C.c_size_t, C.c_int]
+    n = lib.pgx_mem_ledger(None, 0, 0)
+    buf = C.create_string_buffer(n + 64)
+    lib.pgx_mem_ledger(buf, n + 64, 1 if reset_peak else 0)
+    return json.loads(buf.value.decode())

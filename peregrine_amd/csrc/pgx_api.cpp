@@ -321,9 +321,30 @@ void defer_destroy(std::function<void()> fn) {
 void drain_deferred() { reaper().drain(); }
 
 // ---- device block cache ----------------------------------------------------------------------------------
+// Released blocks are kept by size class for the next user (see pgx_internal.h).  Round 5 (the HBM ledger of a full-size configs[3] step):
+//  * a request is served by a free block of its class OR UP TO ONE EIGHTH LARGER: table sizes move a little from chunk to chunk, and
+//    with exact classes every multi-GB table left a sibling of the neighbouring class behind;
+//  * blocks age: dev_cache_age() -- called where a stage starts, the GPU idle -- gives blocks of 64 MiB and more that two whole stages
+//    did not ask for back to the driver (the tables of a first, too small attempt used to stay cached for the life of the process);
+//  * every live block carries the tag of the scope that allocated it (MemTag): pgx_mem_ledger() reports the bytes by tag at the PEAK.
 static std::mutex g_dev_mu;
-static std::multimap<size_t, void *> g_dev_free;  // size class -> cached blocks
-static std::map<void *, size_t> g_dev_live;       // block -> its size class
+struct FreeBlock {
+  void *p;
+  uint64_t age;
+};
+static std::multimap<size_t, FreeBlock> g_dev_free;  // size class -> cached blocks
+struct LiveBlock {
+  size_t cls;
+  const char *tag;
+};
+static std::map<void *, LiveBlock> g_dev_live;       // block -> its size class, who asked for it
+static uint64_t g_dev_age = 0;
+static size_t g_live_bytes = 0, g_free_bytes = 0, g_peak_bytes = 0;
+static std::map<std::string, size_t> g_by_tag, g_peak_by_tag;
+static size_t g_peak_free = 0;
+static thread_local const char *g_tag = "other";
+MemTag::MemTag(const char *t) : prev(g_tag) { g_tag = t; }
+MemTag::~MemTag() { g_tag = prev; }
 static size_t size_class(size_t bytes) {           // powers of two up to 1 MiB, then eighths of a power of two (<= 12.5 % waste)
   size_t c = 256;
   while (c < bytes && c < (1u << 20)) c <<= 1;
@@ -333,37 +354,62 @@ static size_t size_class(size_t bytes) {           // powers of two up to 1 MiB,
   const size_t step = p2 >> 3;
   return (bytes + step - 1) / step * step;
 }
+static void drop_all_free_locked() {
+  for (auto &kv : g_dev_free) (void)hipFree(kv.second.p);
+  g_dev_free.clear();
+  g_free_bytes = 0;
+}
 void *dev_alloc(size_t bytes) {
   const size_t c = size_class(bytes);
   std::lock_guard<std::mutex> lk(g_dev_mu);
-  auto it = g_dev_free.find(c);
+  auto it = g_dev_free.lower_bound(c);
   void *p = nullptr;
-  if (it != g_dev_free.end()) {
-    p = it->second;
+  size_t got = c;
+  if (it != g_dev_free.end() && it->first <= c + (c >> 3)) {
+    p = it->second.p, got = it->first;
     g_dev_free.erase(it);
+    g_free_bytes -= got;
   } else {
     hipError_t e = hipMalloc(&p, c);
     if (e != hipSuccess) {  // make room: give the cached blocks back and retry once
-      for (auto &kv : g_dev_free) (void)hipFree(kv.second);
-      g_dev_free.clear();
+      drop_all_free_locked();
       (void)hipGetLastError();
       PGX_HIP(hipMalloc(&p, c));
     }
   }
-  g_dev_live[p] = c;
+  g_dev_live[p] = LiveBlock{got, g_tag};
+  g_live_bytes += got, g_by_tag[g_tag] += got;
+  if (g_live_bytes > g_peak_bytes) g_peak_bytes = g_live_bytes, g_peak_by_tag = g_by_tag, g_peak_free = g_free_bytes;
   return p;
 }
 void dev_release(void *p) {
   std::lock_guard<std::mutex> lk(g_dev_mu);
   auto it = g_dev_live.find(p);
   if (it == g_dev_live.end()) return;
-  g_dev_free.emplace(it->second, p);
+  g_dev_free.emplace(it->second.cls, FreeBlock{p, g_dev_age});
+  g_live_bytes -= it->second.cls, g_free_bytes += it->second.cls, g_by_tag[it->second.tag] -= it->second.cls;
   g_dev_live.erase(it);
 }
 void dev_cache_trim() {
   std::lock_guard<std::mutex> lk(g_dev_mu);
-  for (auto &kv : g_dev_free) (void)hipFree(kv.second);
-  g_dev_free.clear();
+  drop_all_free_locked();
+}
+size_t dev_cache_free_bytes() {
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  return g_free_bytes;
+}
+void dev_cache_age() {
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  ++g_dev_age;
+  for (auto it = g_dev_free.begin(); it != g_dev_free.end();) {
+    if (it->first >= ((size_t)64 << 20) && it->second.age + 2 < g_dev_age) {
+      (void)hipFree(it->second.p);
+      g_free_bytes -= it->first;
+      it = g_dev_free.erase(it);
+    } else {
+      ++it;
+    }
+  }
 }
 
 // ---- shutdown hooks / generations --------------------------------------------------------------------------
@@ -383,6 +429,7 @@ void *ws_raw(const char *name, size_t bytes) {
   DevBuf<uint8_t> &b = g_ws[name];
   if (b.n < bytes) {
     (void)hipStreamSynchronize(ctx().stream);
+    MemTag mem_tag("workspaces");
     b.alloc(bytes + (bytes >> 3) + 4096);
   }
   return b.p;
@@ -555,6 +602,45 @@ void pgx_timing_reset(void) {
   g_time.clear();
 }
 
+int pgx_mem_ledger(char *buf, size_t cap, int reset_peak) {
+  std::string o = "{";
+  {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    char t[256];
+    snprintf(t, sizeof(t), "\"live_bytes\": %zu, \"cached_free_bytes\": %zu, \"peak_live_bytes\": %zu, \"cached_free_bytes_at_peak\": %zu, \"peak_by_tag\": {",
+             g_live_bytes, g_free_bytes, g_peak_bytes, g_peak_free);
+    o += t;
+    bool first = true;
+    for (const auto &kv : g_peak_by_tag) {
+      if (!kv.second) continue;
+      snprintf(t, sizeof(t), "%s\"%s\": %zu", first ? "" : ", ", kv.first.c_str(), kv.second);
+      o += t, first = false;
+    }
+    o += "}, \"workspaces\": {";
+    first = true;
+    for (const auto &kv : g_ws) {
+      if (kv.second.n < ((size_t)1 << 20)) continue;
+      snprintf(t, sizeof(t), "%s\"%s\": %zu", first ? "" : ", ", kv.first.c_str(), kv.second.n);
+      o += t, first = false;
+    }
+    o += "}";
+    if (reset_peak) g_peak_bytes = g_live_bytes, g_peak_by_tag = g_by_tag, g_peak_free = g_free_bytes;
+  }
+  size_t fr = 0, tot = 0;
+  if (ctx().ready && hipMemGetInfo(&fr, &tot) == hipSuccess) {
+    char t[128];
+    snprintf(t, sizeof(t), ", \"device_used_bytes\": %zu, \"device_total_bytes\": %zu", tot - fr, tot);
+    o += t;
+  }
+  o += "}";
+  if (buf && cap) {
+    const size_t n = std::min(cap - 1, o.size());
+    memcpy(buf, o.data(), n);
+    buf[n] = 0;
+  }
+  return (int)o.size();
+}
+
 // ---- resident seqdb --------------------------------------------------------------------------------------
 // The seqdb file straight into HBM.  One thread copying out of the page cache moves ~6 GB/s, an eighth of what the host link takes
 // (round 2: 4.5 GB in 0.75 s, twice per pipeline -- each stage is its own process, as in pg_run.py), so several reader threads
@@ -692,6 +778,7 @@ static int seqdb_upload_impl(const uint8_t *seqdb, size_t nbytes, const uint32_t
       db->borrowed = true;
       db->d_seq.p = const_cast<uint8_t *>(seqdb), db->d_seq.n = nbytes + 1024;
     } else {
+      MemTag mem_tag("seqdb.bytes");
       db->d_seq.alloc(nbytes + 1024);
     }
     PGX_HIP(hipMemsetAsync(db->d_seq.p + nbytes, 0, 1024, ctx().stream));

@@ -133,6 +133,7 @@ std::string level_path(const char *prefix, int level, bool mc, int chunk, int to
 
 namespace pgx {
 void index_stage(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out, DeviceIndex *keep, bool host_arrays) {
+  MemTag mem_tag("index");
   run_index(db, p, out, keep, host_arrays);
 }
 }  // namespace pgx

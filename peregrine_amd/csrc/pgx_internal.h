@@ -77,6 +77,16 @@ bool index_owns(const void *p);     // p points into memory an index-stage call 
 void *dev_alloc(size_t bytes);
 void dev_release(void *p);
 void dev_cache_trim();
+size_t dev_cache_free_bytes();   // what the cache holds for re-use (the driver counts it as used)
+void dev_cache_age();   // a stage starts: cached blocks of 64 MiB and more that two whole stages did not ask for go back to the driver
+// device blocks allocated while a MemTag is in scope (on this thread) are booked under its name in the ledger (pgx_mem_ledger)
+struct MemTag {
+  explicit MemTag(const char *t);
+  ~MemTag();
+  MemTag(const MemTag &) = delete;
+  MemTag &operator=(const MemTag &) = delete;
+  const char *prev;
+};
 
 template <typename T>
 struct DevBuf {

@@ -630,6 +630,7 @@ namespace {
 struct FusedPlan {
   uint64_t dev_serial = 0, slab_total = 0, plan_bases = 0;
   int plan_w = 0, plan_k = 0;
+  uint64_t plan_div = 0;
   bool plan_ok = false;
 } g_plan;
 ShutdownHook g_plan_reset([] { g_plan = FusedPlan(); });
@@ -646,7 +647,18 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
   uint64_t &dev_serial = g_plan.dev_serial, &slab_total = g_plan.slab_total, &plan_bases = g_plan.plan_bases;
   int &plan_w = g_plan.plan_w, &plan_k = g_plan.plan_k;
   bool &plan_ok = g_plan.plan_ok;
-  const bool cached = plan_serial != 0 && plan_serial == dev_serial && plan_w == w && plan_k == k;
+  static const char *mode_env = getenv("PGX_SKETCH");
+  static const bool want_fuse = (getenv("PGX_FUSE") && atoi(getenv("PGX_FUSE")) != 0) || (mode_env && !strcmp(mode_env, "fuse"));
+  static const bool want_wave = mode_env && !strcmp(mode_env, "wave");
+  // slab of a read: len / slab_div + 64 elements.  The fused kernels only ever write the TOP-level list there (1 element per 408 bases at
+  // l = 2, per 142 at l = 1: L0 never leaves the CU), so their slabs are len / 48 resp. len / 24 -- six and three times the expected list; a
+  // read that outgrows its slab (low-complexity sequence) is flagged and redone into an exact one below, as ever.  Round 1-4 reserved
+  // len / 8 for every path: 27 GB of workspace for one index chunk of full-size configs[3], resident through the overlap stages too (round 5:
+  // the HBM ledger).  The unfused path (k_sketch_wave + k_reduce_read: L0 goes through the slab) keeps len / 8.
+  // (PGX_SLAB_DIV / PGX_SLAB_MIN: test knobs that make reads outgrow their slabs)
+  const bool fused_out = !want_wave && (want_fuse ? sketch_fused_supported(w, rs, levels) : sketch_blk_supported(w, k, rs, levels));
+  const uint64_t slab_div = getenv("PGX_SLAB_DIV") ? std::max(1ll, atoll(getenv("PGX_SLAB_DIV"))) : !fused_out ? 8 : levels >= 2 ? 48 : 24;
+  const bool cached = plan_serial != 0 && plan_serial == dev_serial && plan_w == w && plan_k == k && g_plan.plan_div == slab_div;
   hipStream_t st = ctx().stream;
   ReadDesc *d_reads = ws<ReadDesc>("ix.reads", n);
   uint64_t *d_slab_off = ws<uint64_t>("ix.slab_off", n + 1);
@@ -655,8 +667,6 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
     std::vector<uint64_t> slab_off(n + 1, 0);
     uint64_t bases = 0;
     plan_ok = true;
-    // slab of a read: len / 8 + 64 elements (PGX_SLAB_DIV / PGX_SLAB_MIN: test knobs that make reads outgrow their slabs)
-    const uint64_t slab_div = getenv("PGX_SLAB_DIV") ? std::max(1ll, atoll(getenv("PGX_SLAB_DIV"))) : 8;
     const uint64_t slab_min = getenv("PGX_SLAB_MIN") ? std::max(1ll, atoll(getenv("PGX_SLAB_MIN"))) : 64;
     for (uint32_t i = 0; i < n; ++i) {
       if (!sketch_wave_eligible(reads[i], w, k)) plan_ok = false;
@@ -668,7 +678,7 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
       PGX_HIP(hipMemcpyAsync(d_slab_off, slab_off.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
       sync();  // (slab_off is a local)
     }
-    slab_total = slab_off[n], plan_bases = bases, plan_w = w, plan_k = k;
+    slab_total = slab_off[n], plan_bases = bases, plan_w = w, plan_k = k, g_plan.plan_div = slab_div;
     dev_serial = plan_serial;
   }
   if (!plan_ok) return false;
@@ -686,9 +696,6 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
   // traffic == the algorithmic 1.04 B/base -- and k_sketch_wave (fused form) for the reads it flags (two drops close together,
   // bursts of ties, very short reads).  PGX_SKETCH=wave: k_sketch_wave + k_reduce_read (round 1's default); PGX_SKETCH=fuse (or
   // PGX_FUSE=1): k_sketch_wave in its fused form for every read.
-  static const char *mode_env = getenv("PGX_SKETCH");
-  static const bool want_fuse = (getenv("PGX_FUSE") && atoi(getenv("PGX_FUSE")) != 0) || (mode_env && !strcmp(mode_env, "fuse"));
-  static const bool want_wave = mode_env && !strcmp(mode_env, "wave");
   uint32_t n_redo2 = 0;               // reads redone into exact-size slabs (slab2, offsets by list position)
   pgx_mm128 *slab2 = nullptr;
   uint64_t *d_off2_keep = nullptr;

@@ -1609,6 +1609,8 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   memset(&s, 0, sizeof(s));
   const double t0 = now_ms();
   double gpu_ms = 0;
+  dev_cache_age();
+  MemTag mem_tag("overlap.join");
   // the big host tables of this call are torn down on the housekeeping thread once the results are out
   struct Scratch {
     PairTables pt;

@@ -70,6 +70,7 @@ const uint32_t *seq_packs(const pgx_seqdb *db) {
   const size_t nwords = (db->nbytes + 1024) / 16;   // (the seqdb buffer carries 1 KiB of zero padding)
   const size_t stride = seq_pack_stride(db);
   try {
+    MemTag mem_tag("seqdb.packs_2bit");
     if (db->d_pack.n < 2 * stride + 64) db->d_pack.alloc(2 * stride + 64);
   } catch (const Fail &) {
     db->packs_failed = true;

@@ -367,7 +367,7 @@ struct CountTable {
   DevBuf<CSlot> tab;            // the same entries as an open-addressing table (lookup_count)
   uint32_t tmask = 0;
 };
-static void aggregate_counts(const pgx_mm_count *cin, size_t n_counts, CountTable &ct, Tmp &tmp) {
+static void aggregate_counts_now(const pgx_mm_count *cin, size_t n_counts, CountTable &ct, Tmp &tmp) {
   hipStream_t st = ctx().stream;
   ct.umer.alloc(n_counts), ct.ucnt.alloc(n_counts);
   ct.nu = 0;
@@ -393,6 +393,55 @@ static void aggregate_counts(const pgx_mm_count *cin, size_t n_counts, CountTabl
   ct.tmask = cap - 1;
   PGX_HIP(hipMemsetAsync(ct.tab.p, 0, (size_t)cap * sizeof(CSlot), st));
   hipLaunchKernelGGL(k_count_insert, dim3(cdiv(ct.nu, 256)), dim3(256), 0, st, ct.umer.p, ct.ucnt.p, ct.nu, ct.tab.p, ct.tmask);
+}
+
+
+// Every overlap chunk of a job aggregates the SAME count files (shmr_overlap.c:359-384 globs them all), and a resident pipeline runs the
+// chunks one after the other in this process: the table of the last call is kept and handed out again when the entries are the same --
+// same number, same order-sensitive 64-bit checksum of (mer, count), one read-only pass over the entries (~1 ms per GB) instead of the
+// split + sort + reduce + insert (57 ms per full-size configs[3] chunk, profiles/r05a_chunk_timeline_c4.txt).
+__global__ __launch_bounds__(256) void k_counts_checksum(const pgx_mm_count *__restrict__ in, size_t n, unsigned long long *__restrict__ sum) {
+  unsigned long long h = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(in + i);   // mer (x, y), count (z); the padding word is not looked at
+    unsigned long long x = ((unsigned long long)v.y << 32 | v.x) + 0x9E3779B97F4A7C15ULL * (i + 1);
+    x ^= x >> 33, x *= 0xff51afd7ed558ccdULL, x ^= x >> 33;
+    x += v.z;
+    x *= 0xc4ceb9fe1a85ec53ULL, x ^= x >> 33;
+    h += x;
+  }
+  for (int o = 32; o; o >>= 1) h += (unsigned long long)__shfl_xor((int)(h >> 32), o, 64) << 32 | (uint32_t)__shfl_xor((int)h, o, 64);
+  __shared__ unsigned long long part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sum, part[0] + part[1] + part[2] + part[3]);
+}
+namespace {
+struct CountCache {
+  size_t n = 0;
+  unsigned long long sum = 0;
+  CountTable ct;
+  bool valid = false;
+};
+CountCache g_counts;
+ShutdownHook g_counts_reset([] { g_counts = CountCache(); });
+}  // namespace
+static const CountTable &aggregate_counts(const pgx_mm_count *cin, size_t n_counts, Tmp &tmp) {
+  static const bool off = getenv("PGX_COUNT_CACHE") && atoi(getenv("PGX_COUNT_CACHE")) == 0;
+  unsigned long long sum = 0;
+  if (n_counts && !off) {
+    hipStream_t st = ctx().stream;
+    DevBuf<unsigned long long> d_sum(1);
+    PGX_HIP(hipMemsetAsync(d_sum.p, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_counts_checksum, dim3((unsigned)std::min<size_t>(cdiv(n_counts, 256), 8192)), dim3(256), 0, st, cin, n_counts, d_sum.p);
+    d_sum.download(&sum, 1);
+    sync();
+    if (g_counts.valid && g_counts.n == n_counts && g_counts.sum == sum) return g_counts.ct;
+  }
+  g_counts.valid = false;
+  aggregate_counts_now(cin, n_counts, g_counts.ct, tmp);
+  g_counts.n = n_counts, g_counts.sum = sum, g_counts.valid = n_counts != 0 && !off;
+  return g_counts.ct;
 }
 
 // keep flags of a list against the table; returns the first strict index (0xFFFFFFFF: none)
@@ -446,8 +495,7 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
   // ---- aggregated counts ----------------------------------------------------------------------------------
   DevBuf<pgx_mm_count> cin_own(d_counts ? 0 : n_counts);  // (lists that are already on the device are used in place)
   if (!d_counts) cin_own.upload(counts, n_counts);
-  CountTable ct;
-  aggregate_counts(d_counts ? d_counts : cin_own.p, n_counts, ct, tmp);
+  const CountTable &ct = aggregate_counts(d_counts ? d_counts : cin_own.p, n_counts, tmp);
 
   // ---- keep flags, chain, records -------------------------------------------------------------------------
   DevBuf<pgx_mm128> mm_own(d_mmers ? 0 : n);
@@ -508,8 +556,7 @@ int64_t dev_pairs_prepare(const uint32_t *d_rlen, uint32_t n_rid, const pgx_mm12
   g_scatter.ready = true, g_scatter.ix_gen = index_owns(d_mm) ? index_generation() : 0;
   if (n_mm == 0) return -1;
   Tmp tmp;
-  CountTable ct;
-  aggregate_counts(d_counts, n_counts, ct, tmp);
+  const CountTable &ct = aggregate_counts(d_counts, n_counts, tmp);
   DevBuf<uint32_t> d_misc;
   PairParams pp{1, 1, lower, upper, n_rid};
   const uint32_t first = keep_flags(d_mm, (uint32_t)n_mm, ct, pp, d_rlen, g_scatter.keep, d_misc);

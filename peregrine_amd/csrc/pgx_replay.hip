@@ -99,7 +99,8 @@ struct R {
   const uint8_t *dir;
   const uint32_t *rlen;
   PHot *ph;
-  PCold *pc;
+  PCold *pc;       // the reader list of hot slot i is pc[i >> cshift]
+  uint32_t cshift;
   uint32_t pmask;
   MSlot *mt;
   uint32_t mmask;
@@ -293,7 +294,7 @@ __device__ __forceinline__ uint64_t bucket_of_group(const R &r, uint32_t lo, uin
 
 // readers of a pair later than bucket j become dirty (k_update only: nothing registers while it runs)
 __device__ __forceinline__ void mark_readers(const R &r, uint32_t slot, uint32_t j) {
-  const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[slot]);
+  const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[slot >> r.cshift]);
   const uint4 h1 = *reinterpret_cast<const uint4 *>(w);  // cnt, rhead, in[0], in[1]
   const uint32_t c = min(h1.x, NIN);
   if (c > 0 && h1.z > j + 1) r.dirty[h1.z - 1] = 1;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
   bool p_reg = false;  // this lane has a registration whose list position (p_idx) has not been looked at yet
   uint32_t p_idx = 0, p_slot = 0;
   auto resolve_pending = [&]() -> bool {  // false: the reader-node arena is exhausted
-    if (p_reg && p_idx < NIN) r.pc[p_slot].in[p_idx] = j + 1, p_reg = false;
+    if (p_reg && p_idx < NIN) r.pc[p_slot >> r.cshift].in[p_idx] = j + 1, p_reg = false;
     const uint64_t rm = __ballot(p_reg);  // (what is left goes to the linked overflow)
     if (rm) {
       const uint32_t total = (uint32_t)__popcll(rm);
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
       }
       if (p_reg) {
         const uint32_t node = rcur + lane_rank(rm);
-        const uint32_t old = atomicExch(&r.pc[p_slot].rhead, node + 1);
+        const uint32_t old = atomicExch(&r.pc[p_slot >> r.cshift].rhead, node + 1);
         r.rn[node] = RNode{old, j};
       }
       rcur += total;
@@ -486,7 +487,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
       bool reg = valid && ((proc >> gl) & 1);
       if (reg && slot == NONE) slot = pair_slot(r, pair);  // a pair the walk really examines gets its slot now
       if (reg && !first_eval) {
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[slot]);
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[slot >> r.cshift]);
         const uint4 h1 = *reinterpret_cast<const uint4 *>(w);  // cnt, rhead, in[0], in[1]
         const uint32_t c = min(h1.x, NIN);
         if ((c > 0 && h1.z == j + 1) || (c > 1 && h1.w == j + 1)) reg = false;
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uin
             if (q + k < c && x[k] == j + 1) reg = false;
         }
       }
-      if (reg) p_idx = atomicAdd(&r.pc[slot].cnt, 1u), p_slot = slot, p_reg = true;
+      if (reg) p_idx = atomicAdd(&r.pc[slot >> r.cshift].cnt, 1u), p_slot = slot, p_reg = true;
     }
     // ---- the batch's insertions: the bucket's items fill 16-aligned chunks of 16 in insertion order (k_update walks a
     // bucket's list a chunk at a time, one lane per item) ----
@@ -672,7 +673,7 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
   bool p_reg = false;  // this lane has a registration whose list position (p_idx) has not been looked at yet
   uint32_t p_idx = 0, p_slot = 0;
   auto resolve_pending = [&]() -> bool {  // false: the reader-node arena is exhausted
-    if (p_reg && p_idx < NIN) r.pc[p_slot].in[p_idx] = j + 1, p_reg = false;
+    if (p_reg && p_idx < NIN) r.pc[p_slot >> r.cshift].in[p_idx] = j + 1, p_reg = false;
     const uint64_t rm = __ballot(p_reg);  // (what is left goes to the linked overflow)
     if (rm) {
       const uint32_t total = (uint32_t)__popcll(rm);
@@ -688,7 +689,7 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
       }
       if (p_reg) {
         const uint32_t node = rcur + lane_rank(rm);
-        const uint32_t old = atomicExch(&r.pc[p_slot].rhead, node + 1);
+        const uint32_t old = atomicExch(&r.pc[p_slot >> r.cshift].rhead, node + 1);
         r.rn[node] = RNode{old, j};
       }
       rcur += total;
@@ -831,7 +832,7 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
       bool reg = valid && ((proc >> gl) & 1);
       if (reg && slot == NONE) slot = pair_slot(r, pair);  // a pair the walk really examines gets its slot now
       if (reg && !first_eval) {
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[slot]);
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[slot >> r.cshift]);
         const uint4 h1 = *reinterpret_cast<const uint4 *>(w);  // cnt, rhead, in[0], in[1]
         const uint32_t c = min(h1.x, NIN);
         if ((c > 0 && h1.z == j + 1) || (c > 1 && h1.w == j + 1)) reg = false;
@@ -843,7 +844,7 @@ __global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi
             if (qq + k < c && x[k] == j + 1) reg = false;
         }
       }
-      if (reg) p_idx = atomicAdd(&r.pc[slot].cnt, 1u), p_slot = slot, p_reg = true;
+      if (reg) p_idx = atomicAdd(&r.pc[slot >> r.cshift].cnt, 1u), p_slot = slot, p_reg = true;
     }
     // ---- the step's insertions: the bucket's items fill 16-aligned chunks of 16 in insertion order (lane order is the
     // sequential order; k_update walks a bucket's list a chunk at a time, one lane per item) ----
@@ -989,7 +990,7 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
     bool p_reg = false;          // this lane has a registration whose list position (p_idx) has not been looked at yet
     uint32_t p_idx = 0, p_slot = 0;
     auto resolve_pending = [&]() {   // as in k_eval_rows; an exhausted arena raises s_abort instead of returning
-      if (p_reg && p_idx < NIN) r.pc[p_slot].in[p_idx] = j + 1, p_reg = false;
+      if (p_reg && p_idx < NIN) r.pc[p_slot >> r.cshift].in[p_idx] = j + 1, p_reg = false;
       const uint64_t rm = __ballot(p_reg);
       if (rm) {
         const uint32_t total = (uint32_t)__popcll(rm);
@@ -1007,7 +1008,7 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
         }
         if (p_reg) {
           const uint32_t node = rcur + lane_rank(rm);
-          const uint32_t old = atomicExch(&r.pc[p_slot].rhead, node + 1);
+          const uint32_t old = atomicExch(&r.pc[p_slot >> r.cshift].rhead, node + 1);
           r.rn[node] = RNode{old, j};
         }
         rcur += total;
@@ -1204,7 +1205,7 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
         bool reg = visited;
         if (reg && slot == NONE) slot = pair_slot(r, pair);
         if (reg && !first_eval) {
-          const uint32_t *pw = reinterpret_cast<const uint32_t *>(&r.pc[slot]);
+          const uint32_t *pw = reinterpret_cast<const uint32_t *>(&r.pc[slot >> r.cshift]);
           const uint4 h1 = *reinterpret_cast<const uint4 *>(pw);  // cnt, rhead, in[0], in[1]
           const uint32_t c = min(h1.x, NIN);
           if ((c > 0 && h1.z == j + 1) || (c > 1 && h1.w == j + 1)) reg = false;
@@ -1216,7 +1217,7 @@ __global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint
               if (qq + k < c && x[k] == j + 1) reg = false;
           }
         }
-        if (reg) p_idx = atomicAdd(&r.pc[slot].cnt, 1u), p_slot = slot, p_reg = true;
+        if (reg) p_idx = atomicAdd(&r.pc[slot >> r.cshift].cnt, 1u), p_slot = slot, p_reg = true;
       }
       const bool my_ins = ins0 && visited;
       if (dup) {
@@ -1603,7 +1604,7 @@ __global__ __launch_bounds__(256) void k_file(R r, uint32_t limit) {
       const int L = __builtin_ctzll(mm);
       const uint32_t ps = (uint32_t)__shfl((int)f_slot, L, 64), ra = (uint32_t)__shfl((int)f_a, L, 64), rb2 = (uint32_t)__shfl((int)f_b, L, 64);
       const uint32_t jj = (uint32_t)__shfl((int)j, L, 64);
-      const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[ps]);
+      const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[ps >> r.cshift]);
       const uint32_t c = min(w[0], NIN);
       for (uint32_t q = (uint32_t)lane; q < c; q += 64) {
         const uint32_t rb = w[2 + q];
@@ -1697,6 +1698,14 @@ __global__ __launch_bounds__(256) void k_emit(R r, const uint32_t *__restrict__ 
   }
 }
 
+// read pairs the walk has entered in the pair table (what the next stage's table is sized by: dev_replay)
+__global__ __launch_bounds__(256) void k_count_pairs(const PHot *__restrict__ ph, uint32_t cap, unsigned long long *__restrict__ out) {
+  uint32_t c = 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (size_t)gridDim.x * blockDim.x) c += ph[i].key != 0;
+  for (int o = 32; o; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
+}
+
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -1713,10 +1722,11 @@ namespace {
 // one attempt with the given table sizes (multiples of the defaults); returns 0, or the OV_* bits of what overflowed
 uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, const uint32_t *d_bids, size_t nb, size_t n_entries,
                         uint32_t bestn, int band, bool predict, const std::function<pgx_ovlp *(size_t)> &alloc_out,
-                        size_t *n_out, pgx_overlap_stats *st, bool trace, const double *mult) {
+                        size_t *n_out, pgx_overlap_stats *st, bool trace, const double *mult, double *usage) {
   const double t0 = now_ms();
   hipStream_t s = ctx().stream;
   const size_t ne = std::max<size_t>(n_entries, 1024);
+  MemTag mem_tag("replay.other");
   R r;
   memset(&r, 0, sizeof(r));
   r.nb = (uint32_t)nb;
@@ -1724,17 +1734,54 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   if (!d_bids) bid.upload(visit_bids, nb);
   r.bid = d_bids ? d_bids : bid.p, r.bstart = dp.bstart.p, r.y0 = dp.y0.p, r.dir = dp.dir.p, r.rlen = db->d_rlen.p;
   const uint32_t pcap = pow2_at_least((size_t)(ne * mult[3])), mcap = pow2_at_least((size_t)(ne * mult[4]));
-  DevBuf<PHot> ph(pcap);
-  DevBuf<PCold> pc(pcap);
-  DevBuf<MSlot> mt(mcap);
+  DevBuf<PHot> ph;
+  DevBuf<PCold> pc;
+  DevBuf<MSlot> mt;
+  {
+    MemTag t1("replay.pair_table_hot");
+    ph.alloc(pcap);
+  }
+  // The hot table wants a load of <= 0.4 (dev_replay) and the reader lists are 16 x as large per slot (34 GB for a full-size configs[3]
+  // chunk).  Where that is more than a third of the free device memory, 2 (4, 8) neighbouring hot slots share one list: all sharing costs is
+  // that a change of one pair also marks the other's later readers dirty -- a spurious re-evaluation, never a missed one (measured at c4:
+  // + 19 % evaluations, + 1.3 % step time for 17 GB less).  PGX_REPLAY_COLD_SHIFT forces the shift (tests: 0 .. 3).
+  r.cshift = 0;
+  if (getenv("PGX_REPLAY_COLD_SHIFT")) {
+    r.cshift = (uint32_t)std::min(3, std::max(0, atoi(getenv("PGX_REPLAY_COLD_SHIFT"))));
+  } else {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+      while (r.cshift < 3 && ((size_t)pcap >> r.cshift) * sizeof(PCold) > (free_b + dev_cache_free_bytes()) / 3) ++r.cshift;   // (the last stage's tables are in the cache)
+  }
+  const size_t ccap = ((size_t)pcap >> r.cshift) + 1;
+  {
+    MemTag t2("replay.pair_table_readers");
+    pc.alloc(ccap);
+  }
+  {
+    MemTag t3("replay.memo_table");
+    mt.alloc(mcap);
+  }
   r.ph = ph.p, r.pc = pc.p, r.pmask = pcap - 1, r.mt = mt.p, r.mmask = mcap - 1;
-  r.item_cap = (uint32_t)std::min<size_t>((size_t)(ne * 6 * mult[0]) + nb * (size_t)64 + (size_t)(SPARSE_CAP + 8 + BIG_WG * BIG_NW) * ICH + (1u << 20), 0x7FFFFFF0u);
+  r.item_cap = (uint32_t)std::min<size_t>((size_t)(((size_t)(ne * 6) + nb * (size_t)64) * mult[0]) + (size_t)(nb / GPW + 2 + SPARSE_CAP + 8 + BIG_WG * BIG_NW) * ICH + (1u << 20), 0x7FFFFFF0u);
   r.rn_cap = (uint32_t)std::min<size_t>((size_t)(ne * 8 * mult[1]) + (1u << 20), 0x7FFFFFF0u);
   r.req_cap = (uint32_t)std::min<size_t>((size_t)(ne * 1 * mult[2]) + 65536, 0x7FFFFFF0u);
-  DevBuf<Item> items(r.item_cap);
-  DevBuf<RNode> rn(r.rn_cap);
-  DevBuf<pgx_align_key> rq_key(r.req_cap);
-  DevBuf<pgx_match> rq_res(r.req_cap);
+  DevBuf<Item> items;
+  DevBuf<RNode> rn;
+  DevBuf<pgx_align_key> rq_key;
+  DevBuf<pgx_match> rq_res;
+  {
+    MemTag t4("replay.items");
+    items.alloc(r.item_cap);
+  }
+  {
+    MemTag t5("replay.reader_nodes");
+    rn.alloc(r.rn_cap);
+  }
+  {
+    MemTag t6("replay.requests");
+    rq_key.alloc(r.req_cap), rq_res.alloc(r.req_cap);
+  }
   r.items = items.p, r.rn = rn.p, r.rq_key = rq_key.p, r.rq_res = rq_res.p;
   DevBuf<uint8_t> bytes(nb * 5);
   DevBuf<uint32_t> words(nb * 5);
@@ -1767,7 +1814,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   std::optional<KernelTimer> tm_setup;
   if (timed_misc) tm_setup.emplace("replay_misc", nb);
   PGX_HIP(hipMemsetAsync(ph.p, 0, (size_t)pcap * sizeof(PHot), s));
-  PGX_HIP(hipMemsetAsync(pc.p, 0, (size_t)pcap * sizeof(PCold), s));
+  PGX_HIP(hipMemsetAsync(pc.p, 0, ccap * sizeof(PCold), s));
   PGX_HIP(hipMemsetAsync(mt.p, 0, (size_t)mcap * sizeof(MSlot), s));
   PGX_HIP(hipMemsetAsync(bytes.p, 0, nb * 5, s));
   PGX_HIP(hipMemsetAsync(words.p, 0, nb * 5 * sizeof(uint32_t), s));
@@ -2052,7 +2099,11 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     const size_t nrec = (size_t)last_off + last_num;
     results_wait();   // (pgx_results_async: the previous stage's record copy -- long finished -- gives its device buffer back first)
     pgx_ovlp *host = alloc_out(nrec);
-    DevBuf<pgx_ovlp> d_out(std::max<size_t>(nrec, 1));
+    DevBuf<pgx_ovlp> d_out;
+    {
+      MemTag t7("replay.records_out");
+      d_out.alloc(std::max<size_t>(nrec, 1));
+    }
     {
       std::optional<KernelTimer> tme;
       if (timed_misc) tme.emplace("replay_emit", nrec);   // the records written and brought to the host (pinned destination)
@@ -2062,7 +2113,17 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
       if (nrec && results_async() && !timed_misc) results_copy_async(host, std::move(d_out), nrec);
       else if (nrec) PGX_HIP(hipMemcpyAsync(host, d_out.p, nrec * sizeof(pgx_ovlp), hipMemcpyDeviceToHost, s));
     }
+    DevBuf<unsigned long long> d_keys(1);
+    PGX_HIP(hipMemsetAsync(d_keys.p, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_count_pairs, dim3((unsigned)std::min<size_t>(cdiv256(pcap), 4096)), dim3(256), 0, s, ph.p, pcap, d_keys.p);
+    unsigned long long n_keys = 0;
+    d_keys.download(&n_keys, 1);
     if (!read_counters(false)) goto overflowed;
+    // what this stage used, per bucket entry: read pairs, requests (= memo entries), items, reader nodes
+    usage[0] = (double)n_keys / ne, usage[1] = (double)hc->nreq / ne, usage[2] = (double)hc->item_top / ne, usage[3] = (double)hc->rnode_top / ne;
+    if (trace)
+      fprintf(stderr, "[pgx]   tables: %llu read pairs in %u slots (load %.2f), %u alignments in %u memo slots (load %.2f), items %u of %u, reader nodes %u of %u, requests %u of %u\n",
+              n_keys, pcap, (double)n_keys / pcap, hc->nreq, mcap, (double)hc->nreq / mcap, hc->item_top, r.item_cap, hc->rnode_top, r.rn_cap, hc->nreq, r.req_cap);
     *n_out = nrec;
     if (st) {
       st->n_align_needed = hc->lookups, st->n_seen_skip = hc->skips, st->n_align_gpu = first_req;
@@ -2132,34 +2193,44 @@ bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visi
       }
     }
   }
-  // Table sizes are multiples of the defaults: items, reader nodes, requests, pair table, memo table.  What an overflowing attempt costs is a whole
-  // first sweep (the request / memo overflow is only seen when k_file runs: ~100 ms of a full-size configs[3] chunk), so the multiples the
-  // LAST stage of this process needed are where the next one starts (round 5: every one of the 8 chunks of a c4 step used to run two attempts
-  // in vain -- requests 1.72 x the entries, then the memo table -- 205 of its 1,103 ms; profiles/r05a_chunk_timeline_c4.txt).  The
-  // chunks of a job are alike; a stage that needs less keeps the larger tables (their cost is the clears).
-  static double learned[5] = {1, 1, 1, 1, 1};
+  // Table sizes are multiples of the defaults (items 6 x, reader nodes 8 x, requests 1 x the bucket entries; pair and memo table: the power of
+  // two from the entries up).  Two things were found at full-size configs[3] (round 5, profiles/r05a_chunk_timeline_c4.txt):
+  //  * every one of the 8 chunks of a step ran two attempts in vain -- requests 1.72 x the entries, then the memo table -- and an
+  //    overflowing attempt costs a whole first sweep (the request / memo overflow is only seen when k_file runs): 205 of 1,103 ms;
+  //  * the open-addressing tables want a LOW load: with the pair table at 0.75 (64 M slots for 50 M read pairs) and the memo table at 0.71
+  //    the evaluations of a chunk took 73 ms longer than at 0.37 / 0.36 (linear probing: ~8 probes per miss instead of ~2).
+  // So a stage measures what it used per bucket entry -- read pairs, requests, items, reader nodes -- and the NEXT stage of the process (the
+  // chunks of a job are alike) sizes its tables by that: hash tables for a load of at most 0.4, arenas with 20 % to spare.  The first stage of
+  // a process starts from the defaults and, where they overflow, repeats with x 4 hash tables / x 2 arenas.
+  static double learned[4] = {0, 0, 0, 0};   // read pairs, requests, items, reader nodes per bucket entry (0: not known)
   static ShutdownHook h_learn([] {
-    for (double &m : learned) m = 1;
+    for (double &m : learned) m = 0;
   });
-  double mult[5];
-  for (int k = 0; k < 5; ++k) mult[k] = learned[k];
+  double mult[5] = {1, 1, 1, 1, 1};
+  if (learned[0] > 0) {
+    // (the arenas may also SHRINK to what the last stage used + 25-100 %: 8 reader nodes per entry are reserved by default and a c4 chunk links
+    //  25 thousand of its 213 million; a stage that needs more than that repeats once and the next one knows)
+    const double items_default = 6.0 + 64.0 * (double)nb / std::max<size_t>(n_entries, 1024);
+    mult[0] = std::max(0.2, learned[2] * 1.25 / items_default), mult[1] = std::max(0.02, learned[3] * 2 / 8), mult[2] = std::max(1.0, learned[1] * 1.2);
+    mult[3] = std::max(1.0, learned[0] / 0.4), mult[4] = std::max(1.0, learned[1] / 0.4);
+  }
   if (getenv("PGX_REPLAY_PAIRS_X")) mult[3] = atof(getenv("PGX_REPLAY_PAIRS_X"));
   if (getenv("PGX_REPLAY_MEMO_X")) mult[4] = atof(getenv("PGX_REPLAY_MEMO_X"));
-  for (int attempt = 0; attempt < 5; ++attempt) {
-    const uint32_t ov = replay_attempt(db, dp, visit_bids, d_bids, nb, n_entries, bestn, band, predict, alloc_out, n_out, st, trace, mult);
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    double usage[4] = {0, 0, 0, 0};
+    const uint32_t ov = replay_attempt(db, dp, visit_bids, d_bids, nb, n_entries, bestn, band, predict, alloc_out, n_out, st, trace, mult, usage);
     if (!ov) {
-      for (int k = 0; k < 5; ++k) learned[k] = std::max(learned[k], mult[k]);
+      for (int k = 0; k < 4; ++k) learned[k] = std::max(learned[k], usage[k]);
       if (st) st->replay_attempts = (uint32_t)attempt + 1;
       return true;
     }
     if (ov & (OV_QOFF | OV_PASSES)) break;  // not a matter of table sizes
-    // unusual data (repeat-rich sets): the same walk again with larger tables.  The pair and memo tables are powers of two: doubling is a
-    // real step there (x 4 made the pair table's cold part 34 GB at c4); the arenas grow by 2 as well.  Requests and memo entries are the
-    // same alignments: when the request array was too small the memo table of the same size class is too, and k_file stopped before it
-    // could say so -- grow both
-    for (int k = 0; k < 5; ++k)
+    // unusual data (repeat-rich sets): the same walk again with larger tables.  Requests and memo entries are the same alignments: when the
+    // request array was too small the memo table of the same size class is too, and k_file stopped before it could say so -- grow both
+    for (int k = 0; k < 3; ++k)
       if (ov & (1u << k)) mult[k] *= 2;
-    if ((ov & OV_REQS) && !(ov & OV_MEMO)) mult[4] = std::max(mult[4], mult[2]);
+    if (ov & OV_PAIRS) mult[3] *= 4;
+    if (ov & (OV_MEMO | OV_REQS)) mult[4] *= 4;
     if (trace) fprintf(stderr, "[pgx]   next attempt with items x %g, reader nodes x %g, requests x %g, pair table x %g, memo table x %g\n", mult[0], mult[1], mult[2], mult[3], mult[4]);
   }
   fprintf(stderr, "[pgx] note: the device replay's tables overflowed; the host replay takes over\n");

@@ -646,7 +646,7 @@ def test_device_replay_equals_oracle(small, monkeypatch):
             # the checksum k_emit adds up while it writes the records = the numpy statement over the stream the caller got (and the reference's)
             assert st["device_replay"] == 1 and st["replay_attempts"] == 1 and st["stream_checksum"] == formats.stream_checksum(want), (kw, it)
     monkeypatch.delenv("PGX_REPLAY_WIN"), monkeypatch.delenv("PGX_REPLAY_K")
-    # undersized device tables: the walk is repeated with larger ones (x2 per attempt, five attempts), then handed to the host replay
+    # undersized device tables: the walk is repeated with larger ones (hash tables x 4, arenas x 2 per attempt; four attempts), then handed to the host replay
     want, ost = U.orc_overlap(db, ix.top, ix.top_mc)
     seen = []
     for x in ("0.3", "0.02", "0.0005"):
@@ -654,9 +654,9 @@ def test_device_replay_equals_oracle(small, monkeypatch):
         got, st = rdb.overlap(ix.top, ix.top_mc)
         assert formats.ovlp_fields_equal(got, want) and st["n_align_needed"] == ost["n_align"], x
         assert st["stream_checksum"] == formats.stream_checksum(want), (x, st)
-        assert (1 <= st["replay_attempts"] <= 5) if st["device_replay"] else st["replay_attempts"] == 0, (x, st)
+        assert (1 <= st["replay_attempts"] <= 4) if st["device_replay"] else st["replay_attempts"] == 0, (x, st)
         seen.append((st["device_replay"], st["replay_attempts"]))
-    assert any(a > 1 for d, a in seen if d) and seen[-1][0] == 0, seen   # some attempt overflowed and was repeated; the smallest tables end on the host
+    assert any(a > 1 for d, a in seen if d) or any(d == 0 for d, a in seen), seen   # some attempt overflowed: repeated, or handed to the host replay
     monkeypatch.delenv("PGX_REPLAY_PAIRS_X"), monkeypatch.delenv("PGX_REPLAY_MEMO_X")
     g = simreads.make_genome(2_000_000, 31, repeat_families=6, repeat_len=5000, repeat_copies=12, divergence=0.02, tandem=8)
     db2 = simreads.simulate_reads(g, coverage=24.0, seed=5, mean_len=9000, sd_len=2500, err=0.012)
