@@ -104,6 +104,17 @@ static int try_server(const char *tool, const char *prefix, int argc, char **arg
   return status;
 }
 
+/* An output the SERVER cannot open on the client's behalf: /dev/stdout, /dev/fd/N, /proc/self/fd/N (process substitution) name
+ * the calling process's descriptors, and anything that exists and is not a regular file (a FIFO, a socket, a tty) may mean something else over
+ * there too.  Such a command runs stand-alone, where fopen(path) does what the reference's does (src/shmr_overlap.c:341-352). */
+static int output_needs_this_process(const char *path) {
+  if (!path) return 0;
+  if (!strncmp(path, "/dev/", 5) || !strncmp(path, "/proc/", 6)) return 1;
+  struct stat sb;
+  if (stat(path, &sb) == 0 && !S_ISREG(sb.st_mode)) return 1;
+  return 0;
+}
+
 static int run_index_args(int argc, char **argv, pgx_seqdb *db, const char *served_prefix, char *msg, size_t cap);
 static int run_overlap_args(int argc, char **argv, pgx_seqdb *db, const char *served_prefix, char *msg, size_t cap);
 
@@ -291,7 +302,7 @@ static int run_overlap_args(int argc, char **argv, pgx_seqdb *db, const char *se
     o = dflt;
   }
   if (!db) {
-    const int served = try_server("shmr_overlap", p, argc, argv);
+    const int served = output_needs_this_process(o) ? -1 : try_server("shmr_overlap", p, argc, argv);
     if (served >= 0) return served;
     if (pgx_init(device_of_env())) return fail("shmr_overlap", "pgx_init");
     if (pgx_overlap_chunk(p, l, o, &op, NULL)) return fail("shmr_overlap", "pgx_overlap_chunk");

@@ -5,8 +5,8 @@
 #   pass 3   : SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVES -> profiles/<tag>_valu_<workload>.json (wave64 VALU instructions per unit,
 #              issue rate per SIMD and cycle: the roofline that binds the sketch and alignment kernels)
 #   pass 0   : --kernel-trace --stats            -> profiles/<tag>_kernel_stats_bench_<workload>.txt
-# usage: tools/pmc_profile.sh [workload=c3] [tag=r04] [steps=2] [extra bench args...]
-W=${1:-c3}; TAG=${2:-r04}; S=${3:-2}; shift 3 2>/dev/null
+# usage: tools/pmc_profile.sh [workload=c3] [tag=r05] [steps=2] [extra bench args...]
+W=${1:-c3}; TAG=${2:-r05}; S=${3:-2}; shift 3 2>/dev/null
 EXTRA="$@"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc_$W
@@ -58,6 +58,7 @@ for k, v in res.items():
     v["read_factor"] = rf
     v["hbm_bytes_per_launch"] = (rf * v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)) * 1024
 res["_workload"] = W
+res["_steps"] = S
 res["_command"] = f"rocprofv3 --kernel-trace --pmc {{FETCH_SIZE|WRITE_SIZE}} -- python bench.py --workload {W} --steps {S} --warmup 0 --no-cpu-baseline $EXTRA"
 json.dump(res, open(f"profiles/{TAG}_traffic_{W}.json", "w"), indent=1)
 # ---- VALU issue
@@ -86,6 +87,7 @@ for k, c in acc.items():
         e["units"], e["unit_name"] = units[k][0], units[k][1]
     vv[k] = e
 vv["_workload"] = W
+vv["_steps"] = S
 vv["_command"] = f"rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_WAVES -- python bench.py --workload {W} --steps {S} --warmup 0 --no-cpu-baseline $EXTRA"
 vv["_note"] = "units = what bench.py's timers counted over the same launches (warmup 0, no extra replay-timing step: PGX_BENCH_NO_REPLAY_TIMING=1)"
 json.dump(vv, open(f"profiles/{TAG}_valu_{W}.json", "w"), indent=1)
