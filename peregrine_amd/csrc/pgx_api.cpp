@@ -28,10 +28,12 @@ void set_error(const char *fmt, ...) {
   g_err = buf;
 }
 
+static thread_local Context *tl_ctx = nullptr;
 Context &ctx() {
   static Context c;
-  return c;
+  return tl_ctx ? *tl_ctx : c;
 }
+void set_thread_context(Context *c) { tl_ctx = c; }
 void require_ready() { PGX_REQUIRE(ctx().ready, PGX_ESTATE, "pgx_init() has not been called (or failed)"); }
 
 // ---- large host arrays -------------------------------------------------------------------------------------
@@ -163,8 +165,10 @@ ShutdownHook g_copy_reset([] {
   if (g_copy.stream) (void)hipStreamDestroy(g_copy.stream), g_copy.stream = nullptr;
 });
 }  // namespace
+static std::recursive_mutex g_copy_mu;   // (out_free -> results_wait_if can run on the housekeeping thread or a Python finaliser: ADVICE r4)
 bool &results_async() { return g_results_async; }
 void results_wait() {
+  std::lock_guard<std::recursive_mutex> lk(g_copy_mu);
   if (!g_copy.active) return;
   g_copy.active = false;
   const hipError_t e = hipEventSynchronize(g_copy.done);
@@ -173,6 +177,7 @@ void results_wait() {
   PGX_HIP(e);
 }
 void results_wait_if(const void *host) {
+  std::lock_guard<std::recursive_mutex> lk(g_copy_mu);
   if (g_copy.active && g_copy.host == host) {
     try {
       results_wait();
@@ -181,6 +186,7 @@ void results_wait_if(const void *host) {
   }
 }
 void results_copy_async(pgx_ovlp *host, DevBuf<pgx_ovlp> &&dev, size_t n) {
+  std::lock_guard<std::recursive_mutex> lk(g_copy_mu);
   results_wait();   // (one copy in flight)
   if (!g_copy.stream) {
     PGX_HIP(hipStreamCreateWithFlags(&g_copy.stream, hipStreamNonBlocking));
@@ -331,7 +337,15 @@ static std::mutex g_dev_mu;
 struct FreeBlock {
   void *p;
   uint64_t age;
+  hipStream_t stream;   // the stream of the thread that released it (its last user)
+  hipEvent_t ev;        // multi-stream mode: recorded on that stream at release; a user on ANOTHER stream waits for it
 };
+static bool g_multi_stream = false;
+static std::vector<hipEvent_t> g_ev_pool;
+void dev_cache_multi_stream(bool on) {
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  g_multi_stream = on;
+}
 static std::multimap<size_t, FreeBlock> g_dev_free;  // size class -> cached blocks
 struct LiveBlock {
   size_t cls;
@@ -355,7 +369,10 @@ static size_t size_class(size_t bytes) {           // powers of two up to 1 MiB,
   return (bytes + step - 1) / step * step;
 }
 static void drop_all_free_locked() {
-  for (auto &kv : g_dev_free) (void)hipFree(kv.second.p);
+  for (auto &kv : g_dev_free) {
+    if (kv.second.ev) (void)hipEventSynchronize(kv.second.ev), g_ev_pool.push_back(kv.second.ev);
+    (void)hipFree(kv.second.p);
+  }
   g_dev_free.clear();
   g_free_bytes = 0;
 }
@@ -366,9 +383,22 @@ void *dev_alloc(size_t bytes) {
   void *p = nullptr;
   size_t got = c;
   if (it != g_dev_free.end() && it->first <= c + (c >> 3)) {
-    p = it->second.p, got = it->first;
-    g_dev_free.erase(it);
+    // (prefer a block this stream released itself: among the candidates of the class, the first one with the same stream)
+    hipStream_t me = ctx().stream;
+    auto pick = it;
+    for (auto j = it; j != g_dev_free.end() && j->first == it->first; ++j)
+      if (j->second.stream == me) {
+        pick = j;
+        break;
+      }
+    const FreeBlock fb = pick->second;
+    p = fb.p, got = pick->first;
+    g_dev_free.erase(pick);
     g_free_bytes -= got;
+    if (fb.ev) {
+      if (fb.stream != me) (void)hipStreamWaitEvent(me, fb.ev, 0);   // its last user's work, on the device, before ours
+      g_ev_pool.push_back(fb.ev);
+    }
   } else {
     hipError_t e = hipMalloc(&p, c);
     if (e != hipSuccess) {  // make room: give the cached blocks back and retry once
@@ -386,7 +416,13 @@ void dev_release(void *p) {
   std::lock_guard<std::mutex> lk(g_dev_mu);
   auto it = g_dev_live.find(p);
   if (it == g_dev_live.end()) return;
-  g_dev_free.emplace(it->second.cls, FreeBlock{p, g_dev_age});
+  FreeBlock fb{p, g_dev_age, ctx().stream, nullptr};
+  if (g_multi_stream && ctx().ready) {
+    if (!g_ev_pool.empty()) fb.ev = g_ev_pool.back(), g_ev_pool.pop_back();
+    else if (hipEventCreateWithFlags(&fb.ev, hipEventDisableTiming) != hipSuccess) fb.ev = nullptr;
+    if (fb.ev && hipEventRecord(fb.ev, fb.stream) != hipSuccess) g_ev_pool.push_back(fb.ev), fb.ev = nullptr;
+  }
+  g_dev_free.emplace(it->second.cls, fb);
   g_live_bytes -= it->second.cls, g_free_bytes += it->second.cls, g_by_tag[it->second.tag] -= it->second.cls;
   g_dev_live.erase(it);
 }
@@ -403,6 +439,7 @@ void dev_cache_age() {
   ++g_dev_age;
   for (auto it = g_dev_free.begin(); it != g_dev_free.end();) {
     if (it->first >= ((size_t)64 << 20) && it->second.age + 2 < g_dev_age) {
+      if (it->second.ev) (void)hipEventSynchronize(it->second.ev), g_ev_pool.push_back(it->second.ev);
       (void)hipFree(it->second.p);
       g_free_bytes -= it->first;
       it = g_dev_free.erase(it);
@@ -453,6 +490,7 @@ struct Pending {
 };
 static std::map<std::string, TimeAcc> g_time;
 static std::vector<Pending> g_pending;
+static std::mutex g_time_mu;   // (the prefetch worker times its kernels too)
 
 KernelTimer::KernelTimer(const char *nm, uint64_t u) : name(nm), units(u) {
   (void)hipEventCreate(&e0);
@@ -461,12 +499,22 @@ KernelTimer::KernelTimer(const char *nm, uint64_t u) : name(nm), units(u) {
 }
 KernelTimer::~KernelTimer() {
   (void)hipEventRecord(e1, ctx().stream);
+  std::lock_guard<std::mutex> lk(g_time_mu);
   g_pending.push_back(Pending{name, units, e0, e1});
 }
 void timing_flush() {
-  if (g_pending.empty()) return;
+  {
+    std::lock_guard<std::mutex> lk(g_time_mu);
+    if (g_pending.empty()) return;
+  }
   (void)hipStreamSynchronize(ctx().stream);
+  std::lock_guard<std::mutex> lk(g_time_mu);
+  std::vector<Pending> later;
   for (auto &p : g_pending) {
+    if (hipEventQuery(p.e1) == hipErrorNotReady) {   // (an interval of the other thread's stream that is still open)
+      later.push_back(p);
+      continue;
+    }
     float ms = 0;
     if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
       auto &a = g_time[p.name];
@@ -475,7 +523,7 @@ void timing_flush() {
     (void)hipEventDestroy(p.e0);
     (void)hipEventDestroy(p.e1);
   }
-  g_pending.clear();
+  g_pending.swap(later);
 }
 
 // ---- files -----------------------------------------------------------------------------------------------
@@ -523,7 +571,12 @@ const char *pgx_version(void) { return "pgx 0.1 (gfx950)"; }
 void pgx_free(void *p) { pgx::out_free(p); }
 int pgx_results_async(int on) {
   const int was = pgx::results_async() ? 1 : 0;
-  if (!on) pgx::results_wait();
+  if (!on) {
+    try {   // (a failed copy must not leave the C-ABI as a C++ exception: ADVICE r4; pgx_last_error has the text, pgx_results_wait the code)
+      pgx::results_wait();
+    } catch (const pgx::Fail &) {
+    }
+  }
   pgx::results_async() = on != 0;
   return was;
 }
@@ -585,6 +638,7 @@ void pgx_shutdown(void) {
 
 int pgx_timing_get(const char *kernel, double *total_ms, uint64_t *launches, uint64_t *units) {
   timing_flush();
+  std::lock_guard<std::mutex> lk(g_time_mu);
   auto it = g_time.find(kernel ? kernel : "");
   if (it == g_time.end()) {
     if (total_ms) *total_ms = 0;
@@ -599,6 +653,7 @@ int pgx_timing_get(const char *kernel, double *total_ms, uint64_t *launches, uin
 }
 void pgx_timing_reset(void) {
   timing_flush();
+  std::lock_guard<std::mutex> lk(g_time_mu);
   g_time.clear();
 }
 

@@ -21,6 +21,7 @@
 #include <string.h>
 #include <sys/socket.h>
 #include <sys/stat.h>
+#include <sys/time.h>
 #include <sys/un.h>
 #include <unistd.h>
 
@@ -73,6 +74,10 @@ static int try_server(const char *tool, const char *prefix, int argc, char **arg
   memset(&sa, 0, sizeof(sa));
   sa.sun_family = AF_UNIX;
   strcpy(sa.sun_path, sp);
+  {
+    struct timeval io = {10, 0};   /* (the request must go out promptly; the reply takes as long as the stage does) */
+    (void)setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &io, sizeof(io));
+  }
   if (connect(fd, (struct sockaddr *)&sa, sizeof(sa))) {
     close(fd);
     return -1;
@@ -178,6 +183,11 @@ static int main_serve(int argc, char **argv) {
       if (errno == EINTR) continue;
       break;
     }
+    {  /* a stalled or half-open client must not hold every later command of the job: the request is a few hundred bytes */
+      struct timeval io = {10, 0};
+      (void)setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &io, sizeof(io));
+      (void)setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &io, sizeof(io));
+    }
     static char req[1 << 16];
     size_t got = 0;
     for (;;) {
@@ -205,7 +215,7 @@ static int main_serve(int argc, char **argv) {
         if (!getcwd(here, sizeof(here))) here[0] = 0;
         if (cwd[0] && chdir(cwd)) snprintf(msg, sizeof(msg), "pgx_cli serve: cannot enter %s\n", cwd), status = 1;
         else {
-          optind = 1; /* (glibc: restart getopt) */
+          optind = 0; /* (glibc: 0 re-initialises getopt completely, also after a scan that stopped inside a clustered option) */
           if (!strcmp(tool, "shmr_index")) status = run_index_args(ac, fld + 5, db, prefix, msg, sizeof(msg));
           else if (!strcmp(tool, "shmr_overlap")) status = run_overlap_args(ac, fld + 5, db, prefix, msg, sizeof(msg));
           if (here[0] && chdir(here)) status = status ? status : 1;

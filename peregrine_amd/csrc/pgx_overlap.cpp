@@ -27,6 +27,9 @@
 #include <unistd.h>
 #include <sys/stat.h>
 
+#include <limits.h>
+#include <unistd.h>
+
 #include "pgx_internal.h"
 #include "pgx_khash.h"
 
@@ -1602,29 +1605,39 @@ struct DeviceLists {
   const pgx_mm128 *d_top = nullptr;
   const pgx_mm_count *d_mc = nullptr;
 };
-void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
-                 const pgx_overlap_params *p, OvOut &out, pgx_overlap_stats *st, const DeviceLists *dev = nullptr,
-                 const pgx_pair_rec *d_recs = nullptr, size_t n_recs = 0) {
+// The FRONT of an overlap stage: count table, join, visit order -- everything up to the greedy walk.  It reads only the lists and the
+// parameters, so the front of chunk c + 1 can run (on a second stream, from a second host thread) while chunk c is in its walk: its kernels
+// fill the GPU when the walk's launches leave it idle (the sweeps after the main alignment are chains of small dependent launches), and its
+// one sequential host piece -- the outer khash table -- no longer stops the GPU (pgx_overlap_prefetch_dev, below).
+struct Scratch {   // the big host tables of a stage: torn down on the housekeeping thread once the results are out
+  PairTables pt;
+  Visit visit;
+  PreOuter pre;   // (its destructor joins the thread)
+};
+struct StageFront {
+  Scratch *scratch = nullptr;
+  DevicePairs dpairs;
+  DevBuf<uint32_t> d_bids;
+  bool placed = false, gpu_replay = false;
   pgx_overlap_stats s;
-  memset(&s, 0, sizeof(s));
-  const double t0 = now_ms();
-  double gpu_ms = 0;
-  dev_cache_age();
-  MemTag mem_tag("overlap.join");
-  // the big host tables of this call are torn down on the housekeeping thread once the results are out
-  struct Scratch {
-    PairTables pt;
-    Visit visit;
-    PreOuter pre;   // (its destructor joins the thread)
-  };
-  Scratch *scratch = new Scratch;
-  struct Defer {
-    Scratch *s;
-    ~Defer() {
-      Scratch *z = s;
+  double gpu_ms = 0, t0 = 0, t1 = 0;
+  StageFront() { memset(&s, 0, sizeof(s)); }
+  StageFront(const StageFront &) = delete;
+  StageFront &operator=(const StageFront &) = delete;
+  ~StageFront() {
+    if (scratch) {
+      Scratch *z = scratch;
       defer_destroy([z] { delete z; });
     }
-  } defer_scratch{scratch};
+  }
+};
+void overlap_front(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
+                   const pgx_overlap_params *p, const DeviceLists *dev, const pgx_pair_rec *d_recs, size_t n_recs, StageFront &f) {
+  pgx_overlap_stats &s = f.s;
+  const double t0 = f.t0 = now_ms();
+  double &gpu_ms = f.gpu_ms;
+  MemTag mem_tag("overlap.join");
+  Scratch *scratch = f.scratch = new Scratch;
   PairTables &pt = scratch->pt;
   // The greedy walk itself runs on the GPU (pgx_replay.hip) from 0.2 M pair records on, where it is as fast as or faster than
   // the multi-threaded host replay below and does not lean on the host cores, which the ranks of a multi-GPU job share
@@ -1634,17 +1647,17 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   // fallback for jobs the device tables' encodings do not hold.
   const int gpu_replay_env = getenv("PGX_GPU_REPLAY") ? atoi(getenv("PGX_GPU_REPLAY")) : -1;
   static const size_t gpu_replay_min = 200000;   // pair records from which the device replay wins (tools/crossover.py)
-  bool gpu_replay = gpu_replay_env != 0;  // (decided once the join has counted the records)
+  bool &gpu_replay = f.gpu_replay;
+  gpu_replay = gpu_replay_env != 0;  // (decided once the join has counted the records)
   const bool trace = getenv("PGX_TRACE") != nullptr;
-  const bool predict = true;   // the type of a pending alignment is guessed from the geometry (predict_contained)
-  DevicePairs dpairs;
+  DevicePairs &dpairs = f.dpairs;
   static const bool early_outer = true;   // the outer khash table is replayed by a host thread DURING the join
   // the visit order on the device (pgx_visit.hip): the join's tables stay in HBM, the inner khash tables are replayed there, the
   // host only replays the outer one.  PGX_DEV_VISIT=0: the round-2 form (tables downloaded, inner tables by host threads).
   const bool dev_visit = gpu_replay && early_outer && !(getenv("PGX_DEV_VISIT") && atoi(getenv("PGX_DEV_VISIT")) == 0);
   const unsigned jflags = PAIRS_ORD_TABLES | (gpu_replay ? PAIRS_LAZY_RECORDS : 0u) | (dev_visit ? PAIRS_DEV_TABLES : 0u);
   EarlyFn early;
-  if (early_outer) early = [&](EarlyGroups &&g) { scratch->pre.start(std::move(g), pt.n_rec); };
+  if (early_outer) early = [scratch, &pt](EarlyGroups &&g) { scratch->pre.start(std::move(g), pt.n_rec); };
   if (d_recs)
     dev_pairs_from_records(d_recs, n_recs, pt, gpu_replay ? &dpairs : nullptr, jflags, early);
   else
@@ -1660,14 +1673,14 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     pairs_fetch_records(dpairs, pt);   // (kept on the device in case the device replay ran: the host replay reads them)
     dpairs = DevicePairs();
   }
-  const double t1 = now_ms();
+  const double t1 = f.t1 = now_ms();
   gpu_ms += t1 - t0;
-  NodePin pin;  // from here on the caller and its helper threads stay on one memory node
+  NodePin pin;  // from here on this thread and its helper threads stay on one memory node
   Visit &visit = scratch->visit;
   if (trace) fprintf(stderr, "[pgx]   pinned to a memory node at +%.2f ms after the join\n", now_ms() - t1);
   if (gpu_replay && dpairs.valid) {
-    DevBuf<uint32_t> d_bids;
-    bool placed = false;
+    DevBuf<uint32_t> &d_bids = f.d_bids;
+    bool &placed = f.placed;
     if (dpairs.tables) {
       PreOuter &pre = scratch->pre;
       const uint32_t wave_max = getenv("PGX_VISIT_WAVE_MAX") ? (uint32_t)std::min<long>(atol(getenv("PGX_VISIT_WAVE_MAX")), VISIT_WAVE_MAX) : VISIT_WAVE_MAX;   // (tests: force the fall-back)
@@ -1710,13 +1723,46 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
       fprintf(stderr, "[pgx]   bucket sizes: median %u, 90 %% %u, 99 %% %u, 99.9 %% %u, max %u\n", sz[sz.size() / 2], sz[sz.size() * 9 / 10],
               sz[sz.size() * 99 / 100], sz[sz.size() * 999 / 1000], sz.back());
     }
+    if (visit.on_device && !placed)
+      dev_place_bids(visit.ids_all.data(), visit.ids_all.size(), visit.psrc.data(), visit.pcnt.data(), visit.pdst.data(), visit.n_groups,
+                     visit.n_buckets, d_bids);
+    pgx::sync();   // (everything the walk reads is in place: the front may have run on another stream)
+  }
+}
+
+bool take_prefetched_front(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
+                           const pgx_overlap_params *p, const DeviceLists *dev, const pgx_pair_rec *d_recs, StageFront &f);
+
+void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
+                 const pgx_overlap_params *p, OvOut &out, pgx_overlap_stats *st, const DeviceLists *dev = nullptr,
+                 const pgx_pair_rec *d_recs = nullptr, size_t n_recs = 0) {
+  const double t_call = now_ms();
+  StageFront front;
+  const bool prefetched = take_prefetched_front(db, mmers, n_mm, counts, n_counts, p, dev, d_recs, front);
+  dev_cache_age();
+  if (!prefetched) overlap_front(db, mmers, n_mm, counts, n_counts, p, dev, d_recs, n_recs, front);
+  struct KickAtExit {   // a registered prefetch that the walk did not start (host replay, tiny sets) starts when this stage is over
+    ~KickAtExit() { prefetch_kick_if_pending(); }
+  } kick_at_exit;
+  pgx_overlap_stats s = front.s;
+  s.prefetched_front = prefetched ? 1u : 0u;
+  const double t0 = prefetched ? t_call : front.t0, t1 = prefetched ? t_call : front.t1;
+  double gpu_ms = prefetched ? 0.0 : front.gpu_ms;
+  MemTag mem_tag("overlap.join");
+  Scratch *scratch = front.scratch;
+  PairTables &pt = scratch->pt;
+  bool gpu_replay = front.gpu_replay;
+  const bool trace = getenv("PGX_TRACE") != nullptr;
+  const bool predict = true;   // the type of a pending alignment is guessed from the geometry (predict_contained)
+  DevicePairs &dpairs = front.dpairs;
+  NodePin pin;  // from here on the caller and its helper threads stay on one memory node
+  Visit &visit = scratch->visit;
+  if (gpu_replay && dpairs.valid) {
+    DevBuf<uint32_t> &d_bids = front.d_bids;
     const double r0 = now_ms();
     size_t nrec = 0;
     pgx_overlap_stats rs;
     memset(&rs, 0, sizeof(rs));
-    if (visit.on_device && !placed)
-      dev_place_bids(visit.ids_all.data(), visit.ids_all.size(), visit.psrc.data(), visit.pcnt.data(), visit.pdst.data(), visit.n_groups,
-                     visit.n_buckets, d_bids);
     if (dev_replay(db, dpairs, visit.on_device ? nullptr : visit.bids.data(), visit.on_device ? d_bids.p : nullptr, visit.n_buckets,
                    visit.n_entries, (uint32_t)(uint8_t)p->bestn,
                    p->align_bandwidth, predict, (uint32_t)p->ovlp_upper,
@@ -1872,6 +1918,139 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   if (st) *st = s;
 }
 
+// ---- the front of the NEXT stage, ahead of time (pgx_overlap_prefetch_dev) -------------------------------------------------------
+// One worker thread with its own stream and its own Context (ctx() is per thread).  A request names the lists and parameters of the stage the
+// caller will ask for next; it is STARTED by the running stage at the moment its main alignment launch is enqueued (prefetch_mark /
+// prefetch_kick from pgx_replay.hip) -- the front's kernels then fill the GPU as that launch drains and through the walk's small sweeps -- or,
+// if no walk does, when the running stage ends.  The next stage takes the result if its arguments are the same, else runs its own front.
+// Device blocks change streams through the block cache: a block carries the event of its release (dev_release) and a user on another
+// stream waits for it on the device (dev_alloc), which is how the front's buffers reach the walk.
+namespace {
+struct PrefetchKey {
+  const void *db = nullptr, *mm = nullptr, *mc = nullptr;
+  size_t n_mm = 0, n_mc = 0;
+  pgx_overlap_params p;
+  bool operator==(const PrefetchKey &o) const {
+    return db == o.db && mm == o.mm && mc == o.mc && n_mm == o.n_mm && n_mc == o.n_mc && memcmp(&p, &o.p, sizeof(p)) == 0;
+  }
+};
+struct Prefetcher {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::thread th;
+  bool stop = false;
+  // a request waits in `req` until the running stage starts it (kick); the worker leaves its result in `ready`; the caller may register the
+  // request for stage c + 2 before it asks for stage c + 1, whose front is in `ready` by then
+  bool req_valid = false, running = false, ready_valid = false, ready_ok = false;
+  PrefetchKey req, run_key, ready_key;
+  std::unique_ptr<StageFront> ready;
+  Context wctx;
+  hipEvent_t mark = nullptr;   // recorded on the caller's stream when it starts a front: the worker's stream starts behind it
+  bool marked = false;
+  void loop() {
+    (void)hipSetDevice(ctx().device);   // (ctx(): still the process-wide context here)
+    wctx = ctx();
+    if (hipStreamCreateWithFlags(&wctx.stream, hipStreamNonBlocking) != hipSuccess) wctx.stream = nullptr;
+    set_thread_context(&wctx);
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [&] { return stop || running; });
+      if (stop) break;
+      std::unique_ptr<StageFront> f(new StageFront);
+      const PrefetchKey k = run_key;
+      lk.unlock();
+      bool ok = wctx.stream != nullptr;
+      try {
+        if (ok) PGX_HIP(hipStreamWaitEvent(wctx.stream, mark, 0));
+        const DeviceLists lists{(const pgx_mm128 *)k.mm, (const pgx_mm_count *)k.mc};
+        if (ok) overlap_front((pgx_seqdb *)const_cast<void *>(k.db), nullptr, k.n_mm, nullptr, k.n_mc, &k.p, &lists, nullptr, 0, *f);
+      } catch (...) {
+        ok = false;
+      }
+      timing_flush();
+      lk.lock();
+      ready = std::move(f), ready_key = k, ready_ok = ok, ready_valid = true;
+      running = false;
+      cv.notify_all();
+    }
+    set_thread_context(nullptr);
+    if (wctx.stream) (void)hipStreamDestroy(wctx.stream);
+  }
+  void shutdown() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+      cv.notify_all();
+    }
+    if (th.joinable()) th.join();
+    ready.reset();
+    if (mark) (void)hipEventDestroy(mark), mark = nullptr;
+    stop = req_valid = running = ready_valid = ready_ok = marked = false;
+  }
+};
+Prefetcher &prefetcher() {
+  static Prefetcher p;
+  return p;
+}
+ShutdownHook g_prefetch_reset([] { prefetcher().shutdown(); });
+}  // namespace
+}  // namespace (file-local part; the three entry points below are called from pgx_replay.hip and the C-ABI)
+
+namespace pgx {
+void prefetch_request(pgx_seqdb *db, const pgx_mm128 *d_mm, size_t n_mm, const pgx_mm_count *d_mc, size_t n_mc, const pgx_overlap_params *p) {
+  Prefetcher &pf = prefetcher();
+  std::lock_guard<std::mutex> lk(pf.mu);
+  pf.req.db = db, pf.req.mm = d_mm, pf.req.mc = d_mc, pf.req.n_mm = n_mm, pf.req.n_mc = n_mc, pf.req.p = *p;
+  pf.req_valid = true;
+  if (!pf.th.joinable()) {
+    dev_cache_multi_stream(true);
+    pf.th = std::thread([&pf] { pf.loop(); });
+  }
+}
+static bool record_mark(Prefetcher &pf) {   // (pf.mu held, on the caller's thread)
+  if (!pf.mark && hipEventCreateWithFlags(&pf.mark, hipEventDisableTiming) != hipSuccess) return false;
+  return hipEventRecord(pf.mark, ctx().stream) == hipSuccess;
+}
+void prefetch_mark() {   // just BEFORE the caller's main alignment launch: the front starts behind what is enqueued up to here, i.e. beside that launch
+  Prefetcher &pf = prefetcher();
+  std::lock_guard<std::mutex> lk(pf.mu);
+  if (!pf.req_valid || pf.running || !pf.th.joinable()) return;
+  pf.marked = record_mark(pf);
+}
+void prefetch_kick_if_pending() {
+  Prefetcher &pf = prefetcher();
+  std::lock_guard<std::mutex> lk(pf.mu);
+  if (!pf.req_valid || pf.running || !pf.th.joinable()) return;
+  if (!pf.marked && !record_mark(pf)) return;
+  pf.marked = false;
+  pf.ready.reset(), pf.ready_valid = false;   // (a front nobody asked for any more)
+  pf.run_key = pf.req, pf.req_valid = false, pf.running = true;
+  pf.cv.notify_all();
+}
+}  // namespace pgx
+namespace {
+bool take_prefetched_front(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
+                           const pgx_overlap_params *p, const DeviceLists *dev, const pgx_pair_rec *d_recs, StageFront &f) {
+  Prefetcher &pf = prefetcher();
+  if (!pf.th.joinable()) return false;
+  std::unique_lock<std::mutex> lk(pf.mu);
+  PrefetchKey k;
+  k.db = db, k.mm = dev ? dev->d_top : nullptr, k.mc = dev ? dev->d_mc : nullptr, k.n_mm = n_mm, k.n_mc = n_counts, k.p = *p;
+  const bool eligible = dev && !d_recs && !mmers && !counts;
+  pf.cv.wait(lk, [&] { return !pf.running; });   // (a front in flight finishes first: it is this stage's, or it uses the one join state)
+  if (pf.req_valid && eligible && k == pf.req) pf.req_valid = false;   // registered but never started: this stage does its own front
+  if (!pf.ready_valid) return false;
+  std::unique_ptr<StageFront> r = std::move(pf.ready);
+  const bool ok = pf.ready_ok && eligible && k == pf.ready_key && r && r->scratch;
+  pf.ready_valid = false;
+  lk.unlock();
+  if (!ok) return false;   // (r's buffers go back to the cache)
+  f.scratch = r->scratch, r->scratch = nullptr;
+  f.dpairs = std::move(r->dpairs), f.d_bids = std::move(r->d_bids);
+  f.placed = r->placed, f.gpu_replay = r->gpu_replay, f.s = r->s, f.gpu_ms = r->gpu_ms, f.t0 = r->t0, f.t1 = r->t1;
+  return true;
+}
+
 template <typename T>
 void read_counted_files(const std::string &pattern, std::vector<T> &out) {
   glob_t g;
@@ -2018,6 +2197,23 @@ int pgx_overlap_resident_dev(pgx_seqdb *db, const pgx_mm128 *d_mmers, size_t n_m
   return PGX_OK;
 }
 
+int pgx_overlap_prefetch_dev(pgx_seqdb *db, const pgx_mm128 *d_mmers, size_t n_mm, const pgx_mm_count *d_counts, size_t n_counts,
+                             const pgx_overlap_params *p) {
+  try {
+    require_ready();
+    PGX_REQUIRE(db && d_mmers && n_mm && (n_counts == 0 || d_counts), PGX_EARG, "pgx_overlap_prefetch_dev: null argument");
+    check_params(p);
+    static const bool off = getenv("PGX_PREFETCH") && atoi(getenv("PGX_PREFETCH")) == 0;
+    if (!off) prefetch_request(db, d_mmers, n_mm, d_counts, n_counts, p);
+  } catch (const Fail &f) {
+    return f.code;
+  } catch (const std::bad_alloc &) {
+    set_error("out of host memory");
+    return PGX_ENOMEM;
+  }
+  return PGX_OK;
+}
+
 int pgx_pairs_prepare_dev(pgx_seqdb *db, const pgx_mm128 *d_top, size_t n_top, const pgx_mm_count *d_counts_all,
                           size_t n_counts_all, int mc_lower, int mc_upper, int64_t *first_strict) {
   try {
@@ -2154,14 +2350,27 @@ int pgx_overlap_chunk_db(pgx_seqdb *db, const char *shimmer_prefix, const char *
     const bool trace = getenv("PGX_TRACE") != nullptr;
     const double t0 = now_ms();
     static ListCache cache;
+    // identity = the ABSOLUTE prefix (the server enters each client's directory: two jobs with the same relative prefix are different
+    // files) + every file's name, size and mtime, taken before AND after the read (a file rewritten in between is not cached)
+    std::string abs_prefix = shimmer_prefix;
+    if (!abs_prefix.empty() && abs_prefix[0] != '/') {
+      char cwd[PATH_MAX];
+      if (getcwd(cwd, sizeof(cwd))) abs_prefix = std::string(cwd) + "/" + abs_prefix;
+    }
+    auto identity = [&](std::vector<std::pair<std::string, std::pair<long long, long long>>> &v) {
+      glob_identity(abs_prefix + "-[0-9]*-of-[0-9]*.dat", v);
+      glob_identity(abs_prefix + "-MC-[0-9]*-of-[0-9]*.dat", v);
+    };
     std::vector<std::pair<std::string, std::pair<long long, long long>>> ident;
-    glob_identity(std::string(shimmer_prefix) + "-[0-9]*-of-[0-9]*.dat", ident);
-    glob_identity(std::string(shimmer_prefix) + "-MC-[0-9]*-of-[0-9]*.dat", ident);
-    if (cache.prefix != shimmer_prefix || cache.files != ident || ident.empty()) {
+    identity(ident);
+    if (cache.prefix != abs_prefix || cache.files != ident || ident.empty()) {
       cache.prefix.clear();
       cache.mm.clear(), cache.mc.clear();
+      cache.mm.shrink_to_fit(), cache.mc.shrink_to_fit();   // (another prefix: the old lists' memory goes back first)
       read_index_files(shimmer_prefix, cache.mm, cache.mc);
-      cache.prefix = shimmer_prefix, cache.files = ident;
+      std::vector<std::pair<std::string, std::pair<long long, long long>>> after;
+      identity(after);
+      if (after == ident) cache.prefix = abs_prefix, cache.files = ident;
     }
     const double t1 = now_ms();
     OvOut v;

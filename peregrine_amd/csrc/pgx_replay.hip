@@ -2062,7 +2062,9 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     const size_t batch = nreq - first_req;
     if (sweeps == 1) first_batch = batch;
     r.tail = tail_max && batch <= std::max(tail_max, first_batch / 256) ? ahead : 0u;   // (the NEXT sweep's k_file)
+    if (sweeps == 1) prefetch_mark();   // a front registered for the next stage starts behind everything enqueued so far ...
     dev_align(db, r.rq_key + first_req, batch, band, r.rq_res + first_req, sweeps > 2 ? 2 : sweeps > 1 ? 1 : 0);
+    if (sweeps == 1) prefetch_kick_if_pending();   // ... i.e. beside the main alignment launch and the sweeps behind it
     r.settled = (uint32_t)nreq;
     first_req = nreq;
     {
@@ -2097,6 +2099,11 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     PGX_HIP(hipMemcpyAsync(&last_num, r.inum + nb - 1, 4, hipMemcpyDeviceToHost, s));
     sync();
     const size_t nrec = (size_t)last_off + last_num;
+    // (the table census for the next stage's sizes runs HERE, ahead of the record copy: a memory-bound kernel beside the copy's blit kernel
+    //  crawls -- 40 ms instead of 0.5 for these 2 GB, profiles/r05e_chunk_timeline_c4.txt)
+    DevBuf<unsigned long long> d_keys(1);
+    PGX_HIP(hipMemsetAsync(d_keys.p, 0, sizeof(unsigned long long), s));
+    hipLaunchKernelGGL(k_count_pairs, dim3((unsigned)std::min<size_t>(cdiv256(pcap), 4096)), dim3(256), 0, s, ph.p, pcap, d_keys.p);
     results_wait();   // (pgx_results_async: the previous stage's record copy -- long finished -- gives its device buffer back first)
     pgx_ovlp *host = alloc_out(nrec);
     DevBuf<pgx_ovlp> d_out;
@@ -2113,9 +2120,6 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
       if (nrec && results_async() && !timed_misc) results_copy_async(host, std::move(d_out), nrec);
       else if (nrec) PGX_HIP(hipMemcpyAsync(host, d_out.p, nrec * sizeof(pgx_ovlp), hipMemcpyDeviceToHost, s));
     }
-    DevBuf<unsigned long long> d_keys(1);
-    PGX_HIP(hipMemsetAsync(d_keys.p, 0, sizeof(unsigned long long), s));
-    hipLaunchKernelGGL(k_count_pairs, dim3((unsigned)std::min<size_t>(cdiv256(pcap), 4096)), dim3(256), 0, s, ph.p, pcap, d_keys.p);
     unsigned long long n_keys = 0;
     d_keys.download(&n_keys, 1);
     if (!read_counters(false)) goto overflowed;
