@@ -694,7 +694,7 @@ def main():
     log(f"input ready: {db.n_reads} reads, {db.n_bases} bases")
     eng = GpuEngine(rdb, home)
     ov_params = dict(mc_upper=sp["mc_upper"])
-    SUM_KEYS = ("n_records", "n_pair_records", "n_buckets", "n_align_needed", "n_align_gpu", "n_seen_skip", "n_evaluations", "gpu_ms", "host_ms", "device_visit", "prefetched_front")
+    SUM_KEYS = ("n_records", "n_pair_records", "n_buckets", "n_align_needed", "n_align_gpu", "n_seen_skip", "n_evaluations", "gpu_ms", "host_ms", "device_visit")
     keep_streams = {}
 
     held = {}   # N = 1, several chunks: the concatenated lists live in ONE pair of buffers kept across the steps (sizes repeat)
@@ -759,8 +759,6 @@ def main():
         prev = None                             # (the array of the chunk before: freeing it would wait for its copy)
         for ci, c in enumerate(my_chunks):
             tc0 = time.perf_counter()
-            if ci + 1 < len(my_chunks) and os.environ.get("PGX_BENCH_PREFETCH", "1") != "0":   # the next chunk's join + visit order, beside this chunk's walk
-                rdb.overlap_prefetch_dev(mm_all.data_ptr(), mm_all.numel() // 16, mc_all.data_ptr(), mc_all.numel() // 16, total_chunk=CH, mychunk=my_chunks[ci + 1], **ov_params)
             ov, st = rdb.overlap_dev(mm_all.data_ptr(), mm_all.numel() // 16, mc_all.data_ptr(), mc_all.numel() // 16, total_chunk=CH, mychunk=c, **ov_params)
             if os.environ.get("PGX_BENCH_CHUNK_TIMES"):
                 log("chunk %d: call %.1f ms (library: gpu %.1f + host %.1f), %d records, attempts %d" % (c, (time.perf_counter() - tc0) * 1e3, st["gpu_ms"], st["host_ms"], len(ov), st["replay_attempts"]))

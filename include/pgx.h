@@ -145,7 +145,7 @@ typedef struct {
                                 wavefront replayed (pgx_visit.hip; the others take a lane each) */
   uint32_t replay_attempts;  /* device replay: attempts until the tables were large enough (1: the first sizes held; the sizes a
                                 stage needed are where the next stage of the process starts) */
-  uint32_t prefetched_front; /* 1: the join and the visit order of this stage were computed ahead of time (pgx_overlap_prefetch_dev) */
+  uint32_t reserved0;
   uint64_t stream_checksum;  /* order-sensitive 64-bit checksum of the records' fields (padding bytes excluded), computed where the
                                 records are written: two stages with equal checksums produced the same stream (0: not computed) */
 } pgx_overlap_stats;
@@ -188,14 +188,6 @@ int pgx_overlap_records_dev(pgx_seqdb *db, const pgx_pair_rec *d_records, size_t
 int pgx_overlap_resident_dev(pgx_seqdb *db, const pgx_mm128 *d_mmers, size_t n_mm, const pgx_mm_count *d_counts,
                              size_t n_counts, const pgx_overlap_params *p, pgx_ovlp **out, size_t *n_out,
                              pgx_overlap_stats *stats);
-/* A hint for resident pipelines that run several overlap stages one after the other: the NEXT call of pgx_overlap_resident_dev will be made
- * with exactly these arguments.  The library then computes that stage's front -- count table, join, khash visit order: everything before
- * the greedy walk, which only reads the lists -- on a second stream and host thread while the CURRENT stage is in its walk (started when that
- * stage's main alignment launch is enqueued; the front's kernels fill the GPU during the walk's small dependent launches, and its one
- * sequential host piece, the outer khash table, stops nothing).  The lists must stay valid and unchanged until that next call.  Results are
- * those of the plain call; a next call with other arguments simply ignores what was prepared.  Returns at once. */
-int pgx_overlap_prefetch_dev(pgx_seqdb *db, const pgx_mm128 *d_mmers, size_t n_mm, const pgx_mm_count *d_counts, size_t n_counts,
-                             const pgx_overlap_params *p);
 /* Ordering against another runtime's stream (e.g. the stream torch / RCCL enqueued a collective on) without stopping the host:
  *   pgx_stream_wait(s)   : work the library enqueues from now on starts after everything enqueued on s so far
  *   pgx_stream_signal(s) : work enqueued on s from now on starts after everything the library has enqueued so far

@@ -56,7 +56,7 @@ class OverlapStats(C.Structure):
                 ("n_align_needed", C.c_uint64), ("n_align_gpu", C.c_uint64), ("n_seen_skip", C.c_uint64),
                 ("rounds", C.c_uint32), ("gpu_ms", C.c_double), ("host_ms", C.c_double),
                 ("n_evaluations", C.c_uint64), ("device_replay", C.c_uint32), ("device_visit", C.c_uint32),
-                ("replay_attempts", C.c_uint32), ("prefetched_front", C.c_uint32), ("stream_checksum", C.c_uint64)]
+                ("replay_attempts", C.c_uint32), ("reserved0", C.c_uint32), ("stream_checksum", C.c_uint64)]
 
     def asdict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -73,7 +73,7 @@ EXPORTS = [
     "decode_biseq", "encode_biseq", "mm_sketch", "mm_reduce", "ovlp_match", "free_ovlp_match", "read_mmlist", "write_mmlist",
     "pgx_map", "pgx_map_chunk", "pgx_khash_slot_order", "pgx_khash_slot_order_ex",
     "pgx_seqdb_upload_dev", "pgx_index_resident_dev", "pgx_pairs_prepare_dev", "pgx_pairs_scatter_dev", "pgx_overlap_records_dev",
-    "pgx_overlap_resident_dev", "pgx_overlap_prefetch_dev", "pgx_copy_dev", "pgx_seqdb_adopt_dev", "pgx_stream_wait", "pgx_stream_signal",
+    "pgx_overlap_resident_dev", "pgx_copy_dev", "pgx_seqdb_adopt_dev", "pgx_stream_wait", "pgx_stream_signal",
     "build_shimmer_map4py", "get_shimmers_for_read", "get_mmer_count", "get_shimmer_hits", "pgx_shimmer_map_free",
 ]
 

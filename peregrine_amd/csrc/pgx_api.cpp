@@ -28,12 +28,10 @@ void set_error(const char *fmt, ...) {
   g_err = buf;
 }
 
-static thread_local Context *tl_ctx = nullptr;
 Context &ctx() {
   static Context c;
-  return tl_ctx ? *tl_ctx : c;
+  return c;
 }
-void set_thread_context(Context *c) { tl_ctx = c; }
 void require_ready() { PGX_REQUIRE(ctx().ready, PGX_ESTATE, "pgx_init() has not been called (or failed)"); }
 
 // ---- large host arrays -------------------------------------------------------------------------------------
@@ -337,15 +335,7 @@ static std::mutex g_dev_mu;
 struct FreeBlock {
   void *p;
   uint64_t age;
-  hipStream_t stream;   // the stream of the thread that released it (its last user)
-  hipEvent_t ev;        // multi-stream mode: recorded on that stream at release; a user on ANOTHER stream waits for it
 };
-static bool g_multi_stream = false;
-static std::vector<hipEvent_t> g_ev_pool;
-void dev_cache_multi_stream(bool on) {
-  std::lock_guard<std::mutex> lk(g_dev_mu);
-  g_multi_stream = on;
-}
 static std::multimap<size_t, FreeBlock> g_dev_free;  // size class -> cached blocks
 struct LiveBlock {
   size_t cls;
@@ -369,10 +359,7 @@ static size_t size_class(size_t bytes) {           // powers of two up to 1 MiB,
   return (bytes + step - 1) / step * step;
 }
 static void drop_all_free_locked() {
-  for (auto &kv : g_dev_free) {
-    if (kv.second.ev) (void)hipEventSynchronize(kv.second.ev), g_ev_pool.push_back(kv.second.ev);
-    (void)hipFree(kv.second.p);
-  }
+  for (auto &kv : g_dev_free) (void)hipFree(kv.second.p);
   g_dev_free.clear();
   g_free_bytes = 0;
 }
@@ -383,22 +370,9 @@ void *dev_alloc(size_t bytes) {
   void *p = nullptr;
   size_t got = c;
   if (it != g_dev_free.end() && it->first <= c + (c >> 3)) {
-    // (prefer a block this stream released itself: among the candidates of the class, the first one with the same stream)
-    hipStream_t me = ctx().stream;
-    auto pick = it;
-    for (auto j = it; j != g_dev_free.end() && j->first == it->first; ++j)
-      if (j->second.stream == me) {
-        pick = j;
-        break;
-      }
-    const FreeBlock fb = pick->second;
-    p = fb.p, got = pick->first;
-    g_dev_free.erase(pick);
+    p = it->second.p, got = it->first;
+    g_dev_free.erase(it);
     g_free_bytes -= got;
-    if (fb.ev) {
-      if (fb.stream != me) (void)hipStreamWaitEvent(me, fb.ev, 0);   // its last user's work, on the device, before ours
-      g_ev_pool.push_back(fb.ev);
-    }
   } else {
     hipError_t e = hipMalloc(&p, c);
     if (e != hipSuccess) {  // make room: give the cached blocks back and retry once
@@ -416,13 +390,7 @@ void dev_release(void *p) {
   std::lock_guard<std::mutex> lk(g_dev_mu);
   auto it = g_dev_live.find(p);
   if (it == g_dev_live.end()) return;
-  FreeBlock fb{p, g_dev_age, ctx().stream, nullptr};
-  if (g_multi_stream && ctx().ready) {
-    if (!g_ev_pool.empty()) fb.ev = g_ev_pool.back(), g_ev_pool.pop_back();
-    else if (hipEventCreateWithFlags(&fb.ev, hipEventDisableTiming) != hipSuccess) fb.ev = nullptr;
-    if (fb.ev && hipEventRecord(fb.ev, fb.stream) != hipSuccess) g_ev_pool.push_back(fb.ev), fb.ev = nullptr;
-  }
-  g_dev_free.emplace(it->second.cls, fb);
+  g_dev_free.emplace(it->second.cls, FreeBlock{p, g_dev_age});
   g_live_bytes -= it->second.cls, g_free_bytes += it->second.cls, g_by_tag[it->second.tag] -= it->second.cls;
   g_dev_live.erase(it);
 }
@@ -439,7 +407,6 @@ void dev_cache_age() {
   ++g_dev_age;
   for (auto it = g_dev_free.begin(); it != g_dev_free.end();) {
     if (it->first >= ((size_t)64 << 20) && it->second.age + 2 < g_dev_age) {
-      if (it->second.ev) (void)hipEventSynchronize(it->second.ev), g_ev_pool.push_back(it->second.ev);
       (void)hipFree(it->second.p);
       g_free_bytes -= it->first;
       it = g_dev_free.erase(it);
@@ -490,7 +457,7 @@ struct Pending {
 };
 static std::map<std::string, TimeAcc> g_time;
 static std::vector<Pending> g_pending;
-static std::mutex g_time_mu;   // (the prefetch worker times its kernels too)
+static std::mutex g_time_mu;   // (timers are also closed on the housekeeping thread)
 
 KernelTimer::KernelTimer(const char *nm, uint64_t u) : name(nm), units(u) {
   (void)hipEventCreate(&e0);

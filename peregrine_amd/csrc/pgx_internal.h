@@ -55,8 +55,7 @@ struct Context {
   bool ready = false;
   int num_cu = 256;
 };
-Context &ctx();                          // this thread's context: the process-wide one unless set_thread_context gave it another
-void set_thread_context(Context *c);     // (the prefetch worker: same device, its own stream; nullptr: back to the process-wide context)
+Context &ctx();
 void require_ready();
 // Device state that outlives a call (plan caches, buffers handed out as library-owned views) registers a reset function:
 // pgx_shutdown() runs them all BEFORE it returns the cached blocks to the driver, so nothing survives into the next pgx_init()
@@ -78,8 +77,6 @@ bool index_owns(const void *p);     // p points into memory an index-stage call 
 void *dev_alloc(size_t bytes);
 void dev_release(void *p);
 void dev_cache_trim();
-void dev_cache_multi_stream(bool on);   // from now on a released block carries an event of the releasing thread's stream, and a user on
-                                        // another stream waits for it on the device (two streams allocate: the prefetched front)
 size_t dev_cache_free_bytes();   // what the cache holds for re-use (the driver counts it as used)
 void dev_cache_age();   // a stage starts: cached blocks of 64 MiB and more that two whole stages did not ask for go back to the driver
 // device blocks allocated while a MemTag is in scope (on this thread) are booked under its name in the ledger (pgx_mem_ledger)
@@ -412,12 +409,6 @@ __host__ __device__ inline uint64_t record_checksum(const pgx_ovlp &o, uint64_t 
   h = checksum_mix(h ^ ((uint64_t)(uint32_t)o.match.t_m_end | (uint64_t)(uint32_t)o.match.q_m_end << 32));
   return h;
 }
-
-// the front of the next overlap stage ahead of time (pgx_overlap.cpp: Prefetcher).  mark / kick are called by the running stage's walk around
-// its main alignment launch.
-void prefetch_request(pgx_seqdb *db, const pgx_mm128 *d_mm, size_t n_mm, const pgx_mm_count *d_mc, size_t n_mc, const pgx_overlap_params *p);
-void prefetch_mark();
-void prefetch_kick_if_pending();
 
 // Runs fn on the library's housekeeping thread: tearing down GB-sized host tables (munmap, free) takes tens of
 // milliseconds that the caller does not have to wait for.  At most a few jobs are queued; beyond that fn runs inline.

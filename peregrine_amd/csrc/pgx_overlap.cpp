@@ -1605,10 +1605,10 @@ struct DeviceLists {
   const pgx_mm128 *d_top = nullptr;
   const pgx_mm_count *d_mc = nullptr;
 };
-// The FRONT of an overlap stage: count table, join, visit order -- everything up to the greedy walk.  It reads only the lists and the
-// parameters, so the front of chunk c + 1 can run (on a second stream, from a second host thread) while chunk c is in its walk: its kernels
-// fill the GPU when the walk's launches leave it idle (the sweeps after the main alignment are chains of small dependent launches), and its
-// one sequential host piece -- the outer khash table -- no longer stops the GPU (pgx_overlap_prefetch_dev, below).
+// The FRONT of an overlap stage: count table, join, visit order -- everything up to the greedy walk; it reads only the lists and the
+// parameters.  (Round 5 ran the front of chunk c + 1 on a second stream and host thread beside chunk c's walk -- pgx_overlap_prefetch_dev,
+// commit 503bb51: bit-exact, and 7.12 s per c4 step against 7.06 without: the walk's small launches and the front's sorts
+// time-share the GPU, only the 18 ms wait for the host's outer table was there to win.  Removed again; HISTORY.md "Round 5".)
 struct Scratch {   // the big host tables of a stage: torn down on the housekeeping thread once the results are out
   PairTables pt;
   Visit visit;
@@ -1726,28 +1726,18 @@ void overlap_front(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx
     if (visit.on_device && !placed)
       dev_place_bids(visit.ids_all.data(), visit.ids_all.size(), visit.psrc.data(), visit.pcnt.data(), visit.pdst.data(), visit.n_groups,
                      visit.n_buckets, d_bids);
-    pgx::sync();   // (everything the walk reads is in place: the front may have run on another stream)
   }
 }
-
-bool take_prefetched_front(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
-                           const pgx_overlap_params *p, const DeviceLists *dev, const pgx_pair_rec *d_recs, StageFront &f);
 
 void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
                  const pgx_overlap_params *p, OvOut &out, pgx_overlap_stats *st, const DeviceLists *dev = nullptr,
                  const pgx_pair_rec *d_recs = nullptr, size_t n_recs = 0) {
-  const double t_call = now_ms();
   StageFront front;
-  const bool prefetched = take_prefetched_front(db, mmers, n_mm, counts, n_counts, p, dev, d_recs, front);
   dev_cache_age();
-  if (!prefetched) overlap_front(db, mmers, n_mm, counts, n_counts, p, dev, d_recs, n_recs, front);
-  struct KickAtExit {   // a registered prefetch that the walk did not start (host replay, tiny sets) starts when this stage is over
-    ~KickAtExit() { prefetch_kick_if_pending(); }
-  } kick_at_exit;
+  overlap_front(db, mmers, n_mm, counts, n_counts, p, dev, d_recs, n_recs, front);
   pgx_overlap_stats s = front.s;
-  s.prefetched_front = prefetched ? 1u : 0u;
-  const double t0 = prefetched ? t_call : front.t0, t1 = prefetched ? t_call : front.t1;
-  double gpu_ms = prefetched ? 0.0 : front.gpu_ms;
+  const double t0 = front.t0, t1 = front.t1;
+  double gpu_ms = front.gpu_ms;
   MemTag mem_tag("overlap.join");
   Scratch *scratch = front.scratch;
   PairTables &pt = scratch->pt;
@@ -1918,139 +1908,6 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   if (st) *st = s;
 }
 
-// ---- the front of the NEXT stage, ahead of time (pgx_overlap_prefetch_dev) -------------------------------------------------------
-// One worker thread with its own stream and its own Context (ctx() is per thread).  A request names the lists and parameters of the stage the
-// caller will ask for next; it is STARTED by the running stage at the moment its main alignment launch is enqueued (prefetch_mark /
-// prefetch_kick from pgx_replay.hip) -- the front's kernels then fill the GPU as that launch drains and through the walk's small sweeps -- or,
-// if no walk does, when the running stage ends.  The next stage takes the result if its arguments are the same, else runs its own front.
-// Device blocks change streams through the block cache: a block carries the event of its release (dev_release) and a user on another
-// stream waits for it on the device (dev_alloc), which is how the front's buffers reach the walk.
-namespace {
-struct PrefetchKey {
-  const void *db = nullptr, *mm = nullptr, *mc = nullptr;
-  size_t n_mm = 0, n_mc = 0;
-  pgx_overlap_params p;
-  bool operator==(const PrefetchKey &o) const {
-    return db == o.db && mm == o.mm && mc == o.mc && n_mm == o.n_mm && n_mc == o.n_mc && memcmp(&p, &o.p, sizeof(p)) == 0;
-  }
-};
-struct Prefetcher {
-  std::mutex mu;
-  std::condition_variable cv;
-  std::thread th;
-  bool stop = false;
-  // a request waits in `req` until the running stage starts it (kick); the worker leaves its result in `ready`; the caller may register the
-  // request for stage c + 2 before it asks for stage c + 1, whose front is in `ready` by then
-  bool req_valid = false, running = false, ready_valid = false, ready_ok = false;
-  PrefetchKey req, run_key, ready_key;
-  std::unique_ptr<StageFront> ready;
-  Context wctx;
-  hipEvent_t mark = nullptr;   // recorded on the caller's stream when it starts a front: the worker's stream starts behind it
-  bool marked = false;
-  void loop() {
-    (void)hipSetDevice(ctx().device);   // (ctx(): still the process-wide context here)
-    wctx = ctx();
-    if (hipStreamCreateWithFlags(&wctx.stream, hipStreamNonBlocking) != hipSuccess) wctx.stream = nullptr;
-    set_thread_context(&wctx);
-    std::unique_lock<std::mutex> lk(mu);
-    for (;;) {
-      cv.wait(lk, [&] { return stop || running; });
-      if (stop) break;
-      std::unique_ptr<StageFront> f(new StageFront);
-      const PrefetchKey k = run_key;
-      lk.unlock();
-      bool ok = wctx.stream != nullptr;
-      try {
-        if (ok) PGX_HIP(hipStreamWaitEvent(wctx.stream, mark, 0));
-        const DeviceLists lists{(const pgx_mm128 *)k.mm, (const pgx_mm_count *)k.mc};
-        if (ok) overlap_front((pgx_seqdb *)const_cast<void *>(k.db), nullptr, k.n_mm, nullptr, k.n_mc, &k.p, &lists, nullptr, 0, *f);
-      } catch (...) {
-        ok = false;
-      }
-      timing_flush();
-      lk.lock();
-      ready = std::move(f), ready_key = k, ready_ok = ok, ready_valid = true;
-      running = false;
-      cv.notify_all();
-    }
-    set_thread_context(nullptr);
-    if (wctx.stream) (void)hipStreamDestroy(wctx.stream);
-  }
-  void shutdown() {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      stop = true;
-      cv.notify_all();
-    }
-    if (th.joinable()) th.join();
-    ready.reset();
-    if (mark) (void)hipEventDestroy(mark), mark = nullptr;
-    stop = req_valid = running = ready_valid = ready_ok = marked = false;
-  }
-};
-Prefetcher &prefetcher() {
-  static Prefetcher p;
-  return p;
-}
-ShutdownHook g_prefetch_reset([] { prefetcher().shutdown(); });
-}  // namespace
-}  // namespace (file-local part; the three entry points below are called from pgx_replay.hip and the C-ABI)
-
-namespace pgx {
-void prefetch_request(pgx_seqdb *db, const pgx_mm128 *d_mm, size_t n_mm, const pgx_mm_count *d_mc, size_t n_mc, const pgx_overlap_params *p) {
-  Prefetcher &pf = prefetcher();
-  std::lock_guard<std::mutex> lk(pf.mu);
-  pf.req.db = db, pf.req.mm = d_mm, pf.req.mc = d_mc, pf.req.n_mm = n_mm, pf.req.n_mc = n_mc, pf.req.p = *p;
-  pf.req_valid = true;
-  if (!pf.th.joinable()) {
-    dev_cache_multi_stream(true);
-    pf.th = std::thread([&pf] { pf.loop(); });
-  }
-}
-static bool record_mark(Prefetcher &pf) {   // (pf.mu held, on the caller's thread)
-  if (!pf.mark && hipEventCreateWithFlags(&pf.mark, hipEventDisableTiming) != hipSuccess) return false;
-  return hipEventRecord(pf.mark, ctx().stream) == hipSuccess;
-}
-void prefetch_mark() {   // just BEFORE the caller's main alignment launch: the front starts behind what is enqueued up to here, i.e. beside that launch
-  Prefetcher &pf = prefetcher();
-  std::lock_guard<std::mutex> lk(pf.mu);
-  if (!pf.req_valid || pf.running || !pf.th.joinable()) return;
-  pf.marked = record_mark(pf);
-}
-void prefetch_kick_if_pending() {
-  Prefetcher &pf = prefetcher();
-  std::lock_guard<std::mutex> lk(pf.mu);
-  if (!pf.req_valid || pf.running || !pf.th.joinable()) return;
-  if (!pf.marked && !record_mark(pf)) return;
-  pf.marked = false;
-  pf.ready.reset(), pf.ready_valid = false;   // (a front nobody asked for any more)
-  pf.run_key = pf.req, pf.req_valid = false, pf.running = true;
-  pf.cv.notify_all();
-}
-}  // namespace pgx
-namespace {
-bool take_prefetched_front(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
-                           const pgx_overlap_params *p, const DeviceLists *dev, const pgx_pair_rec *d_recs, StageFront &f) {
-  Prefetcher &pf = prefetcher();
-  if (!pf.th.joinable()) return false;
-  std::unique_lock<std::mutex> lk(pf.mu);
-  PrefetchKey k;
-  k.db = db, k.mm = dev ? dev->d_top : nullptr, k.mc = dev ? dev->d_mc : nullptr, k.n_mm = n_mm, k.n_mc = n_counts, k.p = *p;
-  const bool eligible = dev && !d_recs && !mmers && !counts;
-  pf.cv.wait(lk, [&] { return !pf.running; });   // (a front in flight finishes first: it is this stage's, or it uses the one join state)
-  if (pf.req_valid && eligible && k == pf.req) pf.req_valid = false;   // registered but never started: this stage does its own front
-  if (!pf.ready_valid) return false;
-  std::unique_ptr<StageFront> r = std::move(pf.ready);
-  const bool ok = pf.ready_ok && eligible && k == pf.ready_key && r && r->scratch;
-  pf.ready_valid = false;
-  lk.unlock();
-  if (!ok) return false;   // (r's buffers go back to the cache)
-  f.scratch = r->scratch, r->scratch = nullptr;
-  f.dpairs = std::move(r->dpairs), f.d_bids = std::move(r->d_bids);
-  f.placed = r->placed, f.gpu_replay = r->gpu_replay, f.s = r->s, f.gpu_ms = r->gpu_ms, f.t0 = r->t0, f.t1 = r->t1;
-  return true;
-}
-
 template <typename T>
 void read_counted_files(const std::string &pattern, std::vector<T> &out) {
   glob_t g;
@@ -2188,23 +2045,6 @@ int pgx_overlap_resident_dev(pgx_seqdb *db, const pgx_mm128 *d_mmers, size_t n_m
     run_overlap(db, nullptr, n_mm, nullptr, n_counts, p, v, stats, &dl);
     *n_out = v.n;
     *out = v.release();
-  } catch (const Fail &f) {
-    return f.code;
-  } catch (const std::bad_alloc &) {
-    set_error("out of host memory");
-    return PGX_ENOMEM;
-  }
-  return PGX_OK;
-}
-
-int pgx_overlap_prefetch_dev(pgx_seqdb *db, const pgx_mm128 *d_mmers, size_t n_mm, const pgx_mm_count *d_counts, size_t n_counts,
-                             const pgx_overlap_params *p) {
-  try {
-    require_ready();
-    PGX_REQUIRE(db && d_mmers && n_mm && (n_counts == 0 || d_counts), PGX_EARG, "pgx_overlap_prefetch_dev: null argument");
-    check_params(p);
-    static const bool off = getenv("PGX_PREFETCH") && atoi(getenv("PGX_PREFETCH")) == 0;
-    if (!off) prefetch_request(db, d_mmers, n_mm, d_counts, n_counts, p);
   } catch (const Fail &f) {
     return f.code;
   } catch (const std::bad_alloc &) {

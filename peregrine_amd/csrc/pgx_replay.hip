@@ -2062,9 +2062,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     const size_t batch = nreq - first_req;
     if (sweeps == 1) first_batch = batch;
     r.tail = tail_max && batch <= std::max(tail_max, first_batch / 256) ? ahead : 0u;   // (the NEXT sweep's k_file)
-    if (sweeps == 1) prefetch_mark();   // a front registered for the next stage starts behind everything enqueued so far ...
     dev_align(db, r.rq_key + first_req, batch, band, r.rq_res + first_req, sweeps > 2 ? 2 : sweeps > 1 ? 1 : 0);
-    if (sweeps == 1) prefetch_kick_if_pending();   // ... i.e. beside the main alignment launch and the sweeps behind it
     r.settled = (uint32_t)nreq;
     first_req = nreq;
     {

@@ -123,14 +123,6 @@ class ResidentDB:
                                                       C.byref(out), C.byref(n), C.byref(st)), "pgx_overlap_resident_dev")
         return _lib.take(out.value, n.value, OVLP_DTYPE), st.asdict()
 
-    def overlap_prefetch_dev(self, d_mmers: int, n_mm: int, d_counts: int, n_counts: int, total_chunk=1, mychunk=1, bestn=4, mc_lower=2,
-                             mc_upper=240, align_bandwidth=100, ovlp_upper=120):
-        """hint: the NEXT overlap_dev call will have exactly these arguments -- its join and visit order are computed on a second stream while
-        the current stage is in its greedy walk (pgx_overlap_prefetch_dev)"""
-        p = _lib.OverlapParams(total_chunk, mychunk, bestn, mc_lower, mc_upper, align_bandwidth, ovlp_upper)
-        _lib.check(self._lib.pgx_overlap_prefetch_dev(self.h, C.c_void_p(d_mmers), n_mm, C.c_void_p(d_counts), n_counts, C.byref(p)),
-                   "pgx_overlap_prefetch_dev")
-
     def close(self):
         if self.h:
             self._lib.pgx_seqdb_free(self.h)

@@ -79,47 +79,6 @@ def test_scatter_and_records_path_equal_reference(tmp_path, N, lower, upper):
     rdb.close()
 
 
-@pytest.mark.parametrize("force_device_walk", [False, True])
-def test_prefetched_front_gives_the_same_streams(monkeypatch, force_device_walk):
-    """pgx_overlap_prefetch_dev: the join and the visit order of the NEXT chunk computed on a second stream and host thread while the current
-    chunk is in its walk (device walk: started at the main alignment launch; host walk: when the stage ends).  Same streams, and the stages
-    say that they took the prepared front.  A hint that does not match the next call is ignored."""
-    if force_device_walk:
-        monkeypatch.setenv("PGX_GPU_REPLAY", "1")
-    db = simreads.make_workload("small")
-    dev = torch.device("cuda", 0)
-    rdb = ResidentDB(db, 0)
-    eng = GpuEngine(rdb, dev)
-    N = 4
-    tops, mcs = [], []
-    for c in range(1, N + 1):
-        _, top, mc = eng.index(N, c)
-        tops.append(top.clone()), mcs.append(mc.clone())
-    mm, mc = torch.cat(tops), torch.cat(mcs)
-    torch.cuda.synchronize()
-    args = (mm.data_ptr(), mm.numel() // 16, mc.data_ptr(), mc.numel() // 16)
-    plain = [rdb.overlap_dev(*args, total_chunk=N, mychunk=c) for c in range(1, N + 1)]
-    assert all(st["prefetched_front"] == 0 for _, st in plain) and all(len(ov) > 500 for ov, _ in plain)
-    for rep in range(3):
-        got = []
-        for c in range(1, N + 1):
-            if c < N:
-                rdb.overlap_prefetch_dev(*args, total_chunk=N, mychunk=c + 1)
-            got.append(rdb.overlap_dev(*args, total_chunk=N, mychunk=c))
-        for c, ((ov, st), (ov0, st0)) in enumerate(zip(got, plain), 1):
-            assert formats.ovlp_fields_equal(ov, ov0) and st["stream_checksum"] == st0["stream_checksum"], (rep, c)
-            assert st["prefetched_front"] == (1 if c > 1 else 0), (rep, c, st)
-            assert st["n_pair_records"] == st0["n_pair_records"] and st["n_buckets"] == st0["n_buckets"]
-    # a hint for a stage that is not asked for next: ignored, and the one after it still works
-    rdb.overlap_prefetch_dev(*args, total_chunk=N, mychunk=3)
-    ov, st = rdb.overlap_dev(*args, total_chunk=N, mychunk=2, mc_upper=60)
-    ov_ref, _ = rdb.overlap_dev(*args, total_chunk=N, mychunk=2, mc_upper=60)
-    assert st["prefetched_front"] == 0 and formats.ovlp_fields_equal(ov, ov_ref)
-    ov3, st3 = rdb.overlap_dev(*args, total_chunk=N, mychunk=3)
-    assert formats.ovlp_fields_equal(ov3, plain[2][0])
-    rdb.close()
-
-
 def test_seqdb_from_device_pointer():
     db = simreads.make_workload("tiny")
     t = torch.from_numpy(db.seqdb).to("cuda:0")
