@@ -69,7 +69,10 @@ struct RNode {
   uint32_t next, bucket;
 };
 constexpr uint32_t I_GUESS = 1u << 18, I_UNFILED = 1u << 19;
-constexpr uint32_t SPARSE_CAP = 65536;   // buckets a sparse pass takes from the list
+#ifndef PGX_SPARSE_CAP
+#define PGX_SPARSE_CAP 65536
+#endif
+constexpr uint32_t SPARSE_CAP = PGX_SPARSE_CAP;   // buckets a sparse pass takes from the list
 constexpr uint32_t LIST_CAP = 262144;    // capacity of the list (a window of a dense round is listed whole)
 constexpr uint32_t DEV_LIST = 0xFFFFFFFFu, DEV_LIST_WIN = 0xFFFFFFFEu;  // nlist: the device's list, up to SPARSE_CAP / LIST_CAP entries
 enum : uint32_t { OV_ITEMS = 1, OV_NODES = 2, OV_REQS = 4, OV_PAIRS = 8, OV_MEMO = 16, OV_QOFF = 32, OV_PASSES = 64 };  // Counters::overflow
@@ -1897,7 +1900,10 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   // instead of beside the narrow kernel is worse, 417 ms), so they are constants now; PGX_REPLAY_WIN / _K stay because the parity
   // tests randomise the schedule with them.
   const size_t win0 = 16384, win1 = 131072;   // the first pass ramps its window from win0 up to win1
-  const size_t dense_min = SPARSE_CAP;        // dense rounds from this many dirty buckets
+  // dense rounds only while more than 1 / dense_den of the buckets is dirty.  (Through round 4 also from 65,536 dirty buckets on: the second sweep of a
+  // full-size c4 chunk -- 275 k wrong guesses among 2.7 M buckets -- then went window by window, 41 passes each as long as its longest big bucket, 52 ms;
+  // as sparse passes from the list: 7.06 -> 6.97 s per step, + 0.3 % evaluations.  PGX_REPLAY_DENSE_MIN restores a threshold.)
+  const size_t dense_min = getenv("PGX_REPLAY_DENSE_MIN") ? (size_t)atoll(getenv("PGX_REPLAY_DENSE_MIN")) : (size_t)1 << 40;
   const size_t tail_max = 4000;               // tail mode (file_for_reader, look-ahead) once a sweep asks for at most this many alignments, or 1/256 of the first sweep's
   const uint32_t ahead = 24u;                 // tail mode: partners of a row filed ahead
   const bool use_win_list = true;
