@@ -36,9 +36,20 @@ void run_index(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out, 
   if (keep) keep->valid = false;
   const double t0 = now_ms();
   // read selection: rid % total == mychunk % total, in idx-file order (shmr_index.c:155-157); kept with the seqdb for the next call
-  pgx_seqdb::IndexPlan &plan = db->plan;
-  if (plan.total != p->total_chunk || plan.chunk != p->mychunk) {
-    static uint64_t next_serial = 0;
+  static uint64_t next_serial = 0, use_clock = 0;
+  pgx_seqdb::IndexPlan *found = nullptr;
+  for (auto &pl : db->plans)
+    if (pl.total == p->total_chunk && pl.chunk == p->mychunk) found = &pl;
+  if (!found) {
+    if (db->plans.size() < 32) {
+      db->plans.emplace_back();
+      found = &db->plans.back();
+    } else {
+      found = &db->plans[0];
+      for (auto &pl : db->plans)
+        if (pl.last_use < found->last_use) found = &pl;
+    }
+    pgx_seqdb::IndexPlan &plan = *found;
     plan.reads.clear();
     plan.bases = 0;
     const uint32_t T = (uint32_t)p->total_chunk, c = (uint32_t)p->mychunk % T;
@@ -50,6 +61,8 @@ void run_index(pgx_seqdb *db, const pgx_index_params *p, pgx_index_result *out, 
     }
     plan.total = p->total_chunk, plan.chunk = p->mychunk, plan.serial = ++next_serial;
   }
+  pgx_seqdb::IndexPlan &plan = *found;
+  plan.last_use = ++use_clock;
   const std::vector<ReadDesc> &reads = plan.reads;
   out->bases = plan.bases;
   out->reads = (uint32_t)reads.size();

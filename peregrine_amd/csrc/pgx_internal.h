@@ -175,13 +175,15 @@ struct pgx_seqdb {
   std::vector<uint64_t> roff_by_rid;
   size_t nbytes = 0;
   uint64_t bases = 0;
-  // the read selection of the last index call (rid % total == mychunk % total, idx order): an index stage that is repeated with
-  // the same chunking -- every step of a resident pipeline -- neither rebuilds nor re-uploads it
+  // the read selections of the last index calls (rid % total == mychunk % total, idx order), one per (total, chunk): the steps of a resident
+  // pipeline cycle through the job's chunks, and rebuilding + re-uploading a selection of 775 k reads costs 9.5 ms of host time per stage
+  // (76 ms of a full-size configs[3] step through round 4, when only the LAST selection was kept)
   struct IndexPlan {
     int total = -1, chunk = -1;
-    uint64_t serial = 0, bases = 0;
+    uint64_t serial = 0, bases = 0, last_use = 0;
     std::vector<pgx::ReadDesc> reads;
-  } plan;
+  };
+  std::vector<IndexPlan> plans;   // at most 32, least recently used replaced
 };
 
 namespace pgx {

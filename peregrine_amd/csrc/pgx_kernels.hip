@@ -628,12 +628,16 @@ static double trace_ms() {
 // shutdown + init would otherwise run the sketch kernels on uninitialised descriptors).
 namespace {
 struct FusedPlan {
-  uint64_t dev_serial = 0, slab_total = 0, plan_bases = 0;
+  uint64_t dev_serial = 0, slab_total = 0, plan_bases = 0, last_use = 0;
   int plan_w = 0, plan_k = 0;
   uint64_t plan_div = 0;
   bool plan_ok = false;
-} g_plan;
-ShutdownHook g_plan_reset([] { g_plan = FusedPlan(); });
+  DevBuf<ReadDesc> d_reads;       // the selection's descriptors and slab offsets stay on the device with their plan (one pair per selection:
+  DevBuf<uint64_t> d_slab_off;    // a pipeline that cycles through a job's chunks uploads each once)
+};
+std::vector<FusedPlan> g_plans;   // at most 32, least recently used replaced
+uint64_t g_plan_clock = 0;
+ShutdownHook g_plan_reset([] { g_plans.clear(); });
 }  // namespace
 
 bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, int w, int k, int rs, int levels,
@@ -643,7 +647,28 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
   if (n == 0 || levels < 1 || levels > 2 || rs < 1) return false;
   const bool trace = getenv("PGX_TRACE") != nullptr;
   const double tr0 = trace ? trace_ms() : 0;
-  // slab offsets and read descriptors: computed and uploaded once per plan (file-scope state below: reset by pgx_shutdown)
+  // slab offsets and read descriptors: computed and uploaded once per plan (file-scope state above: reset by pgx_shutdown)
+  FusedPlan *fp = nullptr;
+  if (plan_serial)
+    for (auto &pl : g_plans)
+      if (pl.dev_serial == plan_serial) fp = &pl;
+  if (!fp)   // (a selection without a serial, or a new one: an entry that holds no plan first)
+    for (auto &pl : g_plans)
+      if (pl.dev_serial == 0) fp = &pl;
+  if (!fp) {
+    if (g_plans.size() < 32) {
+      g_plans.emplace_back();
+      fp = &g_plans.back();
+    } else {
+      fp = &g_plans[0];
+      for (auto &pl : g_plans)
+        if (pl.last_use < fp->last_use) fp = &pl;
+      sync();   // (its buffers may still be read by what the last stage enqueued)
+      *fp = FusedPlan();
+    }
+  }
+  FusedPlan &g_plan = *fp;
+  g_plan.last_use = ++g_plan_clock;
   uint64_t &dev_serial = g_plan.dev_serial, &slab_total = g_plan.slab_total, &plan_bases = g_plan.plan_bases;
   int &plan_w = g_plan.plan_w, &plan_k = g_plan.plan_k;
   bool &plan_ok = g_plan.plan_ok;
@@ -660,8 +685,12 @@ bool dev_index_fused(const pgx_seqdb *db, const std::vector<ReadDesc> &reads, in
   const uint64_t slab_div = getenv("PGX_SLAB_DIV") ? std::max(1ll, atoll(getenv("PGX_SLAB_DIV"))) : !fused_out ? 8 : levels >= 2 ? 48 : 24;
   const bool cached = plan_serial != 0 && plan_serial == dev_serial && plan_w == w && plan_k == k && g_plan.plan_div == slab_div;
   hipStream_t st = ctx().stream;
-  ReadDesc *d_reads = ws<ReadDesc>("ix.reads", n);
-  uint64_t *d_slab_off = ws<uint64_t>("ix.slab_off", n + 1);
+  if (!cached) {
+    MemTag plan_tag("index.plans");
+    g_plan.d_reads.alloc(n), g_plan.d_slab_off.alloc((size_t)n + 1);
+  }
+  ReadDesc *d_reads = g_plan.d_reads.p;
+  uint64_t *d_slab_off = g_plan.d_slab_off.p;
   if (!cached) {
     dev_serial = 0;
     std::vector<uint64_t> slab_off(n + 1, 0);

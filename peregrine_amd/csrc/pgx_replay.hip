@@ -300,14 +300,15 @@ __device__ __forceinline__ void mark_readers(const R &r, uint32_t slot, uint32_t
   const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[slot >> r.cshift]);
   const uint4 h1 = *reinterpret_cast<const uint4 *>(w);  // cnt, rhead, in[0], in[1]
   const uint32_t c = min(h1.x, NIN);
-  if (c > 0 && h1.z > j + 1) r.dirty[h1.z - 1] = 1;
-  if (c > 1 && h1.w > j + 1) r.dirty[h1.w - 1] = 1;
+  // (entries are bucket + 1 <= nb: the upper test is a guard, not a rule)
+  if (c > 0 && h1.z > j + 1 && h1.z <= r.nb) r.dirty[h1.z - 1] = 1;
+  if (c > 1 && h1.w > j + 1 && h1.w <= r.nb) r.dirty[h1.w - 1] = 1;
   for (uint32_t q = 2; q < c; q += 8) {  // in[q .. q+8): two 16-byte loads in flight
     const uint4 a = *reinterpret_cast<const uint4 *>(w + 2 + q), b = *reinterpret_cast<const uint4 *>(w + 6 + q);
     const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
     for (uint32_t k = 0; k < 8; ++k)
-      if (q + k < c && x[k] > j + 1) r.dirty[x[k] - 1] = 1;
+      if (q + k < c && x[k] > j + 1 && x[k] <= r.nb) r.dirty[x[k] - 1] = 1;
   }
   if (c < NIN) return;
   for (uint32_t nd = h1.y; nd != NIL; nd = r.rn[nd - 1].next) {
@@ -1907,7 +1908,10 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   const size_t tail_max = 4000;               // tail mode (file_for_reader, look-ahead) once a sweep asks for at most this many alignments, or 1/256 of the first sweep's
   const uint32_t ahead = 24u;                 // tail mode: partners of a row filed ahead
   const bool use_win_list = true;
-  const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 3;
+  // evaluate / update iterations per window of a dense round: 2 (through round 4: 3; at full-size c4 6.89 -> 6.81 s per step with 2 and 6.90 with 1,
+  // c3 / c4s / c5s unchanged; the third iteration of a window mostly re-runs k_eval_big's longest bucket for a handful of dirty buckets that the
+  // sparse passes behind the round pick up anyway)
+  const int inner = getenv("PGX_REPLAY_K") ? atoi(getenv("PGX_REPLAY_K")) : 2;
   const bool wide = true;          // sparse passes: a wavefront per bucket, four rows per step
   const size_t dense_den = 3;      // dense rounds while more than 1/dense_den of the buckets is dirty
   const bool wide_dense = false;   // (the dense rounds keep 16 lanes per bucket: measured)
