@@ -380,9 +380,11 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
     if not U.have_ref():
         return {"value": None, "unit": "overlaps/s", "cores": 0, "kind": "none", "sample": "oracle/_ref (the compiled reference) is not in this tree"}
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    P = max(1, min(ncpu, 24))
-    T = 24 if mode == "full" else 192
-    cs = list(range(1, min(T, 24) + 1))
+    # 24 processes: the reference's own practical ceiling (README.md:127-137: 48 cores no faster than 24).  PGX_BENCH_CPU_PROCS = 48 | 64 runs the
+    # whole-workload leg as that many processes over that many chunks instead -- the leg that says whether 24 is the best one on THIS host
+    P = max(1, min(ncpu, int(os.environ.get("PGX_BENCH_CPU_PROCS", "24"))))
+    T = P if mode == "full" else 192
+    cs = list(range(1, min(T, P) + 1))
     need = int(total * 1.02) + int(db.n_bases * (0.12 if mode == "full" else 0.03)) + (8 << 30)
     base = _scratch_dir(need)
     if base is None:
@@ -428,7 +430,7 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
             del got
         _lib.stream_wait()
         match, compared = True, []
-        for c in cs[:2]:
+        for c in cs[:2]:     # (T != the job's chunking: the GPU on the CPU leg's chunking)
             ov, _ = rdb.overlap_dev(mm_all.data_ptr(), mm_all.numel() // 16, mc_all.data_ptr(), mc_all.numel() // 16, total_chunk=T, mychunk=c, mc_upper=mc_upper)
             ref = formats.read_ovlp(os.path.join(d, "ov.%03d" % c))
             ok = bool(formats.ovlp_fields_equal(np.asarray(ov), ref))
@@ -450,7 +452,7 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
         del keys
         frac = 1.0 if mode == "full" else len(cs) / T
         out = {"value": raw / (t_index + t_ovlp), "unit": "overlaps/s", "cores": P, "kind": "reference",
-               "sample": (f"WHOLE workload {tag} ({db.n_reads} reads, {db.n_bases} bases): {P} processes over 24 index chunks, then over 24 overlap chunks"
+               "sample": (f"WHOLE workload {tag} ({db.n_reads} reads, {db.n_bases} bases): {P} processes over {T} index chunks, then over {T} overlap chunks"
                           if mode == "full" else
                           f"bounded sample of {tag} ({db.n_reads} reads, {db.n_bases} bases): {P} processes over index chunks 1..24 of 192 ({index_bases} bases) and "
                           f"then over overlap chunks 1..24 of 192 (1/8 of the first keys; each process still loads all shimmer / count files and scans "

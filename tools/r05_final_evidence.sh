@@ -16,6 +16,8 @@ cp profiles/r05_*c4* $P/ 2>/dev/null
 ( time timeout -k 5 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --end-to-end > $P/r05_bench_c4_end_to_end.json ) 2> $P/r05_bench_c4_end_to_end.log; tail -3 $P/r05_bench_c4_end_to_end.log
 for w in c3 c4s c5s; do timeout 600 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > $P/r05_bench_$w.json 2> $P/r05_bench_$w.log; done
 timeout 1100 python -m pytest tests -m gpu -q --durations=15 > $P/r05_pytest_gpu.log 2>&1; tail -3 $P/r05_pytest_gpu.log
+# 7. is 24 processes the best CPU leg on this host?  the whole-workload leg as 48 processes over 48 + 48 chunks
+( time PGX_BENCH_CPU_PROCS=48 PGX_BENCH_NO_STREAM_HASH=1 timeout -k 5 1500 python bench.py --steps 2 --warmup 1 --cpu-baseline full > $P/r05_bench_c4_cpu48.json ) 2> $P/r05_bench_c4_cpu48.log; tail -3 $P/r05_bench_c4_cpu48.log
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/prof/r05_bench_*.json")):
