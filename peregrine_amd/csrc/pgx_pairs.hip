@@ -427,9 +427,8 @@ CountCache g_counts;
 ShutdownHook g_counts_reset([] { g_counts = CountCache(); });
 }  // namespace
 static const CountTable &aggregate_counts(const pgx_mm_count *cin, size_t n_counts, Tmp &tmp) {
-  static const bool off = getenv("PGX_COUNT_CACHE") && atoi(getenv("PGX_COUNT_CACHE")) == 0;
   unsigned long long sum = 0;
-  if (n_counts && !off) {
+  if (n_counts) {
     hipStream_t st = ctx().stream;
     DevBuf<unsigned long long> d_sum(1);
     PGX_HIP(hipMemsetAsync(d_sum.p, 0, sizeof(unsigned long long), st));
@@ -440,7 +439,7 @@ static const CountTable &aggregate_counts(const pgx_mm_count *cin, size_t n_coun
   }
   g_counts.valid = false;
   aggregate_counts_now(cin, n_counts, g_counts.ct, tmp);
-  g_counts.n = n_counts, g_counts.sum = sum, g_counts.valid = n_counts != 0 && !off;
+  g_counts.n = n_counts, g_counts.sum = sum, g_counts.valid = n_counts != 0;
   return g_counts.ct;
 }
 

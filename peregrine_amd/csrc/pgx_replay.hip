@@ -1903,8 +1903,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   const size_t win0 = 16384, win1 = 131072;   // the first pass ramps its window from win0 up to win1
   // dense rounds only while more than 1 / dense_den of the buckets is dirty.  (Through round 4 also from 65,536 dirty buckets on: the second sweep of a
   // full-size c4 chunk -- 275 k wrong guesses among 2.7 M buckets -- then went window by window, 41 passes each as long as its longest big bucket, 52 ms;
-  // as sparse passes from the list: 7.06 -> 6.97 s per step, + 0.3 % evaluations.  PGX_REPLAY_DENSE_MIN restores a threshold.)
-  const size_t dense_min = getenv("PGX_REPLAY_DENSE_MIN") ? (size_t)atoll(getenv("PGX_REPLAY_DENSE_MIN")) : (size_t)1 << 40;
+  // as sparse passes from the list: 7.06 -> 6.97 s per step, + 0.3 % evaluations.)
+  const size_t dense_min = (size_t)1 << 40;
   const size_t tail_max = 4000;               // tail mode (file_for_reader, look-ahead) once a sweep asks for at most this many alignments, or 1/256 of the first sweep's
   const uint32_t ahead = 24u;                 // tail mode: partners of a row filed ahead
   const bool use_win_list = true;
@@ -2240,7 +2240,7 @@ bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visi
     // unusual data (repeat-rich sets): the same walk again with larger tables.  Requests and memo entries are the same alignments: when the
     // request array was too small the memo table of the same size class is too, and k_file stopped before it could say so -- grow both
     for (int k = 0; k < 3; ++k)
-      if (ov & (1u << k)) mult[k] *= 2;
+      if (ov & (1u << k)) mult[k] = mult[k] < 1 ? 1.0 : mult[k] * 2;   // (an arena that was shrunk to the last stage's use goes back to the default first)
     if (ov & OV_PAIRS) mult[3] *= 4;
     if (ov & (OV_MEMO | OV_REQS)) mult[4] *= 4;
     if (trace) fprintf(stderr, "[pgx]   next attempt with items x %g, reader nodes x %g, requests x %g, pair table x %g, memo table x %g\n", mult[0], mult[1], mult[2], mult[3], mult[4]);

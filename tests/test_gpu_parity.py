@@ -646,6 +646,13 @@ def test_device_replay_equals_oracle(small, monkeypatch):
             # the checksum k_emit adds up while it writes the records = the numpy statement over the stream the caller got (and the reference's)
             assert st["device_replay"] == 1 and st["replay_attempts"] == 1 and st["stream_checksum"] == formats.stream_checksum(want), (kw, it)
     monkeypatch.delenv("PGX_REPLAY_WIN"), monkeypatch.delenv("PGX_REPLAY_K")
+    # reader lists shared by 2 / 4 / 8 neighbouring hot slots (what the library does by itself when HBM is short): spurious re-evaluations, same walk
+    want, ost = U.orc_overlap(db, ix.top, ix.top_mc)
+    for shift in ("1", "2", "3"):
+        monkeypatch.setenv("PGX_REPLAY_COLD_SHIFT", shift)
+        got, st = rdb.overlap(ix.top, ix.top_mc)
+        assert formats.ovlp_fields_equal(got, want) and st["device_replay"] == 1 and st["n_align_needed"] == ost["n_align"], shift
+    monkeypatch.delenv("PGX_REPLAY_COLD_SHIFT")
     # undersized device tables: the walk is repeated with larger ones (hash tables x 4, arenas x 2 per attempt; four attempts), then handed to the host replay
     want, ost = U.orc_overlap(db, ix.top, ix.top_mc)
     seen = []
