@@ -13,7 +13,7 @@ OUT=gpurun_out/pmc_$W
 rm -rf $OUT; mkdir -p $OUT profiles
 # the simulated set of the one-chunk workloads is made once, outside the profiler (rocprofv3 --pmc aborts inside torch's generator kernels of
 # the repeat-planting genome builder); the extra replay-timing step is switched off so that the profiled launches are exactly the timed ones
-export PGX_BENCH_CACHE=/dev/shm/pgx_bench_cache PGX_BENCH_NO_REPLAY_TIMING=1
+export PGX_BENCH_CACHE=/dev/shm/pgx_bench_cache PGX_BENCH_NO_REPLAY_TIMING=1 PGX_BENCH_NO_STREAM_HASH=1
 CMD="python bench.py --workload $W --steps $S --warmup 0 --no-cpu-baseline $EXTRA"
 timeout 900 $CMD > $OUT/plain.json 2> $OUT/plain.err
 timeout -k 5 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- $CMD > $OUT/stats.json 2> $OUT/stats.err
