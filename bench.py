@@ -528,7 +528,7 @@ def seqdb_sha256_of_device(seq, total, piece=1 << 30):
 PINS_FILE = os.path.join(ROOT, "tests", "golden", "c4_stream_pins.json")
 
 
-def end_to_end_served(seq, total, db, rdb, CH, levels, mc_upper, stream_report):
+def end_to_end_served(seq, total, db, rdb, CH, levels, mc_upper, stream_report, release=None):
     """file -> H2D -> kernels -> D2H -> file at the metric's configuration (pg_run.py:232-244,305-317): the job's CH index + CH overlap
     chunk COMMANDS through bin/native/shmr_index / shmr_overlap attached to one `pgx_cli serve` process, everything on /dev/shm.  This process
     gives its HBM back first (two copies of a 93 GB database do not fit one GPU).  The output files are hashed like the resident streams."""
@@ -545,12 +545,17 @@ def end_to_end_served(seq, total, db, rdb, CH, levels, mc_upper, stream_report):
     try:
         pre = os.path.join(d, "sd")
         t0 = time.perf_counter()
-        simreads.write_seqdb_from_device(pre, seq, total, db.rid, db.rlen, db.roff)
+        simreads.write_seqdb_from_device(pre, seq[0] if isinstance(seq, list) else seq, total, db.rid, db.rlen, db.roff)
         t_files = time.perf_counter() - t0
         rdb.close()
         _lib.shutdown()
         del seq
+        if release is not None:
+            release()          # (the caller's references to the resident seqdb and the lists)
+        import gc
+        gc.collect()
         torch.cuda.empty_cache()
+        log("end to end: %.1f GB of HBM still in use by this process" % ((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9))
         log(f"end to end: seqdb files written in {t_files:.1f} s; this process's HBM released")
         t0 = time.perf_counter()
         srv = subprocess.Popen([cli, "serve", "-p", pre], stderr=subprocess.DEVNULL)
@@ -559,12 +564,16 @@ def end_to_end_served(seq, total, db, rdb, CH, levels, mc_upper, stream_report):
         t_up = time.perf_counter() - t0
         try:
             t0 = time.perf_counter()
+            def run(cmd):
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                if r.returncode:
+                    raise RuntimeError("%s -> %d: %s" % (" ".join(cmd[1:6]), r.returncode, (r.stderr or "")[-600:]))
             for c in range(1, CH + 1):
-                subprocess.run([cli, "shmr_index", "-p", pre, "-t", str(CH), "-c", str(c), "-m", "0", "-l", str(levels), "-o", os.path.join(d, "ix")], check=True, capture_output=True)
+                run([cli, "shmr_index", "-p", pre, "-t", str(CH), "-c", str(c), "-m", "0", "-l", str(levels), "-o", os.path.join(d, "ix")])
             t1 = time.perf_counter()
             for c in range(1, CH + 1):
-                subprocess.run([cli, "shmr_overlap", "-p", pre, "-l", os.path.join(d, "ix-L%d" % levels), "-t", str(CH), "-c", str(c), "-M", str(mc_upper),
-                                "-o", os.path.join(d, "ov.%02d" % c)], check=True, capture_output=True)
+                run([cli, "shmr_overlap", "-p", pre, "-l", os.path.join(d, "ix-L%d" % levels), "-t", str(CH), "-c", str(c), "-M", str(mc_upper),
+                     "-o", os.path.join(d, "ov.%02d" % c)])
             t2 = time.perf_counter()
         finally:
             srv.send_signal(signal.SIGTERM)
@@ -1084,7 +1093,14 @@ def main():
                                "what": "SHA-256 of oracle/_ref/shmr_overlap's stream (padding bytes zeroed) for every overlap chunk of this configuration, "
                                        "made on the GPU box's host cores from the same seqdb bytes (the generator is seeded; read_set_hash and seqdb_sha256 tie the inputs)"}
         if a.end_to_end and strong and world == 1:
-            out["gpu_end_to_end"] = end_to_end_served(seq_dev, total, db, rdb, CH, sp["levels"], sp["mc_upper"], stream_report)
+            seq_box = [seq_dev]
+            seq_dev = None
+
+            def release_all():
+                seq_box.clear()
+                held.clear()
+                keep_streams.clear()
+            out["gpu_end_to_end"] = end_to_end_served(seq_box, total, db, rdb, CH, sp["levels"], sp["mc_upper"], stream_report, release_all)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()

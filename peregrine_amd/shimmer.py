@@ -127,6 +127,7 @@ class ResidentDB:
         if self.h:
             self._lib.pgx_seqdb_free(self.h)
             self.h = C.c_void_p()
+        self._adopted = None   # (the caller's device buffer is the caller's again)
 
     def __del__(self):
         try:
