@@ -114,7 +114,7 @@ static int try_server(const char *tool, const char *prefix, int argc, char **arg
  * there too.  Such a command runs stand-alone, where fopen(path) does what the reference's does (src/shmr_overlap.c:341-352). */
 static int output_needs_this_process(const char *path) {
   if (!path) return 0;
-  if (!strncmp(path, "/dev/", 5) || !strncmp(path, "/proc/", 6)) return 1;
+  if (!strncmp(path, "/dev/std", 8) || !strncmp(path, "/dev/fd/", 8) || !strncmp(path, "/dev/tty", 8) || !strncmp(path, "/proc/", 6)) return 1;   /* (not /dev/shm/...: plain files) */
   struct stat sb;
   if (stat(path, &sb) == 0 && !S_ISREG(sb.st_mode)) return 1;
   return 0;

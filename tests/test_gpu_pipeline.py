@@ -3,6 +3,7 @@ drop-in executables of bin/ (Python) and bin/native/ (one C binary against the C
 shmr_index (several chunks) -> shmr_overlap (several chunks) -> cat | shmr_dedup -> shmr_map reads->contigs and
 contigs->contigs.  Every output file must be byte-identical (MC files: same multiset of (mer, count))."""
 import os
+import shutil
 import subprocess
 import sys
 
@@ -138,6 +139,17 @@ def test_served_mode_writes_the_same_files(tmp_path):
             assert (tmp_path / "srv" / f"ix-L2-{c:02d}-of-02.dat").read_bytes() == (tmp_path / "ref" / f"ix-L2-{c:02d}-of-02.dat").read_bytes()
         for c in (1, 2, 3):
             assert (tmp_path / "srv" / f"ov.{c}").read_bytes() == (tmp_path / "ref" / f"ov.{c}").read_bytes()
+        # -o /dev/stdout with a LIVE server: the server cannot open the client's descriptor -- the command runs stand-alone and the
+        # records arrive on the client's stdout; a file under /dev/shm is a plain file and is served like any other
+        r = subprocess.run([cli, "shmr_overlap", "-p", pre, "-l", "ix-L2", "-t", "3", "-c", "2", "-o", "/dev/stdout"], cwd=tmp_path / "srv", check=True, capture_output=True)
+        assert r.stdout == (tmp_path / "ref" / "ov.2").read_bytes()
+        shm = None
+        if os.path.isdir("/dev/shm"):
+            import tempfile
+            shm = tempfile.mkdtemp(prefix="pgx_srv_", dir="/dev/shm")
+            subprocess.run([cli, "shmr_overlap", "-p", pre, "-l", "ix-L2", "-t", "3", "-c", "1", "-o", os.path.join(shm, "ov.1")], cwd=tmp_path / "srv", check=True, capture_output=True)
+            assert open(os.path.join(shm, "ov.1"), "rb").read() == (tmp_path / "ref" / "ov.1").read_bytes()
+            shutil.rmtree(shm, ignore_errors=True)
         # errors come back with the exit status and the library's message (chunk 7 of 3)
         bad = subprocess.run([cli, "shmr_overlap", "-p", pre, "-l", "ix-L2", "-t", "3", "-c", "7", "-o", "x"], cwd=tmp_path / "srv", capture_output=True, text=True)
         assert bad.returncode != 0 and "pgx_overlap_chunk_db failed" in bad.stderr
