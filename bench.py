@@ -383,6 +383,18 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
     # 24 processes: the reference's own practical ceiling (README.md:127-137: 48 cores no faster than 24).  PGX_BENCH_CPU_PROCS = 48 | 64 runs the
     # whole-workload leg as that many processes over that many chunks instead -- the leg that says whether 24 is the best one on THIS host
     P = max(1, min(ncpu, int(os.environ.get("PGX_BENCH_CPU_PROCS", "24"))))
+    if os.environ.get("PGX_BENCH_CPU_PROCS") and mode == "full":
+        # (round 5: 48 reference processes over the full-size set -- each holds every chunk's lists and its part of the pair map, ~13 GB at l = 2 --
+        #  beside the 93 GB seqdb file in /dev/shm took the GPU box down.  A non-default process count must fit the host's free memory.)
+        try:
+            avail = next(int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.startswith("MemAvailable"))
+            per_proc = 14e9 * db.n_bases / 93.3e9 * (3.2 if levels == 1 else 1.0)
+            fit = int((avail - total * 1.1 - 32e9) // max(per_proc, 1e8))
+            if fit < P:
+                log(f"cpu baseline: {P} reference processes would need ~{P * per_proc / 1e9:.0f} GB of host memory, {avail / 1e9:.0f} GB are available: {max(1, min(P, fit, 24))} instead")
+                P = max(1, min(P, fit, 24))
+        except Exception:
+            P = min(P, 24)
     T = P if mode == "full" else 192
     cs = list(range(1, min(T, P) + 1))
     need = int(total * 1.02) + int(db.n_bases * (0.12 if mode == "full" else 0.03)) + (8 << 30)
