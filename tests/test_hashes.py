@@ -93,3 +93,25 @@ def test_full_size_pins_are_well_formed():
     assert sum(s["records"] for s in pins["streams"]) == 366_003_067     # records_per_step of the graded line
     assert all(len(s["masked_sha256"]) == 64 and int(s["masked_sha256"], 16) >= 0 for s in pins["streams"])
     assert len(set(s["masked_sha256"] for s in pins["streams"])) == 8 and len(pins["seqdb_sha256"]) == 64 and len(pins["read_set_hash"]) == 34
+
+
+def test_read_set_hash_covers_every_byte():
+    """bench.device_read_set_hash (what the ranks of a multi-GPU job compare, and what ties a run to the pins): any single byte changes it, the
+    blocked form equals the one-shot form, trailing bytes beyond a multiple of 8 count too (runs on a CPU tensor here, on the device in bench.py)"""
+    import torch
+    import bench
+    rng = np.random.default_rng(3)
+    n = (1 << 20) + 5
+    a = torch.from_numpy(rng.integers(0, 256, n + 1024, dtype=np.uint8))
+    h = bench.device_read_set_hash(a, n)
+    assert len(h) == 34 and h == bench.device_read_set_hash(a.clone(), n)
+    for pos in (0, 7, 8, 123457, n - 6, n - 1):
+        b = a.clone()
+        b[pos] ^= 1
+        assert bench.device_read_set_hash(b, n) != h, pos
+    b = a.clone()
+    b[n + 3] ^= 0xFF                                    # beyond `total`: the zero tail is not part of the read set
+    assert bench.device_read_set_hash(b, n) == h
+    c = a.clone()
+    c[[10, 18]] = c[[18, 10]]                           # the same bytes in another place
+    assert (c[10] == a[10]) or bench.device_read_set_hash(c, n) != h
