@@ -1,5 +1,6 @@
 #!/bin/bash
-# The evidence of the tree round 5 ends with, in ONE call (order: counters first, so that the graded line attaches the counters of THIS tree):
+# The evidence of the tree round 5 ends with.  (In round 5 the steps were finally run as SEPARATE short calls: a call dies with its client.)
+# In ONE call (order: counters first, so that the graded line attaches the counters of THIS tree):
 #   1. tools/pmc_profile.sh c4 r05 1      -> profiles/r05_{kernel_stats_bench,traffic,valu}_c4.*
 #   2. the driver's command               -> profiles/r05_bench_c4_default.{json,log}   (whole-workload reference CPU leg, hashes, pins)
 #   3. configs[4] at full size, twice     -> profiles/r05_bench_c5_run{1,2}.json        (run 1 with the sample CPU leg)
@@ -16,8 +17,8 @@ cp profiles/r05_*c4* $P/ 2>/dev/null
 ( time timeout -k 5 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --end-to-end > $P/r05_bench_c4_end_to_end.json ) 2> $P/r05_bench_c4_end_to_end.log; tail -3 $P/r05_bench_c4_end_to_end.log
 for w in c3 c4s c5s; do timeout 600 python bench.py --workload $w --steps 10 --warmup 2 --no-cpu-baseline > $P/r05_bench_$w.json 2> $P/r05_bench_$w.log; done
 timeout 1100 python -m pytest tests -m gpu -q --durations=15 > $P/r05_pytest_gpu.log 2>&1; tail -3 $P/r05_pytest_gpu.log
-# 7. is 24 processes the best CPU leg on this host?  the whole-workload leg as 48 processes over 48 + 48 chunks
-( time PGX_BENCH_CPU_PROCS=48 PGX_BENCH_NO_STREAM_HASH=1 timeout -k 5 1500 python bench.py --steps 2 --warmup 1 --cpu-baseline full > $P/r05_bench_c4_cpu48.json ) 2> $P/r05_bench_c4_cpu48.log; tail -3 $P/r05_bench_c4_cpu48.log
+# (7. the whole-workload CPU leg as 48 processes over 48 chunks -- PGX_BENCH_CPU_PROCS=48 -- is NOT part of this script any more: 48 x ~13 GB of
+#  reference processes beside the 93 GB seqdb file in /dev/shm took the GPU box down in round 5; bench.py now checks the host's memory first.)
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob("gpurun_out/prof/r05_bench_*.json")):
