@@ -1096,10 +1096,23 @@ def main():
                 pins = None
             if pins and pins.get("chunks") == CH:
                 want = {c["chunk"]: c for c in pins["streams"]}
-                rows_ok = [want.get(r["chunk"]) is not None and want[r["chunk"]]["records"] == r["records"] and want[r["chunk"]]["masked_sha256"] == r["masked_sha256"]
-                           for r in stream_report]
+                # (every pinned chunk must be there and equal; configs[4] pins a subset of its 24 chunks -- `chunks_pinned` says how many)
+                rows_ok = [want[r["chunk"]]["records"] == r["records"] and want[r["chunk"]]["masked_sha256"] == r["masked_sha256"]
+                           for r in stream_report if r["chunk"] in want]
                 same_input = pins.get("read_set_hash") == read_set_hash and (out.get("seqdb_sha256") is None or out["seqdb_sha256"] == pins.get("seqdb_sha256"))
-                out["streams_match_pins"] = bool(same_input and len(stream_report) == CH and all(rows_ok))
+                out["streams_match_pins"] = bool(same_input and len(stream_report) == CH and len(rows_ok) == len(want) and len(want) > 0 and all(rows_ok))
+                if pins.get("reference_overlap_leg_s") and out.get("overlap_ms_per_step"):
+                    # the SAME job on both sides (VERDICT r5 task 6a): the reference ran exactly these CH overlap chunks (the pinned streams are its output)
+                    # as `reference_overlap_processes` processes side by side on the GPU box's host cores when the pins were made
+                    procs = pins.get("reference_overlap_processes", pins["chunks"])
+                    out.setdefault("gpu_over_cpu", {})["same_job"] = {
+                        "what": "overlap stage of this very job (T = %d, chunks %s): the reference's wall time when the pins were made vs the GPU's overlap time per step; "
+                                "equal streams by the pins" % (CH, "1..%d" % CH if len(want) == CH else sorted(want)),
+                        "cpu_overlap_s": pins["reference_overlap_leg_s"], "cpu_processes": procs, "cpu_chunks": len(want),
+                        "gpu_overlap_s": out["overlap_ms_per_step"] * 1e-3 * len(want) / CH,
+                        "ratio": pins["reference_overlap_leg_s"] / (out["overlap_ms_per_step"] * 1e-3 * len(want) / CH),
+                        "cpu_overlaps_per_s": sum(c["records"] for c in pins["streams"]) / pins["reference_overlap_leg_s"],
+                        "source": "tests/golden/c4_stream_pins.json (reference_overlap_leg_s; tests/golden/make_c4_stream_pins.py)"}
                 out["pins"] = {"file": "tests/golden/c4_stream_pins.json", "same_input_bytes": bool(same_input), "chunks_pinned": len(want),
                                "chunks_equal": int(sum(rows_ok)), "pinned_seqdb_sha256": pins.get("seqdb_sha256"),
                                "what": "SHA-256 of oracle/_ref/shmr_overlap's stream (padding bytes zeroed) for every overlap chunk of this configuration, "

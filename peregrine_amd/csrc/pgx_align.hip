@@ -13,6 +13,8 @@
 // extended by the whole group, 128 codes per iteration (8 per lane with 16 lanes, 16 per lane with 8), with coalesced loads; the order-dependent side results (first
 // diagonal reaching an end, first extension > 16, first occurrence of the strictly longest extension) are resolved
 // lowest-k-first with ballots restricted to the group; band update by ballot of U >= best - band.
+#include <hipcub/hipcub.hpp>
+
 #include "pgx_internal.h"
 
 namespace pgx {
@@ -485,21 +487,33 @@ enum { PH_FETCH = 0, PH_STEP = 1, PH_ROUND = 2, PH_SNAKE = 3, PH_END = 4, PH_BAN
 // (128 with four 64-bit shift / XOR / AND / count sequences before), and fewer steps need an extension at all (a probe of 16 ends
 // 32 % of the main diagonals' matches, one of 8 only 18 %).  seq = the two packs (pack1 = seq + pack_stride dwords); candidates
 // that meet a read with ambiguous bases (nflag) are handed on to the byte-wise launch through esc_list.
+// ROUND 6 -- a WORKGROUP of up to 16 wavefronts shares one run of the request list.  The wavefronts still run on their own (no barrier
+// inside the loop; every V ring belongs to one 8-lane group), but they take their chunks of 8 candidates from a SEGMENT of `seg`
+// consecutive requests that the workgroup claimed from the device-wide counter, through one packed LDS word {segment start, taken}.
+// With the requests of a launch in the order of the packs' layout (order list: dev_align sorts them by the query read's rank) the
+// 128 candidates a workgroup has in flight are neighbours in the layout -- one or two loci -- and a CU (two workgroups) touches a few
+// dozen translation ranges of the 47 GB of packs instead of 512 (pgx_pack.hip; rounds 2-5: a wavefront per workgroup, chunks of 8
+// straight from the device-wide counter: every wavefront of a CU at another locus).
+// PACKED: seq = the packs, roff = d_poff (dword index of a read's forward strand; its reverse complement follows at + ceil(len / 16)).
 template <int GL, typename VT, bool PACKED>
-__global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
-                                                 const uint32_t *__restrict__ rlen, const pgx_align_key *__restrict__ keys,
-                                                 uint32_t n, int band, int ring, pgx_match *__restrict__ out,
-                                                 uint32_t *__restrict__ counter, const uint32_t *__restrict__ redo_n,
-                                                 const uint32_t *__restrict__ redo_list, uint32_t *__restrict__ esc_n,
-                                                 uint32_t *__restrict__ esc_list, const uint32_t *__restrict__ nflag, size_t pack_stride,
-                                                 uint32_t iter_limit) {   // iter_limit != 0: a candidate still running after that many
-                                                                          // wavefront iterations is handed on (esc_list) at its next step
-  // redo_list != nullptr: the candidates are keys[redo_list[0 .. *redo_n)] (the ones a narrow-ring launch handed on);
-  // esc_list != nullptr: a candidate whose band outgrows this launch's V ring is appended there instead of being finished
+__global__ __launch_bounds__(1024, 8) void k_align_ph(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
+                                                      const uint32_t *__restrict__ rlen, const pgx_align_key *__restrict__ keys,
+                                                      uint32_t n, int band, int ring, pgx_match *__restrict__ out,
+                                                      uint32_t *__restrict__ counter, const uint32_t *__restrict__ redo_n,
+                                                      const uint32_t *__restrict__ redo_list, uint32_t *__restrict__ esc_n,
+                                                      uint32_t *__restrict__ esc_list, const uint32_t *__restrict__ nflag, uint32_t seg,
+                                                      uint32_t iter_limit) {   // iter_limit != 0: a candidate still running after that many
+                                                                               // wavefront iterations is handed on (esc_list) at its next step
+  // redo_list != nullptr: the candidates are keys[redo_list[0 .. *redo_n)] (an order list, or the ones another launch handed on);
+  // esc_list != nullptr: stragglers and candidates on reads without 2-bit codes are appended there instead of being finished
   extern __shared__ int32_t Vall[];
+  __shared__ unsigned long long s_state;   // {start of the workgroup's segment : 32 | requests of it handed out : 32}
+  __shared__ uint32_t s_lock;              // held by the wavefront that is claiming the next segment
   static_assert(GL == 8, "the group operations below are written for 8-lane groups (half a DPP row)");
-  const int lane = threadIdx.x, gl = lane & (GL - 1), gbase = lane & ~(GL - 1), gb4 = gbase << 2;
-  VT *V = reinterpret_cast<VT *>(Vall) + (lane / GL) * ring;
+  const int lane = threadIdx.x & 63, gl = lane & (GL - 1), gbase = lane & ~(GL - 1), gb4 = gbase << 2;
+  VT *V = reinterpret_cast<VT *>(Vall) + ((threadIdx.x >> 6) * (64 / GL) + lane / GL) * ring;
+  if (threadIdx.x == 0) s_state = (unsigned long long)seg, s_lock = 0u;   // (an exhausted segment: the first fetch claims one)
+  __syncthreads();
   const int mask = ring - 1, band_size = band * 2;
   constexpr int SL = PACKED ? 32 : (GL == 16 ? 8 : 16);  // codes per lane and snake iteration
   constexpr int PROBE = PACKED ? 16 : 8;                   // codes of a probe
@@ -552,6 +566,7 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
     // them to its groups as they come free.  What a wavefront holds back at the end of a launch is other wavefronts' idle time: alignment
     // kernels per c3 / c4s step with CHUNK 8: 45.5 / 123.8 ms, 16: 46.0 / 127.3, 64: 49.0 / 157.4 (c4s's last candidates are its longest);
     // the last 32 candidates per wavefront taken one by one again: 48.5 / 128.5 (the tail is then the old floor).
+    constexpr uint32_t RETRY = 0xFFFFFFFFu;   // "no chunk this time" (never a request number: n < 2^31)
     const bool fetching = phase == PH_FETCH;
     const uint64_t fw = ballot64(fetching);
     uint32_t na = 0;
@@ -563,11 +578,31 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
       const uint32_t avail = __builtin_amdgcn_readfirstlane(c_end - c_next);
       na = c_next + r;
       if (avail < cnt) {   // a new chunk; what is left of the old one goes out first
-        uint32_t got = 0;
-        if (lane == 0) got = atomicAdd(counter, CHUNK);
+        uint32_t got = RETRY;
+        if (lane == 0) {
+          unsigned long long o = atomicAdd(&s_state, (unsigned long long)CHUNK);   // (one LDS atomic: start and count of one and the same segment)
+          if ((uint32_t)o < seg) {
+            got = (uint32_t)(o >> 32) + (uint32_t)o;
+          } else if (atomicCAS(&s_lock, 0u, 1u) == 0u) {   // the segment is used up and nobody is fetching the next one yet
+            o = atomicAdd(&s_state, (unsigned long long)CHUNK);   // (under the lock: a wavefront may have installed one since the look above)
+            if ((uint32_t)o < seg) {
+              got = (uint32_t)(o >> 32) + (uint32_t)o;
+            } else {
+              got = atomicAdd(counter, seg);
+              atomicExch(&s_state, ((unsigned long long)got << 32) | CHUNK);
+            }
+            atomicExch(&s_lock, 0u);   // (LDS operations of a wavefront execute in order: the segment is in place before the lock opens)
+          }
+          // else: another wavefront of the workgroup is fetching the next segment; this one's idle groups ask again in the next iteration
+        }
         got = __builtin_amdgcn_readfirstlane(got);
-        if (r >= avail) na = got + (r - avail);
-        c_next = got + (cnt - avail), c_end = got + CHUNK;
+        if (got == RETRY) {
+          if (r >= avail) na = RETRY;
+          c_next = c_end = 0;
+        } else {
+          if (r >= avail) na = got + (r - avail);
+          c_next = got + (cnt - avail), c_end = got + CHUNK;
+        }
       } else {
         c_next += cnt;
       }
@@ -575,7 +610,9 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
     if (fetching) {
       iters = 0;
       na = (uint32_t)group_lane((int)na, gb4, 0);
-      if (na >= n) {
+      if (na == RETRY) {
+        // (stays in FETCH)
+      } else if (na >= n) {
         phase = PH_DONE;
       } else {
 #ifdef PGX_ALIGN_STATS
@@ -583,16 +620,17 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
 #endif
         a = redo_list ? redo_list[na] : na;
         const pgx_align_key key = keys[a];
-        if (PACKED) {
-          const uint64_t qg = roff[key.rid0] + key.q_off, tg = roff[key.rid1];
-          q = seq + (key.dir0 ? pack_stride * 4 : 0) + (qg >> 4) * 4, t = seq + (key.dir1 ? pack_stride * 4 : 0) + (tg >> 4) * 4;
-          qo = (uint32_t)(qg & 15), to = (uint32_t)(tg & 15);
+        const uint32_t len0 = rlen[key.rid0], len1 = rlen[key.rid1];
+        if (PACKED) {   // (pgx_pack.hip: [forward | reverse complement] of a read, each strand from a dword on)
+          q = seq + (roff[key.rid0] + (key.dir0 ? (len0 + 15u) >> 4 : 0u) + (key.q_off >> 4)) * 4;
+          t = seq + (roff[key.rid1] + (key.dir1 ? (len1 + 15u) >> 4 : 0u)) * 4;
+          qo = key.q_off & 15u, to = 0;
         } else {
           q = seq + roff[key.rid0] + key.q_off;
           t = seq + roff[key.rid1];
         }
-        q_len = (int)(rlen[key.rid0] - key.q_off);
-        t_len = (int)rlen[key.rid1];
+        q_len = (int)(len0 - key.q_off);
+        t_len = (int)len1;
         qs = key.dir0 ? 4 : 0, ts = key.dir1 ? 4 : 0;
         max_d = (int)(0.3 * (double)(q_len + t_len));  // DWmatch.c:96, one IEEE double multiply
         d = 0, best_m = -1, min_k = 0, max_k = 0, longest = 0;
@@ -808,6 +846,14 @@ __global__ __launch_bounds__(64) void k_align_ph(const uint8_t *__restrict__ seq
   }
 }
 
+// sort keys of an order list: the rank of the query read in the packs' layout, the request number as the value; *n_out = n
+__global__ void k_order_keys(const pgx_align_key *__restrict__ keys, uint32_t n, const uint32_t *__restrict__ prank, uint32_t *__restrict__ k,
+                             uint32_t *__restrict__ v, uint32_t *__restrict__ n_out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *n_out = n;
+  if (i < n) k[i] = prank[keys[i].rid0], v[i] = i;
+}
+
 // The 2-bit packs ahead of the first large launch: run_overlap calls this while the GPU would otherwise wait for the host's outer
 // table, so the first stage's k_pack2 (1.6 ms at 4.5 Gbases) is off the critical path; later stages find the packs in place
 // (pgx_pack.hip: they are kept with the database).
@@ -854,38 +900,76 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
     PGX_HIP(hipGetLastError());
     return;
   }
-  const size_t lds = (size_t)8 * ring * sizeof(uint16_t);
-  const unsigned per_cu = (unsigned)std::min<size_t>(32, (160u << 10) / lds);   // 32 = all the wavefronts a CU holds; alignment kernels per c3 step
-                                                                               // with the chunked work counter: 16 -> 65.3 ms, 20 -> 55.9, 24 -> 50.1, 28 -> 46.3, 32 -> 43.7
-  const unsigned grid = (unsigned)std::min<size_t>((n + 7) / 8, (size_t)ctx().num_cu * per_cu);
-  // The packs are built by the first launch of at least PGX_ALIGN_PACKED_MIN alignments (default 100,000; 4.5 GB of seqdb: 1.6 ms) and
-  // serve every later launch on this database; < 0: never.
+  // k_align_ph: workgroups of NW wavefronts (a V ring of `ring` u16 per 8-lane group), as many as give a CU its 32 wavefronts
+  const size_t lds_wave = (size_t)8 * ring * sizeof(uint16_t);
+  const unsigned waves_cu = (unsigned)std::min<size_t>(32, (158u << 10) / lds_wave);   // 32 = all the wavefronts a CU holds; alignment kernels per c3 step
+                                                                                       // with the chunked work counter: 16 -> 65.3 ms, 20 -> 55.9, 24 -> 50.1, 28 -> 46.3, 32 -> 43.7
+  const long nw_env = getenv("PGX_ALIGN_NW") ? atol(getenv("PGX_ALIGN_NW")) : 0;
+  unsigned NW = 1;   // the widest workgroup that does not cost the CU wavefronts (ring 256: 16 x 2; ring 512: 19 fit -> 16 x 1)
+  for (unsigned c = 16; c >= 1; c >>= 1)
+    if (c <= waves_cu && (waves_cu / c) * c > (waves_cu / NW) * NW) NW = c;
+  if (waves_cu >= 16 && (waves_cu / 16) * 16 >= (waves_cu / NW) * NW) NW = 16;
+  if (nw_env >= 1 && nw_env <= 16 && (unsigned)nw_env <= waves_cu) NW = (unsigned)nw_env;
+  const size_t lds = lds_wave * NW;
+  const unsigned wg_cu = waves_cu / NW;
+  // the packs are built by the first launch of at least PGX_ALIGN_PACKED_MIN alignments (default 100,000) and serve every later launch
+  // on this database; < 0: never.
   const char *pm = getenv("PGX_ALIGN_PACKED_MIN");
   const long packed_min = pm ? atol(pm) : 100000;
   const uint32_t *packs = (packed_min >= 0 && ((long)n >= packed_min || seq_packs_valid(db))) ? seq_packs(db) : nullptr;
+  // segment = the run of requests a workgroup's wavefronts share (a multiple of the chunk of 8): long enough that the workgroup stays at
+  // one place of the list, short enough that the last segments of a launch do not leave the other CUs idle
+  const size_t n_wg = (size_t)ctx().num_cu * wg_cu;
+  auto segment = [&](size_t cnt) {
+    const long se = getenv("PGX_ALIGN_SEG") ? atol(getenv("PGX_ALIGN_SEG")) : 0;
+    size_t sg = se > 0 ? (size_t)se : std::min<size_t>(512, std::max<size_t>(8 * NW, cnt / (n_wg * 16)));
+    return (uint32_t)((sg + 7) & ~(size_t)7);
+  };
+  const uint32_t seg = segment(n);
+  const unsigned grid = (unsigned)std::min<size_t>((n + seg - 1) / seg, n_wg);
   if (packs) {
     const uint32_t iter_limit = getenv("PGX_ALIGN_ITER_LIMIT") ? (uint32_t)atol(getenv("PGX_ALIGN_ITER_LIMIT")) : 2500u;   // (0: no hand-on of stragglers)
     // escalation block: [0] stragglers handed on, [1] candidates that touch a read without 2-bit codes, [2] the byte-wise launch's work
-    // counter, [4 .. 4 + n) the stragglers, [4 + n .. 4 + 2 n) the others
+    // counter, [3] the number of requests (for the order list), [4 .. 4 + n) the stragglers, [4 + n .. 4 + 2 n) the others
     uint32_t *esc = ws<uint32_t>("align.esc", 2 * n + 4);
-    PGX_HIP(hipMemsetAsync(esc, 0, 4 * sizeof(uint32_t), st));
-    hipLaunchKernelGGL((k_align_ph<8, uint16_t, true>), dim3(grid), dim3(64), lds, st, reinterpret_cast<const uint8_t *>(packs), db->d_roff.p,
-                       db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter, (const uint32_t *)nullptr, (const uint32_t *)nullptr, esc,
-                       esc + 4, db->d_nflag.p, seq_pack_stride(db), iter_limit);
+    PGX_HIP(hipMemsetAsync(esc, 0, 3 * sizeof(uint32_t), st));
+    // The requests in the order of the packs' layout (round 6): sorted by the rank of the query read -- stable, so the requests of one read
+    // stay in the walk's order -- when the layout follows the locus keys; results are addressed by request number, nothing downstream
+    // sees the order.  15.7 M requests: ~1 ms of a 150-190 ms launch.
+    const uint32_t *order = nullptr;
+    const long order_min = getenv("PGX_ALIGN_ORDER_MIN") ? atol(getenv("PGX_ALIGN_ORDER_MIN")) : 200000;
+    if (db->locus_ordered && order_min >= 0 && (long)n >= order_min) {
+      const uint32_t nn = (uint32_t)n;
+      uint32_t *k_in = ws<uint32_t>("align.ord_kin", n), *k_out = ws<uint32_t>("align.ord_kout", n), *v_in = ws<uint32_t>("align.ord_vin", n),
+               *v_out = ws<uint32_t>("align.ord_vout", n);
+      hipLaunchKernelGGL(k_order_keys, dim3((nn + 255) / 256), dim3(256), 0, st, d_keys, nn, db->d_prank.p, k_in, v_in, esc + 3);
+      int bits = 1;
+      while (bits < 32 && (db->rlen_by_rid.size() >> bits)) ++bits;
+      size_t tb = 0;
+      PGX_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, k_in, k_out, v_in, v_out, (int)nn, 0, bits, st));
+      void *tmp = ws_raw("align.ord_tmp", tb + 256);
+      PGX_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tb, k_in, k_out, v_in, v_out, (int)nn, 0, bits, st));
+      order = v_out;
+    }
+    hipLaunchKernelGGL((k_align_ph<8, uint16_t, true>), dim3(grid), dim3(64 * NW), lds, st, reinterpret_cast<const uint8_t *>(packs), db->d_poff.p,
+                       db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, counter, order ? esc + 3 : (const uint32_t *)nullptr, order, esc,
+                       esc + 4, db->d_nflag.p, seg, iter_limit);
     // candidates on reads with ambiguous bases: the same phase machine on the seqdb bytes, eight per wavefront, from their list (round 3 gave
     // each a wavefront of its own through k_align1_list: 5 % of the reads flagged = +64 % alignment time at c3).  Only when the database
     // holds such a read at all.
-    if (db->n_flagged_reads)
-      hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3((unsigned)std::min<size_t>(n / 64 + 64, (size_t)ctx().num_cu * per_cu)), dim3(64), lds, st,
+    if (db->n_flagged_reads) {
+      const uint32_t seg2 = segment(n / 16 + 1);
+      hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3((unsigned)std::min<size_t>(n / (64 * NW) + 8, n_wg)), dim3(64 * NW), lds, st,
                          db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out, esc + 2, esc + 1, esc + 4 + n, esc, esc + 4,
-                         (const uint32_t *)nullptr, (size_t)0, iter_limit);
+                         (const uint32_t *)nullptr, seg2, iter_limit);
+    }
     // the stragglers of either launch, a wavefront per candidate, from the list
     hipLaunchKernelGGL(k_align1_list, dim3((unsigned)std::min<size_t>(std::max<size_t>(n / 256, 256), (size_t)ctx().num_cu * 32)), dim3(64),
                        ring * sizeof(int32_t), st, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, esc, esc + 4, band, ring, d_out);
   } else {
-    hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid), dim3(64), lds, st, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys,
+    hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid), dim3(64 * NW), lds, st, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys,
                        (uint32_t)n, band, ring, d_out, counter, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                       (uint32_t *)nullptr, (const uint32_t *)nullptr, (size_t)0, 0u);
+                       (uint32_t *)nullptr, (const uint32_t *)nullptr, seg, 0u);
   }
   PGX_HIP(hipGetLastError());
 }

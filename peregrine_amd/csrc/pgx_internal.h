@@ -162,8 +162,10 @@ struct pgx_seqdb {
   // the packed alignment kernel's view of the reads (pgx_pack.hip): a cache of the immutable seqdb bytes, built on first use
   mutable pgx::DevBuf<uint32_t> d_pack;          // 2-bit packs of the seqdb, both strands
   mutable pgx::DevBuf<uint32_t> d_nflag;         // by rid: the read holds a byte that has no 2-bit code (an ambiguous base)
-  mutable pgx::DevBuf<uint64_t> d_roff_sorted;   // read offsets ascending + their rids (position -> read, for d_nflag)
-  mutable pgx::DevBuf<uint32_t> d_rid_sorted;
+  mutable pgx::DevBuf<uint64_t> d_poff;          // by rid: dword index of the read's forward strand in d_pack (its reverse complement follows)
+  mutable pgx::DevBuf<uint32_t> d_prank;         // by rid: the read's rank in the packs' layout (the alignment launches take their requests in this order)
+  mutable pgx::DevBuf<uint64_t> d_locus_key;     // by rid, only until the packs are built: smallest top-level shimmer hash (pgx_pack.hip)
+  mutable bool locus_key_filled = false, locus_ordered = false;   // (ordered: the packs' reads are laid out by locus key, not in file order)
   mutable bool packs_built = false, packs_failed = false;   // (failed: no HBM for them -- the byte-wise kernels serve this database)
   mutable uint32_t n_flagged_reads = 0;                     // reads marked in d_nflag (known once the packs are built)
   pgx::DevBuf<uint64_t> d_roff;    // indexed by rid
@@ -207,11 +209,14 @@ void dev_count(const pgx_mm128 *d_in, size_t n, int kmer_bits, DevBuf<pgx_mm_cou
 void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int band, pgx_match *d_out,
                int tail_batch = 0);   // tail_batch: 1 = the second request batch of a stage, 2 = a later one (mostly hard candidates: pgx_align.hip)
 void dev_align_prepare(const pgx_seqdb *db);   // the database's 2-bit packs, ahead of the first large launch (no-op once they exist)
-// the 2-bit packs of a read database (pgx_pack.hip: [pack of the low nibbles | pack of the high nibbles], seq_pack_stride dwords
-// each; d_nflag marks the reads with bytes that have no 2-bit code): built on first use, kept with the database; nullptr: no HBM
+// the 2-bit packs of a read database (pgx_pack.hip: read by read, [forward strand | reverse complement] at dword d_poff[rid]; d_nflag
+// marks the reads with bytes that have no 2-bit code): built on first use, kept with the database; nullptr: no HBM
 const uint32_t *seq_packs(const pgx_seqdb *db);
-size_t seq_pack_stride(const pgx_seqdb *db);
 bool seq_packs_valid(const pgx_seqdb *db);
+// the locus key of the reads, gathered by the overlap stage's join before the first seq_packs() (no-ops once the packs exist)
+uint64_t *seq_locus_key_buffer(const pgx_seqdb *db);
+void locus_key_add_mm(const pgx_seqdb *db, const pgx_mm128 *d_mm, size_t n);
+void locus_key_add_records(const pgx_seqdb *db, const uint64_t *d_key0, const uint64_t *d_y0, size_t n);
 
 // Large host arrays.  Never value-initialised (they are about to be overwritten); from 16 MiB up they are pooled anonymous
 // mappings advised to use transparent huge pages, which the allocator would not do for us (THP is in "madvise" mode on
@@ -351,7 +356,8 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
                      size_t n_counts, const PairParams &pp, PairTables &out, unsigned flags = 0,
                      const pgx_mm128 *d_mmers = nullptr, const pgx_mm_count *d_counts = nullptr,  // d_*: the same lists, already on the device
                      DevicePairs *keep = nullptr,   // keep: the sorted records stay on the device too
-                     const EarlyFn &early = nullptr);
+                     const EarlyFn &early = nullptr,
+                     const pgx_seqdb *locus_db = nullptr);   // locus_db: its packs' locus keys are gathered from the lists on the way (pgx_pack.hip)
 // ---- multi-GPU hand-over: counts all-gathered, pair records routed to their owner chunk -------------------------
 // prepare: aggregate ALL chunks' counts, flag the kept shimmers of THIS index chunk's list (both on the device); returns the index
 // of the first shimmer with lower <= count < upper (-1: none).  scatter: the records of every adjacent kept pair from `start` on
@@ -362,7 +368,7 @@ int64_t dev_pairs_prepare(const uint32_t *d_rlen, uint32_t n_rid, const pgx_mm12
                           size_t n_counts, uint32_t lower, uint32_t upper);
 void dev_pairs_scatter(const uint32_t *d_rlen, uint32_t T, int64_t start, const pgx_pair_rec **d_send, uint64_t *counts);
 void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out, DevicePairs *keep_dev, unsigned flags = 0,
-                            const EarlyFn &early = nullptr);
+                            const EarlyFn &early = nullptr, const pgx_seqdb *locus_db = nullptr);
 void pairs_fetch_records(const DevicePairs &dp, PairTables &out);  // the lazily kept records, to the host tables
 
 // The greedy walk over the visit list (visit_bids: the join's bucket ids in visit order) on the GPU; the records go to the

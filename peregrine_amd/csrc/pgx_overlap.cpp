@@ -1659,12 +1659,12 @@ void overlap_front(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx
   EarlyFn early;
   if (early_outer) early = [scratch, &pt](EarlyGroups &&g) { scratch->pre.start(std::move(g), pt.n_rec); };
   if (d_recs)
-    dev_pairs_from_records(d_recs, n_recs, pt, gpu_replay ? &dpairs : nullptr, jflags, early);
+    dev_pairs_from_records(d_recs, n_recs, pt, gpu_replay ? &dpairs : nullptr, jflags, early, db);
   else
     dev_build_pairs(db->d_rlen.p, mmers, n_mm, counts, n_counts,
                     PairParams{(uint32_t)p->total_chunk, (uint32_t)p->mychunk, (uint32_t)p->mc_lower, (uint32_t)p->mc_upper,
                                (uint32_t)db->rlen_by_rid.size()},
-                    pt, jflags, dev ? dev->d_top : nullptr, dev ? dev->d_mc : nullptr, gpu_replay ? &dpairs : nullptr, early);
+                    pt, jflags, dev ? dev->d_top : nullptr, dev ? dev->d_mc : nullptr, gpu_replay ? &dpairs : nullptr, early, db);
   pgx::sync();
   s.n_pair_records = pt.n_rec;
   if (gpu_replay_env < 0) gpu_replay = pt.n_rec >= gpu_replay_min;

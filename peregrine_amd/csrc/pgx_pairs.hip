@@ -480,7 +480,7 @@ static void early_groups(const PairRecs &R, Tmp &tmp, const EarlyFn &early);
 
 void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts,
                      const PairParams &pp, PairTables &out, unsigned flags, const pgx_mm128 *d_mmers, const pgx_mm_count *d_counts,
-                     DevicePairs *keep_dev, const EarlyFn &early) {
+                     DevicePairs *keep_dev, const EarlyFn &early, const pgx_seqdb *locus_db) {
   out = PairTables();
   if (keep_dev) *keep_dev = DevicePairs();
   if (n_mm == 0) return;
@@ -500,6 +500,7 @@ void dev_build_pairs(const uint32_t *d_rlen, const pgx_mm128 *mmers, size_t n_mm
   DevBuf<pgx_mm128> mm_own(d_mmers ? 0 : n);
   if (!d_mmers) mm_own.upload(mmers, n);
   const pgx_mm128 *mm_dev = d_mmers ? d_mmers : mm_own.p;
+  if (locus_db) locus_key_add_mm(locus_db, mm_dev, n);   // (only before the database's packs exist)
   DevBuf<uint8_t> keep;
   DevBuf<uint32_t> d_misc;
   keep_flags(mm_dev, n, ct, pp, d_rlen, keep, d_misc);
@@ -650,7 +651,7 @@ void pairs_fetch_records(const DevicePairs &dp, PairTables &out) {
 }
 
 void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out, DevicePairs *keep_dev, unsigned flags,
-                            const EarlyFn &early) {
+                            const EarlyFn &early, const pgx_seqdb *locus_db) {
   out = PairTables();
   if (keep_dev) *keep_dev = DevicePairs();
   if (n == 0) return;
@@ -664,6 +665,7 @@ void dev_pairs_from_records(const pgx_pair_rec *d_rec, size_t n, PairTables &out
   hipLaunchKernelGGL(k_unpack_rec, dim3(cdiv(nr, 256)), dim3(256), 0, ctx().stream, d_rec, nr, R.key0.p, R.key1.p, R.y0.p, R.dir.p,
                      R.npos.p);
   out.n_rec = nr;
+  if (locus_db) locus_key_add_records(locus_db, R.key0.p, R.y0.p, nr);
   early_groups(R, tmp, early);
   bucketize(R, flags, out, keep_dev, tmp);
 }

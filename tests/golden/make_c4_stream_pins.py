@@ -54,6 +54,9 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "c4_stream_pins.json"))
     ap.add_argument("--scratch", default="/dev/shm")
     ap.add_argument("--keep-files", action="store_true", help="leave the scratch directory (seqdb, index and overlap files) in place and print its path")
+    ap.add_argument("--only", default="", help="comma-separated overlap chunks to pin (default: all); the index stage always runs every chunk")
+    ap.add_argument("--procs", type=int, default=0, help="reference overlap processes side by side (default: one per pinned chunk); a process at -l 1 holds "
+                                                         "~13 GB of lists and tables at full size: price the host's memory first")
     a = ap.parse_args()
     import oracle_util as U
     from peregrine_amd import formats, simreads
@@ -82,18 +85,28 @@ def main():
             list(ex.map(lambda c: U.ref_run("shmr_index", "-p", pre, "-t", CH, "-c", c, "-m", 0, "-l", lv, "-o", os.path.join(d, "ix")), range(1, CH + 1)))
             print(f"[pins +{time.perf_counter() - t_start:.0f} s] reference index chunks done", flush=True)
             # ---- 3. the reference's overlap chunks
+            t_index = time.perf_counter() - t_start
             t0 = time.perf_counter()
-            list(ex.map(lambda c: U.ref_run("shmr_overlap", "-p", pre, "-l", os.path.join(d, "ix-L%d" % lv), "-t", CH, "-c", c, "-M", sp["mc_upper"],
-                                            "-o", os.path.join(d, "ov.%02d" % c)), range(1, CH + 1)))
+            chunks = [int(x) for x in a.only.split(",") if x] or list(range(1, CH + 1))
+            procs = a.procs or len(chunks)
+            mem_kb = {l.split(":")[0]: int(l.split()[1]) for l in open("/proc/meminfo") if l.split(":")[0] in ("MemTotal", "MemAvailable")}
+            print(f"[pins] host memory: {mem_kb.get('MemTotal', 0) / 1e6:.0f} GB total, {mem_kb.get('MemAvailable', 0) / 1e6:.0f} GB available; {procs} overlap "
+                  f"processes side by side over chunks {chunks}", flush=True)
+            with cf.ThreadPoolExecutor(procs) as ex2:
+                secs = list(ex2.map(lambda c: (time.perf_counter(), U.ref_run("shmr_overlap", "-p", pre, "-l", os.path.join(d, "ix-L%d" % lv), "-t", CH, "-c", c, "-M",
+                                                                          sp["mc_upper"], "-o", os.path.join(d, "ov.%02d" % c)), time.perf_counter()), chunks))
+            secs = [t1 - t0_ for t0_, _, t1 in secs]
             t_ovlp = time.perf_counter() - t0
-            print(f"[pins +{time.perf_counter() - t_start:.0f} s] reference overlap chunks done ({t_ovlp:.0f} s, {CH} processes side by side)", flush=True)
+            print(f"[pins +{time.perf_counter() - t_start:.0f} s] reference overlap chunks done ({t_ovlp:.0f} s, {procs} processes side by side)", flush=True)
             # ---- 4. the hashes
-            shas = list(ex.map(lambda c: formats.masked_stream_sha256(os.path.join(d, "ov.%02d" % c)), range(1, CH + 1)))
+            shas = list(ex.map(lambda c: formats.masked_stream_sha256(os.path.join(d, "ov.%02d" % c)), chunks))
             seqdb_sha = sha_job.result()
-        streams = [{"chunk": "%d of %d" % (c, CH), "records": os.path.getsize(os.path.join(d, "ov.%02d" % c)) // 64, "masked_sha256": shas[c - 1]} for c in range(1, CH + 1)]
+        streams = [{"chunk": "%d of %d" % (c, CH), "records": os.path.getsize(os.path.join(d, "ov.%02d" % c)) // 64, "masked_sha256": shas[i], "reference_s": secs[i]}
+                   for i, c in enumerate(chunks)]
         entry = {"workload": a.workload, "genome_mb": a.genome_mb or None, "chunks": CH, "levels": lv, "mc_upper": sp["mc_upper"],
                  "reads": int(len(rlen)), "seqdb_bytes": int(total), "read_set_hash": read_set_hash, "seqdb_sha256": seqdb_sha, "streams": streams,
-                 "reference_overlap_leg_s": t_ovlp,
+                 "reference_overlap_leg_s": t_ovlp, "reference_overlap_processes": procs, "reference_index_and_files_s": t_index,
+                 "host_mem_total_gb": mem_kb.get("MemTotal", 0) / 1e6, "host_cores": os.cpu_count(),
                  "made_by": "tests/golden/make_c4_stream_pins.py: oracle/_ref/shmr_index + shmr_overlap -t %d -c 1..%d -M %d on the files written from the "
                             "device-resident read set; masked = bytes 27 and 60..63 of every record zeroed" % (CH, CH, sp["mc_upper"])}
         key = a.workload if not a.genome_mb else "%s_%gMb" % (a.workload, a.genome_mb)

@@ -849,6 +849,13 @@ ALIGN_VARIANTS = [   # (id, environment, read set): every form dev_align dispatc
     ("ph8-packed-ambiguous", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0"), "withN"),   # ... reads with N: handed on to the byte-wise launch
     ("ph8-packed-stragglers", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_ITER_LIMIT="150"), "small"),   # most candidates outlast
                                                                                     # 150 iterations: handed on to k_align1_list, a wavefront each
+    ("ph8-packed-ordered", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_ORDER_MIN="0"), "small"),   # round 6: the packs of this database are laid
+                                                                                    # out by locus key (its overlap stage ran first) and the requests are taken in layout order
+    ("ph8-packed-ordered-nw4", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_ORDER_MIN="0", PGX_ALIGN_NW="4", PGX_ALIGN_SEG="24"), "small"),   # narrower
+                                                                                    # workgroups, a segment of three chunks: every segment boundary crossed many times
+    ("ph8-packed-nw1", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_NW="1", PGX_ALIGN_SEG="8"), "small"),   # rounds 2-5's form: a wavefront per workgroup
+    ("ph8-packed-file-order", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_ORDER_MIN="0"), "small3"),   # a database that never saw an overlap stage:
+                                                                                    # packs in the order of the seqdb file, no order list
     ("ph8-bytes", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="-1"), "small2"),  # k_align_ph<8, u16> on the seqdb bytes (a database without packs)
     ("one-per-wave", dict(PGX_ALIGN_SMALL="1000000000"), "small"),                  # k_align1 on a LARGE launch
     ("long-reads-int32", dict(PGX_ALIGN_SMALL="0"), "long"),                        # a 100 kb read in the set: k_align4<8, int32>
@@ -872,6 +879,8 @@ def variant_sets():
         want = {band: _oracle_matches(db, keys, band) for band in (100, 20)}
         rep = -(-20000 // len(keys))               # a launch of >= 20 k keys: beyond every small-launch threshold
         sets[name] = (db, rdb, np.tile(keys, rep), {band: np.tile(w, rep) for band, w in want.items()})
+    db3 = simreads.make_workload("small")          # the same reads once more, aligned without an overlap stage before (no locus keys)
+    sets["small3"] = (db3, ResidentDB(db3, 0), sets["small"][2], sets["small"][3])
     yield sets
     for _, rdb, _, _ in sets.values():
         rdb.close()
