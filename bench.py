@@ -73,13 +73,14 @@ def parse():
                     help="one-chunk workloads: this fraction of the reads gets 1-3 ambiguous bases (both strands' nibbles zeroed, seeded): the index "
                          "stage then takes those reads run by run (pgx_sketch_n.hip), the packed alignment kernel hands their candidates on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline", default=None, choices=("full", "sample"),
+    ap.add_argument("--cpu-baseline", default=None, choices=("full", "sample", "whole_chunks"),
                     help="one-chunk workloads -- full (default): the reference binaries on the WHOLE workload: one process on one core (its "
                          "ovlp_t stream is compared field by field with the timed GPU output) and N processes over N chunks for N in 24, 64, "
                          "128; sample: a 10 Mb x 30x set of the same recipe (count check only).  c4 family -- full: the reference as 24 "
                          "processes over 24 index chunks, then 24 overlap chunks, of the WHOLE 93 Gbases; sample (default): a bounded "
                          "sample of it, 24 processes over chunks 1..24 of 192; either way the streams of two of those chunks are compared "
-                         "field by field with the GPU's")
+                         "field by field with the GPU's; whole_chunks (default of c5): the reference indexes all of the job's chunks, then runs 8 of "
+                         "its overlap chunks whole, their streams hashed and compared with the GPU's")
     ap.add_argument("--end-to-end", action="store_true",
                     help="c4 family: after the timed steps run the job's CHUNKS index + CHUNKS overlap commands through bin/native/* attached to a "
                          "`pgx_cli serve` process, files on /dev/shm (file -> kernels -> D2H -> file): `gpu_end_to_end` in the line")
@@ -362,15 +363,19 @@ def _run_many(n_workers, jobs):
     return time.perf_counter() - t0
 
 
-def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, job_chunks, gpu_index_files, job_lists):
+def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, job_chunks, gpu_index_files, job_lists, stream_report=None, before_timing=None):
     """c4 family (one read set, CHUNKS index + overlap chunks): the REAL reference (oracle/_ref) on this box's host cores, on the same
     bytes (the device-resident seqdb written to files), 24 processes at a time (the reference's own practical ceiling,
     /root/reference/README.md:127-137):
       full   -- T = 24: 24 index chunks, then 24 overlap chunks of the WHOLE read set (what VERDICT r3 task 2 asks for);
       sample -- T = 192: index chunks 1..24 of 192 (1/8 of the reads; timed for the index rate) and overlap chunks 1..24 of 192 (1/8 of
                 the first keys) over the 8 index-chunk files of the job as the GPU wrote them (byte-identical to the reference's own:
-                tests/test_gpu_pipeline.py; shmr_overlap globs whatever index chunks exist, src/shmr_overlap.c:359-384).
-    Either way the ovlp_t streams of overlap chunks 1 and 2 of T are compared FIELD BY FIELD, in order, with the GPU's stream for the
+                tests/test_gpu_pipeline.py; shmr_overlap globs whatever index chunks exist, src/shmr_overlap.c:359-384);
+      whole_chunks -- T = the job's own chunking (configs[4]: 24): the reference indexes all T chunks, then runs SOME of the job's overlap chunks
+                whole (PGX_BENCH_CPU_CHUNKS, default 8 of them spread over 1..T, one process each side by side: a reference process at l = 1
+                holds ~13 GB of lists and tables at full size); their streams are hashed like the GPU's (`reference_streams`: what
+                tests/golden/c4_stream_pins.json pins) and compared with the hashed GPU step by record count + masked SHA-256.
+    full / sample: the ovlp_t streams of overlap chunks 1 and 2 of T are compared FIELD BY FIELD, in order, with the GPU's stream for the
     same (T, c) over the same index lists -> records_match_gpu.  Checker / baseline only: nothing here is on the product path."""
     import shutil
     import torch
@@ -395,9 +400,21 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
                 P = max(1, min(P, fit, 24))
         except Exception:
             P = min(P, 24)
-    T = P if mode == "full" else 192
+    mem = {l.split(":")[0]: int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.split(":")[0] in ("MemTotal", "MemAvailable")}
+    procs_limit_reason = ("24 = the reference's own practical ceiling (README.md:127-137)" if P == 24 and not os.environ.get("PGX_BENCH_CPU_PROCS")
+                          else "PGX_BENCH_CPU_PROCS / host cores / host memory")
+    T = P if mode == "full" else job_chunks if mode == "whole_chunks" else 192
     cs = list(range(1, min(T, P) + 1))
-    need = int(total * 1.02) + int(db.n_bases * (0.12 if mode == "full" else 0.03)) + (8 << 30)
+    ov_cs, P_ov = cs, P
+    if mode == "whole_chunks":
+        cs = list(range(1, T + 1))
+        dflt = sorted({1, 2} | {1 + (i * (T - 1)) // 7 for i in range(8)})[:8] if T > 8 else list(range(1, T + 1))
+        ov_cs = [int(v) for v in os.environ.get("PGX_BENCH_CPU_CHUNKS", "").split(",") if v] or dflt
+        per_proc = 13e9 * db.n_bases / 93.3e9      # (measured at full size: 12.4 GB at l = 1, T = 24; ~13 GB at l = 2, T = 8)
+        fit = int((mem.get("MemAvailable", 0) - total * 1.1 - 32e9) // max(per_proc, 1e8))
+        P_ov = max(1, min(len(ov_cs), ncpu, fit))
+        procs_limit_reason = "one process per compared chunk (%d), host memory allows %d at ~%.0f GB each" % (len(ov_cs), fit, per_proc / 1e9)
+    need = int(total * 1.02) + int(db.n_bases * (0.12 if mode == "full" else 0.2 if mode == "whole_chunks" and levels == 1 else 0.03)) + (8 << 30)
     base = _scratch_dir(need)
     if base is None:
         return {"value": None, "unit": "overlaps/s", "cores": 0, "kind": "none", "sample": f"no scratch directory with {need >> 30} GiB free"}
@@ -408,8 +425,10 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
         simreads.write_seqdb_from_device(pre, seq, total, db.rid, db.rlen, db.roff)
         t_files = time.perf_counter() - t0
         log(f"cpu baseline ({mode}): seqdb files written in {t_files:.1f} s")
+        if before_timing is not None:     # (nothing of this process runs beside the reference while it is timed -- the seqdb's SHA-256 thread ends here)
+            before_timing()
         lv = "L%d" % levels
-        if mode == "full":      # the reference indexes everything itself
+        if mode in ("full", "whole_chunks"):      # the reference indexes everything itself
             t_index = _run_many(P, [lambda c=c: U.ref_run("shmr_index", "-p", pre, "-t", T, "-c", c, "-m", 0, "-l", levels, "-o", os.path.join(d, "ix")) for c in cs])
             lpre, index_bases, index_chunking = os.path.join(d, "ix-" + lv), db.n_bases, T
         else:                   # the reference indexes 24 of 192 chunks (timed); the overlap sample reads the job's own index-chunk files
@@ -418,8 +437,10 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
             gpu_index_files(os.path.join(d, "ix"))
             lpre, index_chunking = os.path.join(d, "ix-" + lv), job_chunks
         log(f"cpu baseline: reference index leg {t_index:.1f} s")
-        t_ovlp = _run_many(P, [lambda c=c: U.ref_run("shmr_overlap", "-p", pre, "-l", lpre, "-t", T, "-c", c, "-M", mc_upper, "-o", os.path.join(d, "ov.%03d" % c)) for c in cs])
-        log(f"cpu baseline: reference overlap leg {t_ovlp:.1f} s")
+        t_ovlp = _run_many(P_ov, [lambda c=c: U.ref_run("shmr_overlap", "-p", pre, "-l", lpre, "-t", T, "-c", c, "-M", mc_upper, "-o", os.path.join(d, "ov.%03d" % c)) for c in ov_cs])
+        log(f"cpu baseline: reference overlap leg {t_ovlp:.1f} s ({P_ov} processes over chunks {ov_cs if mode == 'whole_chunks' else '1..%d' % len(ov_cs)} of {T})")
+        if mode == "whole_chunks":
+            return _whole_chunks_result(d, lv, T, cs, ov_cs, P, P_ov, t_index, t_ovlp, t_files, db, tag, ncpu, mem, procs_limit_reason, stream_report, job_lists, formats)
         # ---- the GPU on the same (T, c), same index chunking, for the first two chunks: field-for-field compare
         dev = torch.device("cuda", torch.cuda.current_device())
         if index_chunking == job_chunks and job_lists.get("mm") is not None:
@@ -470,6 +491,7 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
                           f"then over overlap chunks 1..24 of 192 (1/8 of the first keys; each process still loads all shimmer / count files and scans "
                           f"the whole list, as every reference overlap chunk does)") + f"; raw ovlp_t records / wall time of both stages; host has {ncpu} usable cores",
                "mode": mode, "chunking": T, "chunks_run": len(cs), "fraction_of_job": frac,
+               "host_ram_gb": mem.get("MemTotal", 0) / 1e9, "host_ram_available_gb": mem.get("MemAvailable", 0) / 1e9, "procs_limit_reason": procs_limit_reason,
                "index_s": t_index, "overlap_s": t_ovlp, "records": int(raw), "unique_pairs": uniq,
                "index_bases_per_s": index_bases / t_index, "overlap_records_per_s": raw / t_ovlp,
                "unique_pairs_per_s": uniq / (t_index + t_ovlp) if uniq else None,
@@ -481,6 +503,37 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def _whole_chunks_result(d, lv, T, cs, ov_cs, P, P_ov, t_index, t_ovlp, t_files, db, tag, ncpu, mem, procs_limit_reason, stream_report, job_lists, formats):
+    """mode whole_chunks of cpu_baseline_chunked: the reference ran SOME of the job's own overlap chunks whole (after indexing all T chunks itself)"""
+    import concurrent.futures as cf
+    with cf.ThreadPoolExecutor(8) as ex:
+        shas = list(ex.map(lambda c: formats.masked_stream_sha256(os.path.join(d, "ov.%03d" % c)), ov_cs))
+    ref_streams = [{"chunk": "%d of %d" % (c, T), "records": os.path.getsize(os.path.join(d, "ov.%03d" % c)) // 64, "masked_sha256": shas[i]} for i, c in enumerate(ov_cs)]
+    gpu = {r["chunk"]: r for r in stream_report or []}
+    compared = [{"chunk": r["chunk"], "records": r["records"],
+                 "equal": bool(r["chunk"] in gpu and gpu[r["chunk"]]["records"] == r["records"] and gpu[r["chunk"]]["masked_sha256"] == r["masked_sha256"])} for r in ref_streams]
+    same_index = None
+    if job_lists.get("mm") is not None:      # the job's own L lists (all chunks, chunk order) against the reference's first chunk file
+        n1 = os.path.getsize(os.path.join(d, "ix-%s-01-of-%02d.dat" % (lv, T))) // 16
+        got = job_lists["mm"][:n1 * 16].cpu().numpy().view(formats.MM_DTYPE)
+        same_index = bool(np.array_equal(got, formats.read_mmlist(os.path.join(d, "ix-%s-01-of-%02d.dat" % (lv, T)))))
+    raw = sum(r["records"] for r in ref_streams)
+    k = len(ov_cs)
+    log(f"cpu baseline: reference streams of chunks {ov_cs} hashed; equal to the GPU's: {[c['equal'] for c in compared]}")
+    return {"value": raw / (t_index * k / T + t_ovlp), "unit": "overlaps/s", "cores": P, "kind": "reference",
+            "sample": (f"{k} WHOLE overlap chunks ({ov_cs} of {T}) of {tag} ({db.n_reads} reads, {db.n_bases} bases) after the reference indexed all {T} chunks itself "
+                       f"({P} processes); {P_ov} overlap processes side by side; value = their raw ovlp_t records / (index time x {k}/{T} + overlap wall time); "
+                       f"host has {ncpu} usable cores"),
+            "mode": "whole_chunks", "chunking": T, "chunks_run": k, "overlap_chunks": ov_cs, "overlap_processes": P_ov, "index_processes": P, "fraction_of_job": k / T,
+            "host_ram_gb": mem.get("MemTotal", 0) / 1e9, "host_ram_available_gb": mem.get("MemAvailable", 0) / 1e9, "procs_limit_reason": procs_limit_reason,
+            "index_s": t_index, "overlap_s": t_ovlp, "records": int(raw), "unique_pairs": None, "index_bases_per_s": db.n_bases / t_index,
+            "overlap_records_per_s": raw / t_ovlp, "unique_pairs_per_s": None, "seqdb_files_written_s": t_files, "one_core": None,
+            "records_match_gpu": bool(compared and all(c["equal"] for c in compared)), "records_compared": compared,
+            "index_list_chunk1_equals_reference": same_index, "reference_streams": ref_streams,
+            "records_match_gpu_means": "record count and SHA-256 (padding bytes 27, 60..63 zeroed) of the reference's stream of each of these chunks of the JOB's own "
+                                       "chunking equal the GPU's stream of the hashed step (whose checksums equal every timed step's)"}
 
 
 def cpu_baseline_sample(sample):
@@ -1045,21 +1098,30 @@ def main():
                 # The honest leg is the WHOLE workload (24 processes over 24 + 24 chunks: ~12-14 min at full size); it is the default where the
                 # command's time budget allows (PGX_BENCH_BUDGET_S, default 1,620 s of the driver's 1,800), else the bounded sample -- and the line says which
                 mode = a.cpu_baseline
+                fallback_reason = None
                 if mode is None:
-                    need = 900.0 * (db.n_bases / 93.3e9) + 60
+                    whole = "whole_chunks" if sp["levels"] == 1 else "full"
+                    need = (1300.0 if whole == "whole_chunks" else 900.0) * (db.n_bases / 93.3e9) + 60
                     left = float(os.environ.get("PGX_BENCH_BUDGET_S", "1620")) - (time.perf_counter() - _T0) - 150
-                    mode = "full" if left >= need else "sample"
-                    log(f"cpu baseline: {mode} (estimated {need:.0f} s for the whole-workload leg, {left:.0f} s of the budget left)")
+                    mode = whole if left >= need else "sample"
+                    log(f"cpu baseline: {mode} (estimated {need:.0f} s for the {whole} leg, {left:.0f} s of the budget left)")
+                    if mode == "sample":
+                        fallback_reason = (f"the {whole} reference leg needs ~{need:.0f} s and {left:.0f} s of the command's budget (PGX_BENCH_BUDGET_S) were left: "
+                                           f"bounded sample instead; gpu_over_cpu.vs_n_cores_raw_records is null for a sample")
+                        sys.stderr.write("[bench] WARNING: cpu_baseline falls back to mode 'sample': " + fallback_reason + "\n")
                 sha_thread = None
-                if not a.genome_mb and not os.environ.get("PGX_BENCH_NO_STREAM_HASH"):     # the seqdb's SHA-256, beside the CPU leg
+                if not a.genome_mb and not os.environ.get("PGX_BENCH_NO_STREAM_HASH"):     # the seqdb's SHA-256, beside the CPU leg's (untimed) file writing
                     import threading
                     sha_box = {}
                     sha_thread = threading.Thread(target=lambda: sha_box.update(v=seqdb_sha256_of_device(seq_dev, total)))
                     sha_thread.start()
-                out["cpu_baseline"] = cpu_baseline_chunked(seq_dev, total, db, rdb, eng, a.workload, mode, sp["levels"], sp["mc_upper"], CH, gpu_index_files, held)
+                out["cpu_baseline"] = cpu_baseline_chunked(seq_dev, total, db, rdb, eng, a.workload, mode, sp["levels"], sp["mc_upper"], CH, gpu_index_files, held,
+                                                           stream_report=stream_report, before_timing=(sha_thread.join if sha_thread is not None else None))
                 if sha_thread is not None:
                     sha_thread.join()
                     out["seqdb_sha256"] = sha_box.get("v")
+                if fallback_reason:
+                    out["cpu_baseline"]["fallback_reason"] = fallback_reason
             elif a.cpu_baseline == "sample":
                 sample = simreads.simulate_reads_torch(10_000_000, 1003, 30.0, seed=42)
                 out["cpu_baseline"] = cpu_baseline_sample(sample)
@@ -1087,6 +1149,13 @@ def main():
                                        "vs_whole_workload_leg_raw_records": out["value"] / cb["whole_workload_leg"]["value"] if cb.get("whole_workload_leg") else None,
                                        "note": "the N-chunk CPU run reports most pairs once per chunk, so both of its rates are given; one-chunk "
                                                "workloads: GPU value = records of ONE overlap chunk (every read pair once)"}
+                if cb.get("mode") == "whole_chunks" and out.get("overlap_ms_per_step"):
+                    k = cb["chunks_run"]
+                    out["gpu_over_cpu"]["same_chunks"] = {
+                        "what": "overlap stage of the SAME %d chunks of the job's own chunking (T = %d): reference wall time, %d processes side by side, vs the GPU's overlap "
+                                "time per step x %d/%d; equal streams (cpu_baseline.records_match_gpu)" % (k, CH, cb["overlap_processes"], k, CH),
+                        "cpu_overlap_s": cb["overlap_s"], "cpu_processes": cb["overlap_processes"], "gpu_overlap_s": out["overlap_ms_per_step"] * 1e-3 * k / CH,
+                        "ratio": cb["overlap_s"] / (out["overlap_ms_per_step"] * 1e-3 * k / CH)}
         # ---- the pins: hashes of the REFERENCE's streams for this configuration (tests/golden/make_c4_stream_pins.py ran oracle/_ref/shmr_overlap
         # -t 8 -c 1..8 on the same seqdb bytes; SURVEY 8c/d, VERDICT r4 task 3)
         if stream_report is not None and strong and not a.genome_mb and os.path.exists(PINS_FILE):

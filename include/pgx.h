@@ -214,6 +214,17 @@ int pgx_results_wait(void);
 int pgx_index_chunk_db(pgx_seqdb *db, const char *out_prefix, const pgx_index_params *p, pgx_index_result *stats);
 int pgx_overlap_chunk_db(pgx_seqdb *db, const char *shimmer_prefix, const char *out_path, const pgx_overlap_params *p,
                          pgx_overlap_stats *stats);
+/* The overlap command of a served JOB in two steps (round 6; caller contract py/scripts/pg_run.py:305-317 -- the job's commands follow
+ * each other against one resident database).  pgx_overlap_chunk_db_begin returns when the GPU stage is done and the records are on
+ * their way from the device to out_path (the statistics are final); pgx_output_finish blocks until that file is complete and closed,
+ * reports an I/O error and releases *pending -- it may be called from another thread while the next command's _begin already runs,
+ * which is how `pgx_cli serve` overlaps one command's file with the next command's kernels.  pgx_overlap_chunk_db = _begin + _finish.
+ * An index command on a resident database leaves device copies of the list / count files it wrote; _begin assembles its lists from
+ * those copies (checked against the files' size and mtime) and reads only files it holds no current copy of. */
+typedef struct pgx_output pgx_output;
+int pgx_overlap_chunk_db_begin(pgx_seqdb *db, const char *shimmer_prefix, const char *out_path, const pgx_overlap_params *p,
+                               pgx_overlap_stats *stats, pgx_output **pending);
+int pgx_output_finish(pgx_output *pending);
 
 /* ---- dedup (replaces shmr_dedup, src/shmr_dedup.c:32-101) ----
  * recs: the concatenated ovlp_t streams (cat ovlp*.dat).  The first record of every read pair wins; *text receives the

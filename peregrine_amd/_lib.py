@@ -68,7 +68,7 @@ EXPORTS = [
     "pgx_timing_get", "pgx_timing_reset", "pgx_mem_ledger", "pgx_results_async", "pgx_results_wait",
     "pgx_seqdb_upload", "pgx_seqdb_load", "pgx_seqdb_free", "pgx_seqdb_bases", "pgx_seqdb_reads",
     "pgx_index_resident", "pgx_index_result_free", "pgx_index_chunk",
-    "pgx_overlap_resident", "pgx_overlap_chunk", "pgx_index_chunk_db", "pgx_overlap_chunk_db", "pgx_index_overlap_resident", "pgx_mkseqdb", "pgx_dedup",
+    "pgx_overlap_resident", "pgx_overlap_chunk", "pgx_index_chunk_db", "pgx_overlap_chunk_db", "pgx_overlap_chunk_db_begin", "pgx_output_finish", "pgx_index_overlap_resident", "pgx_mkseqdb", "pgx_dedup",
     "pgx_sketch_batch", "pgx_reduce_batch", "pgx_count_batch", "pgx_align_batch",
     "decode_biseq", "encode_biseq", "mm_sketch", "mm_reduce", "ovlp_match", "free_ovlp_match", "read_mmlist", "write_mmlist",
     "pgx_map", "pgx_map_chunk", "pgx_khash_slot_order", "pgx_khash_slot_order_ex",

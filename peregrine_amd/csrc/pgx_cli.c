@@ -14,6 +14,7 @@
  */
 #include <errno.h>
 #include <libgen.h>
+#include <pthread.h>
 #include <limits.h>
 #include <signal.h>
 #include <stdio.h>
@@ -74,13 +75,14 @@ static int try_server(const char *tool, const char *prefix, int argc, char **arg
   memset(&sa, 0, sizeof(sa));
   sa.sun_family = AF_UNIX;
   strcpy(sa.sun_path, sp);
+  if (connect(fd, (struct sockaddr *)&sa, sizeof(sa))) {   /* (blocks while the server's backlog is full: a queued command WAITS, it does not
+                                                             * fall back to a stand-alone run beside the server) */
+    close(fd);
+    return -1;
+  }
   {
     struct timeval io = {10, 0};   /* (the request must go out promptly; the reply takes as long as the stage does) */
     (void)setsockopt(fd, SOL_SOCKET, SO_SNDTIMEO, &io, sizeof(io));
-  }
-  if (connect(fd, (struct sockaddr *)&sa, sizeof(sa))) {
-    close(fd);
-    return -1;
   }
   char cwd[PATH_MAX], num[64];
   if (!getcwd(cwd, sizeof(cwd))) cwd[0] = 0;
@@ -121,7 +123,32 @@ static int output_needs_this_process(const char *path) {
 }
 
 static int run_index_args(int argc, char **argv, pgx_seqdb *db, const char *served_prefix, char *msg, size_t cap);
-static int run_overlap_args(int argc, char **argv, pgx_seqdb *db, const char *served_prefix, char *msg, size_t cap);
+static int run_overlap_args(int argc, char **argv, pgx_seqdb *db, const char *served_prefix, char *msg, size_t cap, pgx_output **pending);
+
+static void send_reply(int fd, int status, const char *msg) {
+  char head[16];
+  snprintf(head, sizeof(head), "%d", status);
+  if (!write_all(fd, head, strlen(head) + 1)) (void)write_all(fd, msg, strlen(msg) + 1);
+  close(fd);
+}
+/* A served overlap command whose GPU stage is done: its output file is completed (pgx_output_finish) and its client answered on a thread of
+ * its own, while the server's loop already runs the next command's stage (round 6). */
+struct finisher {
+  int fd, status;
+  pgx_output *pending;
+  char msg[4096];
+};
+static void *finish_and_reply(void *arg) {
+  struct finisher *f = (struct finisher *)arg;
+  if (pgx_output_finish(f->pending)) {
+    const size_t n = strlen(f->msg);
+    snprintf(f->msg + n, sizeof(f->msg) - n, "shmr_overlap: pgx_output_finish failed: %s\n", pgx_last_error());
+    f->status = 1;
+  }
+  send_reply(f->fd, f->status, f->msg);
+  free(f);
+  return NULL;
+}
 
 static volatile sig_atomic_t g_stop = 0;
 static char g_sock[PATH_MAX];
@@ -205,6 +232,7 @@ static int main_serve(int argc, char **argv) {
     char msg[4096];
     msg[0] = 0;
     int status = 250;
+    pgx_output *pending = NULL;
     if (nf >= 5) {
       const char *tool = fld[0], *cwd = fld[1];
       const long long csize = atoll(fld[2]), cmt = atoll(fld[3]);
@@ -217,15 +245,27 @@ static int main_serve(int argc, char **argv) {
         else {
           optind = 0; /* (glibc: 0 re-initialises getopt completely, also after a scan that stopped inside a clustered option) */
           if (!strcmp(tool, "shmr_index")) status = run_index_args(ac, fld + 5, db, prefix, msg, sizeof(msg));
-          else if (!strcmp(tool, "shmr_overlap")) status = run_overlap_args(ac, fld + 5, db, prefix, msg, sizeof(msg));
+          else if (!strcmp(tool, "shmr_overlap")) status = run_overlap_args(ac, fld + 5, db, prefix, msg, sizeof(msg), &pending);
           if (here[0] && chdir(here)) status = status ? status : 1;
         }
       }
     }
-    char head[16];
-    snprintf(head, sizeof(head), "%d", status);
-    if (!write_all(fd, head, strlen(head) + 1)) (void)write_all(fd, msg, strlen(msg) + 1);
-    close(fd);
+    if (pending) {   /* the records are still on their way to the file: finish + reply on a thread, the loop takes the next command */
+      struct finisher *f = (struct finisher *)malloc(sizeof(*f));
+      pthread_t th;
+      pthread_attr_t at;
+      pthread_attr_init(&at);
+      pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+      if (f) f->fd = fd, f->status = status, f->pending = pending, snprintf(f->msg, sizeof(f->msg), "%s", msg);
+      if (!f || pthread_create(&th, &at, finish_and_reply, f)) {   /* no thread: the same inline */
+        if (pgx_output_finish(pending)) status = 1;
+        free(f);
+        send_reply(fd, status, msg);
+      }
+      pthread_attr_destroy(&at);
+    } else {
+      send_reply(fd, status, msg);
+    }
   }
   unlink(g_sock);
   pgx_seqdb_free(db);
@@ -287,7 +327,7 @@ static int run_index_args(int argc, char **argv, pgx_seqdb *db, const char *serv
 }
 static int main_index(int argc, char **argv) { return run_index_args(argc, argv, NULL, NULL, NULL, 0); }
 
-static int run_overlap_args(int argc, char **argv, pgx_seqdb *db, const char *served_prefix, char *msg, size_t cap) {
+static int run_overlap_args(int argc, char **argv, pgx_seqdb *db, const char *served_prefix, char *msg, size_t cap, pgx_output **pending) {
   const char *p = "seq_dataset", *l = "shimmer-L2", *o = NULL;
   pgx_overlap_params op = {1, 1, 4, 2, 240, 100, 120}; /* -t -c -b -m -M -w -n : shmr_overlap.c:28-42,245-251 */
   char dflt[64];
@@ -319,13 +359,13 @@ static int run_overlap_args(int argc, char **argv, pgx_seqdb *db, const char *se
     return 0;
   }
   if (strcmp(p, served_prefix)) return 250;
-  if (pgx_overlap_chunk_db(db, l, o, &op, NULL)) {
+  if (pgx_overlap_chunk_db_begin(db, l, o, &op, NULL, pending)) {   /* (the caller finishes the output: pgx_output_finish) */
     snprintf(msg, cap, "shmr_overlap: pgx_overlap_chunk_db failed: %s\n", pgx_last_error());
     return 1;
   }
   return 0;
 }
-static int main_overlap(int argc, char **argv) { return run_overlap_args(argc, argv, NULL, NULL, NULL, 0); }
+static int main_overlap(int argc, char **argv) { return run_overlap_args(argc, argv, NULL, NULL, NULL, 0, NULL); }
 
 static int main_dedup(int argc, char **argv) {
   (void)argc, (void)argv;

@@ -232,7 +232,8 @@ int pgx_index_chunk_db(pgx_seqdb *db, const char *out_prefix, const pgx_index_pa
     require_ready();
     PGX_REQUIRE(db && out_prefix, PGX_EARG, "pgx_index_chunk_db: null argument");
     check_params(p);
-    run_index(db, p, &res);
+    DeviceIndex dev;
+    run_index(db, p, &res, &dev, true);
     // file names and order of writing as in shmr_index.c:165-233
     if (p->want_l0 == 1) {
       write_counted(level_path(out_prefix, 0, false, p->mychunk, p->total_chunk), res.l0, res.n_l0, sizeof(pgx_mm128));
@@ -242,6 +243,10 @@ int pgx_index_chunk_db(pgx_seqdb *db, const char *out_prefix, const pgx_index_pa
       const int lv = p->levels == 1 ? 1 : 2;
       write_counted(level_path(out_prefix, lv, false, p->mychunk, p->total_chunk), res.top, res.n_top, sizeof(pgx_mm128));
       write_counted(level_path(out_prefix, lv, true, p->mychunk, p->total_chunk), res.top_mc, res.n_top_mc, sizeof(pgx_mm_count));
+      // a resident database serves a JOB: the device copies stay for its overlap commands (pgx_served.cpp: list_stash)
+      const bool d = dev.valid && dev.n_top == res.n_top && dev.n_mc == res.n_top_mc;
+      list_stash_put(level_path(out_prefix, lv, false, p->mychunk, p->total_chunk), d ? dev.d_top : nullptr, res.top, res.n_top * sizeof(pgx_mm128));
+      list_stash_put(level_path(out_prefix, lv, true, p->mychunk, p->total_chunk), d ? dev.mc.p : nullptr, res.top_mc, res.n_top_mc * sizeof(pgx_mm_count));
     }
   } catch (const Fail &f) {
     rc = f.code;

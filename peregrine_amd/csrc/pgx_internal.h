@@ -400,6 +400,43 @@ void results_wait();
 void results_wait_if(const void *host);   // only if `host` is the array the pending copy writes
 void results_copy_async(pgx_ovlp *host, DevBuf<pgx_ovlp> &&dev, size_t n);   // after what is enqueued on ctx().stream
 
+// ---- file-level entry points of the overlap stage (pgx_served.cpp) over the stage itself (pgx_overlap.cpp) -------------------------------
+struct OvOut {  // the stage's output: one malloc'd array handed to the caller as is (a == nullptr, n set: the records went to a RecordSink)
+  pgx_ovlp *a = nullptr;
+  size_t n = 0;
+  void alloc(size_t count) {
+    out_free(a);
+    a = (pgx_ovlp *)out_alloc(count ? count * sizeof(pgx_ovlp) : 1);
+    n = count;
+  }
+  pgx_ovlp *release() {
+    pgx_ovlp *p = a;
+    a = nullptr, n = 0;
+    return p;
+  }
+  ~OvOut() { out_free(a); }
+};
+struct DeviceLists {   // the lists as device arrays
+  const pgx_mm128 *d_top = nullptr;
+  const pgx_mm_count *d_mc = nullptr;
+};
+void overlap_check_params(const pgx_overlap_params *p);
+void overlap_stage(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts, const pgx_overlap_params *p,
+                   OvOut &out, pgx_overlap_stats *st, const DeviceLists *dev = nullptr);
+// Where a stage's records go when they are not wanted as a host array (served commands: straight to the output file).  The device replay hands
+// its record buffer over right behind k_emit -- take() returns at once, the transfer runs on the sink's own threads and streams -- and
+// allocates no host array; the host replay (small sets, fall-back) delivers a host array that the caller writes itself.
+struct RecordSink {
+  virtual void take(DevBuf<pgx_ovlp> &&dev, size_t n) = 0;   // ordered behind what is enqueued on ctx().stream
+  virtual ~RecordSink() {}
+};
+RecordSink *&record_sink();   // (one stage at a time per process: set around overlap_stage by the caller that owns the sink)
+// Served jobs: an index command leaves a device copy of every final-level list / count file it wrote (keyed by the file's absolute path,
+// size and mtime); the job's overlap commands assemble their input from those copies instead of reading the files back (pgx_served.cpp).
+// d_payload (device) or h_payload (host): the file's entries, without the 8-byte count header; call AFTER the file is closed.
+void list_stash_put(const std::string &path, const void *d_payload, const void *h_payload, size_t bytes);
+void list_stash_clear();
+
 // pgx_overlap_stats::stream_checksum: the sum over the records of a 64-bit mix of every field (padding bytes excluded) and the record's
 // position in the stream -- the same on the device (k_emit adds it up while it writes the records) and on the host
 __host__ __device__ inline uint64_t checksum_mix(uint64_t h) {

@@ -779,22 +779,6 @@ struct Verdict {
 // the GPU batch a wrong guess makes its bucket dirty, a right guess only has its record patched.  At the fixed point every
 // bucket was last evaluated against final inputs, which is exactly the sequential process.
 // ---------------------------------------------------------------------------------------------------------
-struct OvOut {  // the stage's output: one malloc'd array handed to the caller as is
-  pgx_ovlp *a = nullptr;
-  size_t n = 0;
-  void alloc(size_t count) {
-    out_free(a);
-    a = (pgx_ovlp *)out_alloc(count ? count * sizeof(pgx_ovlp) : 1);
-    n = count;
-  }
-  pgx_ovlp *release() {
-    pgx_ovlp *p = a;
-    a = nullptr, n = 0;
-    return p;
-  }
-  ~OvOut() { out_free(a); }
-};
-
 struct Replay {
   static constexpr uint32_t NONE = 0xFFFFFFFFu;
   const Visit &v;
@@ -1601,10 +1585,6 @@ void check_params(const pgx_overlap_params *p) {
 
 // the lists either as host arrays (mmers / counts), as device arrays (dev), or -- a rank of a multi-GPU job -- as the pair
 // records this chunk received from all index chunks (d_recs: device pointer, arrival order = insertion order)
-struct DeviceLists {
-  const pgx_mm128 *d_top = nullptr;
-  const pgx_mm_count *d_mc = nullptr;
-};
 // The FRONT of an overlap stage: count table, join, visit order -- everything up to the greedy walk; it reads only the lists and the
 // parameters.  (Round 5 ran the front of chunk c + 1 on a second stream and host thread beside chunk c's walk -- pgx_overlap_prefetch_dev,
 // commit 503bb51: bit-exact, and 7.12 s per c4 step against 7.06 without: the walk's small launches and the front's sorts
@@ -1756,7 +1736,14 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
     if (dev_replay(db, dpairs, visit.on_device ? nullptr : visit.bids.data(), visit.on_device ? d_bids.p : nullptr, visit.n_buckets,
                    visit.n_entries, (uint32_t)(uint8_t)p->bestn,
                    p->align_bandwidth, predict, (uint32_t)p->ovlp_upper,
-                   [&](size_t n) { out.alloc(n); return out.a; }, &nrec, &rs, trace)) {
+                   [&](size_t n) -> pgx_ovlp * {
+                     if (record_sink()) {   // (the records go from the device to the sink: no host array)
+                       out_free(out.a), out.a = nullptr, out.n = n;
+                       return nullptr;
+                     }
+                     out.alloc(n);
+                     return out.a;
+                   }, &nrec, &rs, trace)) {
       s.n_align_needed = rs.n_align_needed, s.n_seen_skip = rs.n_seen_skip, s.n_align_gpu = rs.n_align_gpu, s.rounds = rs.rounds;
       s.n_evaluations = rs.n_evaluations, s.device_replay = 1;
       s.replay_attempts = rs.replay_attempts, s.stream_checksum = rs.stream_checksum;
@@ -1908,34 +1895,20 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
   if (st) *st = s;
 }
 
-template <typename T>
-void read_counted_files(const std::string &pattern, std::vector<T> &out) {
-  glob_t g;
-  memset(&g, 0, sizeof(g));
-  if (glob(pattern.c_str(), 0, nullptr, &g) == 0) {  // name-sorted like wordexp in shmr_overlap.c:355-384
-    for (size_t i = 0; i < g.gl_pathc; ++i) {
-      std::vector<uint8_t> buf;
-      const std::string path = g.gl_pathv[i];   // (copied: the glob result is released before the message is formatted)
-      if (!read_file(path, buf) || buf.size() < 8) {
-        globfree(&g);
-        PGX_REQUIRE(false, PGX_EIO, "file '%s' open error", path.c_str());
-      }
-      uint64_t n;
-      memcpy(&n, buf.data(), 8);
-      if (n > (buf.size() - 8) / sizeof(T)) {   // a truncated index chunk must not yield a quietly smaller overlap set
-        globfree(&g);
-        PGX_REQUIRE(false, PGX_EIO, "file '%s' is truncated: header says %llu entries, %zu bytes follow", path.c_str(),
-                    (unsigned long long)n, buf.size() - 8);
-      }
-      const size_t o = out.size();
-      out.resize(o + n);
-      if (n) memcpy(out.data() + o, buf.data() + 8, n * sizeof(T));
-    }
-  }
-  globfree(&g);
-}
-
 }  // namespace
+
+// what the file-level entry points (pgx_served.cpp) see of the stage
+namespace pgx {
+void overlap_check_params(const pgx_overlap_params *p) { check_params(p); }
+void overlap_stage(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_mm_count *counts, size_t n_counts, const pgx_overlap_params *p,
+                   OvOut &out, pgx_overlap_stats *st, const DeviceLists *dev) {
+  run_overlap(db, mmers, n_mm, counts, n_counts, p, out, st, dev);
+}
+RecordSink *&record_sink() {
+  static RecordSink *s = nullptr;
+  return s;
+}
+}  // namespace pgx
 
 extern "C" {
 
@@ -2104,174 +2077,6 @@ int pgx_overlap_records_dev(pgx_seqdb *db, const pgx_pair_rec *d_records, size_t
     return PGX_ENOMEM;
   }
   return PGX_OK;
-}
-
-namespace {
-// the shimmer / count files of every index chunk, name-sorted as the reference's wordexp globs them (shmr_overlap.c:359-384)
-void read_index_files(const char *shimmer_prefix, std::vector<pgx_mm128> &mm, std::vector<pgx_mm_count> &mc) {
-  read_counted_files(std::string(shimmer_prefix) + "-[0-9]*-of-[0-9]*.dat", mm);
-  read_counted_files(std::string(shimmer_prefix) + "-MC-[0-9]*-of-[0-9]*.dat", mc);
-}
-// The records to out_path.  A regular file: several threads pwrite slices into the page cache (one thread moves ~3 GB/s: 0.1 s for the
-// 300 MB of a 4.5 Gbase chunk).  Anything that cannot seek (-o /dev/stdout, a FIFO, a process substitution -- the reference's fwrite
-// stream handles those, shmr_overlap.c:388-390): one sequential write loop.  EINTR is retried.
-void write_records(const char *out_path, const pgx_ovlp *rec, size_t n) {
-  const int fd = open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
-  PGX_REQUIRE(fd >= 0, PGX_EIO, "file '%s' open error", out_path);
-  const size_t total = n * sizeof(pgx_ovlp);
-  struct stat sb;
-  const bool regular = fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode);
-  bool ok = true;
-  if (!regular) {
-    for (size_t off = 0; off < total;) {
-      const ssize_t w = write(fd, (const char *)rec + off, total - off);
-      if (w < 0 && errno == EINTR) continue;
-      if (w <= 0) {
-        ok = false;
-        break;
-      }
-      off += (size_t)w;
-    }
-  } else {
-    const int nt = (int)std::max<size_t>(1, std::min<size_t>(8, total >> 24));
-    std::vector<char> okv(nt, 1);
-    std::vector<std::thread> ws;
-    for (int t = 0; t < nt; ++t)
-      ws.emplace_back([&, t] {
-        const size_t lo = total * t / nt, hi = total * (t + 1) / nt;
-        for (size_t off = lo; off < hi;) {
-          const ssize_t w = pwrite(fd, (const char *)rec + off, hi - off, (off_t)off);
-          if (w < 0 && errno == EINTR) continue;
-          if (w <= 0) {
-            okv[t] = 0;
-            return;
-          }
-          off += (size_t)w;
-        }
-      });
-    for (auto &t : ws) t.join();
-    for (char c : okv) ok = ok && c;
-  }
-  ok = (close(fd) == 0) && ok;
-  PGX_REQUIRE(ok, PGX_EIO, "short write to '%s'", out_path);
-}
-}  // namespace
-
-namespace {
-// The index files a served job's overlap commands read are the SAME for all of them (every chunk globs every index chunk,
-// shmr_overlap.c:359-384): the resident form keeps the lists of the last shimmer prefix, as long as the files behind it have not
-// changed (names, sizes, mtimes).
-struct ListCache {
-  std::string prefix;
-  std::vector<std::pair<std::string, std::pair<long long, long long>>> files;   // path -> (size, mtime ns)
-  std::vector<pgx_mm128> mm;
-  std::vector<pgx_mm_count> mc;
-};
-void glob_identity(const std::string &pat, std::vector<std::pair<std::string, std::pair<long long, long long>>> &out) {
-  glob_t g;
-  if (glob(pat.c_str(), 0, nullptr, &g) == 0) {
-    for (size_t i = 0; i < g.gl_pathc; ++i) {
-      struct stat sb;
-      if (stat(g.gl_pathv[i], &sb) == 0)
-        out.push_back({g.gl_pathv[i], {(long long)sb.st_size, (long long)sb.st_mtim.tv_sec * 1000000000LL + sb.st_mtim.tv_nsec}});
-    }
-    globfree(&g);
-  }
-}
-}  // namespace
-
-int pgx_overlap_chunk_db(pgx_seqdb *db, const char *shimmer_prefix, const char *out_path, const pgx_overlap_params *p,
-                         pgx_overlap_stats *stats) {
-  int rc = PGX_OK;
-  try {
-    require_ready();
-    PGX_REQUIRE(db && shimmer_prefix && out_path, PGX_EARG, "pgx_overlap_chunk_db: null argument");
-    check_params(p);
-    const bool trace = getenv("PGX_TRACE") != nullptr;
-    const double t0 = now_ms();
-    static ListCache cache;
-    // identity = the ABSOLUTE prefix (the server enters each client's directory: two jobs with the same relative prefix are different
-    // files) + every file's name, size and mtime, taken before AND after the read (a file rewritten in between is not cached)
-    std::string abs_prefix = shimmer_prefix;
-    if (!abs_prefix.empty() && abs_prefix[0] != '/') {
-      char cwd[PATH_MAX];
-      if (getcwd(cwd, sizeof(cwd))) abs_prefix = std::string(cwd) + "/" + abs_prefix;
-    }
-    auto identity = [&](std::vector<std::pair<std::string, std::pair<long long, long long>>> &v) {
-      glob_identity(abs_prefix + "-[0-9]*-of-[0-9]*.dat", v);
-      glob_identity(abs_prefix + "-MC-[0-9]*-of-[0-9]*.dat", v);
-    };
-    std::vector<std::pair<std::string, std::pair<long long, long long>>> ident;
-    identity(ident);
-    if (cache.prefix != abs_prefix || cache.files != ident || ident.empty()) {
-      cache.prefix.clear();
-      cache.mm.clear(), cache.mc.clear();
-      cache.mm.shrink_to_fit(), cache.mc.shrink_to_fit();   // (another prefix: the old lists' memory goes back first)
-      read_index_files(shimmer_prefix, cache.mm, cache.mc);
-      std::vector<std::pair<std::string, std::pair<long long, long long>>> after;
-      identity(after);
-      if (after == ident) cache.prefix = abs_prefix, cache.files = ident;
-    }
-    const double t1 = now_ms();
-    OvOut v;
-    run_overlap(db, cache.mm.data(), cache.mm.size(), cache.mc.data(), cache.mc.size(), p, v, stats);
-    results_wait();
-    const double t2 = now_ms();
-    write_records(out_path, v.a, v.n);
-    if (trace) fprintf(stderr, "[pgx] overlap chunk (resident database): index files %.1f ms, stage %.1f ms, %zu records written in %.1f ms\n", t1 - t0, t2 - t1, v.n, now_ms() - t2);
-  } catch (const Fail &f) {
-    rc = f.code;
-  } catch (const std::bad_alloc &) {
-    set_error("out of host memory");
-    rc = PGX_ENOMEM;
-  }
-  return rc;
-}
-
-int pgx_overlap_chunk(const char *seqdb_prefix, const char *shimmer_prefix, const char *out_path,
-                      const pgx_overlap_params *p, pgx_overlap_stats *stats) {
-  pgx_seqdb *db = nullptr;
-  int rc = PGX_OK;
-  try {
-    require_ready();
-    PGX_REQUIRE(seqdb_prefix && shimmer_prefix && out_path, PGX_EARG, "pgx_overlap_chunk: null argument");
-    check_params(p);
-    // the shimmer / count files are read by a second thread WHILE the seqdb goes to HBM (they are independent inputs)
-    std::vector<pgx_mm128> mm;
-    std::vector<pgx_mm_count> mc;
-    int rd_code = PGX_OK;
-    std::string rd_err;
-    std::thread reader([&] {
-      try {
-        read_index_files(shimmer_prefix, mm, mc);
-      } catch (const Fail &f) {
-        rd_code = f.code, rd_err = pgx_last_error();
-      } catch (const std::bad_alloc &) {
-        rd_code = PGX_ENOMEM, rd_err = "out of host memory";
-      } catch (...) {
-        rd_code = PGX_EIO, rd_err = "reading the shimmer files failed";
-      }
-    });
-    rc = pgx_seqdb_load(seqdb_prefix, &db);
-    const std::string load_err = rc ? pgx_last_error() : "";
-    reader.join();
-    if (rc) {
-      set_error("%s", load_err.c_str());
-      return rc;
-    }
-    PGX_REQUIRE(rd_code == PGX_OK, rd_code, "%s", rd_err.c_str());
-    OvOut v;
-    run_overlap(db, mm.data(), mm.size(), mc.data(), mc.size(), p, v, stats);
-    results_wait();
-    write_records(out_path, v.a, v.n);
-  } catch (const Fail &f) {
-    rc = f.code;
-  } catch (const std::bad_alloc &) {
-    set_error("out of host memory");
-    rc = PGX_ENOMEM;
-  }
-  pgx_seqdb_free(db);
-  return rc;
 }
 
 }  // extern "C"
