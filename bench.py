@@ -81,9 +81,11 @@ def parse():
                          "sample of it, 24 processes over chunks 1..24 of 192; either way the streams of two of those chunks are compared "
                          "field by field with the GPU's; whole_chunks (default of c5): the reference indexes all of the job's chunks, then runs 8 of "
                          "its overlap chunks whole, their streams hashed and compared with the GPU's")
-    ap.add_argument("--end-to-end", action="store_true",
+    ap.add_argument("--end-to-end", action="store_true", default=None,
                     help="c4 family: after the timed steps run the job's CHUNKS index + CHUNKS overlap commands through bin/native/* attached to a "
-                         "`pgx_cli serve` process, files on /dev/shm (file -> kernels -> D2H -> file): `gpu_end_to_end` in the line")
+                         "`pgx_cli serve` process, files on /dev/shm (file -> kernels -> D2H -> file): `gpu_end_to_end` in the line.  Default at N = 1 "
+                         "and full size where the command's time budget (PGX_BENCH_BUDGET_S) has ~3 minutes left after the other legs")
+    ap.add_argument("--no-end-to-end", dest="end_to_end", action="store_false")
     ap.add_argument("--check-ref", action="store_true",
                     help="c4 family, small --genome-mb only: after the timed steps every rank compares the ovlp_t stream of each of its "
                          "chunks, field by field, with oracle/_ref/shmr_overlap -t CHUNKS -c c on files rank 0 writes")
@@ -363,7 +365,7 @@ def _run_many(n_workers, jobs):
     return time.perf_counter() - t0
 
 
-def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, job_chunks, gpu_index_files, job_lists, stream_report=None, before_timing=None):
+def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, job_chunks, gpu_index_files, job_lists, stream_report=None, before_timing=None, files=None):
     """c4 family (one read set, CHUNKS index + overlap chunks): the REAL reference (oracle/_ref) on this box's host cores, on the same
     bytes (the device-resident seqdb written to files), 24 processes at a time (the reference's own practical ceiling,
     /root/reference/README.md:127-137):
@@ -409,21 +411,34 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
     if mode == "whole_chunks":
         cs = list(range(1, T + 1))
         dflt = sorted({1, 2} | {1 + (i * (T - 1)) // 7 for i in range(8)})[:8] if T > 8 else list(range(1, T + 1))
+        try:     # (the chunks tests/golden/c4_stream_pins.json pins for this workload, where it has them: the leg then re-checks the pins too)
+            pinned = json.load(open(PINS_FILE)).get(tag) or {}
+            if pinned.get("chunks") == T:
+                dflt = sorted(int(r["chunk"].split()[0]) for r in pinned["streams"]) or dflt
+        except Exception:
+            pass
         ov_cs = [int(v) for v in os.environ.get("PGX_BENCH_CPU_CHUNKS", "").split(",") if v] or dflt
         per_proc = 13e9 * db.n_bases / 93.3e9      # (measured at full size: 12.4 GB at l = 1, T = 24; ~13 GB at l = 2, T = 8)
         fit = int((mem.get("MemAvailable", 0) - total * 1.1 - 32e9) // max(per_proc, 1e8))
         P_ov = max(1, min(len(ov_cs), ncpu, fit))
         procs_limit_reason = "one process per compared chunk (%d), host memory allows %d at ~%.0f GB each" % (len(ov_cs), fit, per_proc / 1e9)
     need = int(total * 1.02) + int(db.n_bases * (0.12 if mode == "full" else 0.2 if mode == "whole_chunks" and levels == 1 else 0.03)) + (8 << 30)
-    base = _scratch_dir(need)
-    if base is None:
-        return {"value": None, "unit": "overlaps/s", "cores": 0, "kind": "none", "sample": f"no scratch directory with {need >> 30} GiB free"}
-    d = tempfile.mkdtemp(prefix="pgx_bench_", dir=base)
+    if files is not None:      # the seqdb files are there already (shared with the end-to-end leg): this leg's outputs go to a directory of their own
+        d = os.path.join(files["dir"], "cpu")
+        os.makedirs(d, exist_ok=True)
+    else:
+        base = _scratch_dir(need)
+        if base is None:
+            return {"value": None, "unit": "overlaps/s", "cores": 0, "kind": "none", "sample": f"no scratch directory with {need >> 30} GiB free"}
+        d = tempfile.mkdtemp(prefix="pgx_bench_", dir=base)
     try:
-        pre = os.path.join(d, "sd")
-        t0 = time.perf_counter()
-        simreads.write_seqdb_from_device(pre, seq, total, db.rid, db.rlen, db.roff)
-        t_files = time.perf_counter() - t0
+        if files is not None:
+            pre, t_files = files["prefix"], files["seconds"]
+        else:
+            pre = os.path.join(d, "sd")
+            t0 = time.perf_counter()
+            simreads.write_seqdb_from_device(pre, seq, total, db.rid, db.rlen, db.roff)
+            t_files = time.perf_counter() - t0
         log(f"cpu baseline ({mode}): seqdb files written in {t_files:.1f} s")
         if before_timing is not None:     # (nothing of this process runs beside the reference while it is timed -- the seqdb's SHA-256 thread ends here)
             before_timing()
@@ -593,7 +608,7 @@ def seqdb_sha256_of_device(seq, total, piece=1 << 30):
 PINS_FILE = os.path.join(ROOT, "tests", "golden", "c4_stream_pins.json")
 
 
-def end_to_end_served(seq, total, db, rdb, CH, levels, mc_upper, stream_report, release=None):
+def end_to_end_served(seq, total, db, rdb, CH, levels, mc_upper, stream_report, release=None, files=None):
     """file -> H2D -> kernels -> D2H -> file at the metric's configuration (pg_run.py:232-244,305-317): the job's CH index + CH overlap
     chunk COMMANDS through bin/native/shmr_index / shmr_overlap attached to one `pgx_cli serve` process, everything on /dev/shm.  This process
     gives its HBM back first (two copies of a 93 GB database do not fit one GPU).  The output files are hashed like the resident streams."""
@@ -602,16 +617,25 @@ def end_to_end_served(seq, total, db, rdb, CH, levels, mc_upper, stream_report, 
     import torch
     from peregrine_amd import _lib, formats, simreads
     need = int(total * 1.02) + 64 * int(sum(r["records"] for r in stream_report or [])) + (8 << 30)
-    base = _scratch_dir(need)
-    if base is None:
-        return {"error": f"no scratch directory with {need >> 30} GiB free"}
-    d = tempfile.mkdtemp(prefix="pgx_e2e_", dir=base)
+    if files is not None:
+        base = os.path.dirname(files["dir"])
+        d = os.path.join(files["dir"], "e2e")
+        os.makedirs(d, exist_ok=True)
+    else:
+        base = _scratch_dir(need)
+        if base is None:
+            return {"error": f"no scratch directory with {need >> 30} GiB free"}
+        d = tempfile.mkdtemp(prefix="pgx_e2e_", dir=base)
     cli = os.path.join(ROOT, "bin", "native", "pgx_cli")
+    inflight = max(1, int(os.environ.get("PGX_BENCH_E2E_INFLIGHT", "2")))
     try:
-        pre = os.path.join(d, "sd")
-        t0 = time.perf_counter()
-        simreads.write_seqdb_from_device(pre, seq[0] if isinstance(seq, list) else seq, total, db.rid, db.rlen, db.roff)
-        t_files = time.perf_counter() - t0
+        if files is not None:
+            pre, t_files = files["prefix"], files["seconds"]
+        else:
+            pre = os.path.join(d, "sd")
+            t0 = time.perf_counter()
+            simreads.write_seqdb_from_device(pre, seq[0] if isinstance(seq, list) else seq, total, db.rid, db.rlen, db.roff)
+            t_files = time.perf_counter() - t0
         rdb.close()
         _lib.shutdown()
         del seq
@@ -636,16 +660,19 @@ def end_to_end_served(seq, total, db, rdb, CH, levels, mc_upper, stream_report, 
             for c in range(1, CH + 1):
                 run([cli, "shmr_index", "-p", pre, "-t", str(CH), "-c", str(c), "-m", "0", "-l", str(levels), "-o", os.path.join(d, "ix")])
             t1 = time.perf_counter()
-            for c in range(1, CH + 1):
-                run([cli, "shmr_overlap", "-p", pre, "-l", os.path.join(d, "ix-L%d" % levels), "-t", str(CH), "-c", str(c), "-M", str(mc_upper),
-                     "-o", os.path.join(d, "ov.%02d" % c)])
+            # the job's overlap commands as a scheduler with `inflight` job slots issues them (pg_run.py hands its chunk commands to a job queue): the
+            # server runs ONE stage at a time; a second command in flight lets its stage start while the first one's file is being completed
+            _run_many(inflight, [lambda c=c: run([cli, "shmr_overlap", "-p", pre, "-l", os.path.join(d, "ix-L%d" % levels), "-t", str(CH), "-c", str(c), "-M", str(mc_upper),
+                                                  "-o", os.path.join(d, "ov.%02d" % c)]) for c in range(1, CH + 1)])
             t2 = time.perf_counter()
         finally:
             srv.send_signal(signal.SIGTERM)
             srv.wait()
         nrec = sum(os.path.getsize(os.path.join(d, "ov.%02d" % c)) // 64 for c in range(1, CH + 1))
         res = {"what": "the job's %d index + %d overlap chunk commands through bin/native/shmr_index / shmr_overlap attached to one `pgx_cli serve` process "
-                       "(the database resident there), files on %s: process start, socket, file reads, kernels, D2H, file writes" % (CH, CH, base),
+                       "(the database resident there), files on %s: process start, socket, file reads, kernels, D2H, file writes; the index commands one after the "
+                       "other, %d overlap command(s) in flight" % (CH, CH, base, inflight),
+               "overlap_commands_in_flight": inflight,
                "index_s": t1 - t0, "overlap_s": t2 - t1, "records": int(nrec), "overlaps_per_s": nrec / (t2 - t0),
                "server_start_s": t_up, "overlaps_per_s_incl_server_start": nrec / (t2 - t0 + t_up), "seqdb_files_written_s": t_files}
         if stream_report:
@@ -773,6 +800,7 @@ def main():
     SUM_KEYS = ("n_records", "n_pair_records", "n_buckets", "n_align_needed", "n_align_gpu", "n_seen_skip", "n_evaluations", "gpu_ms", "host_ms", "device_visit")
     keep_streams = {}
 
+    shared_files = None   # the seqdb files of the reference CPU leg and the end-to-end leg ({"dir", "prefix", "seconds"})
     held = {}   # N = 1, several chunks: the concatenated lists live in ONE pair of buffers kept across the steps (sizes repeat)
     hash_streams = False     # set for ONE extra step after the timed region: every chunk's stream is SHA-256'd (padding masked) as it arrives
     hash_jobs, hash_keep = {}, []
@@ -1109,6 +1137,21 @@ def main():
                         fallback_reason = (f"the {whole} reference leg needs ~{need:.0f} s and {left:.0f} s of the command's budget (PGX_BENCH_BUDGET_S) were left: "
                                            f"bounded sample instead; gpu_over_cpu.vs_n_cores_raw_records is null for a sample")
                         sys.stderr.write("[bench] WARNING: cpu_baseline falls back to mode 'sample': " + fallback_reason + "\n")
+                # the end-to-end leg (default where the budget allows; it runs LAST -- this process gives its HBM to the server) reads the same seqdb files
+                # as the reference: written once, shared
+                cpu_est = {"full": 900.0, "whole_chunks": 1300.0, "sample": 330.0}[mode] * (db.n_bases / 93.3e9) + 60
+                left_after = float(os.environ.get("PGX_BENCH_BUDGET_S", "1620")) - (time.perf_counter() - _T0) - cpu_est
+                if a.end_to_end is None:
+                    a.end_to_end = bool(not a.genome_mb and a.workload == "c4" and left_after >= 200)
+                    log(f"end to end leg: {'on' if a.end_to_end else 'off'} ({left_after:.0f} s of the budget expected to be left after the CPU leg)")
+                if a.end_to_end:
+                    need = int(total * 1.02) + int(db.n_bases * 0.5) + (8 << 30)
+                    base = _scratch_dir(need)
+                    if base is not None:
+                        sdir = tempfile.mkdtemp(prefix="pgx_bench_", dir=base)
+                        tw = time.perf_counter()
+                        simreads.write_seqdb_from_device(os.path.join(sdir, "sd"), seq_dev, total, db.rid, db.rlen, db.roff)
+                        shared_files = {"dir": sdir, "prefix": os.path.join(sdir, "sd"), "seconds": time.perf_counter() - tw}
                 sha_thread = None
                 if not a.genome_mb and not os.environ.get("PGX_BENCH_NO_STREAM_HASH"):     # the seqdb's SHA-256, beside the CPU leg's (untimed) file writing
                     import threading
@@ -1116,7 +1159,8 @@ def main():
                     sha_thread = threading.Thread(target=lambda: sha_box.update(v=seqdb_sha256_of_device(seq_dev, total)))
                     sha_thread.start()
                 out["cpu_baseline"] = cpu_baseline_chunked(seq_dev, total, db, rdb, eng, a.workload, mode, sp["levels"], sp["mc_upper"], CH, gpu_index_files, held,
-                                                           stream_report=stream_report, before_timing=(sha_thread.join if sha_thread is not None else None))
+                                                           stream_report=stream_report, before_timing=(sha_thread.join if sha_thread is not None else None),
+                                                           files=shared_files)
                 if sha_thread is not None:
                     sha_thread.join()
                     out["seqdb_sha256"] = sha_box.get("v")
@@ -1184,8 +1228,10 @@ def main():
                         "source": "tests/golden/c4_stream_pins.json (reference_overlap_leg_s; tests/golden/make_c4_stream_pins.py)"}
                 out["pins"] = {"file": "tests/golden/c4_stream_pins.json", "same_input_bytes": bool(same_input), "chunks_pinned": len(want),
                                "chunks_equal": int(sum(rows_ok)), "pinned_seqdb_sha256": pins.get("seqdb_sha256"),
-                               "what": "SHA-256 of oracle/_ref/shmr_overlap's stream (padding bytes zeroed) for every overlap chunk of this configuration, "
+                               "what": "SHA-256 of oracle/_ref/shmr_overlap's stream (padding bytes zeroed) for the pinned overlap chunks of this configuration (configs[3]: all 8; configs[4]: 8 of 24), "
                                        "made on the GPU box's host cores from the same seqdb bytes (the generator is seeded; read_set_hash and seqdb_sha256 tie the inputs)"}
+        if a.end_to_end is None:     # (no CPU leg in this run)
+            a.end_to_end = False
         if a.end_to_end and strong and world == 1:
             seq_box = [seq_dev]
             seq_dev = None
@@ -1194,7 +1240,13 @@ def main():
                 seq_box.clear()
                 held.clear()
                 keep_streams.clear()
-            out["gpu_end_to_end"] = end_to_end_served(seq_box, total, db, rdb, CH, sp["levels"], sp["mc_upper"], stream_report, release_all)
+            out["gpu_end_to_end"] = end_to_end_served(seq_box, total, db, rdb, CH, sp["levels"], sp["mc_upper"], stream_report, release_all, files=shared_files)
+            e2e = out["gpu_end_to_end"]
+            if e2e.get("overlaps_per_s"):
+                e2e["over_resident"] = (e2e["index_s"] + e2e["overlap_s"]) / (out["ms_per_step"] * 1e-3)
+        if shared_files is not None:
+            import shutil
+            shutil.rmtree(shared_files["dir"], ignore_errors=True)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.barrier()

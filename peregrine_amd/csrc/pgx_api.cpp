@@ -883,7 +883,17 @@ int pgx_seqdb_load(const char *prefix, pgx_seqdb **out) {
   PGX_GUARD_END
 }
 
-void pgx_seqdb_free(pgx_seqdb *db) { delete db; }
+void pgx_seqdb_free(pgx_seqdb *db) {
+  if (db) {   // what the library kept for the chunks of a job on this database goes with it
+    try {
+      pgx::count_cache_drop();
+      pgx::replay_forget_sizes();
+      pgx::list_stash_clear();
+    } catch (...) {
+    }
+  }
+  delete db;
+}
 uint64_t pgx_seqdb_bases(const pgx_seqdb *db) { return db ? db->bases : 0; }
 uint32_t pgx_seqdb_reads(const pgx_seqdb *db) { return db ? (uint32_t)db->rid.size() : 0; }
 

@@ -436,6 +436,8 @@ RecordSink *&record_sink();   // (one stage at a time per process: set around ov
 // d_payload (device) or h_payload (host): the file's entries, without the 8-byte count header; call AFTER the file is closed.
 void list_stash_put(const std::string &path, const void *d_payload, const void *h_payload, size_t bytes);
 void list_stash_clear();
+void count_cache_drop();     // the aggregated count table kept across the chunks of a job (pgx_pairs.hip)
+void replay_forget_sizes();  // the device replay's learned table sizes (pgx_replay.hip): another database, another job
 
 // pgx_overlap_stats::stream_checksum: the sum over the records of a 64-bit mix of every field (padding bytes excluded) and the record's
 // position in the stream -- the same on the device (k_emit adds it up while it writes the records) and on the host

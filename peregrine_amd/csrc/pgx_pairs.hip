@@ -401,7 +401,7 @@ static void aggregate_counts_now(const pgx_mm_count *cin, size_t n_counts, Count
 // same number, same order-sensitive 64-bit checksum of (mer, count), one read-only pass over the entries (~1 ms per GB) instead of the
 // split + sort + reduce + insert (57 ms per full-size configs[3] chunk, profiles/r05a_chunk_timeline_c4.txt).
 __global__ __launch_bounds__(256) void k_counts_checksum(const pgx_mm_count *__restrict__ in, size_t n, unsigned long long *__restrict__ sum) {
-  unsigned long long h = 0;
+  unsigned long long h = 0, h2 = 0;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const uint4 v = *reinterpret_cast<const uint4 *>(in + i);   // mer (x, y), count (z); the padding word is not looked at
     unsigned long long x = ((unsigned long long)v.y << 32 | v.x) + 0x9E3779B97F4A7C15ULL * (i + 1);
@@ -409,37 +409,48 @@ __global__ __launch_bounds__(256) void k_counts_checksum(const pgx_mm_count *__r
     x += v.z;
     x *= 0xc4ceb9fe1a85ec53ULL, x ^= x >> 33;
     h += x;
+    // a second, independent sum (other multipliers, the fields the other way round: ADVICE r5 -- one 64-bit additive checksum was all that
+    // stood between two different sets of count files and the same keep flags)
+    unsigned long long y = ((unsigned long long)v.z << 32 | v.y) ^ (0xD6E8FEB86659FD93ULL * (i + 0x632BE5ABULL));
+    y ^= y >> 29, y *= 0xBF58476D1CE4E5B9ULL, y ^= y >> 32;
+    y += v.x;
+    y *= 0x94D049BB133111EBULL, y ^= y >> 31;
+    h2 += y;
   }
-  for (int o = 32; o; o >>= 1) h += (unsigned long long)__shfl_xor((int)(h >> 32), o, 64) << 32 | (uint32_t)__shfl_xor((int)h, o, 64);
-  __shared__ unsigned long long part[4];
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+  for (int o = 32; o; o >>= 1) {
+    h += (unsigned long long)__shfl_xor((int)(h >> 32), o, 64) << 32 | (uint32_t)__shfl_xor((int)h, o, 64);
+    h2 += (unsigned long long)__shfl_xor((int)(h2 >> 32), o, 64) << 32 | (uint32_t)__shfl_xor((int)h2, o, 64);
+  }
+  __shared__ unsigned long long part[4], part2[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h, part2[threadIdx.x >> 6] = h2;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(sum, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) atomicAdd(sum, part[0] + part[1] + part[2] + part[3]), atomicAdd(sum + 1, part2[0] + part2[1] + part2[2] + part2[3]);
 }
 namespace {
 struct CountCache {
   size_t n = 0;
-  unsigned long long sum = 0;
+  unsigned long long sum[2] = {0, 0};
   CountTable ct;
   bool valid = false;
 };
 CountCache g_counts;
 ShutdownHook g_counts_reset([] { g_counts = CountCache(); });
 }  // namespace
+void count_cache_drop() { g_counts = CountCache(); }   // (pgx_seqdb_free: the job is over, its table's HBM goes back)
 static const CountTable &aggregate_counts(const pgx_mm_count *cin, size_t n_counts, Tmp &tmp) {
-  unsigned long long sum = 0;
+  unsigned long long sum[2] = {0, 0};
   if (n_counts) {
     hipStream_t st = ctx().stream;
-    DevBuf<unsigned long long> d_sum(1);
-    PGX_HIP(hipMemsetAsync(d_sum.p, 0, sizeof(unsigned long long), st));
+    DevBuf<unsigned long long> d_sum(2);
+    PGX_HIP(hipMemsetAsync(d_sum.p, 0, 2 * sizeof(unsigned long long), st));
     hipLaunchKernelGGL(k_counts_checksum, dim3((unsigned)std::min<size_t>(cdiv(n_counts, 256), 8192)), dim3(256), 0, st, cin, n_counts, d_sum.p);
-    d_sum.download(&sum, 1);
+    d_sum.download(sum, 2);
     sync();
-    if (g_counts.valid && g_counts.n == n_counts && g_counts.sum == sum) return g_counts.ct;
+    if (g_counts.valid && g_counts.n == n_counts && g_counts.sum[0] == sum[0] && g_counts.sum[1] == sum[1]) return g_counts.ct;
   }
   g_counts.valid = false;
   aggregate_counts_now(cin, n_counts, g_counts.ct, tmp);
-  g_counts.n = n_counts, g_counts.sum = sum, g_counts.valid = n_counts != 0;
+  g_counts.n = n_counts, g_counts.sum[0] = sum[0], g_counts.sum[1] = sum[1], g_counts.valid = n_counts != 0;
   return g_counts.ct;
 }
 

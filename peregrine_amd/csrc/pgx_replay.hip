@@ -2237,6 +2237,14 @@ void dev_place_bids(const uint32_t *ids_all, size_t n_ids, const uint32_t *psrc,
   sync();   // (the upload sources are the caller's host arrays; the temporaries go back to the block cache)
 }
 
+namespace {
+double g_learned[4] = {0, 0, 0, 0};
+ShutdownHook h_learn([] { replay_forget_sizes(); });
+}  // namespace
+void replay_forget_sizes() {
+  for (double &m : g_learned) m = 0;
+}
+
 bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, const uint32_t *d_bids, size_t nb, size_t n_entries,
                 uint32_t bestn, int band, bool predict, uint32_t ovlp_upper, const std::function<pgx_ovlp *(size_t)> &alloc_out,
                 size_t *n_out, pgx_overlap_stats *st, bool trace) {
@@ -2270,10 +2278,7 @@ bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visi
   // So a stage measures what it used per bucket entry -- read pairs, requests, items, reader nodes -- and the NEXT stage of the process (the
   // chunks of a job are alike) sizes its tables by that: hash tables for a load of at most 0.4, arenas with 20 % to spare.  The first stage of
   // a process starts from the defaults and, where they overflow, repeats with x 4 hash tables / x 2 arenas.
-  static double learned[4] = {0, 0, 0, 0};   // read pairs, requests, items, reader nodes per bucket entry (0: not known)
-  static ShutdownHook h_learn([] {
-    for (double &m : learned) m = 0;
-  });
+  double *learned = g_learned;   // read pairs, requests, items, reader nodes per bucket entry (0: not known)
   double mult[5] = {1, 1, 1, 1, 1};
   if (learned[0] > 0) {
     // (the arenas may also SHRINK to what the last stage used + 25-100 %: 8 reader nodes per entry are reserved by default and a c4 chunk links
@@ -2286,7 +2291,25 @@ bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visi
   if (getenv("PGX_REPLAY_MEMO_X")) mult[4] = atof(getenv("PGX_REPLAY_MEMO_X"));
   for (int attempt = 0; attempt < 4; ++attempt) {
     double usage[4] = {0, 0, 0, 0};
-    const uint32_t ov = replay_attempt(db, dp, visit_bids, d_bids, nb, n_entries, bestn, band, predict, alloc_out, n_out, st, trace, mult, usage);
+    uint32_t ov;
+    try {
+      ov = replay_attempt(db, dp, visit_bids, d_bids, nb, n_entries, bestn, band, predict, alloc_out, n_out, st, trace, mult, usage);
+    } catch (const Fail &f) {
+      //  tables sized by what an EARLIER stage used -- possibly another job's in a long-lived server -- may not fit where the
+      // defaults would: once more with the defaults and the memory forgotten, else the host replay (which only needs host memory)
+      if (f.code != PGX_ENOMEM && !(f.code == PGX_EHIP && strstr(pgx_last_error(), "hipMalloc"))) throw;   // (only a failed allocation)
+      (void)hipGetLastError();
+      const bool had_learned = learned[0] > 0;
+      replay_forget_sizes();
+      dev_cache_trim();
+      if (!had_learned || attempt > 0) {
+        fprintf(stderr, "[pgx] note: the device replay's tables could not be allocated (%s); the host replay takes over\n", pgx_last_error());
+        return false;
+      }
+      for (double &m : mult) m = 1;
+      if (trace) fprintf(stderr, "[pgx]   the tables sized by the last stage's use do not fit (%s): once more with the default sizes\n", pgx_last_error());
+      continue;
+    }
     if (!ov) {
       for (int k = 0; k < 4; ++k) learned[k] = std::max(learned[k], usage[k]);
       if (st) st->replay_attempts = (uint32_t)attempt + 1;

@@ -214,7 +214,7 @@ def _scratch(need):
     return best if free >= need else None
 
 
-def test_configs3_at_full_size_on_one_gpu():
+def test_configs3_and_configs4_at_full_size_on_one_gpu():
     """BASELINE configs[3] at its STATED size: a 3.1 Gb repeat-seeded genome x 30x = 6.2 M reads, 93 Gbases, generated
     into one device buffer the library adopts; index_nchunk = ovlp_nchunk = 8 run one after the other on the one GPU (bench.py's default
     workload).  Properties on every chunk, the record count of the whole job, and the stream of EVERY one of the 8 chunks -- the streams the
@@ -262,19 +262,20 @@ def test_configs3_at_full_size_on_one_gpu():
     import json
     import bench
     pins_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c4_stream_pins.json")
-    pins = json.load(open(pins_path)).get("c4") if os.path.exists(pins_path) else None
-    if pins is not None:
-        assert pins["chunks"] == N and pins["read_set_hash"] == bench.device_read_set_hash(seq, total), "the pins were made for another read set"
-        want = {p["chunk"]: p for p in pins["streams"]}
+    assert os.path.exists(pins_path), "tests/golden/c4_stream_pins.json is part of the tree (ADVICE r5: a missing pins file fails, it does not skip)"
+    all_pins = json.load(open(pins_path))
+    pins = all_pins["c4"]
+    read_set_hash = bench.device_read_set_hash(seq, total)
+    assert pins["chunks"] == N and pins["read_set_hash"] == read_set_hash, "the pins were made for another read set"
+    want = {p["chunk"]: p for p in pins["streams"]}
     total_records = 0
     jobs = []
 
     def settle(job):
         c, n, ck, fut, _ = job
         sha = fut.result()
-        if pins is not None:
-            w = want["%d of %d" % (c, N)]
-            assert n == w["records"] and sha == w["masked_sha256"], f"chunk {c} of {N}: the stream differs from the reference's (pinned) stream"
+        w = want["%d of %d" % (c, N)]
+        assert n == w["records"] and sha == w["masked_sha256"], f"chunk {c} of {N}: the stream differs from the reference's (pinned) stream"
 
     with cf.ThreadPoolExecutor(4) as pool:
         for c in range(1, N + 1):
@@ -300,8 +301,36 @@ def test_configs3_at_full_size_on_one_gpu():
         assert total_records == 366_003_067, total_records           # (profiles/r04d_bench_c4_sample.json: records_per_step)
         while jobs:
             settle(jobs.pop(0))
-    if pins is None:
-        pytest.skip("tests/golden/c4_stream_pins.json is not in this tree: properties and the record count were checked, the streams not pinned")
+    # ---- BASELINE configs[4] at its STATED size on the same read set (VERDICT r5 task 2): -l 1 (dense L1 shimmers, 3.2 x the L2 list), mc_upper 240,
+    # index_nchunk = ovlp_nchunk = 24 (bench.py --workload c5); the 8 overlap chunks the reference ran whole on the GPU box's host cores
+    # (profiles/r06_bench_c5.json; tests/golden/pins_from_bench.py) against their pinned SHA-256
+    pins5 = all_pins["c5"]
+    assert pins5["read_set_hash"] == read_set_hash and pins5["levels"] == 1, "the c5 pins were made for another read set"
+    del mm, mc
+    torch.cuda.empty_cache()
+    N5 = pins5["chunks"]
+    tops, mcs = [], []
+    for c in range(1, N5 + 1):
+        ix, top, mc = eng.index(N5, c, 1)
+        _lib.stream_signal()
+        tops.append(top.clone()), mcs.append(mc.clone())
+    mm, mc = torch.cat(tops), torch.cat(mcs)
+    del tops, mcs
+    _lib.stream_wait()
+    want5 = {p["chunk"]: p for p in pins5["streams"]}
+    jobs = []
+    with cf.ThreadPoolExecutor(4) as pool:
+        for key in sorted(want5, key=lambda k: int(k.split()[0])):
+            c = int(key.split()[0])
+            ov, st = rdb.overlap_dev(mm.data_ptr(), mm.numel() // 16, mc.data_ptr(), mc.numel() // 16, total_chunk=N5, mychunk=c, mc_upper=pins5["mc_upper"])
+            assert st["device_replay"] == 1 and st["n_records"] == len(ov)
+            jobs.append((key, len(ov), pool.submit(formats.masked_stream_sha256, ov), ov))
+            while len(jobs) >= 2:
+                k, n, fut, _ = jobs.pop(0)
+                assert n == want5[k]["records"] and fut.result() == want5[k]["masked_sha256"], f"configs[4], chunk {k}: the stream differs from the reference's (pinned) stream"
+            del ov
+        for k, n, fut, _ in jobs:
+            assert n == want5[k]["records"] and fut.result() == want5[k]["masked_sha256"], f"configs[4], chunk {k}: the stream differs from the reference's (pinned) stream"
     rdb.close()
     del seq, mm, mc
     torch.cuda.empty_cache()

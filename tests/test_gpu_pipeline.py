@@ -102,11 +102,15 @@ def test_pipeline_like_the_reference_test_scripts(tmp_path):
 
 
 @pytest.mark.skipif(not U.have_ref(), reason="needs the prebuilt reference binaries (oracle/_ref)")
-def test_served_mode_writes_the_same_files(tmp_path):
+@pytest.mark.parametrize("device_replay", ["default", "1"])
+def test_served_mode_writes_the_same_files(tmp_path, device_replay):
     """`pgx_cli serve -p <prefix>` keeps the read database in HBM; the native shmr_index / shmr_overlap drop-ins attach to it through
     <prefix>.pgx.sock (round 4: a job's 8 + 8 chunk commands upload the seqdb once).  Files byte-identical to the reference's; a
     command for another prefix, a replaced .seqdb file and a dead server all fall back to the stand-alone path; records also go to a
-    pipe (-o /dev/stdout: the sequential writer)."""
+    pipe (-o /dev/stdout: the sequential writer).  Round 6: the server keeps the lists its index commands wrote on the device (and reads files
+    it holds no current copy of), sends the device replay's records straight from the device into the mapped output file (device_replay "1":
+    PGX_GPU_REPLAY=1 in the server; "default": a set this small takes the host replay and the host-array writer) and answers a client when its
+    file is complete while the next command may already run: two commands in flight, and lists that changed behind the server's back."""
     import signal
     import time
     g = simreads.make_genome(200_000, 23, repeat_families=1, repeat_len=3000, repeat_copies=4, divergence=0.02, tandem=2)
@@ -121,7 +125,10 @@ def test_served_mode_writes_the_same_files(tmp_path):
         _ref("shmr_index", "-p", pre, "-t", 2, "-c", c, "-m", 0, "-o", tmp_path / "ref" / "ix")
     for c in (1, 2, 3):
         _ref("shmr_overlap", "-p", pre, "-l", tmp_path / "ref" / "ix-L2", "-t", 3, "-c", c, "-o", tmp_path / "ref" / f"ov.{c}")
-    srv = subprocess.Popen([cli, "serve", "-p", pre], stderr=subprocess.PIPE, text=True)
+    env = dict(os.environ)
+    if device_replay != "default":
+        env["PGX_GPU_REPLAY"] = device_replay
+    srv = subprocess.Popen([cli, "serve", "-p", pre], stderr=subprocess.PIPE, text=True, env=env)
     try:
         for _ in range(600):
             if os.path.exists(pre + ".pgx.sock") or srv.poll() is not None:
@@ -139,6 +146,27 @@ def test_served_mode_writes_the_same_files(tmp_path):
             assert (tmp_path / "srv" / f"ix-L2-{c:02d}-of-02.dat").read_bytes() == (tmp_path / "ref" / f"ix-L2-{c:02d}-of-02.dat").read_bytes()
         for c in (1, 2, 3):
             assert (tmp_path / "srv" / f"ov.{c}").read_bytes() == (tmp_path / "ref" / f"ov.{c}").read_bytes()
+        # two overlap commands in flight (a scheduler with two job slots): the second one's stage runs while the first one's file is completed
+        ps = [subprocess.Popen([cli, "shmr_overlap", "-p", pre, "-l", "ix-L2", "-t", "3", "-c", str(c), "-o", f"par.{c}"], cwd=tmp_path / "srv") for c in (1, 2, 3)]
+        assert [q.wait(timeout=120) for q in ps] == [0, 0, 0]
+        for c in (1, 2, 3):
+            assert (tmp_path / "srv" / f"par.{c}").read_bytes() == (tmp_path / "ref" / f"ov.{c}").read_bytes()
+        # lists the server never wrote (the reference's own index files): read from the files
+        subprocess.run([cli, "shmr_overlap", "-p", pre, "-l", str(tmp_path / "ref" / "ix-L2"), "-t", "3", "-c", "3", "-o", "fromref.3"], cwd=tmp_path / "srv", check=True, capture_output=True)
+        assert (tmp_path / "srv" / "fromref.3").read_bytes() == (tmp_path / "ref" / "ov.3").read_bytes()
+        # a job's lists REPLACED behind the server's back (another chunking under the same prefix): neither the device copies of the index commands nor the
+        # assembled lists may be used -- the streams must be those of the new files (here: T = 1 index, the reference's T = 1 run as the expectation)
+        _ref("shmr_index", "-p", pre, "-t", 1, "-c", 1, "-m", 0, "-o", tmp_path / "ref" / "one")
+        _ref("shmr_overlap", "-p", pre, "-l", tmp_path / "ref" / "one-L2", "-t", 3, "-c", 2, "-o", tmp_path / "ref" / "one.2")
+        for f in (tmp_path / "srv").glob("ix-L2-*"):
+            f.unlink()
+        shutil.copy(tmp_path / "ref" / "one-L2-01-of-01.dat", tmp_path / "srv" / "ix-L2-01-of-01.dat")
+        shutil.copy(tmp_path / "ref" / "one-L2-MC-01-of-01.dat", tmp_path / "srv" / "ix-L2-MC-01-of-01.dat")
+        subprocess.run([cli, "shmr_overlap", "-p", pre, "-l", "ix-L2", "-t", "3", "-c", "2", "-o", "one.2"], cwd=tmp_path / "srv", check=True, capture_output=True)
+        assert (tmp_path / "srv" / "one.2").read_bytes() == (tmp_path / "ref" / "one.2").read_bytes()
+        for c in (1, 2):   # ... and back to the job's own lists (re-indexed by the server: fresh device copies)
+            (tmp_path / "srv" / "ix-L2-01-of-01.dat").unlink(missing_ok=True), (tmp_path / "srv" / "ix-L2-MC-01-of-01.dat").unlink(missing_ok=True)
+            subprocess.run([cli, "shmr_index", "-p", pre, "-t", "2", "-c", str(c), "-m", "0", "-o", "ix"], cwd=tmp_path / "srv", check=True, capture_output=True)
         # -o /dev/stdout with a LIVE server: the server cannot open the client's descriptor -- the command runs stand-alone and the
         # records arrive on the client's stdout; a file under /dev/shm is a plain file and is served like any other
         r = subprocess.run([cli, "shmr_overlap", "-p", pre, "-l", "ix-L2", "-t", "3", "-c", "2", "-o", "/dev/stdout"], cwd=tmp_path / "srv", check=True, capture_output=True)
