@@ -647,7 +647,8 @@ def end_to_end_served(seq, total, db, rdb, CH, levels, mc_upper, stream_report, 
         log("end to end: %.1f GB of HBM still in use by this process" % ((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9))
         log(f"end to end: seqdb files written in {t_files:.1f} s; this process's HBM released")
         t0 = time.perf_counter()
-        srv = subprocess.Popen([cli, "serve", "-p", pre], stderr=subprocess.DEVNULL)
+        tr = os.environ.get("PGX_BENCH_E2E_TRACE")     # a file: the server's PGX_TRACE=1 log (per command: lists, stage, file transfer)
+        srv = subprocess.Popen([cli, "serve", "-p", pre], stderr=open(tr, "w") if tr else subprocess.DEVNULL, env=dict(os.environ, PGX_TRACE="1") if tr else None)
         while not os.path.exists(pre + ".pgx.sock") and srv.poll() is None:
             time.sleep(0.05)
         t_up = time.perf_counter() - t0

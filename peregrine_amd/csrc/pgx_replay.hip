@@ -1628,80 +1628,37 @@ __global__ __launch_bounds__(256) void k_file(R r, uint32_t limit) {
 }
 
 // ---- check the guesses against the results ------------------------------------------------------------------------------
-// fan != 0 (round 6): a guess that turns out REJECTED is the head of a chain -- the pair is withdrawn, the next bucket that holds both reads
-// (it skipped the pair as "seen") aligns it from its own anchors, is rejected again, and so on through the buckets the two reads share, a sweep
-// per hand-over (827 k wrong guesses per full-size c4 chunk are such repeat-induced candidates).  So the lane that finds the rejection files,
-// right here, the alignment every OTHER registered reader of that pair would ask for (file_for_reader) and the row's next `ahead` partners
-// (the rejected candidate does not count towards bestn: the row goes on to them); dev_replay aligns them before the next sweep starts, so
-// those buckets meet a KNOWN result instead of guessing.  A speculative request is just an alignment whose result the memo holds.
-__global__ __launch_bounds__(256) void k_settle(R r, uint32_t fan, uint32_t ahead) {
+__global__ __launch_bounds__(256) void k_settle(R r) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const bool active = j < r.nb && (r.bflags[j] & F_GUESS);
-  if (!__ballot(active)) return;
-  const uint32_t b = active ? r.bid[j] : 0u, s0 = active ? r.bstart[b] : 0u, nn = active ? r.bstart[b + 1] - s0 : 0u;
+  if (j >= r.nb || !(r.bflags[j] & F_GUESS)) return;
+  const uint32_t b = r.bid[j], s0 = r.bstart[b];
   bool bad = false, remain = false;
-  uint32_t it = active ? r.ihead[j] : NIL;
-  for (;;) {
-    bool fo = false;   // this lane found a rejected guess: its pair's other readers (and the row's next partners) are filed below
-    uint32_t f_slot = 0, f_a = 0, f_b = 0, f_ai = 0, f_pi = 0;
-    while (it != NIL && !fo) {
-      Item &im = r.items[it - 1];
-      const uint32_t nxt = im.next;
-      if (im.info & I_GUESS) {
-        const uint32_t req = im.mslot != NONE ? r.mt[im.mslot].req : NONE;
-        if (req >= r.settled) {
-          remain = true;
-        } else {
-          const uint32_t ai = im.info & 0xFF, pi = (im.info >> 8) & 0xFF, gtype = (im.info >> 16) & 3;
-          const Ent e0 = entry_of(r.y0[s0 + ai]), e1 = entry_of(r.y0[s0 + pi]);
-          uint32_t type;
-          const bool acc = classify(r.rq_res[req], r.rlen[e0.rid], r.rlen[e1.rid], e0.pos1 - e1.pos1, &type);
-          if (!acc || type != gtype) {
-            bad = true;
-            if (!acc && fan) fo = true, f_slot = im.pslot, f_a = e0.rid, f_b = e1.rid, f_ai = ai, f_pi = pi;
+  for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) {
+    Item &im = r.items[it - 1];
+    if (!(im.info & I_GUESS)) continue;
+    const uint32_t req = im.mslot != NONE ? r.mt[im.mslot].req : NONE;
+    if (req >= r.settled) {
+      remain = true;
+      continue;
+    }
+    const uint32_t ai = im.info & 0xFF, pi = (im.info >> 8) & 0xFF, gtype = (im.info >> 16) & 3;
+    const Ent e0 = entry_of(r.y0[s0 + ai]), e1 = entry_of(r.y0[s0 + pi]);
+    uint32_t type;
+    const bool acc = classify(r.rq_res[req], r.rlen[e0.rid], r.rlen[e1.rid], e0.pos1 - e1.pos1, &type);
+    if (!acc || type != gtype) bad = true;
 #ifdef PGX_SETTLE_STATS
-            const uint32_t rl0 = r.rlen[e0.rid], rl1 = r.rlen[e1.rid], qo = e0.pos1 - e1.pos1;
-            const uint32_t ol = min(rl0 - qo, rl1);
-            const pgx_match mm = r.rq_res[req];
-            int cat = acc ? 3 : (ol <= 520 ? 4 : (mm.q_end == 0 && mm.t_end == 0 ? 5 : 6));
-            atomicAdd(&r.spread[((j >> 6) % SPREAD) * 8 + cat], 1ULL);
+    if (!acc || type != gtype) {
+      const uint32_t rl0 = r.rlen[e0.rid], rl1 = r.rlen[e1.rid], qo = e0.pos1 - e1.pos1;
+      const uint32_t ol = min(rl0 - qo, rl1);
+      const pgx_match mm = r.rq_res[req];
+      int cat = acc ? 3 : (ol <= 520 ? 4 : (mm.q_end == 0 && mm.t_end == 0 ? 5 : 6));
+      atomicAdd(&r.spread[((j >> 6) % SPREAD) * 8 + cat], 1ULL);
+    }
 #endif
-          } else {
-            im.info &= ~I_GUESS;
-          }
-        }
-      }
-      it = nxt;
-    }
-    const uint64_t fm = __ballot(fo);
-    if (!fm && !__ballot(it != NIL)) break;
-    for (uint64_t mm = fm; mm; mm &= mm - 1) {   // by the whole wavefront: a reader bucket / a partner per lane
-      const int L = __builtin_ctzll(mm);
-      const uint32_t ps = (uint32_t)__shfl((int)f_slot, L, 64), ra = (uint32_t)__shfl((int)f_a, L, 64), rb2 = (uint32_t)__shfl((int)f_b, L, 64);
-      const uint32_t jj = (uint32_t)__shfl((int)j, L, 64), sL = (uint32_t)__shfl((int)s0, L, 64), nL = (uint32_t)__shfl((int)nn, L, 64);
-      const uint32_t aL = (uint32_t)__shfl((int)f_ai, L, 64), pL = (uint32_t)__shfl((int)f_pi, L, 64);
-      for (uint32_t p = pL + 1 + (uint32_t)lane; p < nL && p <= pL + ahead; p += 64) file_entries(r, sL, aL, p);
-      const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[ps >> r.cshift]);
-      const uint32_t c = min(w[0], NIN);
-      for (uint32_t q = (uint32_t)lane; q < c; q += 64) {
-        const uint32_t rb = w[2 + q];
-        if (rb != 0 && rb - 1 != jj && rb - 1 < r.nb) file_for_reader(r, rb - 1, ra, rb2);
-      }
-      if (c >= NIN) {   // the overflow list: every lane walks it (one broadcast load per node), node i goes to lane i % 64
-        uint32_t idx = 0;
-        for (uint32_t nd = w[1]; nd != NIL; nd = r.rn[nd - 1].next, ++idx)
-          if ((idx & 63u) == (uint32_t)lane) {
-            const uint32_t rb = r.rn[nd - 1].bucket;
-            if (rb != jj && rb < r.nb) file_for_reader(r, rb, ra, rb2);
-          }
-      }
-    }
+    else im.info &= ~I_GUESS;
   }
-  if (active) {
-    if (bad) r.dirty[j] = 1;
-    if (!remain) r.bflags[j] &= (uint8_t)~F_GUESS;
-  }
+  if (bad) r.dirty[j] = 1;
+  if (!remain) r.bflags[j] &= (uint8_t)~F_GUESS;
 }
 
 // ---- the ovlp_t records, bucket by bucket in visit order, each bucket's in evaluation order ---------------------------
@@ -1950,11 +1907,10 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   const size_t dense_min = (size_t)1 << 40;
   const size_t tail_max = 4000;               // tail mode (file_for_reader, look-ahead) once a sweep asks for at most this many alignments, or 1/256 of the first sweep's
   const uint32_t ahead = 24u;                 // tail mode: partners of a row filed ahead
-  // round 6: k_settle files the alignments of the OTHER readers of a pair whose guess was rejected (+ the row's next partners) and they are
-  // aligned before the next sweep (PGX_REPLAY_SETTLE_FAN=0: off; PGX_REPLAY_SETTLE_AHEAD: partners of the row)
-  const bool settle_fan = !getenv("PGX_REPLAY_SETTLE_FAN") || atoi(getenv("PGX_REPLAY_SETTLE_FAN")) != 0;
-  const uint32_t settle_ahead = getenv("PGX_REPLAY_SETTLE_AHEAD") ? (uint32_t)atoi(getenv("PGX_REPLAY_SETTLE_AHEAD")) : 2u;
-  size_t n_fanned = 0;
+  // (round 6, tried and removed: k_settle filing, right where it finds a REJECTED guess, the alignment every other reader of that pair would ask
+  //  for and the row's next 0 / 2 / 6 partners, aligned before the next sweep -- bit-exact, and no sweep fewer: 18-19 sweeps and 6.21-6.33 s per
+  //  full-size c4 step against 18 and 6.13 s without, profiles/r06b_settle_fan_c4.txt.  The sweeps behind the second are not hand-overs of one
+  //  pair between its readers -- tail mode's file_for_reader already covers those -- but a dependency chain through DIFFERENT pairs.)
   const bool use_win_list = true;
   // evaluate / update iterations per window of a dense round: 2 (through round 4: 3; at full-size c4 6.89 -> 6.81 s per step with 2 and 6.90 with 1,
   // c3 / c4s / c5s unchanged; the third iteration of a window mostly re-runs k_eval_big's longest bucket for a handful of dirty buckets that the
@@ -2126,19 +2082,12 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     {
       std::optional<KernelTimer> tms;
       if (timed_misc) tms.emplace("replay_misc", 0);
-      hipLaunchKernelGGL(k_settle, dim3(cdiv256(nb)), dim3(256), 0, s, r, settle_fan ? 1u : 0u, settle_ahead);
+      hipLaunchKernelGGL(k_settle, dim3(cdiv256(nb)), dim3(256), 0, s, r);
     }
     count_dirty();
-    if (batch > 100000 || settle_fan) {  // a big batch: worth a round trip to know how many guesses were wrong (dense or sparse next)
+    if (batch > 100000) {  // a big batch: worth a round trip to know how many guesses were wrong (dense or sparse next)
       fetch(false);
       if (hc->overflow) goto overflowed;
-      if (hc->nreq > first_req) {   // what k_settle filed for the other readers of the rejected pairs: aligned now, known to the next sweep
-        const size_t extra = hc->nreq - first_req;
-        if (trace) fprintf(stderr, "[pgx]   %zu alignments filed for the readers of rejected pairs\n", extra);
-        dev_align(db, r.rq_key + first_req, extra, band, r.rq_res + first_req, 2);
-        first_req = hc->nreq, r.settled = (uint32_t)hc->nreq;
-        n_fanned += extra;
-      }
       n_dirty = hc->ndirty, known = true;
       d_lo = n_dirty ? hc->min_dirty : 0, d_hi = n_dirty ? hc->max_dirty + 1 : 0;
       if (trace) fprintf(stderr, "[pgx]   alignments + settle %.2f ms, %zu buckets guessed wrong\n", now_ms() - a0, n_dirty);
@@ -2202,8 +2151,8 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
 #endif
     }
     if (trace)
-      fprintf(stderr, "[pgx] device replay: %u sweeps, %u rounds, %llu evaluations, %zu records, %zu alignments filed by k_settle; emit %.2f ms; alignments %.2f ms; total %.2f ms\n",
-              sweeps, rounds_total, (unsigned long long)hc->evals, nrec, n_fanned, now_ms() - e0, align_ms, now_ms() - t0);
+      fprintf(stderr, "[pgx] device replay: %u sweeps, %u rounds, %llu evaluations, %zu records; emit %.2f ms; alignments %.2f ms; total %.2f ms\n",
+              sweeps, rounds_total, (unsigned long long)hc->evals, nrec, now_ms() - e0, align_ms, now_ms() - t0);
   }
   return 0;
 overflowed:

@@ -124,6 +124,11 @@ def _launch_reference_chunk(name, chunk=3, N=8):
     proc = subprocess.Popen([os.path.join(U.REF_DIR, "shmr_overlap"), "-p", pre, "-l", os.path.join(d, "ix-L%d" % lv), "-t", str(N), "-c", str(chunk),
                              "-M", str(sp["mc_upper"]), "-o", out], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     refs[name] = dict(dir=d, proc=proc, out=out, chunk=chunk, mm=np.concatenate([p.top for p in parts]), mc=np.concatenate([p.top_mc for p in parts]), sp=sp)
+    if name == "c4s":    #  one chunking that is NOT the job's: ovlp_nchunk 13 over the 8 index chunks, chunk 5 -- a thirteenth of the first keys
+        out2 = os.path.join(d, "ref13.ovlp")
+        refs[name]["proc13"] = subprocess.Popen([os.path.join(U.REF_DIR, "shmr_overlap"), "-p", pre, "-l", os.path.join(d, "ix-L%d" % lv), "-t", "13", "-c", "5",
+                                                 "-M", str(sp["mc_upper"]), "-o", out2], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        refs[name]["out13"] = out2
     _SET.setdefault("dirs", []).append(d)
     return refs[name]
 
@@ -349,8 +354,13 @@ def test_repeat_seeded_full_chunk_equals_reference_binary(name, chunk):
     db = _c4s_reads()
     rdb = ResidentDB(db, 0)
     ov, st = rdb.overlap(ref["mm"], ref["mc"], total_chunk=8, mychunk=chunk, mc_upper=ref["sp"]["mc_upper"])
+    ov13 = rdb.overlap(ref["mm"], ref["mc"], total_chunk=13, mychunk=5, mc_upper=ref["sp"]["mc_upper"])[0] if "proc13" in ref else None
     rdb.close()
     assert ref["proc"].wait(timeout=900) == 0
+    if ov13 is not None:     # a chunking that is not the job's (index_nchunk 8, ovlp_nchunk 13)
+        assert ref["proc13"].wait(timeout=900) == 0
+        want13 = formats.read_ovlp(ref["out13"])
+        assert len(want13) > 100_000 and formats.ovlp_fields_equal(ov13, want13), (len(ov13), len(want13))
     want = formats.read_ovlp(ref["out"])
     assert len(want) > 500_000 and len(ov) == len(want), (len(ov), len(want))
     assert st["device_replay"] == 1 and st["device_visit"] >= 1
@@ -364,6 +374,8 @@ def test_zz_scratch_files_removed():
     for r in (_SET.get("refs") or {}).values():
         if r and r["proc"].poll() is None:
             r["proc"].kill()
+        if r and r.get("proc13") is not None and r["proc13"].poll() is None:
+            r["proc13"].kill()
     for d in _SET.get("dirs", []):
         shutil.rmtree(d, ignore_errors=True)
     _SET.clear()
