@@ -402,7 +402,10 @@ static void aggregate_counts_now(const pgx_mm_count *cin, size_t n_counts, Count
 // split + sort + reduce + insert (57 ms per full-size configs[3] chunk, profiles/r05a_chunk_timeline_c4.txt).
 __global__ __launch_bounds__(256) void k_counts_checksum(const pgx_mm_count *__restrict__ in, size_t n, unsigned long long *__restrict__ sum) {
   unsigned long long h = 0, h2 = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+  // a CONTIGUOUS run of entries per workgroup (round 6; a grid-stride loop over the 4 GB of a full-size job's count entries jumped 32 MB per
+  // iteration in every wavefront -- a new translation range each time: 8.1 ms per chunk for what is a 1 ms stream)
+  const size_t per = ((n + gridDim.x - 1) / gridDim.x + 255) & ~(size_t)255, lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     const uint4 v = *reinterpret_cast<const uint4 *>(in + i);   // mer (x, y), count (z); the padding word is not looked at
     unsigned long long x = ((unsigned long long)v.y << 32 | v.x) + 0x9E3779B97F4A7C15ULL * (i + 1);
     x ^= x >> 33, x *= 0xff51afd7ed558ccdULL, x ^= x >> 33;

@@ -27,1688 +27,11 @@
 
 #include <hipcub/hipcub.hpp>
 
-#include "pgx_internal.h"
+#include "pgx_replay.h"
 
 namespace pgx {
+using namespace rp;
 namespace {
-
-constexpr uint32_t NIL = 0;  // list links and reader heads are stored +1
-constexpr uint32_t NONE = 0xFFFFFFFFu;
-constexpr int END_FUZZ = 48;  // READ_END_FUZZINESS, shmr_overlap.c:36
-enum { T_OVERLAP = 0, T_CONTAINS = 1, T_CONTAINED = 2 };
-
-constexpr uint32_t NIN = 58;
-// One read pair = a HOT part {key = (min rid << 32 | max rid) + 1, own = (bucket << 3 | parity << 2 | type) + 1} and a COLD part
-// (its readers).  An evaluation's dependent chain only ever waits for the hot part: 16 bytes per slot, one aligned load, and a
-// table of a few 100 MB that the 256 MB Infinity Cache and the TLBs hold (the 256-byte slots of round 1 made every probe a
-// cold HBM access into a 2 GB table).  Registrations go to the cold part and are not waited for.
-struct alignas(16) PHot {
-  unsigned long long key;
-  uint32_t own;
-  uint32_t pad;
-};
-struct alignas(256) PCold {
-  uint32_t cnt;       // registrations so far; the first NIN sit in in[] (bucket + 1)
-  uint32_t rhead;     // readers beyond the inline ones: linked nodes
-  uint32_t in[NIN];   // (a pair of overlapping 15 kb reads shares ~25-40 buckets: nearly every list fits, and is duplicate-free)
-  uint32_t pad[4];
-};
-static_assert(sizeof(PHot) == 16 && sizeof(PCold) == 256, "pair slot = 16 hot bytes + four cold cache lines");
-struct MSlot {  // one alignment: a = rid0 << 32 | rid1 (never 0), b = (q_off << 2 | dir0 << 1 | dir1) + 1, req = request number
-  unsigned long long a;
-  uint32_t b;
-  uint32_t req;
-};
-struct Item {  // one insertion of a bucket's latest evaluation
-  uint32_t pslot;
-  uint32_t info;  // ai | pi << 8 | type << 16 | I_GUESS | I_UNFILED
-  uint32_t mslot;
-  uint32_t next;
-};
-struct RNode {
-  uint32_t next, bucket;
-};
-constexpr uint32_t I_GUESS = 1u << 18, I_UNFILED = 1u << 19;
-#ifndef PGX_SPARSE_CAP
-#define PGX_SPARSE_CAP 65536
-#endif
-constexpr uint32_t SPARSE_CAP = PGX_SPARSE_CAP;   // buckets a sparse pass takes from the list
-constexpr uint32_t LIST_CAP = 262144;    // capacity of the list (a window of a dense round is listed whole)
-constexpr uint32_t DEV_LIST = 0xFFFFFFFFu, DEV_LIST_WIN = 0xFFFFFFFEu;  // nlist: the device's list, up to SPARSE_CAP / LIST_CAP entries
-enum : uint32_t { OV_ITEMS = 1, OV_NODES = 2, OV_REQS = 4, OV_PAIRS = 8, OV_MEMO = 16, OV_QOFF = 32, OV_PASSES = 64 };  // Counters::overflow
-constexpr uint8_t F_DUP = 1, F_GUESS = 2, F_UNFILED = 4;
-constexpr uint8_t F_BIG = 8;   // a bucket of at least R::big_min entries that holds no read twice: evaluated by a whole workgroup (k_eval_big)
-
-struct alignas(64) Counters {   // three cache lines: the arenas, the dirty statistics, the totals (an atomic holds its line's L2 channel)
-  uint32_t item_top, rnode_top, nreq, overflow;
-  uint32_t pad0[12];
-  uint32_t ndirty, min_dirty, max_dirty, pad;
-  uint32_t nbig;          // big dirty buckets the narrow evaluation kernels of this pass left to k_eval_big (R::blist)
-  uint32_t nbig_total;    // buckets k_setup marked F_BIG (none: k_eval_big is never launched)
-  uint32_t pad1[10];
-  unsigned long long lookups, skips, evals, records;
-#ifdef PGX_BIG_STATS
-  uint32_t big_max_steps, big_long, big_long_n, big_evals;
-  unsigned long long pad2[2];
-#else
-  unsigned long long pad2[4];
-#endif
-};
-
-struct R {
-  uint32_t nb;
-  const uint32_t *bid, *bstart;
-  const uint64_t *y0;
-  const uint8_t *dir;
-  const uint32_t *rlen;
-  PHot *ph;
-  PCold *pc;       // the reader list of hot slot i is pc[i >> cshift]
-  uint32_t cshift;
-  uint32_t pmask;
-  MSlot *mt;
-  uint32_t mmask;
-  Item *items;
-  uint32_t item_cap;
-  RNode *rn;
-  uint32_t rn_cap;
-  pgx_align_key *rq_key;
-  pgx_match *rq_res;
-  uint32_t req_cap, settled;
-  uint32_t memo_used;  // 0: nothing has been filed yet (the first round of the first sweep skips the memo lookups)
-  uint8_t *dirty, *evaluated, *parity, *bflags, *ever;
-  uint32_t *ihead, *inum, *ohead, *lookups, *skips;
-  uint32_t *dlist;  // the dirty buckets, listed by k_count while there are at most LIST_CAP of them (the sparse passes run from the list)
-  uint32_t *blist;  // the big ones among a pass's dirty buckets (any order; Counters::nbig of them)
-  uint32_t wlist0;  // first wcur slot of the list-mode wavefronts
-  uint4 *wcur;  // per wavefront of k_eval: the unused rest of its arena chunks {node cur, node end, item cur, item end}, kept across launches
-  Counters *c;
-  unsigned long long *spread;  // the totals (evaluations, look-ups, skips) over SPREAD cache lines: [line * 8 + {0, 1, 2}], summed by the host
-  uint32_t bestn;
-  uint32_t tail;           // != 0: the sweeps have become small: k_file also files the alignment every OTHER reader of a requested pair would ask
-                           // for and the row's next `tail` partners
-  int predict, predict2;   // margins of predict_contained (0: every pending alignment is guessed a plain overlap)
-  uint32_t big_min;        // buckets from this many entries on (and without a repeated read) go to k_eval_big; 0: none do
-  uint32_t dup_min;        // the same for buckets that hold a read twice (k_eval_big's LDS pair set instead of one partner at a time)
-  uint32_t wbig0;          // first wcur slot of k_eval_big's wavefronts
-};
-
-__device__ __forceinline__ uint64_t mix64(uint64_t h) {
-  h ^= h >> 33, h *= 0xff51afd7ed558ccdULL, h ^= h >> 33, h *= 0xc4ceb9fe1a85ec53ULL, h ^= h >> 33;
-  return h;
-}
-__device__ __forceinline__ uint32_t own_enc(uint32_t j, uint32_t par, uint32_t type) { return ((j << 3) | (par << 2) | type) + 1; }
-__device__ __forceinline__ uint32_t own_bucket(uint32_t v) { return (v - 1) >> 3; }
-__device__ __forceinline__ uint32_t own_parity(uint32_t v) { return ((v - 1) >> 2) & 1; }
-__device__ __forceinline__ uint32_t own_type(uint32_t v) { return (v - 1) & 3; }
-__device__ __forceinline__ uint32_t lane_rank(uint64_t m) {
-  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-__device__ __forceinline__ long iabs64(long x) { return x < 0 ? -x : x; }
-
-// acceptance test and classification of shimmer_to_overlap (shmr_overlap.c:134-160)
-__device__ __forceinline__ bool classify(const pgx_match &m, uint32_t rlen0, uint32_t rlen1, uint32_t q_off, uint32_t *type) {
-  const uint32_t slen0 = rlen0 - q_off, slen1 = rlen1;
-  *type = T_OVERLAP;
-  if (m.q_bgn < END_FUZZ && m.t_bgn < END_FUZZ &&
-      (iabs64((long)slen0 - m.q_end) < END_FUZZ || iabs64((long)slen1 - m.t_end) < END_FUZZ) && m.q_end > 500 &&
-      m.t_end > 500) {
-    if (iabs64((long)rlen0 - ((long)m.q_end - m.q_bgn)) < END_FUZZ * 2 ||
-        iabs64((long)rlen1 - ((long)m.t_end - m.t_bgn)) < END_FUZZ * 2)
-      *type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
-    return true;
-  }
-  return false;
-}
-
-// The type a pending alignment will most likely have (classify above, with the alignment's geometry predicted): the query is
-// read 0 from q_off on (slen0 = rlen0 - q_off bases), the target read 1 from its start.  If the target runs out first
-// (rlen1 <= slen0) its whole length is covered: contained-type.  If the query runs out first, q_end = slen0 and t_end = slen0 +
-// drift: contained-type iff q_off + q_bgn < 96 (the query side) or rlen1 - slen0 < 96 + drift - t_bgn (the target side: a
-// target that sticks out by less than the fuzz still counts as covered).  q_bgn / t_bgn (the first 17-base run) are a few bases,
-// the drift of 1 % indels over 15 kb is ~ +-10: margins mq / mt, both 88 by default.  (Round 1 tested rlen1 <= slen0 on the
-// target side: every pair with 0 < rlen1 - slen0 < ~90, 0.6 % of all, was guessed wrong -- most of the second sweep's work.)
-__device__ __forceinline__ bool predict_contained(uint32_t rlen0, uint32_t rlen1, uint32_t q_off, int mq, int mt) {
-  return (int)rlen1 - (int)(rlen0 - q_off) < mt || q_off < (uint32_t)mq;
-}
-
-// the slot of a read pair, inserting the key if it is new (keys never change once set, so a stale "empty" only costs a
-// failed compare-and-swap)
-__device__ __forceinline__ uint32_t pair_slot(const R &r, uint64_t pair) {
-  const unsigned long long want = pair + 1;
-  uint32_t i = (uint32_t)mix64(pair) & r.pmask;
-  for (int probes = 0; probes < 1024; ++probes) {
-    unsigned long long k = r.ph[i].key;
-    if (k == want) return i;
-    if (k == 0) {
-      k = atomicCAS(&r.ph[i].key, 0ULL, want);
-      if (k == 0 || k == want) return i;
-    }
-    i = (i + 1) & r.pmask;
-  }
-  atomicOr(&r.c->overflow, OV_PAIRS);
-  return i;
-}
-
-// read-only lookup of a pair (speculative partners must not fill the table with pairs the walk never examines); the
-// slot's first 16 bytes -- key, owner, overflow head -- arrive in one load
-__device__ __forceinline__ uint32_t pair_find(const R &r, uint64_t pair, uint32_t *own) {
-  const unsigned long long want = pair + 1;
-  uint32_t i = (uint32_t)mix64(pair) & r.pmask;
-  for (int probes = 0; probes < 1024; ++probes) {
-    const uint4 h = *reinterpret_cast<const uint4 *>(&r.ph[i]);
-    const unsigned long long k = (unsigned long long)h.y << 32 | h.x;
-    if (k == want) {
-      *own = h.z;
-      return i;
-    }
-    if (k == 0) break;
-    i = (i + 1) & r.pmask;
-  }
-  *own = 0;
-  return NONE;
-}
-
-// read-only lookup of an alignment in the memo (nothing inserts while k_eval / k_settle / k_emit run): slot and request
-__device__ __forceinline__ uint32_t memo_find(const R &r, unsigned long long a, uint32_t b, uint32_t *req) {
-  uint32_t i = (uint32_t)mix64(a ^ mix64(b)) & r.mmask;
-  for (int probes = 0; probes < 1024; ++probes) {
-    const uint4 h = *reinterpret_cast<const uint4 *>(&r.mt[i]);
-    const unsigned long long cur = (unsigned long long)h.y << 32 | h.x;
-    if (cur == 0) break;
-    if (cur == a && h.z == b + 1) {
-      *req = h.w;
-      return i;
-    }
-    i = (i + 1) & r.mmask;
-  }
-  *req = NONE;
-  return NONE;
-}
-
-struct Ent {
-  uint32_t rid, pos1;
-};
-__device__ __forceinline__ Ent entry_of(uint64_t y) { return Ent{(uint32_t)(y >> 32), (((uint32_t)y) >> 1) + 1}; }
-
-// ---- flags: buckets holding a read more than once (only those can meet a pair twice within one evaluation) ----------
-__global__ __launch_bounds__(256) void k_setup(R r, uint32_t *hist) {   // hist (trace only): [dup][min(n / 8, 15)] bucket counts
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= r.nb) return;
-  const uint32_t b = r.bid[j], s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
-  bool dup = false;
-  for (uint32_t i = 0; i + 1 < n && !dup; ++i) {
-    const uint32_t ri = (uint32_t)(r.y0[s0 + i] >> 32);
-    for (uint32_t k = i + 1; k < n; ++k)
-      if ((uint32_t)(r.y0[s0 + k] >> 32) == ri) {
-        dup = true;
-        break;
-      }
-  }
-  const bool big = dup ? r.dup_min && n >= r.dup_min : r.big_min && n >= r.big_min;
-  r.bflags[j] = (uint8_t)((dup ? F_DUP : 0) | (big ? F_BIG : 0));
-  if (big) atomicAdd(&r.c->nbig_total, 1u);
-  r.dirty[j] = 1;
-  if (hist) atomicAdd(&hist[(dup ? 16 : 0) + min(n / 8, 15u)], 1u);
-}
-
-// ---- shimmer_to_overlap (shmr_overlap.c:52-180) for every dirty bucket in [lo, hi) -------------------------------------
-// A group of GL lanes per bucket.  The rows (ai, descending) are sequential -- they communicate through the "contained"
-// flags -- but the partners of one row are examined GL at a time, speculatively: lane l takes partner pbase + l, and the
-// sequential semantics (stop once bestn overlaps are counted, or when the row's own read turns out contained) are then
-// resolved with ballots.  What a lane beyond the stop did is harmless: a pair key, a reader registration (only ever costs a
-// spurious re-evaluation), loads.  Buckets that hold a read twice can meet a pair twice within one evaluation: they run one
-// partner at a time.  A single evaluation is a chain of dependent memory round trips, so the group form is what bounds
-// the latency of a pass: rows x ~4 round trips instead of examinations x ~4.
-constexpr uint32_t NCH = 256;  // reader-node arena chunk of a wavefront
-constexpr uint32_t SPREAD = 256;
-constexpr uint32_t ICH = 128;  // item arena piece of a wavefront slot (8 chunks of 16)
-
-// every wavefront slot of k_eval starts with its own piece of the item arena (no atomic at all for its first ICH items); the
-// shared counter starts behind the pieces
-// (slots [0, n_dense): the dense rounds' wavefronts, GPW buckets each; [wlist0, nslots): the list-mode wavefronts; the slots
-// between them are only used by the one-bucket-per-wavefront dense variant and start empty)
-__global__ void k_init_slots(uint4 *__restrict__ wcur, uint32_t nslots, uint32_t n_dense, uint32_t wlist0, Counters *c) {
-  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w == 0) c->item_top = (n_dense + (nslots - wlist0)) * ICH;
-  if (w >= nslots) return;
-  if (w < n_dense || w >= wlist0) {
-    const uint32_t piece = w < n_dense ? w : n_dense + (w - wlist0);
-    wcur[w] = make_uint4(0u, 0u, piece * ICH, (piece + 1) * ICH);
-  } else {
-    wcur[w] = make_uint4(0u, 0u, 0u, 0u);
-  }
-}
-
-#ifndef PGX_REPLAY_GL
-#define PGX_REPLAY_GL 16
-#endif
-constexpr int GL = PGX_REPLAY_GL;  // lanes per bucket
-constexpr uint32_t GPW = 64 / GL, GPB = 256 / GL;
-__device__ __forceinline__ uint64_t gbits(uint64_t wave_mask, int gbase) { return (wave_mask >> gbase) & ((1ULL << GL) - 1ULL); }
-
-// group g of the launch -> its bucket (a range of buckets, or the dirty list)
-__device__ __forceinline__ uint64_t bucket_of_group(const R &r, uint32_t lo, uint32_t hi, uint32_t nlist, uint32_t g) {
-  if (nlist) {
-    const uint32_t n = nlist == DEV_LIST ? min(r.c->ndirty, SPARSE_CAP) : nlist == DEV_LIST_WIN ? min(r.c->ndirty, LIST_CAP) : nlist;  // (DEV_LIST*: as many as the last count listed)
-    return g < n ? (uint64_t)r.dlist[g] : (uint64_t)hi;
-  }
-  return (uint64_t)lo + g;
-}
-
-// readers of a pair later than bucket j become dirty (k_update only: nothing registers while it runs)
-__device__ __forceinline__ void mark_readers(const R &r, uint32_t slot, uint32_t j) {
-  const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[slot >> r.cshift]);
-  const uint4 h1 = *reinterpret_cast<const uint4 *>(w);  // cnt, rhead, in[0], in[1]
-  const uint32_t c = min(h1.x, NIN);
-  // (entries are bucket + 1 <= nb: the upper test is a guard, not a rule)
-  if (c > 0 && h1.z > j + 1 && h1.z <= r.nb) r.dirty[h1.z - 1] = 1;
-  if (c > 1 && h1.w > j + 1 && h1.w <= r.nb) r.dirty[h1.w - 1] = 1;
-  for (uint32_t q = 2; q < c; q += 8) {  // in[q .. q+8): two 16-byte loads in flight
-    const uint4 a = *reinterpret_cast<const uint4 *>(w + 2 + q), b = *reinterpret_cast<const uint4 *>(w + 6 + q);
-    const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (uint32_t k = 0; k < 8; ++k)
-      if (q + k < c && x[k] > j + 1 && x[k] <= r.nb) r.dirty[x[k] - 1] = 1;
-  }
-  if (c < NIN) return;
-  for (uint32_t nd = h1.y; nd != NIL; nd = r.rn[nd - 1].next) {
-    const uint32_t rb = r.rn[nd - 1].bucket;
-    if (rb > j) r.dirty[rb] = 1;
-  }
-}
-
-// ---- shimmer_to_overlap (shmr_overlap.c:52-180) for every dirty bucket of the launch ------------------------------------
-// A group of 16 lanes per bucket.  The rows (ai, descending) are sequential -- they communicate through the "contained"
-// flags -- but the partners of one row are examined 16 at a time, speculatively: lane l takes partner pbase + l, and the
-// sequential semantics (stop once bestn overlaps are counted, or when the row's own read turns out contained) are then
-// resolved with ballots.  What a lane beyond the stop did is harmless: loads.  Buckets that hold a read twice can meet a
-// pair twice within one evaluation: they run one partner at a time.  A single evaluation is a chain of dependent memory
-// round trips, which is what bounds a sparse pass: the bucket's entries are staged in LDS once, a probe brings key and
-// owner in one 16-byte load, and registrations / item stores are not waited for.
-__global__ __launch_bounds__(256) void k_eval(R r, uint32_t lo, uint32_t hi, uint32_t nlist) {
-  __shared__ uint32_t s_rid[GPB][128], s_pos[GPB][128], s_rl[GPB][128];
-  __shared__ uint8_t s_dir[GPB][128];
-  const int lane = threadIdx.x & 63, gl = lane & (GL - 1), gbase = lane & ~(GL - 1), gib = threadIdx.x / GL;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPW + (uint32_t)(lane / GL));
-  const uint32_t j = (uint32_t)jj;
-  bool alive = jj < hi && r.dirty[j] && !r.c->overflow;
-  if (alive && (r.bflags[j] & F_BIG)) {   // a big bucket: left to k_eval_big, which runs behind this kernel from the list written here
-    if (gl == 0) {
-      const uint32_t at = atomicAdd(&r.c->nbig, 1u);
-      if (at < LIST_CAP) r.blist[at] = j;   // (beyond the list: the bucket stays dirty and is listed again by the next pass)
-    }
-    alive = false;
-  }
-  {
-    const uint64_t am = __ballot(alive);
-    if (!am) return;
-    if (lane == (int)__builtin_ctzll(am)) atomicAdd(&r.spread[(wave % SPREAD) * 8], (unsigned long long)(__popcll(am) / GL));
-  }
-  // reader-node arena: wave-uniform cursor; the wavefront that evaluates these buckets next time continues where this one stops
-  const uint32_t wave_id = nlist ? r.wlist0 + wave : (uint32_t)(((uint64_t)lo + (uint64_t)wave * GPW) / GPW);
-  const uint4 wc = r.wcur[wave_id];
-  uint32_t rcur = wc.x, rend = wc.y;
-  uint32_t icur = wc.z, iend = wc.w;   // item arena of this wavefront slot (multiples of 16), same idea
-  uint32_t s0 = 0, n = 0;
-  bool dup = false, first_eval = true;
-  if (alive) {
-    const uint32_t b = r.bid[j];
-    s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
-    dup = (r.bflags[j] & F_DUP) != 0;
-    first_eval = r.ever[j] == 0;
-    for (uint32_t i = (uint32_t)gl; i < n; i += GL) {  // the bucket's entries -> LDS
-      const uint64_t y = r.y0[s0 + i];
-      const uint32_t rid = (uint32_t)(y >> 32);
-      s_rid[gib][i] = rid, s_pos[gib][i] = (((uint32_t)y) >> 1) + 1, s_dir[gib][i] = r.dir[s0 + i], s_rl[gib][i] = r.rlen[rid];
-    }
-    if (gl == 0) {
-      r.dirty[j] = 0;
-      r.evaluated[j] = 1;
-      r.ever[j] = 1;
-      r.parity[j] ^= 1;
-      r.ohead[j] = r.ihead[j];
-    }
-  }
-  uint64_t clo = 0, chi = 0;  // "contained" flags of the bucket's entries (n <= 128)
-  auto cget = [&](uint32_t i) { return (((i < 64 ? clo : chi) >> (i & 63)) & 1) != 0; };
-  uint32_t head = NIL, num = 0, lookups = 0, skips = 0;
-  uint32_t chunk = 0;  // base of the item chunk holding insertion ordinals [num & ~15, ...)
-  bool any_guess = false, any_unfiled = false;
-  int ai = (int)n - 1;  // (the first row opened is n - 2)
-  bool row_open = false;
-  uint32_t pbase = 0, got = 0, rid0 = 0, pos0 = 0, rlen0 = 0, dir0 = 0;
-  bool p_reg = false;  // this lane has a registration whose list position (p_idx) has not been looked at yet
-  uint32_t p_idx = 0, p_slot = 0;
-  auto resolve_pending = [&]() -> bool {  // false: the reader-node arena is exhausted
-    if (p_reg && p_idx < NIN) r.pc[p_slot >> r.cshift].in[p_idx] = j + 1, p_reg = false;
-    const uint64_t rm = __ballot(p_reg);  // (what is left goes to the linked overflow)
-    if (rm) {
-      const uint32_t total = (uint32_t)__popcll(rm);
-      if (rcur + total > rend) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&r.c->rnode_top, NCH);
-        base = (uint32_t)__shfl((int)base, 0, 64);
-        if ((uint64_t)base + NCH > r.rn_cap) {
-          atomicOr(&r.c->overflow, OV_NODES);
-          return false;
-        }
-        rcur = base, rend = base + NCH;
-      }
-      if (p_reg) {
-        const uint32_t node = rcur + lane_rank(rm);
-        const uint32_t old = atomicExch(&r.pc[p_slot >> r.cshift].rhead, node + 1);
-        r.rn[node] = RNode{old, j};
-      }
-      rcur += total;
-      p_reg = false;
-    }
-    return true;
-  };
-  for (;;) {
-    if (alive && !row_open) {
-      do --ai;
-      while (ai >= 0 && cget((uint32_t)ai));
-      if (ai < 0 || r.bestn == 0) {  // the bucket is done
-        if (gl == 0) {
-          r.ihead[j] = head, r.inum[j] = num, r.lookups[j] = lookups, r.skips[j] = skips;
-          r.bflags[j] = (uint8_t)((dup ? F_DUP : 0) | (any_guess ? F_GUESS : 0) | (any_unfiled ? F_UNFILED : 0));
-        }
-        alive = false;
-      } else {
-        rid0 = s_rid[gib][ai], pos0 = s_pos[gib][ai], rlen0 = s_rl[gib][ai], dir0 = s_dir[gib][ai];
-        got = 0, pbase = (uint32_t)ai + 1, row_open = true;
-      }
-    }
-    if (!__ballot(alive)) {
-      if (!resolve_pending()) return;
-      if (lane == 0) r.wcur[wave_id] = make_uint4(rcur, rend, icur, iend);
-      break;
-    }
-    // ---- one batch of partners ----
-    const uint32_t step = dup ? 1u : (uint32_t)GL;
-    const uint32_t pi = pbase + (uint32_t)gl;
-    bool valid = alive && (uint32_t)gl < step && pi < n && !cget(pi);
-    uint32_t rid1 = 0, pos1 = 0;
-    if (valid) {
-      rid1 = s_rid[gib][pi], pos1 = s_pos[gib][pi];
-      if (rid1 == rid0) valid = false;
-    }
-    uint32_t slot = NONE, v = 0;
-    const uint64_t pair = rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0);
-    if (valid) slot = pair_find(r, pair, &v);
-    const uint64_t vm = __ballot(valid);
-    bool present = false, accepted = false, guessed = false;
-    uint32_t ptype = 0, type = 0, mslot = NONE;
-    if (valid) {
-      present = v != 0 && own_bucket(v) < j;
-      ptype = present ? own_type(v) : 0;
-      if (!present && dup && slot != NONE)  // inserted earlier in THIS evaluation?
-        for (uint32_t it = head; it != NIL; it = r.items[it - 1].next)
-          if (r.items[it - 1].pslot == slot) {
-            present = true, ptype = (r.items[it - 1].info >> 16) & 3;
-            break;
-          }
-      if (!present) {
-        const uint32_t rlen1 = s_rl[gib][pi], dir1 = s_dir[gib][pi];
-        const uint32_t q_off = pos0 - pos1;
-        if (q_off >= (1u << 30)) atomicOr(&r.c->overflow, OV_QOFF);
-        uint32_t req = NONE;
-        if (r.memo_used) mslot = memo_find(r, (unsigned long long)rid0 << 32 | rid1, q_off << 2 | dir0 << 1 | dir1, &req);
-        if (req < r.settled) {
-          accepted = classify(r.rq_res[req], rlen0, rlen1, q_off, &type);
-        } else {
-          accepted = true, guessed = true, type = T_OVERLAP;
-          if (r.predict && predict_contained(rlen0, rlen1, q_off, r.predict, r.predict2)) type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
-        }
-      }
-    }
-    if (!resolve_pending()) return;  // (the previous batch's registrations: their atomics have returned behind the loads above)
-    // ---- the sequential semantics of the row over this batch, lowest partner first ----
-    const uint64_t Vg = gbits(vm, gbase);
-    const uint64_t P = gbits(__ballot(valid && present), gbase);
-    const uint64_t PO = gbits(__ballot(valid && present && ptype == T_OVERLAP), gbase);
-    const uint64_t A = gbits(__ballot(valid && !present && accepted), gbase);
-    const uint64_t AO = gbits(__ballot(valid && !present && accepted && type == T_OVERLAP), gbase);
-    const uint64_t AC = gbits(__ballot(valid && !present && accepted && type == T_CONTAINED), gbase);
-    uint64_t AP = gbits(__ballot(valid && !present && accepted && type == T_CONTAINS), gbase);
-    const uint64_t inc = PO | AO;
-    int stop = GL;  // the last partner the sequential loop processes in this batch (GL: all of them, and the row goes on)
-    if (alive && row_open) {
-      const uint32_t need = r.bestn - got;  // >= 1
-      if ((uint32_t)__popcll(inc) >= need) {
-        uint64_t m = inc;
-        for (uint32_t k = 1; k < need; ++k) m &= m - 1;
-        stop = __builtin_ctzll(m);
-      }
-      if (AC) stop = min(stop, (int)__builtin_ctzll(AC));
-    }
-    const uint64_t proc = (2ULL << stop) - 1ULL;
-    const uint64_t ins = A & proc;
-    {  // the partners the sequential loop really examined register as readers of their pairs (the lists are only read by
-       // k_update, after this kernel); a bucket listed by an earlier evaluation is not listed again.  The list position comes
-       // from an atomic whose result is only looked at after the NEXT batch's loads have been issued (resolve_pending).
-      bool reg = valid && ((proc >> gl) & 1);
-      if (reg && slot == NONE) slot = pair_slot(r, pair);  // a pair the walk really examines gets its slot now
-      if (reg && !first_eval) {
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[slot >> r.cshift]);
-        const uint4 h1 = *reinterpret_cast<const uint4 *>(w);  // cnt, rhead, in[0], in[1]
-        const uint32_t c = min(h1.x, NIN);
-        if ((c > 0 && h1.z == j + 1) || (c > 1 && h1.w == j + 1)) reg = false;
-        for (uint32_t q = 2; q < c && reg; q += 8) {
-          const uint4 a = *reinterpret_cast<const uint4 *>(w + 2 + q), b = *reinterpret_cast<const uint4 *>(w + 6 + q);
-          const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-          for (uint32_t k = 0; k < 8; ++k)
-            if (q + k < c && x[k] == j + 1) reg = false;
-        }
-      }
-      if (reg) p_idx = atomicAdd(&r.pc[slot >> r.cshift].cnt, 1u), p_slot = slot, p_reg = true;
-    }
-    // ---- the batch's insertions: the bucket's items fill 16-aligned chunks of 16 in insertion order (k_update walks a
-    // bucket's list a chunk at a time, one lane per item) ----
-    const bool my_ins = valid && !present && accepted && ((proc >> gl) & 1);
-    const uint32_t cins = (uint32_t)__popcll(ins);
-    const bool need_chunk = cins != 0 && (num == 0 || ((num + cins - 1) >> 4) != ((num - 1) >> 4));  // group-uniform
-    uint32_t fresh = 0;
-    {
-      const uint64_t cm = __ballot(need_chunk && gl == 0);
-      if (cm) {
-        const uint32_t want = 16u * (uint32_t)__popcll(cm);
-        if (icur + want > iend) {  // refill: one atomic on the shared counter per ICH items instead of one per chunk
-          const uint32_t take = want > ICH ? want : ICH;
-          uint32_t base = 0;
-          if (lane == (int)__builtin_ctzll(cm)) base = atomicAdd(&r.c->item_top, take);
-          base = (uint32_t)__shfl((int)base, (int)__builtin_ctzll(cm), 64);
-          if ((uint64_t)base + take > r.item_cap) {
-            atomicOr(&r.c->overflow, OV_ITEMS);
-            return;
-          }
-          icur = base, iend = base + take;   // (what was left of the old piece, < want, is not used)
-        }
-        fresh = icur + 16u * (uint32_t)__popcll(cm & ((1ULL << gbase) - 1ULL));  // (gl == 0 lanes: one bit per group)
-        icur += want;
-      }
-    }
-    if (cins) {
-      if (my_ins) {
-        const uint32_t ord = num + (uint32_t)__popcll(ins & ((1ULL << gl) - 1ULL));  // insertion ordinal within the bucket
-        const bool in_fresh = need_chunk && (num == 0 || (ord >> 4) != ((num - 1) >> 4));
-        const uint32_t idx = (in_fresh ? fresh : chunk) + (ord & 15);
-        uint32_t next;
-        if (ord == 0) next = NIL;
-        else if ((ord & 15) == 0) next = chunk + 16;  // the last item of the previous chunk, + 1
-        else next = idx;                              // the item before this one, + 1
-        uint32_t info = (uint32_t)ai | pi << 8 | type << 16;
-        if (guessed) info |= I_GUESS;
-        if (mslot == NONE) info |= I_UNFILED;
-        r.items[idx] = Item{slot, info, mslot, next};
-      }
-      const uint32_t last = num + cins - 1;
-      if (need_chunk && (num == 0 || (last >> 4) != ((num - 1) >> 4))) chunk = fresh;
-      head = chunk + (last & 15) + 1;
-      num += cins;
-    }
-    {
-      const uint64_t g1 = gbits(__ballot(my_ins && guessed), gbase), g2 = gbits(__ballot(my_ins && mslot == NONE), gbase);
-      any_guess |= g1 != 0, any_unfiled |= g2 != 0;
-    }
-    if (alive && row_open) {
-      got += (uint32_t)__popcll(inc & proc);
-      skips += (uint32_t)__popcll(P & proc);
-      lookups += (uint32_t)__popcll(Vg & ~P & proc);
-      AP &= proc;
-      if (AP) {  // partners found contained: entry pbase + l
-        if (pbase < 64) {
-          clo |= AP << pbase;
-          if (pbase) chi |= AP >> (64 - pbase);
-        } else {
-          chi |= AP << (pbase - 64);
-        }
-      }
-      if (AC & proc) {
-        if (ai < 64) clo |= 1ULL << ai;
-        else chi |= 1ULL << (ai - 64);
-      }
-      if (stop < GL || pbase + step >= n) row_open = false;
-      else pbase += step;
-    }
-  }
-}
-
-// 128-bit masks over a row's partners / a bucket's entries (k_eval_rows, k_eval_big)
-struct M128 {
-  uint64_t lo, hi;
-};
-__device__ __forceinline__ int popc128(M128 m) { return __popcll(m.lo) + __popcll(m.hi); }
-__device__ __forceinline__ bool any128(M128 m) { return (m.lo | m.hi) != 0; }
-__device__ __forceinline__ int ctz128(M128 m) { return m.lo ? __builtin_ctzll(m.lo) : 64 + __builtin_ctzll(m.hi); }   // (m != 0)
-__device__ __forceinline__ int nth128(M128 m, uint32_t nth) {   // position of the nth set bit (nth >= 1, nth <= popc128(m))
-  const uint32_t cl = (uint32_t)__popcll(m.lo);
-  uint64_t w = m.lo;
-  int base = 0;
-  if (nth > cl) w = m.hi, nth -= cl, base = 64;
-  for (uint32_t k = 1; k < nth; ++k) w &= w - 1;
-  return base + __builtin_ctzll(w);
-}
-__device__ __forceinline__ M128 upto128(int stop) {   // bits 0 .. stop (stop >= 127: all)
-  M128 m;
-  m.lo = stop >= 63 ? ~0ULL : ((2ULL << stop) - 1ULL);
-  m.hi = stop < 64 ? 0ULL : (stop >= 127 ? ~0ULL : ((2ULL << (stop - 64)) - 1ULL));
-  return m;
-}
-__device__ __forceinline__ M128 and128(M128 a, M128 b) { return M128{a.lo & b.lo, a.hi & b.hi}; }
-__device__ __forceinline__ M128 andn128(M128 a, M128 b) { return M128{a.lo & ~b.lo, a.hi & ~b.hi}; }   // a & ~b
-__device__ __forceinline__ M128 shr128(M128 m, uint32_t s) {   // m >> s, s <= 128
-  if (s >= 128) return M128{0, 0};
-  if (s >= 64) return M128{m.hi >> (s - 64), 0};
-  if (s == 0) return m;
-  return M128{m.lo >> s | m.hi << (64 - s), m.hi >> s};
-}
-
-
-// ---- the same evaluation with FOUR ROWS PER STEP, for the sparse passes (a wavefront per bucket: lanes are plentiful there and
-// a pass lasts as long as its longest bucket's chain of rows).  Lane l works row l / PW, partner l % PW; the rows are committed
-// in order while each one is complete within its PW partners and no earlier row of the step set a contained flag (then the
-// rows below are looked at again with the new flags); a row that needs more partners is continued alone, GLT per step.
-template <int GLT, int PW>
-__global__ __launch_bounds__(256) void k_eval_rows(R r, uint32_t lo, uint32_t hi, uint32_t nlist) {
-  constexpr uint32_t GPWT = 64 / GLT, GPBT = 256 / GLT;
-  constexpr int SH = PW == 16 ? 4 : 2;  // log2(PW)
-  constexpr uint64_t RM = (1ULL << PW) - 1ULL;  // one row's lanes
-  __shared__ uint32_t s_rid[GPBT][128], s_pos[GPBT][128], s_rl[GPBT][128];
-  __shared__ uint8_t s_dir[GPBT][128];
-  const int lane = threadIdx.x & 63, gl = lane & (GLT - 1), gbase = lane & ~(GLT - 1), gib = threadIdx.x / GLT;
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPWT + (uint32_t)(lane / GLT));
-  const uint32_t j = (uint32_t)jj;
-  bool alive = jj < hi && r.dirty[j] && !r.c->overflow;
-  if (alive && (r.bflags[j] & F_BIG)) {   // a big bucket: left to k_eval_big, which runs behind this kernel from the list written here
-    if (gl == 0) {
-      const uint32_t at = atomicAdd(&r.c->nbig, 1u);
-      if (at < LIST_CAP) r.blist[at] = j;   // (beyond the list: the bucket stays dirty and is listed again by the next pass)
-    }
-    alive = false;
-  }
-  {
-    const uint64_t am = __ballot(alive);
-    if (!am) return;
-    if (lane == (int)__builtin_ctzll(am)) atomicAdd(&r.spread[(wave % SPREAD) * 8], (unsigned long long)(__popcll(am) / GLT));
-  }
-  // reader-node arena: wave-uniform cursor; the wavefront that evaluates these buckets next time continues where this one stops
-  const uint32_t wave_id = nlist ? r.wlist0 + wave : (uint32_t)(((uint64_t)lo + (uint64_t)wave * GPWT) / GPWT);
-  const uint4 wc = r.wcur[wave_id];
-  uint32_t rcur = wc.x, rend = wc.y;
-  uint32_t icur = wc.z, iend = wc.w;   // item arena of this wavefront slot (multiples of 16), same idea
-  uint32_t s0 = 0, n = 0;
-  bool dup = false, first_eval = true;
-  if (alive) {
-    const uint32_t b = r.bid[j];
-    s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
-    dup = (r.bflags[j] & F_DUP) != 0;
-    first_eval = r.ever[j] == 0;
-    for (uint32_t i = (uint32_t)gl; i < n; i += GLT) {  // the bucket's entries -> LDS
-      const uint64_t y = r.y0[s0 + i];
-      const uint32_t rid = (uint32_t)(y >> 32);
-      s_rid[gib][i] = rid, s_pos[gib][i] = (((uint32_t)y) >> 1) + 1, s_dir[gib][i] = r.dir[s0 + i], s_rl[gib][i] = r.rlen[rid];
-    }
-    if (gl == 0) {
-      r.dirty[j] = 0;
-      r.evaluated[j] = 1;
-      r.ever[j] = 1;
-      r.parity[j] ^= 1;
-      r.ohead[j] = r.ihead[j];
-    }
-  }
-  auto gbits = [&](uint64_t wave_mask, int) { return GLT == 64 ? wave_mask : ((wave_mask >> gbase) & ((1ULL << (GLT & 63)) - 1ULL)); };
-  uint64_t clo = 0, chi = 0;  // "contained" flags of the bucket's entries (n <= 128)
-  auto cget = [&](uint32_t i) { return (((i < 64 ? clo : chi) >> (i & 63)) & 1) != 0; };
-  auto cset = [&](uint32_t i) {
-    if (i < 64) clo |= 1ULL << i;
-    else chi |= 1ULL << (i - 64);
-  };
-  uint32_t head = NIL, num = 0, lookups = 0, skips = 0;
-  uint32_t chunk = 0;  // base of the item chunk holding insertion ordinals [num & ~15, ...)
-  bool any_guess = false, any_unfiled = false;
-  int done_to = (int)n - 1;  // rows >= done_to are finished (the first row is n - 2)
-  bool row_open = false;     // a single row (cur_row) is in progress, sixteen partners per step from pbase
-  int cur_row = 0, a0 = -1, a1 = -1, a2 = -1, a3 = -1, nrows = 0;
-  uint32_t pbase = 0, got = 0;
-  bool p_reg = false;  // this lane has a registration whose list position (p_idx) has not been looked at yet
-  uint32_t p_idx = 0, p_slot = 0;
-  auto resolve_pending = [&]() -> bool {  // false: the reader-node arena is exhausted
-    if (p_reg && p_idx < NIN) r.pc[p_slot >> r.cshift].in[p_idx] = j + 1, p_reg = false;
-    const uint64_t rm = __ballot(p_reg);  // (what is left goes to the linked overflow)
-    if (rm) {
-      const uint32_t total = (uint32_t)__popcll(rm);
-      if (rcur + total > rend) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(&r.c->rnode_top, NCH);
-        base = (uint32_t)__shfl((int)base, 0, 64);
-        if ((uint64_t)base + NCH > r.rn_cap) {
-          atomicOr(&r.c->overflow, OV_NODES);
-          return false;
-        }
-        rcur = base, rend = base + NCH;
-      }
-      if (p_reg) {
-        const uint32_t node = rcur + lane_rank(rm);
-        const uint32_t old = atomicExch(&r.pc[p_slot >> r.cshift].rhead, node + 1);
-        r.rn[node] = RNode{old, j};
-      }
-      rcur += total;
-      p_reg = false;
-    }
-    return true;
-  };
-  for (;;) {
-    if (alive && !row_open) {  // the next (up to four) rows that are not contained
-      nrows = 0, a0 = a1 = a2 = a3 = -1;
-      int x = done_to;
-      while (nrows < 4) {
-        do --x;
-        while (x >= 0 && cget((uint32_t)x));
-        if (x < 0) break;
-        if (nrows == 0) a0 = x;
-        else if (nrows == 1) a1 = x;
-        else if (nrows == 2) a2 = x;
-        else a3 = x;
-        ++nrows;
-      }
-      if (nrows == 0 || r.bestn == 0) {  // the bucket is done
-        if (gl == 0) {
-          r.ihead[j] = head, r.inum[j] = num, r.lookups[j] = lookups, r.skips[j] = skips;
-          r.bflags[j] = (uint8_t)((dup ? F_DUP : 0) | (any_guess ? F_GUESS : 0) | (any_unfiled ? F_UNFILED : 0));
-        }
-        alive = false;
-      } else if (dup) {
-        cur_row = a0, got = 0, pbase = (uint32_t)a0 + 1, row_open = true;
-      }
-    }
-    if (!__ballot(alive)) {
-      if (!resolve_pending()) return;
-      if (lane == 0) r.wcur[wave_id] = make_uint4(rcur, rend, icur, iend);
-      break;
-    }
-    // ---- this step's (row, partner) of the lane ----
-    const bool single = row_open;  // group-uniform
-    const uint32_t step = dup ? 1u : (uint32_t)GLT;
-    const int q = gl >> SH;
-    const int myrow = single ? cur_row : (q == 0 ? a0 : q == 1 ? a1 : q == 2 ? a2 : a3);
-    const uint32_t pi = single ? pbase + (uint32_t)gl : (uint32_t)(myrow + 1 + (gl & (PW - 1)));
-    bool valid = alive && (single ? (uint32_t)gl < step : q < nrows) && pi < n && !cget(pi);
-    uint32_t rid0 = 0, pos0 = 0, rlen0 = 0, dir0 = 0, rid1 = 0, pos1 = 0;
-    if (valid) {
-      rid0 = s_rid[gib][myrow], pos0 = s_pos[gib][myrow], rlen0 = s_rl[gib][myrow], dir0 = s_dir[gib][myrow];
-      rid1 = s_rid[gib][pi], pos1 = s_pos[gib][pi];
-      if (rid1 == rid0) valid = false;
-    }
-    uint32_t slot = NONE, v = 0;
-    const uint64_t pair = rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0);
-    if (valid) slot = pair_find(r, pair, &v);
-    const uint64_t vm = __ballot(valid);
-    bool present = false, accepted = false, guessed = false;
-    uint32_t ptype = 0, type = 0, mslot = NONE;
-    if (valid) {
-      present = v != 0 && own_bucket(v) < j;
-      ptype = present ? own_type(v) : 0;
-      if (!present && dup && slot != NONE)  // inserted earlier in THIS evaluation?
-        for (uint32_t it = head; it != NIL; it = r.items[it - 1].next)
-          if (r.items[it - 1].pslot == slot) {
-            present = true, ptype = (r.items[it - 1].info >> 16) & 3;
-            break;
-          }
-      if (!present) {
-        const uint32_t rlen1 = s_rl[gib][pi], dir1 = s_dir[gib][pi];
-        const uint32_t q_off = pos0 - pos1;
-        if (q_off >= (1u << 30)) atomicOr(&r.c->overflow, OV_QOFF);
-        uint32_t req = NONE;
-        if (r.memo_used) mslot = memo_find(r, (unsigned long long)rid0 << 32 | rid1, q_off << 2 | dir0 << 1 | dir1, &req);
-        if (req < r.settled) {
-          accepted = classify(r.rq_res[req], rlen0, rlen1, q_off, &type);
-        } else {
-          accepted = true, guessed = true, type = T_OVERLAP;
-          if (r.predict && predict_contained(rlen0, rlen1, q_off, r.predict, r.predict2)) type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
-        }
-      }
-    }
-    if (!resolve_pending()) return;  // (the previous step's registrations: their atomics have returned behind the loads above)
-    // ---- the sequential semantics over this step, lowest lane first ----
-    const uint64_t Vg = gbits(vm, gbase);
-    const uint64_t P = gbits(__ballot(valid && present), gbase);
-    const uint64_t PO = gbits(__ballot(valid && present && ptype == T_OVERLAP), gbase);
-    const uint64_t A = gbits(__ballot(valid && !present && accepted), gbase);
-    const uint64_t AO = gbits(__ballot(valid && !present && accepted && type == T_OVERLAP), gbase);
-    const uint64_t AC = gbits(__ballot(valid && !present && accepted && type == T_CONTAINED), gbase);
-    const uint64_t AP = gbits(__ballot(valid && !present && accepted && type == T_CONTAINS), gbase);
-    const uint64_t inc = PO | AO;
-    uint64_t proc = 0;  // the lanes the sequential walk really visits in this step
-    if (alive && single) {
-      int stop = GLT;  // the last partner the row processes in this step (GLT: all of them, and the row goes on)
-      const uint32_t need = r.bestn - got;  // >= 1
-      if ((uint32_t)__popcll(inc) >= need) {
-        uint64_t m = inc;
-        for (uint32_t k = 1; k < need; ++k) m &= m - 1;
-        stop = __builtin_ctzll(m);
-      }
-      if (AC) stop = min(stop, (int)__builtin_ctzll(AC));
-      proc = stop >= 63 ? ~0ULL : ((2ULL << stop) - 1ULL);
-      got += (uint32_t)__popcll(inc & proc);
-      for (uint64_t m = AP & proc; m; m &= m - 1) cset(pbase + (uint32_t)__builtin_ctzll(m));  // partners found contained
-      if (AC & proc) cset((uint32_t)cur_row);
-      if (stop < GLT || pbase + step >= n) row_open = false, done_to = cur_row;
-      else pbase += step;
-    } else if (alive) {
-      int committed = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (k >= nrows || committed != k) continue;
-        const int row = k == 0 ? a0 : k == 1 ? a1 : k == 2 ? a2 : a3;
-        // partners an EARLIER row of this step found contained (or that were such a row) are not examined by this row: their lanes are
-        // dropped from its masks here (round 3 ended the step at the first row that changed a flag; a row's partners lie above it, so
-        // the rows themselves are never flagged by an earlier row of the step)
-        const uint32_t gone = (uint32_t)shr128(M128{clo, chi}, (uint32_t)row + 1).lo & (uint32_t)RM;
-        const uint32_t inc_k = (uint32_t)((inc >> (PW * k)) & RM) & ~gone, ac_k = (uint32_t)((AC >> (PW * k)) & RM) & ~gone,
-                       ap_k = (uint32_t)((AP >> (PW * k)) & RM) & ~gone;
-        int stop = PW;
-        if ((uint32_t)__popc(inc_k) >= r.bestn) {
-          uint32_t m = inc_k;
-          for (uint32_t t = 1; t < r.bestn; ++t) m &= m - 1;
-          stop = __builtin_ctz(m);
-        }
-        if (ac_k) stop = min(stop, (int)__builtin_ctz(ac_k));
-        if (stop == PW && (uint32_t)row + 1 + PW < n) continue;  // the row needs more partners: it is continued alone (committed stays k)
-        const uint32_t proc_k = (stop < PW ? (2u << stop) - 1u : (uint32_t)RM) & ~gone;
-        proc |= (uint64_t)proc_k << (PW * k);
-        ++committed;
-        for (uint32_t m = ap_k & proc_k; m; m &= m - 1) cset((uint32_t)row + 1 + (uint32_t)__builtin_ctz(m));   // partners found contained
-        if (ac_k & proc_k) cset((uint32_t)row);
-      }
-      if (committed == 0) cur_row = a0, got = 0, pbase = (uint32_t)a0 + 1, row_open = true;  // (nothing done in this step)
-      else done_to = committed == 1 ? a0 : committed == 2 ? a1 : committed == 3 ? a2 : a3;
-    }
-    skips += (uint32_t)__popcll(P & proc);
-    lookups += (uint32_t)__popcll(Vg & ~P & proc);
-    const uint64_t ins = A & proc;
-    {  // the partners the walk really examined register as readers of their pairs (the lists are only read by k_update, after
-       // this kernel); a bucket listed by an earlier evaluation is not listed again.  The list position comes from an atomic
-       // whose result is only looked at after the NEXT step's loads have been issued (resolve_pending).
-      bool reg = valid && ((proc >> gl) & 1);
-      if (reg && slot == NONE) slot = pair_slot(r, pair);  // a pair the walk really examines gets its slot now
-      if (reg && !first_eval) {
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[slot >> r.cshift]);
-        const uint4 h1 = *reinterpret_cast<const uint4 *>(w);  // cnt, rhead, in[0], in[1]
-        const uint32_t c = min(h1.x, NIN);
-        if ((c > 0 && h1.z == j + 1) || (c > 1 && h1.w == j + 1)) reg = false;
-        for (uint32_t qq = 2; qq < c && reg; qq += 8) {
-          const uint4 a = *reinterpret_cast<const uint4 *>(w + 2 + qq), b = *reinterpret_cast<const uint4 *>(w + 6 + qq);
-          const uint32_t x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-          for (uint32_t k = 0; k < 8; ++k)
-            if (qq + k < c && x[k] == j + 1) reg = false;
-        }
-      }
-      if (reg) p_idx = atomicAdd(&r.pc[slot >> r.cshift].cnt, 1u), p_slot = slot, p_reg = true;
-    }
-    // ---- the step's insertions: the bucket's items fill 16-aligned chunks of 16 in insertion order (lane order is the
-    // sequential order; k_update walks a bucket's list a chunk at a time, one lane per item) ----
-    const bool my_ins = valid && !present && accepted && ((proc >> gl) & 1);
-    const uint32_t cins = (uint32_t)__popcll(ins);  // up to 64 in one step here: it may open several 16-item chunks
-    static_assert(GLT == 64, "one bucket per wavefront: the chunk allocation below is wave-uniform");
-    if (cins) {
-      const uint32_t cur_no = num ? (num - 1) >> 4 : 0;                 // number of the chunk `chunk` (meaningless while num == 0)
-      const uint32_t first_new = num ? cur_no + 1 : 0;                   // number of the first chunk this step has to open
-      const uint32_t last = num + cins - 1, last_no = last >> 4;
-      const uint32_t nnew = last_no + 1 > first_new ? last_no + 1 - first_new : 0;
-      uint32_t fresh = 0;
-      if (nnew) {
-        const uint32_t want = 16u * nnew;
-        if (icur + want > iend) {
-          const uint32_t take = want > ICH ? want : ICH;
-          uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(&r.c->item_top, take);
-          base = (uint32_t)__shfl((int)base, 0, 64);
-          if ((uint64_t)base + take > r.item_cap) {
-            atomicOr(&r.c->overflow, OV_ITEMS);
-            return;
-          }
-          icur = base, iend = base + take;
-        }
-        fresh = icur, icur += want;
-      }
-      auto base_of = [&](uint32_t no) { return no >= first_new ? fresh + 16u * (no - first_new) : chunk; };
-      if (my_ins) {
-        const uint32_t ord = num + (uint32_t)__popcll(ins & ((1ULL << gl) - 1ULL));  // insertion ordinal within the bucket
-        const uint32_t idx = base_of(ord >> 4) + (ord & 15);
-        uint32_t next;
-        if (ord == 0) next = NIL;
-        else if ((ord & 15) == 0) next = base_of((ord >> 4) - 1) + 16;  // the last item of the previous chunk, + 1
-        else next = idx;                                                // the item before this one, + 1
-        uint32_t info = (uint32_t)myrow | pi << 8 | type << 16;
-        if (guessed) info |= I_GUESS;
-        if (mslot == NONE) info |= I_UNFILED;
-        r.items[idx] = Item{slot, info, mslot, next};
-      }
-      chunk = base_of(last_no);
-      head = chunk + (last & 15) + 1;
-      num += cins;
-    }
-    {
-      const uint64_t g1 = gbits(__ballot(my_ins && guessed), gbase), g2 = gbits(__ballot(my_ins && mslot == NONE), gbase);
-      any_guess |= g1 != 0, any_unfiled |= g2 != 0;
-    }
-  }
-}
-
-
-// ---- the same evaluation by a WHOLE WORKGROUP, for big buckets (round 3) -----------------------------------------------------------
-// A bucket of a repeat family holds ~100 entries and its walk examines ~5,000 pairs, nearly all of them "seen" skips that do not
-// count towards bestn: every row scans most of its partners.  With a wavefront per bucket (k_eval_rows: four rows x 16 partners,
-// a row that needs more continued alone, 64 partners per step) that is 100-200 dependent steps of ~20 us -- 3.4 ms per
-// evaluation, and a sparse pass lasts as long as its largest bucket: 0.47 s of a 1.07 s step at C4 scale went there
-// (profiles/r03a_kernel_stats_bench_c4s.txt), and the ~15 tail sweeps of a human-scale chunk are little else.  Here eight
-// wavefronts take FOUR rows x 128 partners per step (a bucket holds at most 128 entries, so a row is always complete within its
-// step): the rows are committed in order through masks exchanged in LDS, exactly like k_eval_rows' four-row form; a partner that an
-// earlier row of the step found contained is dropped from the later rows' masks in place (round 4).
-#ifndef PGX_BIG_NW
-#define PGX_BIG_NW 8
-#endif
-constexpr int BIG_NW = PGX_BIG_NW;              // wavefronts per bucket: rows slot = wave / 2, partner half = wave % 2
-constexpr int BIG_NR = BIG_NW / 2;              // rows of a step
-constexpr uint32_t BIG_WG = 512;                // workgroups of a launch (persistent: they stride over the list / the range, 512 entries at a time; 1024 / 2048: c4s 302-305 ms against 306, c4 unchanged)
-// Buckets that hold a read TWICE (tandem arrays, low-complexity runs: the same shimmer pair several times within a read) can
-// meet a read pair more than once within one evaluation, and the second meeting must see the first one's insertion.  The
-// narrower kernels therefore run them one partner at a time -- up to 5,000 dependent steps for a 100-entry bucket, and those
-// few hundred buckets were what a sparse pass at C4 scale really waited for (3.5 ms per pass, 136 passes per step).  Here the
-// pairs this evaluation has inserted so far sit in an LDS set that every probe consults, and duplicates WITHIN a step are
-// found by letting the would-be inserters claim their pair in a second LDS table: the step is cut in front of the first lane (in
-// walk order) whose pair an earlier lane of the same step claims, the cut row is continued alone from that partner in the next
-// step -- when the insertion is in the set -- and everything before the cut is exact.  Progress per step >= one new pair, so a
-// bucket of d distinct read pairs takes at most ~d steps instead of rows x partners.
-constexpr uint32_t SET_CAP = 2048, CLAIM_CAP = 1024;   // LDS tables of k_eval_big (open addressing, power-of-two sizes)
-__global__ __launch_bounds__(64 * BIG_NW) void k_eval_big(R r, uint32_t lo, uint32_t hi, uint32_t nlist) {
-  enum { MV = 0, MP, MPO, MA, MAO, MAC, MAP, MGU, MUF, MDF, NM };
-  __shared__ uint32_t s_rid[128], s_pos[128], s_rl[128];
-  __shared__ uint8_t s_dir[128];
-  __shared__ uint64_t s_m[BIG_NW][NM];
-  __shared__ uint32_t s_fresh, s_abort, s_bail;
-  __shared__ unsigned long long s_setk[SET_CAP];      // pairs inserted by this evaluation (key + 1; 0: empty) ...
-  __shared__ uint8_t s_sett[SET_CAP];                 // ... and their types
-  __shared__ unsigned long long s_clk[CLAIM_CAP];     // this step's claims: pair (key + 1) ...
-  __shared__ uint32_t s_clw[CLAIM_CAP];               // ... and the lowest walk index claiming it
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t wave_id = r.wbig0 + blockIdx.x * BIG_NW + (uint32_t)w;
-  const uint4 wc = r.wcur[wave_id];
-  uint32_t rcur = wc.x, rend = wc.y;   // reader-node arena of this wavefront
-  uint32_t icur = wc.z, iend = wc.w;   // item arena of the workgroup (only thread 0's copy is used)
-  if (threadIdx.x == 0) s_abort = 0;
-  // its buckets: the big list of the pass.  Two kinds of entries: a bucket id, noted by a narrow kernel that ran over a RANGE and met the
-  // bucket (k_eval / k_eval_rows skip big buckets); and a position in the dirty list | 2^31, noted by the count that made the list
-  // (k_count_b) -- those count only in a list-mode launch, and only below `lo` = the number of list entries the narrow kernel and the
-  // k_update of this pass cover (an evaluation k_update does not see would be lost)
-  const uint32_t list_limit = nlist ? lo : 0u;
-  const uint32_t nbig = min(r.c->nbig, LIST_CAP);
-  for (uint32_t g = blockIdx.x; g < nbig; g += gridDim.x) {
-  {
-    const uint32_t e = r.blist[g];
-    if ((e & 0x80000000u) && (e & 0x7FFFFFFFu) >= list_limit) continue;   // (workgroup-uniform)
-    const uint32_t j = (e & 0x80000000u) ? (r.dlist[e & 0x7FFFFFFFu] & 0x7FFFFFFFu) : e;
-    __syncthreads();   // (the previous bucket's LDS is done with)
-    if (threadIdx.x == 0) {   // one thread decides for the workgroup (a flag another workgroup raises meanwhile must not split it)
-      if (r.c->overflow) s_abort = 1;
-      s_bail = 0, s_fresh = (j < hi && r.dirty[j]) ? 1u : 0u;   // (s_fresh doubles as "go": a listed bucket is dirty unless the list is stale)
-    }
-    __syncthreads();
-    if (s_abort) break;
-    if (!s_fresh) continue;
-    const uint32_t b = r.bid[j], s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
-    const bool first_eval = r.ever[j] == 0;
-    const bool dup = (r.bflags[j] & F_DUP) != 0;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-      const uint64_t y = r.y0[s0 + i];
-      const uint32_t rid = (uint32_t)(y >> 32);
-      s_rid[i] = rid, s_pos[i] = (((uint32_t)y) >> 1) + 1, s_dir[i] = r.dir[s0 + i], s_rl[i] = r.rlen[rid];
-    }
-    if (dup) {
-      for (uint32_t i = threadIdx.x; i < SET_CAP; i += blockDim.x) s_setk[i] = 0;
-      for (uint32_t i = threadIdx.x; i < CLAIM_CAP; i += blockDim.x) s_clk[i] = 0, s_clw[i] = 0xFFFFFFFFu;
-    }
-    __syncthreads();   // (entries staged; everybody has read ever[] / dirty[] / bflags[] before thread 0 changes them)
-    if (threadIdx.x == 0) {
-      r.dirty[j] = 0, r.evaluated[j] = 1, r.ever[j] = 1, r.parity[j] ^= 1, r.ohead[j] = r.ihead[j];
-      atomicAdd(&r.spread[(blockIdx.x % SPREAD) * 8], 1ULL);
-    }
-    // ---- workgroup-uniform state (every thread holds a copy and updates it identically) ----
-    uint64_t clo = 0, chi = 0;   // "contained" flags of the bucket's entries
-    auto cget = [&](uint32_t i) { return (((i < 64 ? clo : chi) >> (i & 63)) & 1) != 0; };
-    auto cset = [&](uint32_t i) {
-      if (i < 64) clo |= 1ULL << i;
-      else chi |= 1ULL << (i - 64);
-    };
-    uint32_t head = NIL, num = 0, lookups = 0, skips = 0, chunk = 0;
-    bool any_guess = false, any_unfiled = false;
-    int done_to = (int)n - 1;   // rows >= done_to are finished (the first row is n - 2)
-    bool row_open = false;       // one row (cur_row) is being continued alone, from partner pbase, with `got` overlaps counted so far
-    int cur_row = 0;
-    uint32_t pbase = 0, got = 0;
-    bool p_reg = false;          // this lane has a registration whose list position (p_idx) has not been looked at yet
-    uint32_t p_idx = 0, p_slot = 0;
-    auto resolve_pending = [&]() {   // as in k_eval_rows; an exhausted arena raises s_abort instead of returning
-      if (p_reg && p_idx < NIN) r.pc[p_slot >> r.cshift].in[p_idx] = j + 1, p_reg = false;
-      const uint64_t rm = __ballot(p_reg);
-      if (rm) {
-        const uint32_t total = (uint32_t)__popcll(rm);
-        if (rcur + total > rend) {
-          uint32_t base = 0;
-          if (lane == 0) base = atomicAdd(&r.c->rnode_top, NCH);
-          base = (uint32_t)__shfl((int)base, 0, 64);
-          if ((uint64_t)base + NCH > r.rn_cap) {
-            atomicOr(&r.c->overflow, OV_NODES);
-            s_abort = 1;
-            p_reg = false;
-            return;
-          }
-          rcur = base, rend = base + NCH;
-        }
-        if (p_reg) {
-          const uint32_t node = rcur + lane_rank(rm);
-          const uint32_t old = atomicExch(&r.pc[p_slot >> r.cshift].rhead, node + 1);
-          r.rn[node] = RNode{old, j};
-        }
-        rcur += total;
-        p_reg = false;
-      }
-    };
-#ifdef PGX_BIG_STATS
-    uint32_t st_steps = 0, st_rows = 0, st_cut = 0, st_cont = 0, st_full = 0;
-#endif
-    for (;;) {
-      // the rows of this step: the open row alone, or the next (up to four) rows that are not contained
-      int a[BIG_NR], nrows = 0;
-#pragma unroll
-      for (int k = 0; k < BIG_NR; ++k) a[k] = -1;
-      if (row_open) {
-        a[0] = cur_row, nrows = 1;
-      } else {
-        for (int x = done_to; nrows < BIG_NR;) {
-          do --x;
-          while (x >= 0 && cget((uint32_t)x));
-          if (x < 0) break;
-          a[nrows++] = x;
-        }
-      }
-      if (nrows == 0 || r.bestn == 0) break;
-      // ---- this step's (row, partner) of the lane: slot q = wave / 2 takes row a[q], partners first + (wave % 2) * 64 + lane ----
-      const int q = w >> 1, off = (w & 1) * 64 + lane;   // off: partner offset within the row's 128 (= its bit in the row's masks)
-      const int myrow = a[q];
-      const uint32_t first = row_open ? pbase : (uint32_t)(myrow + 1);
-      const uint32_t pi = first + (uint32_t)off;
-      const uint32_t wi = (uint32_t)(q * 128 + off);     // position in walk order
-      bool valid = q < nrows && pi < n && !cget(pi);
-      uint32_t rid0 = 0, pos0 = 0, rlen0 = 0, dir0 = 0, rid1 = 0, pos1 = 0;
-      if (valid) {
-        rid0 = s_rid[myrow], pos0 = s_pos[myrow], rlen0 = s_rl[myrow], dir0 = s_dir[myrow];
-        rid1 = s_rid[pi], pos1 = s_pos[pi];
-        if (rid1 == rid0) valid = false;
-      }
-      uint32_t slot = NONE, v = 0;
-      const uint64_t pair = rid0 < rid1 ? ((uint64_t)rid0 << 32 | rid1) : ((uint64_t)rid1 << 32 | rid0);
-      if (valid) slot = pair_find(r, pair, &v);
-      bool present = false, accepted = false, guessed = false;
-      uint32_t ptype = 0, type = 0, mslot = NONE;
-      if (valid) {
-        present = v != 0 && own_bucket(v) < j;
-        ptype = present ? own_type(v) : 0;
-        if (!present && dup) {   // inserted earlier in THIS evaluation?
-          for (uint32_t i = (uint32_t)mix64(pair) & (SET_CAP - 1);; i = (i + 1) & (SET_CAP - 1)) {
-            const unsigned long long kk = s_setk[i];
-            if (kk == 0) break;
-            if (kk == pair + 1) {
-              present = true, ptype = s_sett[i];
-              break;
-            }
-          }
-        }
-        if (!present) {
-          const uint32_t rlen1 = s_rl[pi], dir1 = s_dir[pi];
-          const uint32_t q_off = pos0 - pos1;
-          if (q_off >= (1u << 30)) atomicOr(&r.c->overflow, OV_QOFF);
-          uint32_t req = NONE;
-          if (r.memo_used) mslot = memo_find(r, (unsigned long long)rid0 << 32 | rid1, q_off << 2 | dir0 << 1 | dir1, &req);
-          if (req < r.settled) {
-            accepted = classify(r.rq_res[req], rlen0, rlen1, q_off, &type);
-          } else {
-            accepted = true, guessed = true, type = T_OVERLAP;
-            if (r.predict && predict_contained(rlen0, rlen1, q_off, r.predict, r.predict2)) type = rlen0 >= rlen1 ? T_CONTAINS : T_CONTAINED;
-          }
-        }
-      }
-      resolve_pending();   // (the previous step's registrations: their atomics have returned behind the loads above)
-      const bool ins0 = valid && !present && accepted;
-      uint32_t my_claim = NONE;
-      if (dup) {   // would-be inserters claim their pair: the lowest walk index wins
-        if (ins0) {
-          for (uint32_t i = (uint32_t)(mix64(pair) >> 20) & (CLAIM_CAP - 1);; i = (i + 1) & (CLAIM_CAP - 1)) {
-            unsigned long long kk = s_clk[i];
-            if (kk == 0) kk = atomicCAS(&s_clk[i], 0ULL, (unsigned long long)pair + 1), kk = kk ? kk : pair + 1;
-            if (kk == pair + 1) {
-              atomicMin(&s_clw[i], wi);
-              my_claim = i;
-              break;
-            }
-          }
-        }
-      }
-      {
-        const uint64_t mv = __ballot(valid), mp = __ballot(valid && present), mpo = __ballot(valid && present && ptype == T_OVERLAP);
-        const uint64_t ma = __ballot(ins0), mao = __ballot(ins0 && type == T_OVERLAP), mac = __ballot(ins0 && type == T_CONTAINED);
-        const uint64_t map = __ballot(ins0 && type == T_CONTAINS), mgu = __ballot(ins0 && guessed), muf = __ballot(ins0 && mslot == NONE);
-        if (lane == 0)
-          s_m[w][MV] = mv, s_m[w][MP] = mp, s_m[w][MPO] = mpo, s_m[w][MA] = ma, s_m[w][MAO] = mao, s_m[w][MAC] = mac, s_m[w][MAP] = map,
-          s_m[w][MGU] = mgu, s_m[w][MUF] = muf, s_m[w][MDF] = 0;
-      }
-      __syncthreads();
-      if (dup) {   // a lane whose pair a LOWER lane of this step would insert is FLAGGED: its row is cut in front of it (below).  That
-                   // holds for EVERY lane that found the pair absent, also one whose own alignment is rejected: sequentially it would
-                   // have found the pair seen and skipped it.
-        bool dflag = false;
-        if (my_claim != NONE) {
-          dflag = s_clw[my_claim] < wi;
-        } else if (valid && !present) {
-          for (uint32_t i = (uint32_t)(mix64(pair) >> 20) & (CLAIM_CAP - 1);; i = (i + 1) & (CLAIM_CAP - 1)) {
-            const unsigned long long kk = s_clk[i];
-            if (kk == 0) break;
-            if (kk == pair + 1) {
-              dflag = s_clw[i] < wi;
-              break;
-            }
-          }
-        }
-        const uint64_t mdf = __ballot(dflag);
-        if (lane == 0) s_m[w][MDF] = mdf;
-        __syncthreads();
-      }
-      if (s_abort) break;
-      // ---- the sequential semantics over this step: the rows in order, each over its 128 partners, lowest first (uniform) ----
-      M128 proc[BIG_NR];
-#pragma unroll
-      for (int k = 0; k < BIG_NR; ++k) proc[k] = M128{0, 0};
-      int committed = 0;         // rows completed in this step
-      bool open_next = false;    // the row after them was cut: it is continued alone
-      int open_row = 0;
-      uint32_t open_pbase = 0, open_got = 0;
-      for (int k = 0; k < nrows; ++k) {
-        // A partner that an EARLIER row of this step found contained (or that was such a row) is not examined by this row: its lane is dropped
-        // from the row's masks right here.  (Round 3 ended the step at the first row that changed a flag and looked at the rows below again
-        // in the next one.  Rows themselves are never flagged by an earlier row of the step: a row's partners lie above it.)
-        const uint32_t first_k = row_open ? pbase : (uint32_t)(a[k] + 1);
-        const M128 gone = shr128(M128{clo, chi}, first_k);
-        const M128 inc = andn128(M128{s_m[2 * k][MPO] | s_m[2 * k][MAO], s_m[2 * k + 1][MPO] | s_m[2 * k + 1][MAO]}, gone);
-        const M128 ac = andn128(M128{s_m[2 * k][MAC], s_m[2 * k + 1][MAC]}, gone), ap = andn128(M128{s_m[2 * k][MAP], s_m[2 * k + 1][MAP]}, gone);
-        // the row's cut: its first flagged lane.  (Round 3 took ONE cut for the step, the lowest flagged lane of all rows -- which most often lay
-        // beyond the stop of its row, among lanes the walk never visits, and still ended the step there: 69 % of all steps ended with rows left,
-        // 1.5 of 4 rows committed per step, profiles/r04w_big_stats_c4s.txt.  A flag whose lower claimant turns out unvisited is void but harmless:
-        // the lane is looked at again in the next step.)
-        const M128 df = andn128(M128{s_m[2 * k][MDF], s_m[2 * k + 1][MDF]}, gone);
-        const int cut = any128(df) ? ctz128(df) : 128;   // first offset of the row that may not be processed
-        if (cut == 0) break;                             // the cut lies in front of this row
-        const uint32_t need = r.bestn - (row_open ? got : 0u);   // >= 1
-        int stop = 128;
-        if ((uint32_t)popc128(inc) >= need) stop = nth128(inc, need);
-        if (any128(ac)) stop = min(stop, ctz128(ac));
-        const bool complete = stop < cut || (cut == 128);   // the row ends before the cut (or there is none in it)
-        proc[k] = andn128(complete ? upto128(stop) : upto128(cut - 1), gone);
-        const M128 apk = and128(ap, proc[k]);
-        for (uint64_t m = apk.lo; m; m &= m - 1) cset(first_k + (uint32_t)__builtin_ctzll(m));   // partners found contained
-        for (uint64_t m = apk.hi; m; m &= m - 1) cset(first_k + 64u + (uint32_t)__builtin_ctzll(m));
-        const bool rowc = any128(and128(ac, proc[k]));
-        if (rowc) cset((uint32_t)a[k]);
-        if (!complete) {
-          open_next = true, open_row = a[k], open_pbase = first_k + (uint32_t)cut, open_got = (row_open ? got : 0u) + (uint32_t)popc128(and128(inc, proc[k]));
-          break;
-        }
-        ++committed;
-      }
-#ifdef PGX_BIG_STATS
-      ++st_steps, st_rows += (uint32_t)committed, st_cut += open_next ? 1u : 0u, st_full += (committed == nrows) ? 1u : 0u;
-      st_cont += (!open_next && committed < nrows) ? 1u : 0u;
-#endif
-      if (committed) done_to = a[committed - 1];
-      row_open = open_next;
-      if (open_next) cur_row = open_row, pbase = open_pbase, got = open_got;
-      // per wavefront: what the walk really visits, and the insertions in walk order (row, then partner)
-      uint32_t cins = 0, before = 0;
-      uint64_t myproc = 0;
-      for (int ww = 0; ww < BIG_NW; ++ww) {
-        const int k = ww >> 1;
-        const uint64_t pw = (ww & 1) ? proc[k].hi : proc[k].lo;
-        const uint32_t c = (uint32_t)__popcll(s_m[ww][MA] & pw);
-        if (ww < w) before += c;
-        if (ww == w) myproc = pw;
-        cins += c;
-        skips += (uint32_t)__popcll(s_m[ww][MP] & pw);
-        lookups += (uint32_t)__popcll(s_m[ww][MV] & ~s_m[ww][MP] & pw);
-        any_guess |= (s_m[ww][MGU] & pw) != 0, any_unfiled |= (s_m[ww][MUF] & pw) != 0;
-      }
-      // the item chunks this step opens (one allocation for the workgroup, by thread 0)
-      const uint32_t cur_no = num ? (num - 1) >> 4 : 0, first_new = num ? cur_no + 1 : 0;
-      const uint32_t last = num + cins - 1, last_no = last >> 4;
-      const uint32_t nnew = cins && last_no + 1 > first_new ? last_no + 1 - first_new : 0;
-      if (threadIdx.x == 0 && nnew) {
-        const uint32_t want = 16u * nnew;
-        if (icur + want > iend) {
-          const uint32_t take = want > ICH ? want : ICH;
-          const uint32_t base = atomicAdd(&r.c->item_top, take);
-          if ((uint64_t)base + take > r.item_cap) atomicOr(&r.c->overflow, OV_ITEMS), s_abort = 1;
-          icur = base, iend = base + take;
-        }
-        s_fresh = icur, icur += want;
-      }
-      const bool visited = valid && ((myproc >> lane) & 1);
-      {  // the partners the walk really examined register as readers of their pairs (as in k_eval_rows)
-        bool reg = visited;
-        if (reg && slot == NONE) slot = pair_slot(r, pair);
-        if (reg && !first_eval) {
-          const uint32_t *pw = reinterpret_cast<const uint32_t *>(&r.pc[slot >> r.cshift]);
-          const uint4 h1 = *reinterpret_cast<const uint4 *>(pw);  // cnt, rhead, in[0], in[1]
-          const uint32_t c = min(h1.x, NIN);
-          if ((c > 0 && h1.z == j + 1) || (c > 1 && h1.w == j + 1)) reg = false;
-          for (uint32_t qq = 2; qq < c && reg; qq += 8) {
-            const uint4 xa = *reinterpret_cast<const uint4 *>(pw + 2 + qq), xb = *reinterpret_cast<const uint4 *>(pw + 6 + qq);
-            const uint32_t x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-#pragma unroll
-            for (uint32_t k = 0; k < 8; ++k)
-              if (qq + k < c && x[k] == j + 1) reg = false;
-          }
-        }
-        if (reg) p_idx = atomicAdd(&r.pc[slot >> r.cshift].cnt, 1u), p_slot = slot, p_reg = true;
-      }
-      const bool my_ins = ins0 && visited;
-      if (dup) {
-        if (my_claim != NONE) s_clk[my_claim] = 0, s_clw[my_claim] = 0xFFFFFFFFu;   // (the claim table is empty again for the next step)
-        if (my_ins) {   // this evaluation's insertions, for the probes of the steps to come
-          uint32_t tries = 0;
-          for (uint32_t i = (uint32_t)mix64(pair) & (SET_CAP - 1);; i = (i + 1) & (SET_CAP - 1)) {
-            const unsigned long long kk = atomicCAS(&s_setk[i], 0ULL, (unsigned long long)pair + 1);
-            if (kk == 0 || kk == pair + 1) {
-              s_sett[i] = (uint8_t)type;
-              break;
-            }
-            if (++tries >= SET_CAP) {   // the set is full (not with <= 128 entries and bestn <= ~8; kept as a guard): leave the bucket to k_eval_rows
-              s_bail = 1;
-              break;
-            }
-          }
-        }
-      }
-      __syncthreads();   // (s_fresh is there; nobody reads this step's masks any more; the set holds this step's insertions)
-      if (s_abort) break;
-      if (cins) {
-        const uint32_t fresh = s_fresh;
-        auto base_of = [&](uint32_t no) { return no >= first_new ? fresh + 16u * (no - first_new) : chunk; };
-        if (my_ins) {
-          const uint32_t ord = num + before + (uint32_t)__popcll(s_m[w][MA] & myproc & ((1ULL << lane) - 1ULL));   // insertion ordinal within the bucket
-          const uint32_t idx = base_of(ord >> 4) + (ord & 15);
-          uint32_t next;
-          if (ord == 0) next = NIL;
-          else if ((ord & 15) == 0) next = base_of((ord >> 4) - 1) + 16;  // the last item of the previous chunk, + 1
-          else next = idx;                                                // the item before this one, + 1
-          uint32_t info = (uint32_t)myrow | pi << 8 | type << 16;
-          if (guessed) info |= I_GUESS;
-          if (mslot == NONE) info |= I_UNFILED;
-          r.items[idx] = Item{slot, info, mslot, next};
-        }
-        chunk = base_of(last_no);
-        head = chunk + (last & 15) + 1;
-        num += cins;
-      }
-      __syncthreads();   // (s_m[w][MA] was read above: the next step may overwrite the masks now)
-      if (s_bail) break;
-    }
-    resolve_pending();
-#ifdef PGX_BIG_STATS
-    if (threadIdx.x == 0) {   // [3] steps, [4] rows committed, [5] steps cut at a duplicate, [6] steps ended by a containment, [7] steps that committed all their rows
-      unsigned long long *line = r.spread + (blockIdx.x % SPREAD) * 8;
-      atomicAdd(line + 3, (unsigned long long)st_steps), atomicAdd(line + 4, (unsigned long long)st_rows), atomicAdd(line + 5, (unsigned long long)st_cut);
-      atomicAdd(line + 6, (unsigned long long)st_cont), atomicAdd(line + 7, (unsigned long long)st_full);
-      atomicMax(&r.c->big_max_steps, st_steps);
-      if (st_steps >= 64) atomicAdd(&r.c->big_long, 1u), atomicAdd(&r.c->big_long_n, n);
-      atomicAdd(&r.c->big_evals, 1u);
-    }
-#endif
-    if (threadIdx.x == 0) {
-      if (s_bail) {   // (guard path: evaluated again by k_eval_rows, one partner at a time; the lists written so far are simply dropped)
-        r.dirty[j] = 1, r.evaluated[j] = 0, r.parity[j] ^= 1;
-        r.bflags[j] = (uint8_t)((r.bflags[j] & ~F_BIG));
-      } else {
-        r.ihead[j] = head, r.inum[j] = num, r.lookups[j] = lookups, r.skips[j] = skips;
-        r.bflags[j] = (uint8_t)(F_BIG | (dup ? F_DUP : 0) | (any_guess ? F_GUESS : 0) | (any_unfiled ? F_UNFILED : 0));
-      }
-    }
-  }
-  if (s_abort) break;
-  }
-  if (lane == 0) r.wcur[wave_id] = make_uint4(rcur, rend, icur, iend);
-}
-
-// ---- apply the evaluated buckets' lists to the pair table: a group per bucket, a lane per item ---------------------------
-__device__ __forceinline__ void apply_insertion(const R &r, uint32_t j, uint32_t pnew, const Item &im) {
-  const uint32_t slot = im.pslot, type = (im.info >> 16) & 3;
-  const uint32_t mine = own_enc(j, pnew, type);
-  uint32_t v = r.ph[slot].own;
-  for (;;) {
-    if (v != 0 && own_bucket(v) < j) {  // an earlier bucket got in first: this evaluation is stale
-      r.dirty[j] = 1;
-      return;
-    }
-    const uint32_t prev = atomicCAS(&r.ph[slot].own, v, mine);
-    if (prev == v) {
-      if (v == 0 || own_bucket(v) > j) mark_readers(r, slot, j);  // absent -> present, or a later owner displaced (it reads the pair too)
-      else if ((own_type(v) == T_OVERLAP) != (type == T_OVERLAP)) mark_readers(r, slot, j);  // ours before: readers see the type class
-      return;
-    }
-    v = prev;
-  }
-}
-__global__ __launch_bounds__(256) void k_update(R r, uint32_t lo, uint32_t hi, uint32_t nlist) {
-  const int lane = threadIdx.x & 63, gl = lane & (GL - 1);
-  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const uint64_t jj = bucket_of_group(r, lo, hi, nlist, wave * GPW + (uint32_t)(lane / GL)) & 0x7FFFFFFFull;   // (a listed big bucket: k_count_b's mark off)
-  const uint32_t j = (uint32_t)jj;
-  const bool alive = jj < hi && r.evaluated[j] && !r.c->overflow;
-  if (blockIdx.x == 0 && threadIdx.x == 0) r.c->nbig = 0;   // (k_eval_big has consumed the pass's list; the next pass starts a new one)
-  // (the dirty statistics are NOT touched here: the list-mode blocks of this very launch read ndirty as their list length, and
-  // the count that follows writes absolute values)
-  if (!__ballot(alive)) return;
-  const uint32_t pnew = alive ? r.parity[j] : 0, pold = pnew ^ 1;
-  // what this evaluation inserts: take or refresh ownership (lowest bucket wins)
-  uint32_t cur = alive ? r.ihead[j] : NIL;
-  while (__ballot(cur != NIL)) {
-    if (cur != NIL) {
-      const uint32_t last = cur - 1, base = last & ~15u, cnt = (last & 15) + 1;
-      const Item first = r.items[base];
-      for (uint32_t o = (uint32_t)gl; o < cnt; o += GL) apply_insertion(r, j, pnew, o == 0 ? first : r.items[base + o]);
-      cur = first.next;
-    }
-  }
-  // what the previous evaluation inserted and this one did not refresh: withdraw
-  cur = alive ? r.ohead[j] : NIL;
-  while (__ballot(cur != NIL)) {
-    if (cur != NIL) {
-      const uint32_t last = cur - 1, base = last & ~15u, cnt = (last & 15) + 1;
-      const uint32_t nxt = r.items[base].next;
-      for (uint32_t o = (uint32_t)gl; o < cnt; o += GL) {
-        const uint32_t slot = r.items[base + o].pslot;
-        const uint32_t v = r.ph[slot].own;
-        if (v != 0 && own_bucket(v) == j && own_parity(v) == pold)
-          if (atomicCAS(&r.ph[slot].own, v, 0u) == v) mark_readers(r, slot, j);
-      }
-      cur = nxt;
-    }
-  }
-  if (alive && gl == 0) r.evaluated[j] = 0, r.ohead[j] = NIL;
-}
-
-// ---- the dirty buckets: how many, in which range, and (while they fit) their list, LOWEST FIRST -------------------------
-// Two small launches: blocks of CB buckets count theirs (16 flags per lane, one 16-byte load), then every block adds up the
-// counts of the blocks before it and writes its ids at that offset.  The list is exactly ascending, so when more than LIST_CAP
-// buckets are dirty the list keeps the LOWEST ones (evaluating those first wastes the fewest evaluations -- the round-1 form
-// took list positions by atomics in arrival order, and atomics on one address cost ~12 ns each: with every block holding a
-// dirty bucket a count took 0.46 ms, ten times per step).
-constexpr uint32_t CB = 4096;  // buckets per block of the count kernels (256 lanes x 16)
-__device__ __forceinline__ uint32_t dirty16(const R &r, uint32_t j0, uint32_t end) {  // bit i: bucket j0 + i < end is dirty (j0 a multiple of 16)
-  if (j0 >= end) return 0;
-  uint32_t m = 0;
-  if (j0 + 16 <= end) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(r.dirty + j0);
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) m |= ((w[q] >> (8 * b)) & 0xFFu) ? 1u << (4 * q + b) : 0u;
-  } else {
-    for (uint32_t i = 0; j0 + i < end; ++i) m |= r.dirty[j0 + i] ? 1u << i : 0u;
-  }
-  return m;
-}
-__global__ __launch_bounds__(256) void k_count_a(R r, uint32_t rlo, uint32_t rhi, uint32_t *__restrict__ blk) {  // blk[3 b + {0, 1, 2}] = count, lowest, highest
-  __shared__ uint32_t s_c[4], s_lo[4], s_hi[4];
-  const uint32_t j0 = rlo + blockIdx.x * CB + threadIdx.x * 16;   // (rlo: a multiple of 16)
-  const uint32_t m = dirty16(r, j0, rhi);
-  uint32_t c = (uint32_t)__popc(m), lo = m ? j0 + (uint32_t)__builtin_ctz(m) : 0xFFFFFFFFu, hi = m ? j0 + 31u - (uint32_t)__builtin_clz(m) : 0u;
-  for (int o = 32; o; o >>= 1) {
-    c += (uint32_t)__shfl_xor((int)c, o, 64);
-    lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
-    hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
-  }
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) s_c[w] = c, s_lo[w] = lo, s_hi[w] = hi;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (blockIdx.x == 0) r.c->nbig = 0;   // (k_count_b lists the big buckets by their POSITION in the list it writes: positions of an older list must be gone)
-    blk[3 * blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
-    blk[3 * blockIdx.x + 1] = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
-    blk[3 * blockIdx.x + 2] = max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3]));
-  }
-}
-__global__ __launch_bounds__(256) void k_count_b(R r, uint32_t rlo, uint32_t rhi, const uint32_t *__restrict__ blk, uint32_t nblk) {
-  __shared__ uint32_t s_part[4], s_lo[4], s_hi[4], s_tot[4], s_w[4];
-  // the counts of the blocks before this one (and, in block 0, the totals of all of them)
-  uint32_t before = 0, total = 0, lo = 0xFFFFFFFFu, hi = 0;
-  const bool totals = blockIdx.x == 0;
-  for (uint32_t b = threadIdx.x; b < nblk; b += 256) {
-    const uint32_t c = blk[3 * b];
-    if (b < blockIdx.x) before += c;
-    if (totals) total += c, lo = min(lo, blk[3 * b + 1]), hi = max(hi, blk[3 * b + 2]);
-  }
-  for (int o = 32; o; o >>= 1) {
-    before += (uint32_t)__shfl_xor((int)before, o, 64);
-    if (totals) {
-      total += (uint32_t)__shfl_xor((int)total, o, 64);
-      lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
-      hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
-    }
-  }
-  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) s_part[w] = before, s_tot[w] = total, s_lo[w] = lo, s_hi[w] = hi;
-  const uint32_t j0 = rlo + blockIdx.x * CB + threadIdx.x * 16;   // (rlo: a multiple of 16)
-  const uint32_t m = dirty16(r, j0, rhi);
-  const uint32_t c = (uint32_t)__popc(m);
-  uint32_t incl = c;   // lanes of a wavefront: inclusive scan
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-    if (lane >= o) incl += t;
-  }
-  if (lane == 63) s_w[w] = incl;
-  __syncthreads();
-  if (totals && threadIdx.x == 0) {
-    const uint32_t n = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
-    r.c->ndirty = n;
-    r.c->min_dirty = n ? min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3])) : 0xFFFFFFFFu;
-    r.c->max_dirty = n ? max(max(s_hi[0], s_hi[1]), max(s_hi[2], s_hi[3])) : 0u;
-  }
-  if (!m) return;
-  uint32_t at = s_part[0] + s_part[1] + s_part[2] + s_part[3] + incl - c;
-  for (int q = 0; q < w; ++q) at += s_w[q];
-  // (round 3) a big bucket is marked in the list (bit 31: the narrow kernels and their wavefront slots pass it over -- its index is
-  // beyond every `hi` -- and k_update takes the mark off) and entered in the big list right here, so that k_eval_big does not have
-  // to wait for the narrow kernel of the pass to find it: the two run side by side
-  for (uint32_t mm = m; mm && at < LIST_CAP; mm &= mm - 1, ++at) {
-    const uint32_t j = j0 + (uint32_t)__builtin_ctz(mm);
-    const bool big = (r.bflags[j] & F_BIG) != 0;
-    r.dlist[at] = j | (big ? 0x80000000u : 0u);
-    if (big) {   // (listed by POSITION: k_eval_big only takes the part of the list that the pass's narrow kernel and k_update cover)
-      const uint32_t bat = atomicAdd(&r.c->nbig, 1u);
-      if (bat < LIST_CAP) r.blist[bat] = at | 0x80000000u;
-    }
-  }
-}
-
-// Tail sweeps.  A pair whose alignment is rejected is not entered in the seen-pair table, so the next bucket holding both reads
-// aligns it again from its own anchors -- and is rejected again, and so on through the ~30 buckets the two reads share: one
-// sweep (one lone 0.33 ms alignment) per hand-over, which is what the last ~15 sweeps of a 4.5 Gbase set consist of.  Once
-// the sweeps are small, a bucket that files an alignment therefore also files the one every other registered reader of that
-// pair would ask for (its rows for the two reads, its anchors): the results are in the memo when those buckets come to it.
-// A speculative request is just an alignment whose result the memo holds; at worst it is never asked for.
-// file the alignment of entries (row, par) of a bucket whose records start at s0, unless the memo knows it already
-__device__ __forceinline__ void file_entries(const R &r, uint32_t s0, uint32_t row, uint32_t par) {
-  const Ent e0 = entry_of(r.y0[s0 + row]), e1 = entry_of(r.y0[s0 + par]);
-  if (e0.pos1 < e1.pos1 || e0.rid == e1.rid) return;
-  const uint32_t dir0 = r.dir[s0 + row], dir1 = r.dir[s0 + par], q_off = e0.pos1 - e1.pos1;
-  if (q_off >= (1u << 30)) return;
-  const unsigned long long a = (unsigned long long)e0.rid << 32 | e1.rid;
-  const uint32_t bk = q_off << 2 | dir0 << 1 | dir1;
-  uint32_t i = (uint32_t)mix64(a ^ mix64(bk)) & r.mmask;
-  for (int probes = 0; probes < 1024; ++probes) {
-    unsigned long long cur = r.mt[i].a;
-    if (cur == 0) {
-      cur = atomicCAS(&r.mt[i].a, 0ULL, a);
-      if (cur == 0) {  // new: a request of its own
-        r.mt[i].b = bk + 1;
-        const uint32_t my = atomicAdd(&r.c->nreq, 1u);
-        if (my >= r.req_cap) {
-          atomicOr(&r.c->overflow, OV_REQS);
-          return;
-        }
-        pgx_align_key key;
-        key.rid0 = e0.rid, key.rid1 = e1.rid, key.q_off = q_off, key.dir0 = (uint8_t)dir0, key.dir1 = (uint8_t)dir1, key.pad[0] = key.pad[1] = 0;
-        r.rq_key[my] = key;
-        r.mt[i].req = my;
-        return;
-      }
-    }
-    if (cur == a && *(volatile uint32_t *)&r.mt[i].b == bk + 1) return;  // known already
-    i = (i + 1) & r.mmask;
-  }
-}
-__device__ __forceinline__ void file_for_reader(const R &r, uint32_t C, uint32_t rid_a, uint32_t rid_b) {
-  const uint32_t b = r.bid[C], s0 = r.bstart[b], n = r.bstart[b + 1] - s0;
-  int ia = -1, ib = -1;
-  bool twice = false;
-  for (uint32_t i = 0; i < n; ++i) {
-    const uint32_t rid = (uint32_t)(r.y0[s0 + i] >> 32);
-    if (rid == rid_a) twice |= ia >= 0, ia = (int)i;
-    else if (rid == rid_b) twice |= ib >= 0, ib = (int)i;
-  }
-  if (ia < 0 || ib < 0 || twice) return;
-  file_entries(r, s0, (uint32_t)min(ia, ib), (uint32_t)max(ia, ib));  // (the row is the entry with the smaller index)
-}
-
-// ---- file the alignments the converged lists still need ---------------------------------------------------------------
-// (Only buckets that are not dirty right now are filed -- the others are about to be evaluated again.  Filing while the sweep
-// is still running is always safe: a request is just an alignment whose result the memo will hold; at worst it is never
-// asked for again.)
-__global__ __launch_bounds__(256) void k_file(R r, uint32_t limit) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = j < limit && (r.bflags[j] & F_UNFILED) && !r.dirty[j];
-  __shared__ uint32_t s_tot[4], s_base;
-  if (!__syncthreads_or(active)) return;   // (block-uniform)
-  uint32_t cnt = 0;
-  if (active)
-    for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) cnt += (r.items[it - 1].info & I_UNFILED) ? 1u : 0u;
-  // request numbers: ONE atomic per block.  The request counter is one address, and an L2 channel serves same-address atomics one
-  // wavefront-instruction at a time (~12 ns): with an add per wavefront the first sweep's launch -- 9.4 M requests at c4s, 46 M in a
-  // human-scale chunk -- lasted exactly requests / 64 x 12 ns (2.0 ms, 8.7 ms)
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  uint32_t incl = cnt;
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64);
-    if (lane >= o) incl += t;
-  }
-  const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
-  if (lane == 63) s_tot[wv] = total;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t all = s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3];
-    s_base = all ? atomicAdd(&r.c->nreq, all) : 0u;
-  }
-  __syncthreads();
-  uint32_t base = s_base;
-  for (int w = 0; w < wv; ++w) base += s_tot[w];
-  if (!__ballot(active)) return;
-  // (from here on every lane of the wavefront stays in step: the fan-out below is done by all of them together)
-  bool run = active && cnt != 0;
-  if (active && !cnt) r.bflags[j] &= (uint8_t)~F_UNFILED;
-  if (!__ballot(run)) return;
-  if ((unsigned long long)base + total > r.req_cap) {
-    if (run) atomicOr(&r.c->overflow, OV_REQS);
-    return;
-  }
-  uint32_t my = base + incl - cnt;
-  const uint32_t b = run ? r.bid[j] : 0u, s0 = run ? r.bstart[b] : 0u;
-  uint32_t it = run ? r.ihead[j] : NIL;
-  const bool tail = r.tail != 0;
-  const uint32_t nn = run ? r.bstart[b + 1] - s0 : 0u;
-  for (;;) {
-    // ---- this lane's next unfiled item ----
-    bool fan = false;             // the item filed a NEW alignment (tail mode): its pair's other readers are looked at below
-    bool ah = false;              // the item was filed in tail mode: its row's next partners are filed ahead below
-    uint32_t f_slot = 0, f_a = 0, f_b = 0, ah_ai = 0, ah_pi = 0;
-    while (it != NIL && !fan && !ah) {
-      Item &im = r.items[it - 1];
-      const uint32_t nxt = im.next;
-      if (im.info & I_UNFILED) {
-        const uint32_t ai = im.info & 0xFF, pi = (im.info >> 8) & 0xFF;
-        const Ent e0 = entry_of(r.y0[s0 + ai]), e1 = entry_of(r.y0[s0 + pi]);
-        const uint32_t dir0 = r.dir[s0 + ai], dir1 = r.dir[s0 + pi], q_off = e0.pos1 - e1.pos1;
-        const unsigned long long a = (unsigned long long)e0.rid << 32 | e1.rid;
-        const uint32_t bk = q_off << 2 | dir0 << 1 | dir1;
-        pgx_align_key key;
-        key.rid0 = e0.rid, key.rid1 = e1.rid, key.q_off = q_off, key.dir0 = (uint8_t)dir0, key.dir1 = (uint8_t)dir1, key.pad[0] = key.pad[1] = 0;
-        // find or insert.  Another lane may be inserting the same key right now: its `b` may still read 0, in which case this
-        // lane files a duplicate in another slot (same alignment, same result -- harmless).
-        uint32_t i = (uint32_t)mix64(a ^ mix64(bk)) & r.mmask, found = NONE;
-        bool fresh = false;
-        for (int probes = 0; probes < 1024; ++probes) {
-          unsigned long long cur = r.mt[i].a;
-          if (cur == 0) {
-            cur = atomicCAS(&r.mt[i].a, 0ULL, a);
-            if (cur == 0) {
-              r.mt[i].b = bk + 1;
-              found = i, fresh = true;
-              break;
-            }
-          }
-          if (cur == a && *(volatile uint32_t *)&r.mt[i].b == bk + 1) {
-            found = i;
-            break;
-          }
-          i = (i + 1) & r.mmask;
-        }
-        if (found == NONE) {   // (this bucket stays unfiled; the overflow bit sends the walk to larger tables)
-          atomicOr(&r.c->overflow, OV_MEMO);
-          run = false, it = NIL;
-          break;
-        }
-        r.rq_key[my] = key;  // (a request slot whose key was already filed by someone else just repeats that alignment)
-        if (fresh) r.mt[found].req = my;
-        ++my;
-        im.mslot = found;
-        im.info &= ~I_UNFILED;
-        if (tail) ah = true, ah_ai = ai, ah_pi = pi;   // ... and the row's next partners (below)
-        if (tail && fresh) fan = true, f_slot = im.pslot, f_a = e0.rid, f_b = e1.rid;
-      }
-      it = nxt;
-    }
-    const uint64_t fm = __ballot(fan), am = __ballot(ah);
-    if (!fm && !am && !__ballot(it != NIL)) break;
-    // ---- tail mode: the row's next partners -- if this candidate is rejected the row goes on to them (a row of a repeat-rich bucket can
-    // have dozens of candidates, each rejection otherwise costing a sweep) -- a partner per lane.  (Through round 3 the filing lane walked
-    // its r.tail partners itself, a dependent memo probe each, item after item: the tail sweeps' k_file launches took up to 7 ms at c4s.)
-    for (uint64_t mm = am; mm; mm &= mm - 1) {
-      const int L = __builtin_ctzll(mm);
-      const uint32_t sL = (uint32_t)__shfl((int)s0, L, 64), aL = (uint32_t)__shfl((int)ah_ai, L, 64), pL = (uint32_t)__shfl((int)ah_pi, L, 64);
-      const uint32_t nL = (uint32_t)__shfl((int)nn, L, 64);
-      for (uint32_t p = pL + 1 + (uint32_t)lane; p < nL && p <= pL + r.tail; p += 64) file_entries(r, sL, aL, p);
-    }
-    // ---- tail mode: the alignment every OTHER reader of a newly requested pair would ask for (file_for_reader) -- by the whole
-    // wavefront, a reader bucket per lane.  (Round 2 left this to the filing lane alone: a pair of a repeat-rich set has dozens of
-    // readers of up to 128 entries each, scanned one after the other -- k_file was 21 ms of a c4s step and 42 ms of c5s'.)
-    for (uint64_t mm = fm; mm; mm &= mm - 1) {
-      const int L = __builtin_ctzll(mm);
-      const uint32_t ps = (uint32_t)__shfl((int)f_slot, L, 64), ra = (uint32_t)__shfl((int)f_a, L, 64), rb2 = (uint32_t)__shfl((int)f_b, L, 64);
-      const uint32_t jj = (uint32_t)__shfl((int)j, L, 64);
-      const uint32_t *w = reinterpret_cast<const uint32_t *>(&r.pc[ps >> r.cshift]);
-      const uint32_t c = min(w[0], NIN);
-      for (uint32_t q = (uint32_t)lane; q < c; q += 64) {
-        const uint32_t rb = w[2 + q];
-        if (rb != 0 && rb - 1 != jj && rb - 1 < r.nb) file_for_reader(r, rb - 1, ra, rb2);
-      }
-      if (c >= NIN) {   // the overflow list: every lane walks it (one broadcast load per node), node i goes to lane i % 64
-        uint32_t idx = 0;
-        for (uint32_t nd = w[1]; nd != NIL; nd = r.rn[nd - 1].next, ++idx)
-          if ((idx & 63u) == (uint32_t)lane) {
-            const uint32_t rb = r.rn[nd - 1].bucket;
-            if (rb != jj && rb < r.nb) file_for_reader(r, rb, ra, rb2);
-          }
-      }
-    }
-  }
-  if (run) r.bflags[j] &= (uint8_t)~F_UNFILED;
-}
-
-// ---- check the guesses against the results ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_settle(R r) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= r.nb || !(r.bflags[j] & F_GUESS)) return;
-  const uint32_t b = r.bid[j], s0 = r.bstart[b];
-  bool bad = false, remain = false;
-  for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next) {
-    Item &im = r.items[it - 1];
-    if (!(im.info & I_GUESS)) continue;
-    const uint32_t req = im.mslot != NONE ? r.mt[im.mslot].req : NONE;
-    if (req >= r.settled) {
-      remain = true;
-      continue;
-    }
-    const uint32_t ai = im.info & 0xFF, pi = (im.info >> 8) & 0xFF, gtype = (im.info >> 16) & 3;
-    const Ent e0 = entry_of(r.y0[s0 + ai]), e1 = entry_of(r.y0[s0 + pi]);
-    uint32_t type;
-    const bool acc = classify(r.rq_res[req], r.rlen[e0.rid], r.rlen[e1.rid], e0.pos1 - e1.pos1, &type);
-    if (!acc || type != gtype) bad = true;
-#ifdef PGX_SETTLE_STATS
-    if (!acc || type != gtype) {
-      const uint32_t rl0 = r.rlen[e0.rid], rl1 = r.rlen[e1.rid], qo = e0.pos1 - e1.pos1;
-      const uint32_t ol = min(rl0 - qo, rl1);
-      const pgx_match mm = r.rq_res[req];
-      int cat = acc ? 3 : (ol <= 520 ? 4 : (mm.q_end == 0 && mm.t_end == 0 ? 5 : 6));
-      atomicAdd(&r.spread[((j >> 6) % SPREAD) * 8 + cat], 1ULL);
-    }
-#endif
-    else im.info &= ~I_GUESS;
-  }
-  if (bad) r.dirty[j] = 1;
-  if (!remain) r.bflags[j] &= (uint8_t)~F_GUESS;
-}
-
-// ---- the ovlp_t records, bucket by bucket in visit order, each bucket's in evaluation order ---------------------------
-__global__ __launch_bounds__(256) void k_emit(R r, const uint32_t *__restrict__ off, pgx_ovlp *__restrict__ out) {
-  const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long lk = 0, sk = 0, ck = 0;
-  if (j < r.nb) {
-    lk = r.lookups[j], sk = r.skips[j];
-    const uint32_t num = r.inum[j];
-    if (num) {
-      const uint32_t b = r.bid[j], s0 = r.bstart[b];
-      uint32_t k = 0;
-      for (uint32_t it = r.ihead[j]; it != NIL; it = r.items[it - 1].next, ++k) {  // the list runs newest first
-        const Item im = r.items[it - 1];
-        const uint32_t ai = im.info & 0xFF, pi = (im.info >> 8) & 0xFF;
-        const uint64_t ya = r.y0[s0 + ai], yb = r.y0[s0 + pi];
-        pgx_ovlp o;
-        o.y0 = ya, o.y1 = yb;
-        o.rl0 = r.rlen[(uint32_t)(ya >> 32)], o.rl1 = r.rlen[(uint32_t)(yb >> 32)];
-        o.strand0 = r.dir[s0 + ai], o.strand1 = r.dir[s0 + pi], o.ovlp_type = (uint8_t)((im.info >> 16) & 3), o.pad0 = 0;
-        o.match = r.rq_res[r.mt[im.mslot].req];
-        o.pad1 = 0;
-        out[(size_t)off[j] + (num - 1 - k)] = o;
-        ck += record_checksum(o, (uint64_t)off[j] + (num - 1 - k));
-      }
-    }
-  }
-  // totals: one atomic pair per wavefront
-  for (int o = 32; o; o >>= 1) {
-    lk += (unsigned long long)__shfl_xor((int)(lk >> 32), o, 64) << 32 | (uint32_t)__shfl_xor((int)lk, o, 64);
-    sk += (unsigned long long)__shfl_xor((int)(sk >> 32), o, 64) << 32 | (uint32_t)__shfl_xor((int)sk, o, 64);
-    ck += (unsigned long long)__shfl_xor((int)(ck >> 32), o, 64) << 32 | (uint32_t)__shfl_xor((int)ck, o, 64);
-  }
-  if ((threadIdx.x & 63) == 0 && (lk | sk | ck)) {
-    unsigned long long *line = r.spread + ((j >> 6) % SPREAD) * 8;
-    atomicAdd(line + 1, lk);
-    atomicAdd(line + 2, sk);
-#if !defined(PGX_BIG_STATS) && !defined(PGX_SETTLE_STATS)   // (the statistics builds count in the same words)
-    atomicAdd(line + 7, ck);
-#endif
-  }
-}
-
-// read pairs the walk has entered in the pair table (what the next stage's table is sized by: dev_replay)
-__global__ __launch_bounds__(256) void k_count_pairs(const PHot *__restrict__ ph, uint32_t cap, unsigned long long *__restrict__ out) {
-  uint32_t c = 0;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (size_t)gridDim.x * blockDim.x) c += ph[i].key != 0;
-  for (int o = 32; o; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
-  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, (unsigned long long)c);
-}
 
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -1720,9 +43,6 @@ uint32_t pow2_at_least(size_t x) {
 }
 unsigned cdiv256(size_t n) { return (unsigned)((n + 255) / 256); }
 
-}  // namespace
-
-namespace {
 // one attempt with the given table sizes (multiples of the defaults); returns 0, or the OV_* bits of what overflowed
 uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, const uint32_t *d_bids, size_t nb, size_t n_entries,
                         uint32_t bestn, int band, bool predict, const std::function<pgx_ovlp *(size_t)> &alloc_out,
