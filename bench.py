@@ -390,6 +390,10 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
     # 24 processes: the reference's own practical ceiling (README.md:127-137: 48 cores no faster than 24).  PGX_BENCH_CPU_PROCS = 48 | 64 runs the
     # whole-workload leg as that many processes over that many chunks instead -- the leg that says whether 24 is the best one on THIS host
     P = max(1, min(ncpu, int(os.environ.get("PGX_BENCH_CPU_PROCS", "24"))))
+    if P > 24 and os.environ.get("PGX_BENCH_CPU_PROCS_FORCE") != "1":
+        # (rounds 5 and 6: both attempts at a 48-process whole-workload leg lost the GPU box within minutes, whatever the host's free memory said)
+        log(f"cpu baseline: {P} reference processes asked for; 24 is the most this leg runs (both 48-process attempts lost the GPU box: PGX_BENCH_CPU_PROCS_FORCE=1 overrides)")
+        P = 24
     if os.environ.get("PGX_BENCH_CPU_PROCS") and mode == "full":
         # (round 5: 48 reference processes over the full-size set -- each holds every chunk's lists and its part of the pair map, ~13 GB at l = 2 --
         #  beside the 93 GB seqdb file in /dev/shm took the GPU box down.  A non-default process count must fit the host's free memory.)
@@ -403,7 +407,20 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
         except Exception:
             P = min(P, 24)
     mem = {l.split(":")[0]: int(l.split()[1]) * 1024 for l in open("/proc/meminfo") if l.split(":")[0] in ("MemTotal", "MemAvailable")}
-    procs_limit_reason = ("24 = the reference's own practical ceiling (README.md:127-137)" if P == 24 and not os.environ.get("PGX_BENCH_CPU_PROCS")
+    # what the CONTAINER may use (its cgroup's limit) can be far below what /proc/meminfo reports for the host: a leg of 48 reference processes
+    # (~13 GB each) took the GPU box down in round 5 AND in round 6 on a host with 3.2 TB of RAM, 3.0 TB of it "available"
+    for f, g in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"), ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            lim = open(f).read().strip()
+            if lim.isdigit() and int(lim) < (1 << 60):
+                mem["CgroupLimit"] = int(lim)
+                mem["MemAvailable"] = min(mem.get("MemAvailable", int(lim)), int(lim) - int(open(g).read().strip()))
+            break
+        except Exception:
+            continue
+    procs_limit_reason = ("24 = the reference's own practical ceiling (README.md:127-137); a 48-process leg was attempted in round 5 and in round 6 and lost the GPU "
+                          "box both times within minutes (its container's memory limit, not the 3.2 TB the host reports); 64 / 128 processes were slower than 24 at configs[2] (round 3)"
+                          if P == 24 and not os.environ.get("PGX_BENCH_CPU_PROCS")
                           else "PGX_BENCH_CPU_PROCS / host cores / host memory")
     T = P if mode == "full" else job_chunks if mode == "whole_chunks" else 192
     cs = list(range(1, min(T, P) + 1))
@@ -506,7 +523,8 @@ def cpu_baseline_chunked(seq, total, db, rdb, eng, tag, mode, levels, mc_upper, 
                           f"then over overlap chunks 1..24 of 192 (1/8 of the first keys; each process still loads all shimmer / count files and scans "
                           f"the whole list, as every reference overlap chunk does)") + f"; raw ovlp_t records / wall time of both stages; host has {ncpu} usable cores",
                "mode": mode, "chunking": T, "chunks_run": len(cs), "fraction_of_job": frac,
-               "host_ram_gb": mem.get("MemTotal", 0) / 1e9, "host_ram_available_gb": mem.get("MemAvailable", 0) / 1e9, "procs_limit_reason": procs_limit_reason,
+               "host_ram_gb": mem.get("MemTotal", 0) / 1e9, "host_ram_available_gb": mem.get("MemAvailable", 0) / 1e9, "cgroup_limit_gb": mem.get("CgroupLimit", 0) / 1e9 or None,
+               "procs_limit_reason": procs_limit_reason,
                "index_s": t_index, "overlap_s": t_ovlp, "records": int(raw), "unique_pairs": uniq,
                "index_bases_per_s": index_bases / t_index, "overlap_records_per_s": raw / t_ovlp,
                "unique_pairs_per_s": uniq / (t_index + t_ovlp) if uniq else None,
