@@ -27,7 +27,7 @@ extern "C" {
 #define PGX_EIO -2     /* file open/read/write failure (the reference would exit(1)) */
 #define PGX_EHIP -3    /* HIP runtime error / no device */
 #define PGX_ENOMEM -4
-#define PGX_ESTATE -5  /* pgx_init not called */
+#define PGX_ESTATE -5  /* pgx_init not called; or the call needs something the state no longer has (the seqdb bytes after pgx_seqdb_release_bytes) */
 
 /* ---- types shared with the on-disk formats (src/shimmer.h:24-30,61-64,97-110) ---- */
 typedef struct { uint64_t x, y; } pgx_mm128;                        /* x = hash<<8|span ; y = rid<<32|lastPos<<1|strand */
@@ -85,6 +85,13 @@ int pgx_seqdb_upload_dev(const uint8_t *d_seqdb, size_t nbytes, const uint32_t *
 int pgx_seqdb_adopt_dev(uint8_t *d_seqdb, size_t nbytes, size_t capacity, const uint32_t *rid, const uint32_t *rlen,
                         const uint64_t *roff, uint32_t nreads, pgx_seqdb **out);
 void pgx_seqdb_free(pgx_seqdb *db);
+/* The seqdb's BYTES out of HBM once the 2-bit packs exist (a quarter of the size, the same information; built by the first overlap stage on
+ * the database, or here): the index stage's closed-form kernels and every alignment kernel of the default path read the packs.  Refused --
+ * PGX_ESTATE, bytes kept -- for a database with a read that holds an ambiguous base (sketched run by run / aligned nibble by nibble from the
+ * bytes: src/mm_sketch.c:112-113, src/DWmatch.c:136-137) or a read longer than 65,535 bases.  Afterwards the entry points that need bytes (w / k
+ * other than 80 / 16, want_l0, pgx_*_batch, pgx_map*) return PGX_ESTATE; a buffer handed over with pgx_seqdb_adopt_dev is no longer referenced. */
+int pgx_seqdb_release_bytes(pgx_seqdb *db);
+int pgx_seqdb_has_bytes(const pgx_seqdb *db);
 uint64_t pgx_seqdb_bases(const pgx_seqdb *db);
 uint32_t pgx_seqdb_reads(const pgx_seqdb *db);
 

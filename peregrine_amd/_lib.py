@@ -66,7 +66,7 @@ class OverlapStats(C.Structure):
 EXPORTS = [
     "pgx_init", "pgx_shutdown", "pgx_last_error", "pgx_device_count", "pgx_version", "pgx_free",
     "pgx_timing_get", "pgx_timing_reset", "pgx_mem_ledger", "pgx_results_async", "pgx_results_wait",
-    "pgx_seqdb_upload", "pgx_seqdb_load", "pgx_seqdb_free", "pgx_seqdb_bases", "pgx_seqdb_reads",
+    "pgx_seqdb_upload", "pgx_seqdb_load", "pgx_seqdb_free", "pgx_seqdb_bases", "pgx_seqdb_reads", "pgx_seqdb_release_bytes", "pgx_seqdb_has_bytes",
     "pgx_index_resident", "pgx_index_result_free", "pgx_index_chunk",
     "pgx_overlap_resident", "pgx_overlap_chunk", "pgx_index_chunk_db", "pgx_overlap_chunk_db", "pgx_overlap_chunk_db_begin", "pgx_output_finish", "pgx_index_overlap_resident", "pgx_mkseqdb", "pgx_dedup",
     "pgx_sketch_batch", "pgx_reduce_batch", "pgx_count_batch", "pgx_align_batch",
@@ -106,6 +106,8 @@ def load():
         lib.pgx_seqdb_bases.argtypes = [C.c_void_p]
         lib.pgx_seqdb_reads.restype = C.c_uint32
         lib.pgx_seqdb_reads.argtypes = [C.c_void_p]
+        lib.pgx_seqdb_release_bytes.argtypes = [C.c_void_p]
+        lib.pgx_seqdb_has_bytes.argtypes = [C.c_void_p]
         lib.pgx_seqdb_upload.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         lib.pgx_seqdb_load.argtypes = [C.c_char_p, C.c_void_p]
         lib.pgx_index_resident.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -150,6 +152,9 @@ def load():
         lib.pgx_shimmer_map_free.argtypes = [C.c_void_p]
         _lib = lib
     return _lib
+
+
+PGX_ESTATE = -5   # include/pgx.h
 
 
 def check(rc: int, what: str = "pgx"):

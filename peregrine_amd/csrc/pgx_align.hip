@@ -99,16 +99,30 @@ __device__ __forceinline__ int wave_max_i32(int v) {  // DPP tree: 6 VALU ops, r
 
 }  // namespace
 
+// 16 codes of two 2-bit packs compared (pgx_pack.hip): q / t address the dword that holds base 0, xq / yt = position from there on
+__device__ __forceinline__ int match16p(const uint8_t *q, uint32_t xq, const uint8_t *t, uint32_t yt) {
+  uint2 qd, td;
+  __builtin_memcpy(&qd, q + (xq >> 4) * 4, 8), __builtin_memcpy(&td, t + (yt >> 4) * 4, 8);
+  const uint32_t df = __builtin_amdgcn_alignbit(qd.y, qd.x, (xq & 15) << 1) ^ __builtin_amdgcn_alignbit(td.y, td.x, (yt & 15) << 1);
+  return (int)min(ffbl_or_ones(df) >> 1, 16u);
+}
+// PACKED (round 6): seq = the 2-bit packs, roff = d_poff (dword index of a read's forward strand; its reverse complement follows): a probe
+// compares 16 codes, a snake iteration 64 x 16.  The run a diagonal is extended by is the same whatever the piece size, so the results are
+// those of the byte form; candidates on reads without 2-bit codes never come here (dev_align).
+template <bool PACKED>
 __device__ __forceinline__ void align_one_per_wave(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
                                                    const uint32_t *__restrict__ rlen, const pgx_align_key *__restrict__ keys, uint32_t a, int band,
                                                    int ring, pgx_match *__restrict__ out) {
   extern __shared__ int32_t V[];
+  constexpr int PB = PACKED ? 16 : 8;   // codes of a probe / of a lane's piece of a snake iteration
   const int lane = threadIdx.x;
   const pgx_align_key key = keys[a];
-  const uint8_t *q = seq + roff[key.rid0] + key.q_off;
-  const uint8_t *t = seq + roff[key.rid1];
-  const int q_len = (int)(rlen[key.rid0] - key.q_off);
-  const int t_len = (int)rlen[key.rid1];
+  const uint32_t len0 = rlen[key.rid0], len1 = rlen[key.rid1];
+  const uint8_t *q = PACKED ? seq + (roff[key.rid0] + (key.dir0 ? (len0 + 15u) >> 4 : 0u) + (key.q_off >> 4)) * 4 : seq + roff[key.rid0] + key.q_off;
+  const uint8_t *t = PACKED ? seq + (roff[key.rid1] + (key.dir1 ? (len1 + 15u) >> 4 : 0u)) * 4 : seq + roff[key.rid1];
+  const uint32_t qo = PACKED ? key.q_off & 15u : 0u;
+  const int q_len = (int)(len0 - key.q_off);
+  const int t_len = (int)len1;
   const int qs = key.dir0 ? 4 : 0, ts = key.dir1 ? 4 : 0;
   const int max_d = (int)(0.3 * (double)(q_len + t_len));  // DWmatch.c:96, one IEEE double multiply
   const int band_size = band * 2;
@@ -140,10 +154,10 @@ __device__ __forceinline__ void align_one_per_wave(const uint8_t *__restrict__ s
         // probe: the first 8 codes.  Off-diagonal fronts almost always stop here.
         const int rem = min(q_len - x, t_len - y);
         if (rem > 0) {
-          int m = match8(load_u64_unaligned(q + x), load_u64_unaligned(t + y), qs, ts);
+          int m = PACKED ? match16p(q, qo + (uint32_t)x, t, (uint32_t)y) : match8(load_u64_unaligned(q + x), load_u64_unaligned(t + y), qs, ts);
           m = min(m, rem);
           x += m, y += m;
-          more = (m == 8) && (rem > 8);
+          more = (m == PB) && (rem > PB);
         }
       }
       // long snakes (normally one per step): the whole wavefront extends one diagonal, 512 codes per iteration
@@ -152,16 +166,18 @@ __device__ __forceinline__ void align_one_per_wave(const uint8_t *__restrict__ s
         const int L = __builtin_ctzll(mm);
         const int xs = __builtin_amdgcn_readlane(x, L), ys = __builtin_amdgcn_readlane(y, L);
         const int rem = min(q_len - xs, t_len - ys);  // > 0 by construction
-        const int off = lane * 8;
+        const int off = lane * PB;
         int m = 0;
-        if (off < rem) m = min(match8(load_u64_unaligned(q + xs + off), load_u64_unaligned(t + ys + off), qs, ts), rem - off);
-        const uint64_t stop = ballot64(m < 8);
+        if (off < rem)
+          m = min(PACKED ? match16p(q, qo + (uint32_t)(xs + off), t, (uint32_t)(ys + off))
+                         : match8(load_u64_unaligned(q + xs + off), load_u64_unaligned(t + ys + off), qs, ts), rem - off);
+        const uint64_t stop = ballot64(m < PB);
         int ext;
         if (stop) {
           const int f = __builtin_ctzll(stop);
-          ext = 8 * f + __builtin_amdgcn_readlane(m, f);
+          ext = PB * f + __builtin_amdgcn_readlane(m, f);
         } else {
-          ext = 512;
+          ext = 64 * PB;
         }
         if (lane == L) x += ext, y += ext;
         if (stop || ext >= rem) mm &= mm - 1;  // this diagonal is done (mismatch found or an end reached)
@@ -227,16 +243,18 @@ __device__ __forceinline__ void align_one_per_wave(const uint8_t *__restrict__ s
     out[a] = r;
   }
 }
+template <bool PACKED>
 __global__ __launch_bounds__(64) void k_align1(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
                                               const uint32_t *__restrict__ rlen,
                                               const pgx_align_key *__restrict__ keys, uint32_t n, int band,
                                               int ring, pgx_match *__restrict__ out) {
-  if (blockIdx.x < n) align_one_per_wave(seq, roff, rlen, keys, blockIdx.x, band, ring, out);
+  if (blockIdx.x < n) align_one_per_wave<PACKED>(seq, roff, rlen, keys, blockIdx.x, band, ring, out);
 }
 // the same over a device-resident list of candidates (the ones a grouped launch handed on: reads with ambiguous bases, and the
 // STRAGGLERS -- round 3: at C4 scale ~600 of 9 M candidates of a launch run through low-complexity sequence with a band of up to 100
 // diagonals for thousands of steps; 8 lanes take 13 rounds per step for them, and the launch waited ~100 ms for them alone
 // (profiles/r03c_align_iterations.txt).  A whole wavefront takes such a band in two rounds.)
+template <bool PACKED>
 __global__ __launch_bounds__(64) void k_align1_list(const uint8_t *__restrict__ seq, const uint64_t *__restrict__ roff,
                                                    const uint32_t *__restrict__ rlen, const pgx_align_key *__restrict__ keys,
                                                    const uint32_t *__restrict__ list_n, const uint32_t *__restrict__ list, int band, int ring,
@@ -244,7 +262,7 @@ __global__ __launch_bounds__(64) void k_align1_list(const uint8_t *__restrict__ 
   const uint32_t cnt = *list_n;
   for (uint32_t i = blockIdx.x; i < cnt; i += gridDim.x) {
     __syncthreads();   // (the previous candidate's V ring is done with)
-    align_one_per_wave(seq, roff, rlen, keys, list[i], band, ring, out);
+    align_one_per_wave<PACKED>(seq, roff, rlen, keys, list[i], band, ring, out);
   }
 }
 
@@ -885,9 +903,18 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
   int ring = 64;
   while (ring < 2 * band + 8) ring <<= 1;
   hipStream_t st = ctx().stream;
+  // the one-candidate-per-wavefront kernels read the 2-bit packs too (round 6) where the database has them and none of its reads lacks 2-bit codes
+  // (n_flagged_reads: such candidates compare nibbles, DWmatch.c:136-137); PGX_ALIGN1_PACKED=0 keeps them on the bytes while those are there
+  const bool one_packed = seq_packs_valid(db) && db->n_flagged_reads == 0 && db->max_rlen <= 65535u &&
+                          (!db->d_seq.p || !(getenv("PGX_ALIGN1_PACKED") && atoi(getenv("PGX_ALIGN1_PACKED")) == 0));
+  PGX_REQUIRE(db->d_seq.p || one_packed, PGX_ESTATE, "the seqdb's bytes were released (pgx_seqdb_release_bytes) and its packs are gone");
   if ((long)n <= small_max) {
-    hipLaunchKernelGGL(k_align1, dim3((unsigned)n), dim3(64), ring * sizeof(int32_t), st, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys,
-                       (uint32_t)n, band, ring, d_out);
+    if (one_packed)
+      hipLaunchKernelGGL(k_align1<true>, dim3((unsigned)n), dim3(64), ring * sizeof(int32_t), st, reinterpret_cast<const uint8_t *>(db->d_pack.p), db->d_poff.p,
+                         db->d_rlen.p, d_keys, (uint32_t)n, band, ring, d_out);
+    else
+      hipLaunchKernelGGL(k_align1<false>, dim3((unsigned)n), dim3(64), ring * sizeof(int32_t), st, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys,
+                         (uint32_t)n, band, ring, d_out);
     PGX_HIP(hipGetLastError());
     return;
   }
@@ -964,8 +991,13 @@ void dev_align(const pgx_seqdb *db, const pgx_align_key *d_keys, size_t n, int b
                          (const uint32_t *)nullptr, seg2, iter_limit);
     }
     // the stragglers of either launch, a wavefront per candidate, from the list
-    hipLaunchKernelGGL(k_align1_list, dim3((unsigned)std::min<size_t>(std::max<size_t>(n / 256, 256), (size_t)ctx().num_cu * 32)), dim3(64),
-                       ring * sizeof(int32_t), st, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, esc, esc + 4, band, ring, d_out);
+    const dim3 g1((unsigned)std::min<size_t>(std::max<size_t>(n / 256, 256), (size_t)ctx().num_cu * 32));
+    if (one_packed)
+      hipLaunchKernelGGL(k_align1_list<true>, g1, dim3(64), ring * sizeof(int32_t), st, reinterpret_cast<const uint8_t *>(packs), db->d_poff.p, db->d_rlen.p,
+                         d_keys, esc, esc + 4, band, ring, d_out);
+    else
+      hipLaunchKernelGGL(k_align1_list<false>, g1, dim3(64), ring * sizeof(int32_t), st, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys, esc, esc + 4, band,
+                         ring, d_out);
   } else {
     hipLaunchKernelGGL((k_align_ph<8, uint16_t, false>), dim3(grid), dim3(64 * NW), lds, st, db->d_seq.p, db->d_roff.p, db->d_rlen.p, d_keys,
                        (uint32_t)n, band, ring, d_out, counter, (const uint32_t *)nullptr, (const uint32_t *)nullptr, (uint32_t *)nullptr,

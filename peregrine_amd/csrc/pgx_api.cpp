@@ -883,6 +883,28 @@ int pgx_seqdb_load(const char *prefix, pgx_seqdb **out) {
   PGX_GUARD_END
 }
 
+// The byte seqdb out of HBM (round 6, VERDICT r5 task 5): once the 2-bit packs exist they carry the same information at a quarter of the
+// size (pgx_pack.hip), and the kernels of the default path read them -- k_sketch_blk / k_sketch_wave (fused list form), k_align_ph,
+// k_align1 / k_align1_list.  What cannot work from the packs keeps the bytes: a database with a read that holds an ambiguous base (no 2-bit
+// code: those reads are sketched run by run and aligned nibble by nibble from the bytes) or a read beyond 65,535 bases (k_align4) is REFUSED
+// (PGX_ESTATE, bytes kept, nothing changed).  After a release: pgx_index_resident* (w = 80, k = 16, levels 1 / 2, no L0 output),
+// pgx_overlap_* and the file-level forms over them work as before; entry points that need the bytes (other w / k, want_l0, the batch
+// functions, pgx_map*) fail with PGX_ESTATE.  A buffer the library adopted (pgx_seqdb_adopt_dev) is no longer referenced: the caller may free it.
+int pgx_seqdb_release_bytes(pgx_seqdb *db) {
+  PGX_GUARD_BEGIN
+  require_ready();
+  PGX_REQUIRE(db, PGX_EARG, "pgx_seqdb_release_bytes: null argument");
+  if (!db->d_seq.p) return PGX_OK;   // (released already)
+  PGX_REQUIRE(db->max_rlen <= 65535u, PGX_ESTATE, "pgx_seqdb_release_bytes: a read of %u bases (> 65,535) needs the byte-wise alignment kernel: bytes kept", db->max_rlen);
+  PGX_REQUIRE(seq_packs(db) != nullptr, PGX_ESTATE, "pgx_seqdb_release_bytes: the 2-bit packs could not be built: bytes kept");
+  PGX_REQUIRE(db->n_flagged_reads == 0, PGX_ESTATE, "pgx_seqdb_release_bytes: %u reads hold an ambiguous base (no 2-bit code): bytes kept", db->n_flagged_reads);
+  pgx::sync();
+  if (db->borrowed) db->d_seq.p = nullptr, db->d_seq.n = 0;
+  else db->d_seq.release();
+  PGX_GUARD_END
+}
+int pgx_seqdb_has_bytes(const pgx_seqdb *db) { return db && db->d_seq.p ? 1 : 0; }
+
 void pgx_seqdb_free(pgx_seqdb *db) {
   if (db) {   // what the library kept for the chunks of a job on this database goes with it
     try {

@@ -425,6 +425,7 @@ void launch_sketch_general(const pgx_seqdb *db, const ReadDesc *d_reads, const s
     uint32_t *PY = ws<uint32_t>("sk.gen_py", acc);
     PGX_HIP(hipMemcpyAsync(d_so, so.data(), so.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
     const unsigned grid = (unsigned)std::min<size_t>(b1 - b0, (size_t)ctx().num_cu * 16);
+    PGX_REQUIRE(db->d_seq.p, PGX_ESTATE, "the seqdb's bytes were released (pgx_seqdb_release_bytes): the general sketch kernel (other w / k, L0 output) needs them");
     hipLaunchKernelGGL(k_sketch_general, dim3(grid), dim3(64), 0, st, db->d_seq.p, d_reads, d_list + b0, (uint32_t)(b1 - b0), w, k,
                        d_so, H, PY, WMv, T1, T2, d_slab, d_slab_off, d_counts, d_flags);
     PGX_HIP(hipGetLastError());

@@ -139,7 +139,7 @@ void locus_key_add_records(const pgx_seqdb *db, const uint64_t *d_key0, const ui
 // the packs (layout above); nullptr: their HBM could not be allocated (the caller uses the byte-wise kernels)
 const uint32_t *seq_packs(const pgx_seqdb *db) {
   if (seq_packs_valid(db)) return db->d_pack.p;
-  if (db->packs_failed) return nullptr;
+  if (db->packs_failed || !db->d_seq.p) return nullptr;   // (no bytes to pack from: they were released, and then the packs are valid)
   hipStream_t st = ctx().stream;
   const size_t nr = db->rlen_by_rid.size();
   size_t total_words = 0;

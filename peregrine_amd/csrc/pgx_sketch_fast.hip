@@ -301,12 +301,17 @@ __device__ __forceinline__ void phase_b1(Lds &s, int lane, int q, int bq, bool a
 
 // FUSED = false: the read's L0 minimizers go to its slab.  FUSED = true: they are reduced `levels` times on the fly
 // (reduce_flush) and only the final level reaches the slab -- L0 never leaves the CU.
-template <bool FUSED, int A>
+// PACKED (round 6): the read comes from its 2-bit pack (pgx_pack.hip: forward strand from dword poff[rid] on, base i in bits 2 (i % 16) .. + 1 of
+// dword i / 16) instead of the seqdb's bytes: a lane's block is ONE dword, F its 16 fields in reverse order, R its complement -- 6 lane-ops
+// instead of ~40 for the nibble decode, a quarter of the bytes, and the read starts at its first block (lead = 0).  A read with an ambiguous base
+// has no pack (nflag): it is flagged like one whose bytes fail the one-hot test.
+template <bool FUSED, int A, bool PACKED = false>
 __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ seq, const ReadDesc *__restrict__ reads,
                                                     const uint32_t *__restrict__ list, uint32_t n_list,
                                                     pgx_mm128 *__restrict__ slab, const uint64_t *__restrict__ slab_off,
                                                     uint32_t *__restrict__ counts, uint32_t *__restrict__ flags, int rs,
-                                                    int levels, uint32_t *__restrict__ need, int off_by_list) {
+                                                    int levels, uint32_t *__restrict__ need, int off_by_list,
+                                                    const uint64_t *__restrict__ poff = nullptr, const uint32_t *__restrict__ nflag = nullptr) {
   // need (optional): the number of elements the read produces, written even when its slab was too small (a second launch
   // with exact slabs then redoes exactly those reads); off_by_list: slab_off is indexed by the position in `list`, not by slot
   constexpr int W = 16 * A;  // window size in entries = A chunks of 16
@@ -319,8 +324,8 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
   const uint32_t slot = list ? list[blockIdx.x] : blockIdx.x;
   const ReadDesc rd = reads[slot];
   const int len = (int)rd.len;
-  const int lead = (int)(rd.off & 15);
-  const uint8_t *base = seq + (rd.off - (uint64_t)lead);
+  const int lead = PACKED ? 0 : (int)(rd.off & 15);
+  const uint8_t *base = PACKED ? seq + poff[rd.rid] * 4 : seq + (rd.off - (uint64_t)lead);
   const int span = lead + len;
   const int ntiles = (span + TILE - 1) / TILE;
   const uint32_t oi = off_by_list ? blockIdx.x : slot;
@@ -361,7 +366,12 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
     }
   };
   uint4 raw_next = make_uint4(0, 0, 0, 0);
-  if (lane * 16 < span) raw_next = *reinterpret_cast<const uint4 *>(base + lane * 16);
+  if (PACKED) {
+    if (nflag[rd.rid] & 1u) bad |= 1;   // (an ambiguous base somewhere in the read: the run-by-run path takes it)
+    if (lane * 16 < span) raw_next.x = reinterpret_cast<const uint32_t *>(base)[lane];
+  } else if (lane * 16 < span) {
+    raw_next = *reinterpret_cast<const uint4 *>(base + lane * 16);
+  }
   for (int t = 0; t < ntiles; ++t) {
     // ---- compaction: move the live chunks [ddone, ceil(E/16)) to the front of the buffer -----------------------
     if (ddone > qbase) {
@@ -391,12 +401,20 @@ __global__ __launch_bounds__(64) void k_sketch_wave(const uint8_t *__restrict__ 
     const int i0 = b0 - lead;             // read position of the block's first base
     const uint4 raw = raw_next;           // loaded one tile ahead: the HBM latency hides behind the previous tile
     raw_next = make_uint4(0, 0, 0, 0);
-    if (b0 + TILE < span) raw_next = *reinterpret_cast<const uint4 *>(base + b0 + TILE);
+    if (PACKED) {
+      if (b0 + TILE < span) raw_next.x = reinterpret_cast<const uint32_t *>(base)[(b0 + TILE) >> 4];
+    } else if (b0 + TILE < span) {
+      raw_next = *reinterpret_cast<const uint4 *>(base + b0 + TILE);
+    }
     const uint32_t dw[4] = {raw.x, raw.y, raw.z, raw.w};
     uint32_t F = 0;
     const bool inside = i0 >= 0 && i0 + 16 <= len;
+    if (PACKED) {   // the block's 16 fields in reverse order: earlier bases at higher bits
+      const uint32_t br = __builtin_bitreverse32(raw.x);
+      F = ((br & 0x55555555u) << 1) | ((br >> 1) & 0x55555555u);
+    }
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
+    for (int d = 0; d < 4 && !PACKED; ++d) {
       const uint32_t n = dw[d] & 0x0F0F0F0Fu;  // forward-strand one-hot nibbles (src/shmr_utils.c:18-30)
       const uint32_t c = ((n >> 1) & 0x07070707u) - ((n >> 3) & 0x01010101u);  // {1,2,4,8} -> {0,1,2,3} bytewise
       const uint32_t tt = n - 0x01010101u;
@@ -812,11 +830,12 @@ __device__ __forceinline__ uint32_t blk_tile(BlkLds<A> &s, BlkState &st, const i
 }
 }  // namespace
 
-template <int A>
+template <int A, bool PACKED = false>   // PACKED: from the read's 2-bit pack, as in k_sketch_wave above
 __global__ __launch_bounds__(64, 4) void k_sketch_blk(const uint8_t *__restrict__ seq, const ReadDesc *__restrict__ reads,
                                                       uint32_t n_reads, pgx_mm128 *__restrict__ slab,
                                                       const uint64_t *__restrict__ slab_off, uint32_t *__restrict__ counts,
-                                                      uint32_t *__restrict__ flags, int rs, int levels, int dbg) {
+                                                      uint32_t *__restrict__ flags, int rs, int levels, int dbg,
+                                                      const uint64_t *__restrict__ poff = nullptr, const uint32_t *__restrict__ nflag = nullptr) {
   constexpr int W = 16 * A;          // window size in entries
   __shared__ __attribute__((aligned(16))) BlkLds<A> s;
   __shared__ RedLds red;
@@ -826,11 +845,15 @@ __global__ __launch_bounds__(64, 4) void k_sketch_blk(const uint8_t *__restrict_
   if (slot >= n_reads) return;
   const ReadDesc rd = reads[slot];
   const int len = (int)rd.len;
-  const int lead = (int)(rd.off & 15);
-  const uint8_t *base = seq + (rd.off - (uint64_t)lead);
+  const int lead = PACKED ? 0 : (int)(rd.off & 15);
+  const uint8_t *base = PACKED ? seq + poff[rd.rid] * 4 : seq + (rd.off - (uint64_t)lead);
   const int span = lead + len;
   if (len < W + K - 1 + 200) {  // fewer than a window of entries, or too short for the drop rules: the general kernel
     if (lane == 0) counts[slot] = 0, flags[slot] = 1;   // (flag bits: see the end of the kernel)
+    return;
+  }
+  if (PACKED && (nflag[rd.rid] & 1u)) {   // an ambiguous base somewhere in the read (no 2-bit code): the run-by-run path
+    if (lane == 0) counts[slot] = 0, flags[slot] = 2;
     return;
   }
   const int ntiles = (((span - 1) >> 4) + A) / 64 + 1;  // the block of the last base is decided by global lane + A
@@ -868,21 +891,37 @@ __global__ __launch_bounds__(64, 4) void k_sketch_blk(const uint8_t *__restrict_
   uint32_t Fc = 0, Rc = 0;        // packs of the block left of the tile (wave uniform)
 
   uint4 raw_next = make_uint4(0, 0, 0, 0);
-  if (lane * 16 < span) raw_next = *reinterpret_cast<const uint4 *>(base + lane * 16);
+  if (PACKED) {
+    if (lane * 16 < span) raw_next.x = reinterpret_cast<const uint32_t *>(base)[lane];
+  } else if (lane * 16 < span) {
+    raw_next = *reinterpret_cast<const uint4 *>(base + lane * 16);
+  }
   for (int t = 0; t < ntiles; ++t) {
     const int G = t * 64 + lane;
     const int b0 = t * TILE + lane * 16;   // byte offset of the block from `base`
     const int ibase = b0 - lead;           // read position of its first base
     const uint4 raw = raw_next;
     raw_next = make_uint4(0, 0, 0, 0);
-    if (b0 + TILE < span) raw_next = *reinterpret_cast<const uint4 *>(base + b0 + TILE);
+    if (PACKED) {
+      if (b0 + TILE < span) raw_next.x = reinterpret_cast<const uint32_t *>(base)[(b0 + TILE) >> 4];
+    } else if (b0 + TILE < span) {
+      raw_next = *reinterpret_cast<const uint4 *>(base + b0 + TILE);
+    }
     const bool edge = (t == 0) || ((t + 1) * TILE - lead > len);
     // ---- decode ----------------------------------------------------------------------------------------------------
     uint32_t flagacc = 0, popc = 0;
-    const uint32_t Fcomp = decode16c(raw, flagacc, popc);
-    const uint32_t F = ~Fcomp;
-    const uint32_t R = revcomp_of_comp(Fcomp);
-    if (!edge) {
+    uint32_t F, R;
+    if (PACKED) {   // the block's dword: F = its 16 fields in reverse order (earlier bases at higher bits), R = its complement as it stands
+      const uint32_t br = __builtin_bitreverse32(raw.x);
+      F = ((br & 0x55555555u) << 1) | ((br >> 1) & 0x55555555u);
+      R = ~raw.x;
+    } else {
+      const uint32_t Fcomp = decode16c(raw, flagacc, popc);
+      F = ~Fcomp;
+      R = revcomp_of_comp(Fcomp);
+    }
+    if (PACKED) {
+    } else if (!edge) {
       if ((flagacc & 0x04040404u) | (popc != 16u ? 1u : 0u)) st.bad |= 2;
     } else {  // blocks that reach over a read end: only the read's own bytes count
       const uint32_t dw[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -974,6 +1013,14 @@ __global__ __launch_bounds__(64, 4) void k_sketch_blk(const uint8_t *__restrict_
 }
 
 // host side ------------------------------------------------------------------------------------------------
+// the closed-form kernels read the 2-bit packs once a stage has built them (the first overlap stage on the database: pgx_pack.hip) -- always when
+// the bytes were released; PGX_SKETCH_PACKED=0 keeps them on the bytes (the parity tests run both forms)
+static bool sketch_from_packs(const pgx_seqdb *db) {
+  if (!seq_packs_valid(db)) return false;
+  if (!db->d_seq.p) return true;
+  const char *e = getenv("PGX_SKETCH_PACKED");
+  return !(e && atoi(e) == 0);
+}
 bool sketch_wave_eligible(const ReadDesc &rd, int w, int k) {
   return k == K && (w == 64 || w == 80 || w == 96 || w == 128) && rd.len < (1u << 30);
 }
@@ -982,8 +1029,14 @@ template <bool FUSED, int A>
 static void launch_w(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n, pgx_mm128 *d_slab,
                      const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags, int rs, int levels, uint32_t *d_need = nullptr,
                      int off_by_list = 0) {
+  if (FUSED && sketch_from_packs(db)) {   // (round 6: from the 2-bit packs once they exist)
+    hipLaunchKernelGGL((k_sketch_wave<FUSED, A, true>), dim3(n), dim3(64), 0, ctx().stream, reinterpret_cast<const uint8_t *>(db->d_pack.p), d_reads, d_list, n,
+                       d_slab, d_slab_off, d_counts, d_flags, rs, levels, d_need, off_by_list, db->d_poff.p, db->d_nflag.p);
+    return;
+  }
+  PGX_REQUIRE(db->d_seq.p, PGX_ESTATE, "the seqdb's bytes were released (pgx_seqdb_release_bytes): this sketch form needs them");
   hipLaunchKernelGGL((k_sketch_wave<FUSED, A>), dim3(n), dim3(64), 0, ctx().stream, db->d_seq.p, d_reads, d_list, n, d_slab,
-                     d_slab_off, d_counts, d_flags, rs, levels, d_need, off_by_list);
+                     d_slab_off, d_counts, d_flags, rs, levels, d_need, off_by_list, (const uint64_t *)nullptr, (const uint32_t *)nullptr);
 }
 
 void launch_sketch_wave(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n_list, int w,
@@ -1018,8 +1071,14 @@ void launch_sketch_blk(const pgx_seqdb *db, const ReadDesc *d_reads, uint32_t n,
                        const uint64_t *d_slab_off, uint32_t *d_counts, uint32_t *d_flags) {
   if (!n) return;
   const int dbg = 0;   // (round 2's timing experiments: bit 1 no emission, 2 no reduce, 4 no edge variants)
-  hipLaunchKernelGGL((k_sketch_blk<5>), dim3(n), dim3(64), 0, ctx().stream, db->d_seq.p, d_reads, n, d_slab, d_slab_off, d_counts,
-                     d_flags, rs, levels, dbg);
+  if (sketch_from_packs(db)) {
+    hipLaunchKernelGGL((k_sketch_blk<5, true>), dim3(n), dim3(64), 0, ctx().stream, reinterpret_cast<const uint8_t *>(db->d_pack.p), d_reads, n, d_slab,
+                       d_slab_off, d_counts, d_flags, rs, levels, dbg, db->d_poff.p, db->d_nflag.p);
+  } else {
+    PGX_REQUIRE(db->d_seq.p, PGX_ESTATE, "the seqdb's bytes were released (pgx_seqdb_release_bytes) and its packs are gone");
+    hipLaunchKernelGGL((k_sketch_blk<5>), dim3(n), dim3(64), 0, ctx().stream, db->d_seq.p, d_reads, n, d_slab, d_slab_off, d_counts,
+                       d_flags, rs, levels, dbg, (const uint64_t *)nullptr, (const uint32_t *)nullptr);
+  }
   PGX_HIP(hipGetLastError());
 }
 void launch_sketch_fused_list(const pgx_seqdb *db, const ReadDesc *d_reads, const uint32_t *d_list, uint32_t n_list, int rs,

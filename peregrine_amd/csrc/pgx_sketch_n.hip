@@ -364,6 +364,7 @@ void dev_sketch_nreads(const pgx_seqdb *db, const ReadDesc *d_reads, const uint3
   nl0_off.alloc((size_t)nn + 1);
   if (nn == 0) return;
   hipStream_t st = ctx().stream;
+  PGX_REQUIRE(db->d_seq.p, PGX_ESTATE, "the seqdb's bytes were released (pgx_seqdb_release_bytes): reads with ambiguous bases are sketched from them");
   const uint8_t *seq = db->d_seq.p;
   // segments
   DevBuf<uint64_t> seg_off((size_t)nn + 1);

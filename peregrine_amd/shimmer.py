@@ -123,6 +123,21 @@ class ResidentDB:
                                                       C.byref(out), C.byref(n), C.byref(st)), "pgx_overlap_resident_dev")
         return _lib.take(out.value, n.value, OVLP_DTYPE), st.asdict()
 
+    def release_bytes(self) -> bool:
+        """The seqdb's BYTES out of HBM (pgx_seqdb_release_bytes): the 2-bit packs carry the same information at a quarter of the size and
+        the default path's kernels read them.  Returns False -- bytes kept, nothing changed -- for a database with an ambiguous base or a
+        read beyond 65,535 bases; True: an adopted device buffer is no longer referenced (this object drops its hold on it)."""
+        rc = self._lib.pgx_seqdb_release_bytes(self.h)
+        if rc == _lib.PGX_ESTATE:
+            return False
+        _lib.check(rc, "pgx_seqdb_release_bytes")
+        self._adopted = None
+        return True
+
+    @property
+    def has_bytes(self) -> bool:
+        return bool(self._lib.pgx_seqdb_has_bytes(self.h))
+
     def close(self):
         if self.h:
             self._lib.pgx_seqdb_free(self.h)

@@ -857,7 +857,10 @@ ALIGN_VARIANTS = [   # (id, environment, read set): every form dev_align dispatc
     ("ph8-packed-file-order", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_ORDER_MIN="0"), "small3"),   # a database that never saw an overlap stage:
                                                                                     # packs in the order of the seqdb file, no order list
     ("ph8-bytes", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="-1"), "small2"),  # k_align_ph<8, u16> on the seqdb bytes (a database without packs)
-    ("one-per-wave", dict(PGX_ALIGN_SMALL="1000000000"), "small"),                  # k_align1 on a LARGE launch
+    ("one-per-wave", dict(PGX_ALIGN_SMALL="1000000000"), "small"),                  # k_align1 on a LARGE launch (round 6: from the 2-bit packs -- this database has them by now)
+    ("one-per-wave-bytes", dict(PGX_ALIGN_SMALL="1000000000", PGX_ALIGN1_PACKED="0"), "small"),   # ... on the seqdb bytes
+    ("one-per-wave-ambiguous", dict(PGX_ALIGN_SMALL="1000000000"), "withN"),         # a database with reads that have no 2-bit codes: bytes
+    ("ph8-packed-stragglers-bytes", dict(PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_ITER_LIMIT="150", PGX_ALIGN1_PACKED="0"), "small"),   # k_align1_list on the bytes
     ("long-reads-int32", dict(PGX_ALIGN_SMALL="0"), "long"),                        # a 100 kb read in the set: k_align4<8, int32>
 ]
 
@@ -1005,3 +1008,93 @@ def test_device_visit_order_equals_oracle_and_host_visit(monkeypatch):
         monkeypatch.delenv("PGX_REPLAY_PAIRS_X"), monkeypatch.delenv("PGX_REPLAY_MEMO_X")
         assert st2["device_replay"] == 0 and formats.ovlp_fields_equal(got2, want), kw
     rdb.close()
+
+
+def _env(**kw):
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        saved = {k: os.environ.get(k) for k in kw}
+        os.environ.update(kw)
+        try:
+            yield
+        finally:
+            for k, v in saved.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    return cm()
+
+
+def test_index_and_overlap_from_the_packs_and_with_the_bytes_released():
+    """Round 6 (VERDICT r5 task 5): once a database has its 2-bit packs the closed-form sketch kernels (k_sketch_blk, and k_sketch_wave for the reads
+    it flags: short reads, drops, tie bursts of tandem arrays) and the one-candidate-per-wavefront alignment kernels read THEM, and
+    pgx_seqdb_release_bytes gives the bytes' HBM back.  Lists and streams equal the byte forms' and the oracle's before and after the release, under
+    the device and the host replay; what needs bytes says so; a database with an ambiguous base keeps its bytes."""
+    g = simreads.make_genome(500_000, 19, repeat_families=2, repeat_len=4000, repeat_copies=6, tandem=60)
+    db = simreads.simulate_reads(g, seed=47, coverage=24, mean_len=6000, sd_len=3000, min_len=200)
+    assert int(db.rlen.min()) < 295 and int(db.rlen.max()) > 12000       # reads shorter than a window + 200 (flag 1) among them
+    rdb = ResidentDB(db, 0)
+    T = 2
+    byte_lists = [rdb.index(total_chunk=T, mychunk=c) for c in (1, 2)]     # no packs yet: the byte kernels
+    assert any(p.reads_literal >= 0 for p in byte_lists)
+    mm, mc = np.concatenate([p.top for p in byte_lists]), np.concatenate([p.top_mc for p in byte_lists])
+    for c, p in enumerate(byte_lists, 1):                                   # ... equal to the oracle's lists
+        mine = np.flatnonzero(db.rid % T == c % T)
+        want = np.concatenate([U.orc_reduce(U.orc_reduce(U.orc_sketch_seqdb(db.seqdb[int(db.roff[r]):int(db.roff[r]) + int(db.rlen[r])], 80, 16, int(db.rid[r])), 6), 6) for r in mine])
+        assert np.array_equal(p.top, want), c
+    want_l1 = {c: np.concatenate([U.orc_reduce(U.orc_sketch_seqdb(db.seqdb[int(db.roff[r]):int(db.roff[r]) + int(db.rlen[r])], 80, 16, int(db.rid[r])), 6)
+                                  for r in np.flatnonzero(db.rid % T == c % T)]) for c in (1, 2)}
+    want_ov = {c: U.orc_overlap(db, mm, mc, mychunk=c, total=3)[0] for c in (1, 3)}
+    with _env(PGX_ALIGN_PACKED_MIN="0", PGX_GPU_REPLAY="1"):
+        ov, st = rdb.overlap(mm, mc, total_chunk=3, mychunk=1)                # the first large launch builds the packs (laid out by locus key)
+    assert st["device_replay"] == 1 and len(ov) > 2000 and formats.ovlp_fields_equal(ov, want_ov[1])
+    assert rdb.has_bytes
+
+    def check_lists(tag):
+        for c, p in enumerate(byte_lists, 1):
+            q = rdb.index(total_chunk=T, mychunk=c)
+            assert np.array_equal(q.top, p.top), (tag, c)
+            assert np.array_equal(formats.mc_as_sorted_pairs(q.top_mc), formats.mc_as_sorted_pairs(p.top_mc)), (tag, c)
+            q1 = rdb.index(total_chunk=T, mychunk=c, levels=1)                # the fused form with one reduce level
+            assert np.array_equal(q1.top, want_l1[c]), (tag, c, "levels=1")
+
+    def check_streams(tag):
+        for env in (dict(PGX_GPU_REPLAY="1"), dict(PGX_GPU_REPLAY="1", PGX_ALIGN_SMALL="0", PGX_ALIGN_PACKED_MIN="0", PGX_ALIGN_ITER_LIMIT="300"),
+                    dict(PGX_GPU_REPLAY="0"), dict(PGX_GPU_REPLAY="1", PGX_ALIGN_SMALL="1000000000")):
+            with _env(**env):
+                for c in (1, 3):
+                    got, _ = rdb.overlap(mm, mc, total_chunk=3, mychunk=c)
+                    assert formats.ovlp_fields_equal(got, want_ov[c]), (tag, env, c)
+
+    check_lists("packs, bytes still there")                                   # the sketch kernels read the packs now
+    with _env(PGX_SKETCH_PACKED="0"):
+        check_lists("bytes")
+    check_streams("bytes still there")
+    # ---- the bytes out of HBM
+    import torch
+    used0 = torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]
+    assert rdb.release_bytes() is True and not rdb.has_bytes
+    assert rdb.release_bytes() is True                                         # (idempotent)
+    check_lists("released")
+    check_streams("released")
+    ix, ov1, st1 = rdb.index_overlap()                                          # the one-chunk pipeline (lists stay in HBM between the stages)
+    assert st1["n_records"] == len(ov1) and len(ov1) > 5000
+    for call in (lambda: rdb.index(want_l0=True), lambda: rdb.index(window=64), lambda: rdb.index(kmer=15)):   # what needs the bytes says so
+        with pytest.raises(_lib.PgxError, match="released"):
+            call()
+    check_lists("released, after the refused calls")
+    rdb.close()
+    del used0
+    # ---- a database with an ambiguous base keeps its bytes
+    sd = db.seqdb.copy()
+    o = int(db.roff[5])
+    sd[o + 100] = 0
+    sd[o + int(db.rlen[5]) - 1 - 100] &= 0x0F
+    dbn = formats.SeqDB(sd, db.rid, db.rlen, db.roff, None)
+    rn = ResidentDB(dbn, 0)
+    assert rn.release_bytes() is False and rn.has_bytes                         # (the packs are built by the call; read 5 is flagged)
+    pn = rn.index(total_chunk=T, mychunk=2)
+    wantn = np.concatenate([U.orc_reduce(U.orc_reduce(U.orc_sketch_seqdb(sd[int(db.roff[r]):int(db.roff[r]) + int(db.rlen[r])], 80, 16, int(db.rid[r])), 6), 6)
+                            for r in np.flatnonzero(db.rid % T == 0)])
+    assert np.array_equal(pn.top, wantn)
+    rn.close()

@@ -18,7 +18,8 @@ except Exception as e:
 st = d["overlap_stats_rank0"]
 print("%-44s %8.1f ms/step  %6.2f M/s  index %6.1f  overlap %7.1f | " % (sys.argv[1], d["ms_per_step"], d["value"] / 1e6, d["index_ms_per_step"], d["overlap_ms_per_step"]) +
       "  ".join("%s %.0f" % (n, v["ms_total"] / v["steps"]) for n, v in sorted(k.items(), key=lambda kv: -kv[1]["ms_total"] / kv[1]["steps"])[:5]),
-      " sweeps %d  evals %.2f M  aligned %.1f M" % (st["rounds"], st["n_evaluations"] / 1e6, st["n_align_gpu"] / 1e6), " pins", d.get("streams_match_pins"))
+      " sweeps %d  evals %.2f M  aligned %.1f M" % (st["rounds"], st["n_evaluations"] / 1e6, st["n_align_gpu"] / 1e6), " pins", d.get("streams_match_pins"),
+      " hbm %.1f GB released %s" % (d.get("hbm_bytes_in_use", 0) / 1e9, d.get("hbm_ledger", {}).get("seqdb_bytes_released_after_warmup")))
 P
   tail -2 gpurun_out/ab2_c4_$i.err
 done
