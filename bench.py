@@ -268,7 +268,7 @@ def attach_counters(cands, kern, workload):
                            # (profiles/r03_valu_issue.txt).  Rounds 3-4 priced the alignment kernel against 0.25 and read 0.22 as "93 % of the ceiling": it was
                            # the work counter's same-address atomic that held it there (round 4: DESIGN 4.4); with chunks of 8 it issues 0.31.
     N_SIMD = 1024          # 256 CUs x 4 SIMDs
-    for tag in ("r05", "r04", "r03"):
+    for tag in ("r06", "r05", "r04", "r03"):
         tfile = os.path.join("profiles", f"{tag}_traffic_{workload}.json")
         if os.path.exists(os.path.join(ROOT, tfile)):
             break
@@ -284,7 +284,7 @@ def attach_counters(cands, kern, workload):
             if nm in cands and kk:
                 # PER STEP (the PMC pass and the timed tree may split a step into different numbers of launches): what the counters
                 # saw over one step of the PMC pass; `traffic` (the contract's per-launch figure) = that / THIS run's launches per step
-                per_step = tr[kk]["hbm_bytes_per_launch"] * tr[kk]["launches"] / pmc_steps
+                per_step = tr[kk]["hbm_bytes_per_launch"] * tr[kk]["launches"] / tr[kk].get("steps", pmc_steps)
                 cands[nm]["traffic_bytes_per_step"] = per_step
                 cands[nm]["traffic"] = per_step / (kern[nm]["launches"] / kern[nm]["steps"])
                 cands[nm]["traffic_read_side_raw"] = tr[kk].get("FETCH_SIZE_KB_per_launch", 0) * 1024 if "FETCH_SIZE_KB_per_launch" in tr[kk] else None
@@ -293,7 +293,7 @@ def attach_counters(cands, kern, workload):
         pass
     # the roofline that BINDS the sketch and alignment kernels: VALU issue (VERDICT r3 task 4).  From the committed SQ passes: wave64 VALU
     # instructions per unit and the issue rate they were executed at, against the four-cycle class's ceiling
-    for tag in ("r05", "r04", "r03"):
+    for tag in ("r06", "r05", "r04", "r03"):
         vfile = os.path.join("profiles", f"{tag}_valu_{workload}.json")
         if os.path.exists(os.path.join(ROOT, vfile)):
             break
