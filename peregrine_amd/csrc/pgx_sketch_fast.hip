@@ -966,25 +966,29 @@ __global__ __launch_bounds__(64, 4) void k_sketch_blk(const uint8_t *__restrict_
       const int einc = wave_incl_scan_dpp(ec);
       const int ex = einc - ec;
       const int etot = __builtin_amdgcn_readlane(einc, 63);
-      if (etot > QCAP || etot > RSTAGE) {
-        st.bad |= 64;   // a burst of ties (low-complexity read): the general kernel
-      } else {
-        int w = ex;
+      // A burst of ties (a homopolymer or a short-period tandem array makes EVERY position a tied window minimum: up to 1,024 entries of a
+      // tile) is queued and staged in pieces of at most EB entries (round 6; through round 5 such a tile sent its read to k_sketch_wave: 10.7 %
+      // of the reads of the repeat-seeded set, 4.4 ms per chunk of redo).
+      constexpr int EB = QCAP < RSTAGE ? QCAP : RSTAGE;
+      const int pbase = ibase - W;
+      for (int b0 = 0; b0 < etot; b0 += EB) {   // (wave-uniform; one piece for an ordinary tile)
+        const int bn = min(EB, etot - b0);
+        int w = ex - b0;
         uint32_t em = emask;
-        const int pbase = ibase - W;
         while (em) {
           const int o = __builtin_ctz(em);
           em &= em - 1;
-          s.Q[w++] = (uint32_t)(pbase + o);
+          if ((uint32_t)w < (uint32_t)bn) s.Q[w] = (uint32_t)(pbase + o);
+          ++w;
         }
         __syncthreads();
-        if (rst[0].nnew + etot > RSTAGE) {
+        if (rst[0].nnew + bn > RSTAGE) {
           if (dbg & 2) rst[0].nnew = 0;
           else fused_flush();
         }
-        for (int e0 = 0; e0 < etot; e0 += 64) {
+        for (int e0 = 0; e0 < bn; e0 += 64) {
           const int e = e0 + lane;
-          if (e < etot) {
+          if (e < bn) {
             const int ip = (int)s.Q[e];
             const int bb = ip + lead, B = bb >> 4, o = bb & 15;
             const uint64_t fq = ((uint64_t)s.Fr[(B - 1) & 127] << 32) | s.Fr[B & 127];
@@ -995,7 +999,7 @@ __global__ __launch_bounds__(64, 4) void k_sketch_blk(const uint8_t *__restrict_
             red.y[0][wq] = ((uint32_t)ip << 1) | (fw > rv ? 1u : 0u);
           }
         }
-        rst[0].nnew += etot;
+        rst[0].nnew += bn;
         __syncthreads();
       }
     }
