@@ -1159,91 +1159,101 @@ def main():
                                   "copies, RCCL; the replay's kernels are timed in an extra step WITHOUT their second stream and the record copy of a multi-chunk "
                                   "step overlaps the next chunk, so the sum can exceed the step; tools/timeline.py / chunk_timeline.py on a rocprofv3 "
                                   "kernel trace give the busy / idle split kernel by kernel")
-        if world == 1 and not a.no_cpu_baseline:
-            if strong:
-                def gpu_index_files(prefix):     # the job's index chunk files, as bin/shmr_index writes them
-                    for c in range(1, CH + 1):
-                        p = rdb.index(total_chunk=CH, mychunk=c, levels=sp["levels"])
-                        formats.write_mmlist("%s-L%d-%02d-of-%02d.dat" % (prefix, sp["levels"], c, CH), p.top)
-                        formats.write_mm_count("%s-L%d-MC-%02d-of-%02d.dat" % (prefix, sp["levels"], c, CH), p.top_mc)
-                # The honest leg is the WHOLE workload (24 processes over 24 + 24 chunks: ~12-14 min at full size); it is the default where the
-                # command's time budget allows (PGX_BENCH_BUDGET_S, default 1,620 s of the driver's 1,800), else the bounded sample -- and the line says which
-                mode = a.cpu_baseline
-                fallback_reason = None
-                if mode is None:
-                    whole = "whole_chunks" if sp["levels"] == 1 else "full"
-                    need = (1300.0 if whole == "whole_chunks" else 900.0) * (db.n_bases / 93.3e9) + 60
-                    left = float(os.environ.get("PGX_BENCH_BUDGET_S", "1620")) - (time.perf_counter() - _T0) - 150
-                    mode = whole if left >= need else "sample"
-                    log(f"cpu baseline: {mode} (estimated {need:.0f} s for the {whole} leg, {left:.0f} s of the budget left)")
-                    if mode == "sample":
-                        fallback_reason = (f"the {whole} reference leg needs ~{need:.0f} s and {left:.0f} s of the command's budget (PGX_BENCH_BUDGET_S) were left: "
-                                           f"bounded sample instead; gpu_over_cpu.vs_n_cores_raw_records is null for a sample")
-                        sys.stderr.write("[bench] WARNING: cpu_baseline falls back to mode 'sample': " + fallback_reason + "\n")
-                # the end-to-end leg (default where the budget allows; it runs LAST -- this process gives its HBM to the server) reads the same seqdb files
-                # as the reference: written once, shared
-                cpu_est = {"full": 900.0, "whole_chunks": 1300.0, "sample": 330.0}[mode] * (db.n_bases / 93.3e9) + 60
-                left_after = float(os.environ.get("PGX_BENCH_BUDGET_S", "1620")) - (time.perf_counter() - _T0) - cpu_est
-                if a.end_to_end is None:
-                    a.end_to_end = bool(not a.genome_mb and a.workload == "c4" and left_after >= 200)
-                    log(f"end to end leg: {'on' if a.end_to_end else 'off'} ({left_after:.0f} s of the budget expected to be left after the CPU leg)")
-                if a.end_to_end:
-                    need = int(total * 1.02) + int(db.n_bases * 0.5) + (8 << 30)
-                    base = _scratch_dir(need)
-                    if base is not None:
-                        sdir = tempfile.mkdtemp(prefix="pgx_bench_", dir=base)
-                        tw = time.perf_counter()
-                        simreads.write_seqdb_from_device(os.path.join(sdir, "sd"), seq_bytes(), total, db.rid, db.rlen, db.roff)
-                        shared_files = {"dir": sdir, "prefix": os.path.join(sdir, "sd"), "seconds": time.perf_counter() - tw}
-                sha_thread = None
-                if not a.genome_mb and not os.environ.get("PGX_BENCH_NO_STREAM_HASH"):     # the seqdb's SHA-256, beside the CPU leg's (untimed) file writing
-                    import threading
-                    sha_box = {}
-                    sha_src = seq_bytes()
-                    sha_thread = threading.Thread(target=lambda: sha_box.update(v=seqdb_sha256_of_device(sha_src, total)))
-                    sha_thread.start()
-                out["cpu_baseline"] = cpu_baseline_chunked(seq_bytes(), total, db, rdb, eng, a.workload, mode, sp["levels"], sp["mc_upper"], CH, gpu_index_files, held,
-                                                           stream_report=stream_report, before_timing=(sha_thread.join if sha_thread is not None else None),
-                                                           files=shared_files)
-                if sha_thread is not None:
-                    sha_thread.join()
-                    out["seqdb_sha256"] = sha_box.get("v")
-                if fallback_reason:
-                    out["cpu_baseline"]["fallback_reason"] = fallback_reason
-            elif a.cpu_baseline == "sample":
-                sample = simreads.simulate_reads_torch(10_000_000, 1003, 30.0, seed=42)
-                out["cpu_baseline"] = cpu_baseline_sample(sample)
-            else:
-                out["cpu_baseline"] = cpu_baseline(db, keep_streams[1], a.workload, sp["levels"], sp["mc_upper"])
-            cb = out["cpu_baseline"]
-            if strong and cb.get("mode") == "sample" and not a.genome_mb:
-                # the bounded sample UNDERSTATES the reference: each of its processes still loads every shimmer / count file and scans the whole
-                # list (a fixed cost per process) for 1/8 of the first keys.  The whole-workload leg of the same tree family is committed:
-                try:
-                    full = json.load(open(os.path.join(ROOT, "profiles", "r04e_bench_c4_full.json")))["cpu_baseline"]
-                    if a.workload == "c4" and full.get("mode") == "full":
-                        cb["whole_workload_leg"] = {"value": full["value"], "unit": "overlaps/s", "cores": full["cores"], "index_s": full["index_s"], "overlap_s": full["overlap_s"],
-                                                    "records": full["records"], "unique_pairs_per_s": full.get("unique_pairs_per_s"),
-                                                    "source": "profiles/r04e_bench_c4_full.json (python bench.py --cpu-baseline full: 24 processes over 24 + 24 chunks of the whole 93 Gbases, "
-                                                              "13 min 43 s of the box; not re-run in the default command)"}
-                        cb["sample_note"] = ("the sample's rate is lower than the whole-workload leg's (fixed per-process cost over 1/8 of the work): compare `value` with "
-                                             "whole_workload_leg.value")
-                except Exception:
-                    pass
-            if cb.get("value"):
-                out["gpu_over_cpu"] = {"vs_n_cores_raw_records": out["value"] / cb["value"] if cb.get("mode") != "sample" else None,
-                                       "vs_n_cores_unique_pairs": out["value"] / cb["unique_pairs_per_s"] if cb.get("unique_pairs_per_s") and cb.get("mode") != "sample" else None,
-                                       "vs_one_core": out["value"] / cb["one_core"]["value"] if cb.get("one_core") else None, "cpu_cores": cb["cores"],
-                                       "vs_whole_workload_leg_raw_records": out["value"] / cb["whole_workload_leg"]["value"] if cb.get("whole_workload_leg") else None,
-                                       "note": "the N-chunk CPU run reports most pairs once per chunk, so both of its rates are given; one-chunk "
-                                               "workloads: GPU value = records of ONE overlap chunk (every read pair once)"}
-                if cb.get("mode") == "whole_chunks" and out.get("overlap_ms_per_step"):
-                    k = cb["chunks_run"]
-                    out["gpu_over_cpu"]["same_chunks"] = {
-                        "what": "overlap stage of the SAME %d chunks of the job's own chunking (T = %d): reference wall time, %d processes side by side, vs the GPU's overlap "
-                                "time per step x %d/%d; equal streams (cpu_baseline.records_match_gpu)" % (k, CH, cb["overlap_processes"], k, CH),
-                        "cpu_overlap_s": cb["overlap_s"], "cpu_processes": cb["overlap_processes"], "gpu_overlap_s": out["overlap_ms_per_step"] * 1e-3 * k / CH,
-                        "ratio": cb["overlap_s"] / (out["overlap_ms_per_step"] * 1e-3 * k / CH)}
+        # (the legs below run the reference on the host and shell out: whatever goes wrong there, the line of the timed steps still goes out)
+        try:
+            if world == 1 and not a.no_cpu_baseline:
+                if strong:
+                    def gpu_index_files(prefix):     # the job's index chunk files, as bin/shmr_index writes them
+                        for c in range(1, CH + 1):
+                            p = rdb.index(total_chunk=CH, mychunk=c, levels=sp["levels"])
+                            formats.write_mmlist("%s-L%d-%02d-of-%02d.dat" % (prefix, sp["levels"], c, CH), p.top)
+                            formats.write_mm_count("%s-L%d-MC-%02d-of-%02d.dat" % (prefix, sp["levels"], c, CH), p.top_mc)
+                    # The honest leg is the WHOLE workload (24 processes over 24 + 24 chunks: ~12-14 min at full size); it is the default where the
+                    # command's time budget allows (PGX_BENCH_BUDGET_S, default 1,620 s of the driver's 1,800), else the bounded sample -- and the line says which
+                    mode = a.cpu_baseline
+                    fallback_reason = None
+                    if mode is None:
+                        whole = "whole_chunks" if sp["levels"] == 1 else "full"
+                        need = (1300.0 if whole == "whole_chunks" else 900.0) * (db.n_bases / 93.3e9) + 60
+                        left = float(os.environ.get("PGX_BENCH_BUDGET_S", "1620")) - (time.perf_counter() - _T0) - 150
+                        mode = whole if left >= need else "sample"
+                        log(f"cpu baseline: {mode} (estimated {need:.0f} s for the {whole} leg, {left:.0f} s of the budget left)")
+                        if mode == "sample":
+                            fallback_reason = (f"the {whole} reference leg needs ~{need:.0f} s and {left:.0f} s of the command's budget (PGX_BENCH_BUDGET_S) were left: "
+                                               f"bounded sample instead; gpu_over_cpu.vs_n_cores_raw_records is null for a sample")
+                            sys.stderr.write("[bench] WARNING: cpu_baseline falls back to mode 'sample': " + fallback_reason + "\n")
+                    # the end-to-end leg (default where the budget allows; it runs LAST -- this process gives its HBM to the server) reads the same seqdb files
+                    # as the reference: written once, shared
+                    cpu_est = {"full": 900.0, "whole_chunks": 1300.0, "sample": 330.0}[mode] * (db.n_bases / 93.3e9) + 60
+                    left_after = float(os.environ.get("PGX_BENCH_BUDGET_S", "1620")) - (time.perf_counter() - _T0) - cpu_est
+                    if a.end_to_end is None:
+                        a.end_to_end = bool(not a.genome_mb and a.workload == "c4" and left_after >= 200)
+                        log(f"end to end leg: {'on' if a.end_to_end else 'off'} ({left_after:.0f} s of the budget expected to be left after the CPU leg)")
+                    if a.end_to_end:
+                        need = int(total * 1.02) + int(db.n_bases * 0.5) + (8 << 30)
+                        base = _scratch_dir(need)
+                        if base is not None:
+                            sdir = tempfile.mkdtemp(prefix="pgx_bench_", dir=base)
+                            tw = time.perf_counter()
+                            simreads.write_seqdb_from_device(os.path.join(sdir, "sd"), seq_bytes(), total, db.rid, db.rlen, db.roff)
+                            shared_files = {"dir": sdir, "prefix": os.path.join(sdir, "sd"), "seconds": time.perf_counter() - tw}
+                    sha_thread = None
+                    if not a.genome_mb and not os.environ.get("PGX_BENCH_NO_STREAM_HASH"):     # the seqdb's SHA-256, beside the CPU leg's (untimed) file writing
+                        import threading
+                        sha_box = {}
+                        sha_src = seq_bytes()
+                        sha_thread = threading.Thread(target=lambda: sha_box.update(v=seqdb_sha256_of_device(sha_src, total)))
+                        sha_thread.start()
+                    out["cpu_baseline"] = cpu_baseline_chunked(seq_bytes(), total, db, rdb, eng, a.workload, mode, sp["levels"], sp["mc_upper"], CH, gpu_index_files, held,
+                                                               stream_report=stream_report, before_timing=(sha_thread.join if sha_thread is not None else None),
+                                                               files=shared_files)
+                    if sha_thread is not None:
+                        sha_thread.join()
+                        out["seqdb_sha256"] = sha_box.get("v")
+                        sha_src = sha_thread = None     # (the thread's hold on the regenerated 93 GB: the end-to-end leg needs that HBM for its server)
+                    if fallback_reason:
+                        out["cpu_baseline"]["fallback_reason"] = fallback_reason
+                elif a.cpu_baseline == "sample":
+                    sample = simreads.simulate_reads_torch(10_000_000, 1003, 30.0, seed=42)
+                    out["cpu_baseline"] = cpu_baseline_sample(sample)
+                else:
+                    out["cpu_baseline"] = cpu_baseline(db, keep_streams[1], a.workload, sp["levels"], sp["mc_upper"])
+                cb = out["cpu_baseline"]
+                if strong and cb.get("mode") == "sample" and not a.genome_mb:
+                    # the bounded sample UNDERSTATES the reference: each of its processes still loads every shimmer / count file and scans the whole
+                    # list (a fixed cost per process) for 1/8 of the first keys.  The whole-workload leg of the same tree family is committed:
+                    try:
+                        full = json.load(open(os.path.join(ROOT, "profiles", "r04e_bench_c4_full.json")))["cpu_baseline"]
+                        if a.workload == "c4" and full.get("mode") == "full":
+                            cb["whole_workload_leg"] = {"value": full["value"], "unit": "overlaps/s", "cores": full["cores"], "index_s": full["index_s"], "overlap_s": full["overlap_s"],
+                                                        "records": full["records"], "unique_pairs_per_s": full.get("unique_pairs_per_s"),
+                                                        "source": "profiles/r04e_bench_c4_full.json (python bench.py --cpu-baseline full: 24 processes over 24 + 24 chunks of the whole 93 Gbases, "
+                                                                  "13 min 43 s of the box; not re-run in the default command)"}
+                            cb["sample_note"] = ("the sample's rate is lower than the whole-workload leg's (fixed per-process cost over 1/8 of the work): compare `value` with "
+                                                 "whole_workload_leg.value")
+                    except Exception:
+                        pass
+                if cb.get("value"):
+                    out["gpu_over_cpu"] = {"vs_n_cores_raw_records": out["value"] / cb["value"] if cb.get("mode") != "sample" else None,
+                                           "vs_n_cores_unique_pairs": out["value"] / cb["unique_pairs_per_s"] if cb.get("unique_pairs_per_s") and cb.get("mode") != "sample" else None,
+                                           "vs_one_core": out["value"] / cb["one_core"]["value"] if cb.get("one_core") else None, "cpu_cores": cb["cores"],
+                                           "vs_whole_workload_leg_raw_records": out["value"] / cb["whole_workload_leg"]["value"] if cb.get("whole_workload_leg") else None,
+                                           "note": "the N-chunk CPU run reports most pairs once per chunk, so both of its rates are given; one-chunk "
+                                                   "workloads: GPU value = records of ONE overlap chunk (every read pair once)"}
+                    if cb.get("mode") == "whole_chunks" and out.get("overlap_ms_per_step"):
+                        k = cb["chunks_run"]
+                        out["gpu_over_cpu"]["same_chunks"] = {
+                            "what": "overlap stage of the SAME %d chunks of the job's own chunking (T = %d): reference wall time, %d processes side by side, vs the GPU's overlap "
+                                    "time per step x %d/%d; equal streams (cpu_baseline.records_match_gpu)" % (k, CH, cb["overlap_processes"], k, CH),
+                            "cpu_overlap_s": cb["overlap_s"], "cpu_processes": cb["overlap_processes"], "gpu_overlap_s": out["overlap_ms_per_step"] * 1e-3 * k / CH,
+                            "ratio": cb["overlap_s"] / (out["overlap_ms_per_step"] * 1e-3 * k / CH)}
+        except Exception as e:
+            import traceback
+            sys.stderr.write("[bench] WARNING: the reference CPU leg failed: %s\n%s" % (e, traceback.format_exc()))
+            cb = out.get("cpu_baseline") or {}
+            cb.update({"error": repr(e)})
+            cb.setdefault("value", None), cb.setdefault("unit", "overlaps/s"), cb.setdefault("cores", 0), cb.setdefault("kind", "none"), cb.setdefault("sample", "the leg failed: see `error`")
+            out["cpu_baseline"] = cb
         # ---- the pins: hashes of the REFERENCE's streams for this configuration (tests/golden/make_c4_stream_pins.py ran oracle/_ref/shmr_overlap
         # -t 8 -c 1..8 on the same seqdb bytes; SURVEY 8c/d, VERDICT r4 task 3)
         if stream_report is not None and strong and not a.genome_mb and os.path.exists(PINS_FILE):
@@ -1277,8 +1287,14 @@ def main():
         if a.end_to_end is None:     # (no CPU leg in this run)
             a.end_to_end = False
         if a.end_to_end and strong and world == 1:
-            seq_box = [seq_bytes() if shared_files is None else seq_dev]     # (the files exist already: nothing to write)
+            try:
+                seq_box = [seq_bytes() if shared_files is None else seq_dev]     # (the files exist already: nothing to write)
+            except Exception as e:
+                seq_box = [None]
+                out["gpu_end_to_end"] = {"error": "the seqdb bytes could not be generated again: " + repr(e)}
+                a.end_to_end = False
             seq_dev = None
+        if a.end_to_end and strong and world == 1:
 
             def release_all():
                 seq_box.clear()

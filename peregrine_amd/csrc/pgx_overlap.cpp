@@ -135,6 +135,7 @@ void overlap_front(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx
         DevVisit dv;
         dev_visit_inner(dpairs, (uint32_t)p->ovlp_upper, dv);            // (enqueued: the GPU replays the inner tables ...
         if (pt.n_rec >= ((size_t)2 << 20)) dev_align_prepare(db);        //  ... and packs the reads for the alignments ...
+        if (pt.n_rec >= ((size_t)2 << 20)) replay_preclear();            //  ... and clears the replay's tables (round 6: 7-8 ms of a full-size chunk) ...
         pre.join();                                                      //  ... while the outer table finishes here)
         const double tw = now_ms();
         for (size_t i = 0; ok && i < dpairs.key_sample.size(); ++i) ok = pre.eg.keys[i * KEY_SAMPLE_STRIDE] == dpairs.key_sample[i];

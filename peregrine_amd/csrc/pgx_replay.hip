@@ -43,6 +43,27 @@ uint32_t pow2_at_least(size_t x) {
 }
 unsigned cdiv256(size_t n) { return (unsigned)((n + 255) / 256); }
 
+// Round 6: the three hash tables of a stage (hot pair table, reader lists, memo: 38.6 GB at full-size configs[3]) must start all zero, and clearing them
+// takes 7-8 ms -- on a GPU that sits idle for ~18 ms of every chunk while the host finishes the outer khash table (pgx_overlap.cpp: overlap_front).
+// So the front allocates and clears tables of the sizes the LAST stage used inside that window (replay_preclear); replay_attempt takes them over when
+// its own sizes come out the same (the chunks of a job are alike, the sizes are powers of two) and clears its own otherwise.
+struct PreCleared {
+  DevBuf<PHot> ph;
+  DevBuf<PCold> pc;
+  DevBuf<MSlot> mt;
+  uint32_t pcap = 0, mcap = 0;
+  size_t ccap = 0;
+  bool valid = false;
+  void drop() {
+    ph.release(), pc.release(), mt.release();
+    valid = false;
+  }
+};
+PreCleared g_pre;
+uint32_t g_last_pcap = 0, g_last_mcap = 0;   // what the last successful stage of the process used
+size_t g_last_ccap = 0;
+ShutdownHook h_pre([] { g_pre.drop(), g_last_pcap = g_last_mcap = 0, g_last_ccap = 0; });
+
 // one attempt with the given table sizes (multiples of the defaults); returns 0, or the OV_* bits of what overflowed
 uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, const uint32_t *d_bids, size_t nb, size_t n_entries,
                         uint32_t bestn, int band, bool predict, const std::function<pgx_ovlp *(size_t)> &alloc_out,
@@ -61,7 +82,13 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   DevBuf<PHot> ph;
   DevBuf<PCold> pc;
   DevBuf<MSlot> mt;
-  {
+  // (what the pre-cleared tables hold was free memory when round 5 measured the rule below: counted as free here too)
+  const size_t pre_hold = g_pre.valid ? (size_t)g_pre.pcap * sizeof(PHot) + g_pre.ccap * sizeof(PCold) + (size_t)g_pre.mcap * sizeof(MSlot) : 0;
+  bool precleared = false;
+  if (g_pre.valid && g_pre.pcap == pcap && g_pre.mcap == mcap && !getenv("PGX_REPLAY_COLD_SHIFT")) {   // (its reader lists: checked below, once the shift is known)
+    ph = std::move(g_pre.ph), mt = std::move(g_pre.mt);
+    precleared = true;
+  } else {
     MemTag t1("replay.pair_table_hot");
     ph.alloc(pcap);
   }
@@ -75,17 +102,22 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   } else {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-      while (r.cshift < 3 && ((size_t)pcap >> r.cshift) * sizeof(PCold) > (free_b + dev_cache_free_bytes()) / 3) ++r.cshift;   // (the last stage's tables are in the cache)
+      while (r.cshift < 3 && ((size_t)pcap >> r.cshift) * sizeof(PCold) > (free_b + dev_cache_free_bytes() + pre_hold) / 3) ++r.cshift;   // (the last stage's tables are in the cache)
   }
   const size_t ccap = ((size_t)pcap >> r.cshift) + 1;
-  {
+  const bool pc_pre = precleared && g_pre.ccap == ccap;
+  if (pc_pre) {
+    pc = std::move(g_pre.pc);
+  } else {
     MemTag t2("replay.pair_table_readers");
+    g_pre.pc.release();
     pc.alloc(ccap);
   }
-  {
+  if (!precleared) {
     MemTag t3("replay.memo_table");
     mt.alloc(mcap);
   }
+  g_pre.drop();   // (whatever was not taken over goes back to the block cache)
   r.ph = ph.p, r.pc = pc.p, r.pmask = pcap - 1, r.mt = mt.p, r.mmask = mcap - 1;
   r.item_cap = (uint32_t)std::min<size_t>((size_t)(((size_t)(ne * 6) + nb * (size_t)64) * mult[0]) + (size_t)(nb / GPW + 2 + SPARSE_CAP + 8 + BIG_WG * BIG_NW) * ICH + (1u << 20), 0x7FFFFFF0u);
   r.rn_cap = (uint32_t)std::min<size_t>((size_t)(ne * 8 * mult[1]) + (1u << 20), 0x7FFFFFF0u);
@@ -137,9 +169,10 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
   const bool timed_misc = getenv("PGX_REPLAY_TIMING") && atoi(getenv("PGX_REPLAY_TIMING")) != 0;   // "replay_misc" / "replay_emit" in pgx_timing_get
   std::optional<KernelTimer> tm_setup;
   if (timed_misc) tm_setup.emplace("replay_misc", nb);
-  PGX_HIP(hipMemsetAsync(ph.p, 0, (size_t)pcap * sizeof(PHot), s));
-  PGX_HIP(hipMemsetAsync(pc.p, 0, ccap * sizeof(PCold), s));
-  PGX_HIP(hipMemsetAsync(mt.p, 0, (size_t)mcap * sizeof(MSlot), s));
+  if (!precleared) PGX_HIP(hipMemsetAsync(ph.p, 0, (size_t)pcap * sizeof(PHot), s));
+  if (!pc_pre) PGX_HIP(hipMemsetAsync(pc.p, 0, ccap * sizeof(PCold), s));
+  if (!precleared) PGX_HIP(hipMemsetAsync(mt.p, 0, (size_t)mcap * sizeof(MSlot), s));
+  if (trace && precleared) fprintf(stderr, "[pgx]   replay tables taken over pre-cleared (pair table%s, memo)\n", pc_pre ? ", reader lists" : "");
   PGX_HIP(hipMemsetAsync(bytes.p, 0, nb * 5, s));
   PGX_HIP(hipMemsetAsync(words.p, 0, nb * 5 * sizeof(uint32_t), s));
   PGX_HIP(hipMemsetAsync(dc.p, 0, sizeof(Counters), s));
@@ -461,6 +494,7 @@ uint32_t replay_attempt(const pgx_seqdb *db, const DevicePairs &dp, const uint32
     if (trace)
       fprintf(stderr, "[pgx]   tables: %llu read pairs in %u slots (load %.2f), %u alignments in %u memo slots (load %.2f), items %u of %u, reader nodes %u of %u, requests %u of %u\n",
               n_keys, pcap, (double)n_keys / pcap, hc->nreq, mcap, (double)hc->nreq / mcap, hc->item_top, r.item_cap, hc->rnode_top, r.rn_cap, hc->nreq, r.req_cap);
+    g_last_pcap = pcap, g_last_mcap = mcap, g_last_ccap = ccap;
     *n_out = nrec;
     if (st) {
       st->n_align_needed = hc->lookups, st->n_seen_skip = hc->skips, st->n_align_gpu = first_req;
@@ -512,12 +546,47 @@ ShutdownHook h_learn([] { replay_forget_sizes(); });
 }  // namespace
 void replay_forget_sizes() {
   for (double &m : g_learned) m = 0;
+  g_pre.drop();
+  g_last_pcap = g_last_mcap = 0, g_last_ccap = 0;
+}
+
+// called by the stage's front while the GPU would otherwise wait for the host's outer table: tables of the last stage's sizes, cleared, on ctx().stream
+void replay_preclear() {
+  if (!g_last_pcap || g_pre.valid || (getenv("PGX_REPLAY_PRECLEAR") && atoi(getenv("PGX_REPLAY_PRECLEAR")) == 0)) return;
+  size_t free_b = 0, total_b = 0;
+  const size_t need = (size_t)g_last_pcap * sizeof(PHot) + g_last_ccap * sizeof(PCold) + (size_t)g_last_mcap * sizeof(MSlot);
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b + dev_cache_free_bytes()) return;   // (no room ahead of time: the attempt decides)
+  try {
+    hipStream_t s = ctx().stream;
+    {
+      MemTag t1("replay.pair_table_hot");
+      g_pre.ph.alloc(g_last_pcap);
+    }
+    {
+      MemTag t2("replay.pair_table_readers");
+      g_pre.pc.alloc(g_last_ccap);
+    }
+    {
+      MemTag t3("replay.memo_table");
+      g_pre.mt.alloc(g_last_mcap);
+    }
+    PGX_HIP(hipMemsetAsync(g_pre.ph.p, 0, (size_t)g_last_pcap * sizeof(PHot), s));
+    PGX_HIP(hipMemsetAsync(g_pre.pc.p, 0, g_last_ccap * sizeof(PCold), s));
+    PGX_HIP(hipMemsetAsync(g_pre.mt.p, 0, (size_t)g_last_mcap * sizeof(MSlot), s));
+    g_pre.pcap = g_last_pcap, g_pre.mcap = g_last_mcap, g_pre.ccap = g_last_ccap, g_pre.valid = true;
+  } catch (const Fail &) {
+    (void)hipGetLastError();
+    g_pre.drop();
+  }
 }
 
 bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visit_bids, const uint32_t *d_bids, size_t nb, size_t n_entries,
                 uint32_t bestn, int band, bool predict, uint32_t ovlp_upper, const std::function<pgx_ovlp *(size_t)> &alloc_out,
                 size_t *n_out, pgx_overlap_stats *st, bool trace) {
   *n_out = 0;
+  struct DropPre {   // (tables cleared ahead of time that no attempt took over do not outlive the stage)
+    ~DropPre() { g_pre.drop(); }
+  } drop_pre;
   // what the encodings hold (anything else goes to the host replay)
   if (ovlp_upper > 128 || nb >= (1u << 29) - 2 || n_entries >= (1ULL << 31) || !dp.valid) return false;
   if (nb == 0) {
@@ -530,6 +599,7 @@ bool dev_replay(const pgx_seqdb *db, const DevicePairs &dp, const uint32_t *visi
                         nb * (size_t)(64 * sizeof(Item) + 64) + (256u << 20);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > free_b) {
+      g_pre.drop();      // (tables cleared ahead of time are part of what `need` prices)
       dev_cache_trim();  // (blocks the cache holds for re-use count as used)
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b) {
         fprintf(stderr, "[pgx] note: the device replay's tables (%.1f GB) do not fit the free device memory (%.1f GB); the host replay takes over\n",
