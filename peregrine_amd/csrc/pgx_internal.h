@@ -438,6 +438,7 @@ void list_stash_put(const std::string &path, const void *d_payload, const void *
 void list_stash_clear();
 void count_cache_drop();     // the aggregated count table kept across the chunks of a job (pgx_pairs.hip)
 void replay_forget_sizes();  // the device replay's learned table sizes (pgx_replay.hip): another database, another job
+void replay_drop_precleared();
 void replay_preclear();      // tables of the last stage's sizes, allocated and cleared ahead of the replay (while the GPU waits for the host's outer table)
 
 // pgx_overlap_stats::stream_checksum: the sum over the records of a 64-bit mix of every field (padding bytes excluded) and the record's

@@ -181,6 +181,9 @@ void run_overlap(pgx_seqdb *db, const pgx_mm128 *mmers, size_t n_mm, const pgx_m
                  const pgx_pair_rec *d_recs = nullptr, size_t n_recs = 0) {
   StageFront front;
   dev_cache_age();
+  struct DropPre {   // (tables the front cleared ahead of time for a device replay that then did not run: an exception, the host path)
+    ~DropPre() { replay_drop_precleared(); }
+  } drop_pre;
   overlap_front(db, mmers, n_mm, counts, n_counts, p, dev, d_recs, n_recs, front);
   pgx_overlap_stats s = front.s;
   const double t0 = front.t0, t1 = front.t1;

@@ -550,6 +550,8 @@ void replay_forget_sizes() {
   g_last_pcap = g_last_mcap = 0, g_last_ccap = 0;
 }
 
+void replay_drop_precleared() { g_pre.drop(); }   // (a stage that ended without a device replay: nothing cleared ahead of time outlives it)
+
 // called by the stage's front while the GPU would otherwise wait for the host's outer table: tables of the last stage's sizes, cleared, on ctx().stream
 void replay_preclear() {
   if (!g_last_pcap || g_pre.valid || (getenv("PGX_REPLAY_PRECLEAR") && atoi(getenv("PGX_REPLAY_PRECLEAR")) == 0)) return;

@@ -399,7 +399,8 @@ void list_stash_put(const std::string &path, const void *d_payload, const void *
     g_stash.erase(old);
   }
 }
-void list_stash_clear() {
+void list_stash_clear() {   // (also the assembled lists of the last job: both belong to the database that is going away)
+  g_lists.clear();
   std::lock_guard<std::mutex> lk(g_stash_mu);
   g_stash.clear();
   g_stash_bytes = 0;
