@@ -89,7 +89,7 @@ void pgx_seqdb_free(pgx_seqdb *db);
  * the database, or here): the index stage's closed-form kernels and every alignment kernel of the default path read the packs.  Refused --
  * PGX_ESTATE, bytes kept -- for a database with a read that holds an ambiguous base (sketched run by run / aligned nibble by nibble from the
  * bytes: src/mm_sketch.c:112-113, src/DWmatch.c:136-137) or a read longer than 65,535 bases.  Afterwards the entry points that need bytes (w / k
- * other than 80 / 16, want_l0, pgx_*_batch, pgx_map*) return PGX_ESTATE; a buffer handed over with pgx_seqdb_adopt_dev is no longer referenced. */
+ * other than 80 / 16, want_l0, pgx_sketch_batch) return PGX_ESTATE; a buffer handed over with pgx_seqdb_adopt_dev is no longer referenced. */
 int pgx_seqdb_release_bytes(pgx_seqdb *db);
 int pgx_seqdb_has_bytes(const pgx_seqdb *db);
 uint64_t pgx_seqdb_bases(const pgx_seqdb *db);

@@ -888,8 +888,8 @@ int pgx_seqdb_load(const char *prefix, pgx_seqdb **out) {
 // k_align1 / k_align1_list.  What cannot work from the packs keeps the bytes: a database with a read that holds an ambiguous base (no 2-bit
 // code: those reads are sketched run by run and aligned nibble by nibble from the bytes) or a read beyond 65,535 bases (k_align4) is REFUSED
 // (PGX_ESTATE, bytes kept, nothing changed).  After a release: pgx_index_resident* (w = 80, k = 16, levels 1 / 2, no L0 output),
-// pgx_overlap_* and the file-level forms over them work as before; entry points that need the bytes (other w / k, want_l0, the batch
-// functions, pgx_map*) fail with PGX_ESTATE.  A buffer the library adopted (pgx_seqdb_adopt_dev) is no longer referenced: the caller may free it.
+// pgx_overlap_*, pgx_align_batch and the file-level forms over them work as before; entry points that need the bytes (other w / k, want_l0,
+// pgx_sketch_batch) fail with PGX_ESTATE.  A buffer the library adopted (pgx_seqdb_adopt_dev) is no longer referenced: the caller may free it.
 int pgx_seqdb_release_bytes(pgx_seqdb *db) {
   PGX_GUARD_BEGIN
   require_ready();
